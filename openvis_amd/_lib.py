@@ -1,0 +1,66 @@
+"""ctypes binding of libopenvis_hip.so (the C-ABI drop-in boundary).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C openvis_amd/csrc``.  Loading fails loudly: there is no fallback path.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libopenvis_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "openvis_hip.h")
+
+_lib = None
+
+
+class OvisError(RuntimeError):
+    pass
+
+
+def declared_symbols(header_path=HEADER_PATH):
+    """Names of every function declared in include/openvis_hip.h."""
+    src = open(header_path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ovis_[a-z0-9_]+)\s*\(", src)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OvisError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C openvis_amd/csrc`). openvis_amd has no CPU/eager fallback.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.ovis_last_error.restype = ctypes.c_char_p
+        _lib.ovis_abi_version.restype = ctypes.c_int
+    return _lib
+
+
+def _conv(a):
+    """torch.Tensor -> device pointer; ints/floats pass through."""
+    import torch
+    if a is None:
+        return ctypes.c_void_p(0)
+    if isinstance(a, torch.Tensor):
+        if not a.is_contiguous():
+            raise OvisError("non-contiguous tensor passed to the C ABI")
+        return ctypes.c_void_p(a.data_ptr())
+    if isinstance(a, float):
+        return ctypes.c_float(a)
+    return a
+
+
+def call(name, *args):
+    """Call an int-returning ovis_* entry point; raise OvisError on a non-zero code."""
+    fn = getattr(lib(), name)
+    rc = fn(*[_conv(a) for a in args])
+    if rc != 0:
+        raise OvisError(f"{name} failed (code {rc}): {lib().ovis_last_error().decode()}")
+
+
+def stream_ptr():
+    """Current torch HIP stream as a void* for the ABI's `stream` argument."""
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,40 @@
+// Shared helpers for libopenvis_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdarg>
+#include <cstdint>
+#include "../../include/openvis_hip.h"
+
+namespace ovis {
+
+char* err_buf();  // thread-local, 512 bytes
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(OVIS_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return OVIS_OK;
+}
+
+// Bijective XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), so give
+// each XCD a contiguous chunk of the logical grid -> neighbouring tiles hit the same L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+  const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u;
+  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace ovis
+
+#define OVIS_REQUIRE(cond, ...) \
+  do { if (!(cond)) return ovis::fail(OVIS_EINVAL, __VA_ARGS__); } while (0)

@@ -1,0 +1,184 @@
+// K1 — multi-scale deformable attention forward for gfx950 (MI355X).
+//
+// Replaces the reference's CUDA op (openvis/modeling/pixel_decoder/ops/src/cuda/
+// ms_deform_im2col_cuda.cuh:242-304 + :39-89; host side cuda/ms_deform_attn_cuda.cu:25-85).
+//
+// MI355X design (HBM/L2-bound gather, no matrix work):
+//  * The reference maps ONE thread to ONE output channel: a 64-wide wavefront then covers two
+//    (query, head) rows and every tap is a 4-byte gather. Here one lane owns VEC=4 consecutive
+//    channels, so D/4 lanes cover a head and — for the encoder's M*D = 256 — one wavefront is
+//    exactly one query: its 4 taps x 12 points are 128-byte row segments of
+//    value[b, idx, m, 0:32] fetched as dwordx4, and its output is one coalesced 1 KiB store.
+//  * sampling_loc / attn_weight of a (query, head) are 24 + 12 contiguous floats read as
+//    dwordx4 (same address across the D/4 lanes of a head -> one request, broadcast).
+//  * L (levels) and P (points) are compile-time for the model's 3x4 configuration so all 16
+//    row gathers of a level are in flight together; other (L,P) take the runtime-loop variant.
+//  * blockIdx -> query mapping is XCD-aware (common.h:xcd_remap): each XCD's private 4 MiB L2
+//    serves a contiguous range of queries, whose sampling windows overlap spatially.
+//  * Arithmetic is evaluated in exactly the order of the CUDA kernel, without FMA contraction,
+//    so the result is bit-identical to oracle/msda_ref.c.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+template <typename T, int VEC> struct VecOf;
+template <> struct VecOf<float, 4> { using type = float4; };
+template <> struct VecOf<float, 1> { using type = float; };
+template <> struct VecOf<double, 1> { using type = double; };
+
+template <typename T> __device__ __forceinline__ T tfloor(T x);
+template <> __device__ __forceinline__ float tfloor<float>(float x) { return floorf(x); }
+template <> __device__ __forceinline__ double tfloor<double>(double x) { return floor(x); }
+
+template <typename T, int VEC>
+__device__ __forceinline__ void load_vec(T (&v)[VEC], const T* p, bool pred) {
+  if constexpr (VEC == 4) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pred) t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    v[0] = pred ? p[0] : T(0);
+  }
+}
+
+// One sampling point: 4 predicated row loads + bilinear blend, accumulated into acc.
+template <typename T, int VEC>
+__device__ __forceinline__ void sample_point(T (&acc)[VEC], const T* vp, int H, int W, int qid_stride,
+                                             T loc_w, T loc_h, T weight) {
+  const T h_im = loc_h * (T)H - (T)0.5;
+  const T w_im = loc_w * (T)W - (T)0.5;
+  if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+    const int h_low = (int)tfloor<T>(h_im), w_low = (int)tfloor<T>(w_im);
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    const T lh = h_im - h_low, lw = w_im - w_low;
+    const T hh = 1 - lh, hw = 1 - lw;
+    const long long h_stride = (long long)W * qid_stride;
+    const T* r0 = vp + h_low * h_stride;
+    const T* r1 = r0 + h_stride;
+    T v1[VEC], v2[VEC], v3[VEC], v4[VEC];
+    load_vec<T, VEC>(v1, r0 + (long long)w_low * qid_stride, h_low >= 0 && w_low >= 0);
+    load_vec<T, VEC>(v2, r0 + (long long)w_high * qid_stride, h_low >= 0 && w_high <= W - 1);
+    load_vec<T, VEC>(v3, r1 + (long long)w_low * qid_stride, h_high <= H - 1 && w_low >= 0);
+    load_vec<T, VEC>(v4, r1 + (long long)w_high * qid_stride, h_high <= H - 1 && w_high <= W - 1);
+    const T w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const T val = (w1 * v1[i] + w2 * v2[i] + w3 * v3[i] + w4 * v4[i]);
+      acc[i] += val * weight;
+    }
+  }
+}
+
+// LT/PT > 0: compile-time levels/points (fully unrolled per level); 0: runtime loops.
+template <typename T, int VEC, int LT, int PT>
+__global__ void __launch_bounds__(256)
+msda_fwd_kernel(const T* __restrict__ value, const int64_t* __restrict__ shapes,
+                const int64_t* __restrict__ lsi, const T* __restrict__ loc,
+                const T* __restrict__ attw, T* __restrict__ out, long long n_items, int S, int M,
+                int D, int L_rt, int Lq, int P_rt) {
+  const int L = LT > 0 ? LT : L_rt;
+  const int P = PT > 0 ? PT : P_rt;
+  const unsigned blk = ovis::xcd_remap(blockIdx.x, gridDim.x);
+  const long long item = (long long)blk * blockDim.x + threadIdx.x;
+  if (item >= n_items) return;
+  const int dv = D / VEC;
+  const int cv = (int)(item % dv);
+  const long long sidx = item / dv;  // (b*Lq + q)*M + m
+  const int m = (int)(sidx % M);
+  const long long b = sidx / ((long long)M * Lq);
+  const int qid_stride = M * D;
+  const T* lp = loc + sidx * L * P * 2;
+  const T* wp = attw + sidx * L * P;
+  const T* vbase = value + b * (long long)S * qid_stride + m * D + cv * VEC;
+
+  T acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0;
+
+  if constexpr (LT > 0 && PT == 4 && VEC == 4) {
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const T* vp = vbase + lsi[l] * (long long)qid_stride;
+      const float4 la = *reinterpret_cast<const float4*>(lp + l * 8);
+      const float4 lb = *reinterpret_cast<const float4*>(lp + l * 8 + 4);
+      const float4 w = *reinterpret_cast<const float4*>(wp + l * 4);
+      sample_point<T, VEC>(acc, vp, H, W, qid_stride, la.x, la.y, w.x);
+      sample_point<T, VEC>(acc, vp, H, W, qid_stride, la.z, la.w, w.y);
+      sample_point<T, VEC>(acc, vp, H, W, qid_stride, lb.x, lb.y, w.z);
+      sample_point<T, VEC>(acc, vp, H, W, qid_stride, lb.z, lb.w, w.w);
+    }
+  } else {
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const T* vp = vbase + lsi[l] * (long long)qid_stride;
+      for (int p = 0; p < P; ++p) {
+        const T loc_w = lp[(l * P + p) * 2], loc_h = lp[(l * P + p) * 2 + 1];
+        sample_point<T, VEC>(acc, vp, H, W, qid_stride, loc_w, loc_h, wp[l * P + p]);
+      }
+    }
+  }
+
+  T* op = out + sidx * D + cv * VEC;
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(op) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  } else {
+    op[0] = acc[0];
+  }
+}
+
+template <typename T>
+int msda_dispatch(const T* value, const int64_t* shapes, const int64_t* lsi, const T* loc,
+                  const T* attw, T* out, int B, int S, int M, int D, int L, int Lq, int P,
+                  hipStream_t stream) {
+  OVIS_REQUIRE(value && shapes && lsi && loc && attw && out, "msda_forward: null pointer");
+  OVIS_REQUIRE(B > 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq > 0 && P > 0,
+               "msda_forward: non-positive dimension (B=%d S=%d M=%d D=%d L=%d Lq=%d P=%d)", B, S, M, D,
+               L, Lq, P);
+  constexpr int TPB = 256;
+  bool vec4 = false;
+  if constexpr (sizeof(T) == 4) {
+    vec4 = (D % 4 == 0) && (((uintptr_t)value | (uintptr_t)out) % 16 == 0);
+  }
+  const bool loc_vec = vec4 && P == 4 && (((uintptr_t)loc | (uintptr_t)attw) % 16 == 0);
+  const long long n_items = (long long)B * Lq * M * (vec4 ? D / 4 : D);
+  const unsigned grid = ovis::cdiv(n_items, TPB);
+#define LAUNCH(VEC, LT, PT)                                                                         \
+  hipLaunchKernelGGL((msda_fwd_kernel<T, VEC, LT, PT>), dim3(grid), dim3(TPB), 0, stream, value,    \
+                     shapes, lsi, loc, attw, out, n_items, S, M, D, L, Lq, P)
+  if constexpr (sizeof(T) == 4) {
+    if (loc_vec && L == 3) LAUNCH(4, 3, 4);
+    else if (loc_vec && L == 4) LAUNCH(4, 4, 4);
+    else if (loc_vec && L == 1) LAUNCH(4, 1, 4);
+    else if (vec4) LAUNCH(4, 0, 0);
+    else LAUNCH(1, 0, 0);
+  } else {
+    LAUNCH(1, 0, 0);
+  }
+#undef LAUNCH
+  return ovis::check_launch("msda_forward");
+}
+
+}  // namespace
+
+extern "C" int ovis_msda_forward_f32(const float* value, const int64_t* spatial_shapes,
+                                     const int64_t* level_start_index, const float* sampling_loc,
+                                     const float* attn_weight, float* out, int batch,
+                                     int spatial_size, int num_heads, int channels, int num_levels,
+                                     int num_query, int num_point, ovis_stream_t stream) {
+  return msda_dispatch<float>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out,
+                              batch, spatial_size, num_heads, channels, num_levels, num_query,
+                              num_point, (hipStream_t)stream);
+}
+
+extern "C" int ovis_msda_forward_f64(const double* value, const int64_t* spatial_shapes,
+                                     const int64_t* level_start_index, const double* sampling_loc,
+                                     const double* attn_weight, double* out, int batch,
+                                     int spatial_size, int num_heads, int channels, int num_levels,
+                                     int num_query, int num_point, ovis_stream_t stream) {
+  return msda_dispatch<double>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                               out, batch, spatial_size, num_heads, channels, num_levels, num_query,
+                               num_point, (hipStream_t)stream);
+}

@@ -1,0 +1,35 @@
+"""CPU: the C-ABI library loads and exports every symbol include/openvis_hip.h declares;
+argument validation happens before any device work (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+from openvis_amd import _lib
+
+
+def test_library_exports_every_declared_symbol():
+    syms = _lib.declared_symbols()
+    assert "ovis_msda_forward_f32" in syms and "ovis_last_error" in syms
+    lib = _lib.lib()
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert lib.ovis_abi_version() >= 1
+
+
+def test_header_cites_reference_for_every_entry_point_group():
+    src = open(os.path.join(ROOT, "include", "openvis_hip.h")).read()
+    assert "ms_deform_im2col_cuda.cuh:242-304" in src and "vision.cpp:19" in src
+
+
+def test_invalid_arguments_are_rejected_before_launch():
+    lib = _lib.lib()
+    n = ctypes.c_void_p(0)
+    rc = lib.ovis_msda_forward_f32(n, n, n, n, n, n, 1, 1, 1, 1, 1, 1, 1, n)
+    assert rc == 1  # OVIS_EINVAL
+    assert b"null pointer" in lib.ovis_last_error()
+
+
+def test_no_torch_types_in_abi_signatures():
+    src = open(os.path.join(ROOT, "include", "openvis_hip.h")).read()
+    assert not re.search(r"at::|torch::|Tensor", src)

@@ -1,0 +1,22 @@
+"""The product package must never import, call or link the oracle (or the reference)."""
+import os
+import re
+
+from conftest import ROOT
+
+
+def _sources():
+    for d, _, files in os.walk(os.path.join(ROOT, "openvis_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
+                yield os.path.join(d, f)
+    yield os.path.join(ROOT, "MultiScaleDeformableAttention.py")
+
+
+def test_product_does_not_touch_oracle_or_reference():
+    bad = []
+    for p in _sources():
+        s = open(p).read()
+        if re.search(r"^\s*(from|import)\s+oracle\b", s, re.M) or "liboracle" in s or "/root/reference" in s:
+            bad.append(p)
+    assert not bad, bad
