@@ -32,6 +32,10 @@ def lib():
             raise OvisError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C openvis_amd/csrc`). openvis_amd has no CPU/eager fallback.")
+        # torch bundles its own HIP runtime (soname libamdhip64.so.7); import it FIRST so this
+        # library binds to that already-loaded runtime instead of pulling /opt/rocm's copy into
+        # the process (two runtimes => "no ROCm-capable device" and foreign streams).
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ovis_last_error.restype = ctypes.c_char_p
         _lib.ovis_abi_version.restype = ctypes.c_int

@@ -80,7 +80,89 @@ def gen_msda():
     print("wrote msda.npz", {k: v.shape for k, v in out.items() if k.endswith("out32") or k.endswith("_out")})
 
 
-GENERATORS = {"msda": gen_msda}
+def _spec_arrays(spec):
+    import json
+    return np.frombuffer(json.dumps([[k, list(s)] for k, s in spec]).encode(), dtype=np.uint8)
+
+
+def _build_pixel_decoder():
+    md = R.ref("openvis.modeling.pixel_decoder.msdeformattn")
+    SS = sys.modules["detectron2.layers"].ShapeSpec
+    inshape = {"res2": SS(channels=256, stride=4), "res3": SS(channels=512, stride=8),
+               "res4": SS(channels=1024, stride=16), "res5": SS(channels=2048, stride=32)}
+    return md.MSDeformAttnPixelDecoder(
+        inshape, transformer_dropout=0.0, transformer_nheads=8, transformer_dim_feedforward=1024,
+        transformer_enc_layers=6, conv_dim=256, mask_dim=256, norm="GN",
+        transformer_in_features=["res3", "res4", "res5"], common_stride=4).eval()
+
+
+def _load_synth(module, seed):
+    from tests._synth import synth_weights, spec_of
+    spec = spec_of(module.state_dict())
+    module.load_state_dict(synth_weights(spec, seed), strict=True)
+    return spec
+
+
+PD_SEED, PD_IN_SEED, DEC_SEED, CLIP_SEED = 101, 102, 103, 104
+PD_T, PD_H, PD_W = 2, 32, 64
+
+
+def pd_input_shapes(T=PD_T, H=PD_H, W=PD_W):
+    return [(T, 256, H // 4, W // 4), (T, 512, H // 8, W // 8), (T, 1024, H // 16, W // 16), (T, 2048, H // 32, W // 32)]
+
+
+def gen_pixel_decoder_and_decoder():
+    """Reference MSDeformAttnPixelDecoder.forward_features (msdeformattn.py:329-380) and
+    VideoMultiScaleMaskedTransformerDecoder.forward (video decoder:380-452) on synthetic weights."""
+    from tests._synth import synth_inputs
+    pd = _build_pixel_decoder()
+    spec_pd = _load_synth(pd, PD_SEED)
+    f = synth_inputs(pd_input_shapes(), PD_IN_SEED)
+    feats = dict(zip(["res2", "res3", "res4", "res5"], f))
+    vd = R.ref("openvis.modeling.transformer_decoder.video_mask2former_transformer_decoder")
+    dec = vd.VideoMultiScaleMaskedTransformerDecoder(
+        256, True, num_classes=1, hidden_dim=256, num_queries=100, nheads=8, dim_feedforward=2048, dec_layers=9,
+        pre_norm=False, mask_dim=256, enforce_input_project=False, num_frames=2).eval()
+    spec_dec = _load_synth(dec, DEC_SEED)
+    with torch.no_grad():
+        mf, o0, ms = pd.forward_features(feats)
+        out = dec(ms, mf)
+    d = dict(spec_pd=_spec_arrays(spec_pd), spec_dec=_spec_arrays(spec_dec),
+             seeds=np.array([PD_SEED, PD_IN_SEED, DEC_SEED]), thw=np.array([PD_T, PD_H, PD_W]),
+             mask_features=mf.numpy(), ms0=ms[0].numpy(), ms1=ms[1].numpy(), ms2=ms[2].numpy(),
+             pred_logits=out["pred_logits"].numpy(), pred_masks=out["pred_masks"].numpy(),
+             aux_masks_0=out["aux_outputs"][0]["pred_masks"].numpy(),
+             aux_masks_5=out["aux_outputs"][5]["pred_masks"].numpy())
+    np.savez_compressed(os.path.join(GOLD, "pixel_decoder_decoder.npz"), **d)
+    print("wrote pixel_decoder_decoder.npz", mf.shape, out["pred_masks"].shape)
+
+
+def gen_clip_visual():
+    """Reference VisionTransformer.forward(x, m=None) (mask_adapted_clip/model.py:327-362) on a tiny ViT."""
+    from tests._synth import synth_inputs
+    m = R.ref("mask_adapted_clip.model")
+    vit = m.VisionTransformer(input_resolution=64, patch_size=16, mask_prompt_depth=0, width=128, layers=3,
+                              heads=2, output_dim=64).eval()
+    spec = _load_synth(vit, CLIP_SEED)
+    x = synth_inputs([(3, 3, 64, 64)], CLIP_SEED + 1)[0]
+    with torch.no_grad():
+        y = vit(x)
+    np.savez_compressed(os.path.join(GOLD, "clip_visual_tiny.npz"), spec=_spec_arrays(spec),
+                        seeds=np.array([CLIP_SEED, CLIP_SEED + 1]), out=y.numpy())
+    print("wrote clip_visual_tiny.npz", y.shape)
+
+
+def gen_position_encodings():
+    pe2 = R.ref("openvis.modeling.pixel_decoder.position_encoding").PositionEmbeddingSine2D(128, normalize=True)
+    pe3 = R.ref("openvis.modeling.transformer_decoder.position_encoding").PositionEmbeddingSine3D(128, normalize=True)
+    a = pe2(torch.zeros(1, 1, 5, 7))
+    b = pe3(torch.zeros(1, 3, 1, 4, 6))
+    np.savez_compressed(os.path.join(GOLD, "position_encodings.npz"), pe2d_5x7=a.numpy(), pe3d_3x4x6=b.numpy())
+    print("wrote position_encodings.npz")
+
+
+GENERATORS = {"msda": gen_msda, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual,
+              "pe": gen_position_encodings}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

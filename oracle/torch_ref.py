@@ -1,0 +1,530 @@
+"""TEST INFRASTRUCTURE ONLY — CPU restatement (plain torch, fp32/fp64) of the reference's
+per-frame dense inference path for the OpenVIS meta-architecture.
+
+Never imported by the product package.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg use it, as the checker / the timed CPU baseline ("port").
+
+Each function cites the reference file:line it follows (paths relative to /root/reference/).
+State-dict key names are the reference's.  Pinning status:
+  * pixel decoder, decoders, position encodings, CLIP visual tower: PINNED — checked against
+    the reference's own modules imported in the build container (oracle/make_golden.py ->
+    tests/golden/*.npz; tests/test_oracle_*.py).
+  * detectron2 ResNet-50 / ImageList / BitMasks boxes, torchvision roi_align: the sources are NOT
+    under /root/reference (un-vendored third-party deps: detectron2 v0.6 per INSTALL.md:9-13,
+    torchvision 0.11) -> restated from their published semantics; "parity unpinned" for those rows.
+  * dtype: the reference's GPU path casts crops to fp16 (clip_adapter/adapter.py:108-111) and runs
+    under autocast; this oracle follows the CPU (fp32) semantics of the same statements with the
+    `.cuda()` / `.half()` casts dropped.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------------------------
+# A1  pre-processing: openvis/openvis.py:57-62 (video_maskformer.py:178-183); Base.yaml:6-7
+# ----------------------------------------------------------------------------------------------
+PIXEL_MEAN = (123.675, 116.280, 103.530)
+PIXEL_STD = (58.395, 57.120, 57.375)
+
+
+def preprocess(frames, size_divisibility=32, mean=PIXEL_MEAN, std=PIXEL_STD):
+    """frames: list/tensor of uint8 [3,H,W] -> (fp32 [T,3,Hp,Wp] zero-padded right/bottom, (H,W)).
+    detectron2 ImageList.from_tensors(tensors, size_divisibility): pad to ceil(max/div)*div, value 0."""
+    mean = torch.tensor(mean, dtype=torch.float32).view(-1, 1, 1)
+    std = torch.tensor(std, dtype=torch.float32).view(-1, 1, 1)
+    imgs = [(x - mean) / std for x in frames]
+    H = max(i.shape[-2] for i in imgs)
+    W = max(i.shape[-1] for i in imgs)
+    Hp = (H + size_divisibility - 1) // size_divisibility * size_divisibility
+    Wp = (W + size_divisibility - 1) // size_divisibility * size_divisibility
+    out = imgs[0].new_zeros(len(imgs), 3, Hp, Wp)
+    for i, im in enumerate(imgs):
+        out[i, :, : im.shape[-2], : im.shape[-1]] = im
+    return out, (imgs[0].shape[-2], imgs[0].shape[-1])
+
+
+# ----------------------------------------------------------------------------------------------
+# A2  ResNet-50 backbone — detectron2 build_resnet_backbone (configs/openvoc_ytvis_coco/Base.yaml:2-16:
+#     DEPTH 50, STRIDE_IN_1X1 False, FrozenBN default, out res2..res5).  UN-VENDORED: restated from
+#     detectron2 v0.6 modeling/backbone/resnet.py (BasicStem, BottleneckBlock) + layers/batch_norm.py
+#     (FrozenBatchNorm2d, eps 1e-5).  parity unpinned.
+# ----------------------------------------------------------------------------------------------
+def _frozen_bn(x, W, prefix, eps=1e-5):
+    scale = W[prefix + ".weight"] * (W[prefix + ".running_var"] + eps).rsqrt()
+    bias = W[prefix + ".bias"] - W[prefix + ".running_mean"] * scale
+    return x * scale.reshape(1, -1, 1, 1) + bias.reshape(1, -1, 1, 1)
+
+
+def _conv_bn(x, W, prefix, stride=1, padding=0):
+    x = F.conv2d(x, W[prefix + ".weight"], None, stride=stride, padding=padding)
+    return _frozen_bn(x, W, prefix + ".norm")
+
+
+RESNET50_STAGES = (("res2", 3, 1), ("res3", 4, 2), ("res4", 6, 2), ("res5", 3, 2))
+
+
+def resnet50(x, W, prefix="backbone."):
+    x = F.relu(_conv_bn(x, W, prefix + "stem.conv1", stride=2, padding=3))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    feats = {}
+    for name, nblocks, first_stride in RESNET50_STAGES:
+        for i in range(nblocks):
+            p = f"{prefix}{name}.{i}"
+            stride = first_stride if i == 0 else 1
+            if (p + ".shortcut.weight") in W:
+                sc = _conv_bn(x, W, p + ".shortcut", stride=stride)
+            else:
+                sc = x
+            out = F.relu(_conv_bn(x, W, p + ".conv1", stride=1))            # STRIDE_IN_1X1 False
+            out = F.relu(_conv_bn(out, W, p + ".conv2", stride=stride, padding=1))
+            out = _conv_bn(out, W, p + ".conv3")
+            x = F.relu(out + sc)
+        feats[name] = x
+    return feats
+
+
+# ----------------------------------------------------------------------------------------------
+# A3  position encodings
+# ----------------------------------------------------------------------------------------------
+def pe_sine_2d(B, H, W, num_pos_feats=128, temperature=10000, scale=2 * math.pi, dtype=torch.float32):
+    """openvis/modeling/pixel_decoder/position_encoding.py:29-53 (normalize=True, mask all-False)."""
+    y_embed = torch.arange(1, H + 1, dtype=torch.float32).view(1, H, 1).expand(B, H, W)
+    x_embed = torch.arange(1, W + 1, dtype=torch.float32).view(1, 1, W).expand(B, H, W)
+    eps = 1e-6
+    y_embed = y_embed / (y_embed[:, -1:, :] + eps) * scale
+    x_embed = x_embed / (x_embed[:, :, -1:] + eps) * scale
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_t = dim_t.div(2, rounding_mode="floor")
+    dim_t = temperature ** (2 * dim_t / num_pos_feats)
+    pos_x = x_embed[:, :, :, None] / dim_t
+    pos_y = y_embed[:, :, :, None] / dim_t
+    pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2).to(dtype)
+
+
+def pe_sine_3d(B, T, H, W, num_pos_feats=128, temperature=10000, scale=2 * math.pi):
+    """openvis/modeling/transformer_decoder/position_encoding.py:135-165 -> [B,T,2*npf,H,W]."""
+    z_embed = torch.arange(1, T + 1, dtype=torch.float32).view(1, T, 1, 1).expand(B, T, H, W)
+    y_embed = torch.arange(1, H + 1, dtype=torch.float32).view(1, 1, H, 1).expand(B, T, H, W)
+    x_embed = torch.arange(1, W + 1, dtype=torch.float32).view(1, 1, 1, W).expand(B, T, H, W)
+    eps = 1e-6
+    z_embed = z_embed / (z_embed[:, -1:, :, :] + eps) * scale
+    y_embed = y_embed / (y_embed[:, :, -1:, :] + eps) * scale
+    x_embed = x_embed / (x_embed[:, :, :, -1:] + eps) * scale
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32).div(2, rounding_mode="floor")
+    dim_t = temperature ** (2 * dim_t / num_pos_feats)
+    dim_t_z = torch.arange(num_pos_feats * 2, dtype=torch.float32).div(2, rounding_mode="floor")
+    dim_t_z = temperature ** (2 * dim_t_z / (num_pos_feats * 2))
+    pos_x = x_embed[..., None] / dim_t
+    pos_y = y_embed[..., None] / dim_t
+    pos_z = z_embed[..., None] / dim_t_z
+    pos_x = torch.stack((pos_x[..., 0::2].sin(), pos_x[..., 1::2].cos()), dim=5).flatten(4)
+    pos_y = torch.stack((pos_y[..., 0::2].sin(), pos_y[..., 1::2].cos()), dim=5).flatten(4)
+    pos_z = torch.stack((pos_z[..., 0::2].sin(), pos_z[..., 1::2].cos()), dim=5).flatten(4)
+    return (torch.cat((pos_y, pos_x), dim=4) + pos_z).permute(0, 1, 4, 2, 3)
+
+
+# ----------------------------------------------------------------------------------------------
+# A5  K1 in torch (same tap rules / accumulation order as oracle/msda_ref.c), any float dtype
+# ----------------------------------------------------------------------------------------------
+def msda_torch(value, shapes, lsi, loc, attw):
+    """ms_deform_im2col_cuda.cuh:242-304 restated with gathers; l-then-p accumulation order."""
+    B, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    out = value.new_zeros(B, Lq, M, D)
+    bidx = torch.arange(B).view(B, 1, 1).expand(B, Lq, M)
+    midx = torch.arange(M).view(1, 1, M).expand(B, Lq, M)
+    for l in range(L):
+        H, W = int(shapes[l][0]), int(shapes[l][1])
+        start = int(lsi[l])
+        v = value[:, start:start + H * W]
+        for p in range(P):
+            w_im = loc[:, :, :, l, p, 0] * W - 0.5
+            h_im = loc[:, :, :, l, p, 1] * H - 0.5
+            inside = (h_im > -1) & (w_im > -1) & (h_im < H) & (w_im < W)
+            h_low = torch.floor(h_im)
+            w_low = torch.floor(w_im)
+            lh, lw = h_im - h_low, w_im - w_low
+            hh, hw = 1 - lh, 1 - lw
+            h_low, w_low = h_low.long(), w_low.long()
+            h_high, w_high = h_low + 1, w_low + 1
+
+            def tap(hi, wi):
+                ok = (hi >= 0) & (hi <= H - 1) & (wi >= 0) & (wi <= W - 1)
+                idx = (hi.clamp(0, H - 1) * W + wi.clamp(0, W - 1))
+                g = v[bidx, idx, midx]  # [B,Lq,M,D]
+                return g * ok[..., None].to(g.dtype)
+
+            v1, v2, v3, v4 = tap(h_low, w_low), tap(h_low, w_high), tap(h_high, w_low), tap(h_high, w_high)
+            w1, w2, w3, w4 = (hh * hw)[..., None], (hh * lw)[..., None], (lh * hw)[..., None], (lh * lw)[..., None]
+            val = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4)
+            out = out + (val * attw[:, :, :, l, p, None]) * inside[..., None].to(val.dtype)
+    return out.reshape(B, Lq, M * D)
+
+
+# ----------------------------------------------------------------------------------------------
+# A3-A6  MSDeformAttnPixelDecoder.forward_features — openvis/modeling/pixel_decoder/msdeformattn.py:329-380
+# ----------------------------------------------------------------------------------------------
+def _gn(x, W, prefix, groups=32):
+    return F.group_norm(x, groups, W[prefix + ".weight"], W[prefix + ".bias"], eps=1e-5)
+
+
+def msdeform_attn(W, p, query, ref_points, src, shapes, lsi, n_heads=8, n_levels=3, n_points=4):
+    """ops/modules/ms_deform_attn.py:82-125."""
+    N, Lq, C = query.shape
+    value = F.linear(src, W[p + "value_proj.weight"], W[p + "value_proj.bias"]).view(N, -1, n_heads, C // n_heads)
+    off = F.linear(query, W[p + "sampling_offsets.weight"], W[p + "sampling_offsets.bias"]).view(
+        N, Lq, n_heads, n_levels, n_points, 2)
+    aw = F.linear(query, W[p + "attention_weights.weight"], W[p + "attention_weights.bias"]).view(
+        N, Lq, n_heads, n_levels * n_points)
+    aw = F.softmax(aw, -1).view(N, Lq, n_heads, n_levels, n_points)
+    normalizer = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+    loc = ref_points[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+    out = msda_torch(value, shapes, lsi, loc, aw)
+    return F.linear(out, W[p + "output_proj.weight"], W[p + "output_proj.bias"])
+
+
+def encoder_reference_points(shapes_list):
+    """msdeformattn.py:155-168 with valid_ratios == 1 -> [1,S,L,2]."""
+    refs = []
+    for (H_, W_) in shapes_list:
+        ref_y, ref_x = torch.meshgrid(torch.linspace(0.5, H_ - 0.5, H_, dtype=torch.float32),
+                                      torch.linspace(0.5, W_ - 0.5, W_, dtype=torch.float32), indexing="ij")
+        ref_y = ref_y.reshape(-1)[None] / H_
+        ref_x = ref_x.reshape(-1)[None] / W_
+        refs.append(torch.stack((ref_x, ref_y), -1))
+    ref = torch.cat(refs, 1)
+    return ref[:, :, None].expand(-1, -1, len(shapes_list), -1)
+
+
+def pixel_decoder(feats, W, prefix="sem_seg_head.pixel_decoder.", n_layers=6, return_intermediate=False):
+    """feats: dict res2..res5 (fp32 NCHW) -> (mask_features, out[0], multi_scale_features[3])."""
+    p = prefix
+    srcs, poss = [], []
+    for idx, f in enumerate(["res5", "res4", "res3"]):                       # msdeformattn.py:332-337
+        x = feats[f].float()
+        y = F.conv2d(x, W[f"{p}input_proj.{idx}.0.weight"], W[f"{p}input_proj.{idx}.0.bias"])
+        srcs.append(_gn(y, W, f"{p}input_proj.{idx}.1"))
+        poss.append(pe_sine_2d(x.shape[0], x.shape[2], x.shape[3]))
+    # MSDeformAttnTransformerEncoderOnly.forward: msdeformattn.py:76-104
+    shapes_list = [(s.shape[2], s.shape[3]) for s in srcs]
+    src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+    pos = torch.cat([q.flatten(2).transpose(1, 2) + W[p + "transformer.level_embed"][l].view(1, 1, -1)
+                     for l, q in enumerate(poss)], 1)
+    shapes = torch.as_tensor(shapes_list, dtype=torch.long)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    ref = encoder_reference_points(shapes_list).expand(src.shape[0], -1, -1, -1)
+    inter = {"src0": src, "pos": pos}
+    out = src
+    for i in range(n_layers):                                               # msdeformattn.py:137-146
+        lp = f"{p}transformer.encoder.layers.{i}."
+        src2 = msdeform_attn(W, lp + "self_attn.", out + pos, ref, out, shapes, lsi)
+        out = F.layer_norm(out + src2, (256,), W[lp + "norm1.weight"], W[lp + "norm1.bias"])
+        src2 = F.linear(F.relu(F.linear(out, W[lp + "linear1.weight"], W[lp + "linear1.bias"])),
+                        W[lp + "linear2.weight"], W[lp + "linear2.bias"])
+        out = F.layer_norm(out + src2, (256,), W[lp + "norm2.weight"], W[lp + "norm2.bias"])
+    inter["memory"] = out
+    bs = out.shape[0]
+    ys = torch.split(out, [h * w for h, w in shapes_list], dim=1)            # msdeformattn.py:349-362
+    outs = [z.transpose(1, 2).reshape(bs, -1, h, w) for z, (h, w) in zip(ys, shapes_list)]
+    # FPN on res2: msdeformattn.py:365-373
+    x = feats["res2"].float()
+    cur = _gn(F.conv2d(x, W[p + "adapter_1.weight"]), W, p + "adapter_1.norm")
+    y = cur + F.interpolate(outs[-1], size=cur.shape[-2:], mode="bilinear", align_corners=False)
+    y = F.relu(_gn(F.conv2d(y, W[p + "layer_1.weight"], padding=1), W, p + "layer_1.norm"))
+    outs.append(y)
+    mask_features = F.conv2d(outs[-1], W[p + "mask_features.weight"], W[p + "mask_features.bias"])
+    if return_intermediate:
+        return mask_features, outs[0], outs[:3], inter
+    return mask_features, outs[0], outs[:3]
+
+
+# ----------------------------------------------------------------------------------------------
+# A7/A8  VideoMultiScaleMaskedTransformerDecoder — transformer_decoder/video_mask2former_transformer_decoder.py:380-471
+# ----------------------------------------------------------------------------------------------
+def _mha(W, p, query, key, value, attn_mask=None, nheads=8):
+    """nn.MultiheadAttention (seq-first) via torch's own functional definition."""
+    out, _ = F.multi_head_attention_forward(
+        query, key, value, query.shape[-1], nheads, W[p + "in_proj_weight"], W[p + "in_proj_bias"], None, None,
+        False, 0.0, W[p + "out_proj.weight"], W[p + "out_proj.bias"], training=False, key_padding_mask=None,
+        need_weights=False, attn_mask=attn_mask)
+    return out
+
+
+def _ln(x, W, p):
+    return F.layer_norm(x, (x.shape[-1],), W[p + ".weight"], W[p + ".bias"])
+
+
+def _mlp3(x, W, p):
+    x = F.relu(F.linear(x, W[p + "layers.0.weight"], W[p + "layers.0.bias"]))
+    x = F.relu(F.linear(x, W[p + "layers.1.weight"], W[p + "layers.1.bias"]))
+    return F.linear(x, W[p + "layers.2.weight"], W[p + "layers.2.bias"])
+
+
+def prediction_heads(W, p, output, mask_features, target_size, nheads=8):
+    """video decoder:454-471. output [Q,bs,C]; mask_features [bs,T,C,H,W]."""
+    dec = _ln(output, W, p + "decoder_norm").transpose(0, 1)
+    outputs_class = F.linear(dec, W[p + "class_embed.weight"], W[p + "class_embed.bias"])
+    mask_embed = _mlp3(dec, W, p + "mask_embed.")
+    outputs_mask = torch.einsum("bqc,btchw->bqthw", mask_embed, mask_features)
+    b, q, t, _, _ = outputs_mask.shape
+    am = F.interpolate(outputs_mask.flatten(0, 1), size=target_size, mode="bilinear", align_corners=False).view(
+        b, q, t, target_size[0], target_size[1])
+    am = (am.sigmoid().flatten(2).unsqueeze(1).repeat(1, nheads, 1, 1).flatten(0, 1) < 0.5).bool()
+    return outputs_class, outputs_mask, am
+
+
+def video_decoder(ms_feats, mask_features, W, prefix="sem_seg_head.predictor.", n_layers=9, nheads=8,
+                  return_intermediate=False):
+    """eval mode: bs = 1, t = T (video decoder:381-383). Returns pred_logits [1,Q,C+1], pred_masks [1,Q,T,H,W]."""
+    p = prefix
+    bt, c_m, h_m, w_m = mask_features.shape
+    bs, t = 1, bt
+    mask_features = mask_features.view(bs, t, c_m, h_m, w_m)
+    src, pos, size_list = [], [], []
+    for i in range(3):
+        h, w = ms_feats[i].shape[-2:]
+        size_list.append((h, w))
+        pe = pe_sine_3d(bs, t, h, w).flatten(3)                               # [bs,t,c,hw]
+        s = ms_feats[i].flatten(2) + W[p + "level_embed.weight"][i][None, :, None]
+        c = s.shape[1]
+        pos.append(pe.view(bs, t, c, h * w).permute(1, 3, 0, 2).flatten(0, 1))
+        src.append(s.view(bs, t, c, h * w).permute(1, 3, 0, 2).flatten(0, 1))
+    query_embed = W[p + "query_embed.weight"].unsqueeze(1).repeat(1, bs, 1)
+    output = W[p + "query_feat.weight"].unsqueeze(1).repeat(1, bs, 1)
+    inter = []
+    cls, msk, attn_mask = prediction_heads(W, p, output, mask_features, size_list[0], nheads)
+    inter.append(msk)
+    for i in range(n_layers):
+        li = i % 3
+        attn_mask[torch.where(attn_mask.sum(-1) == attn_mask.shape[-1])] = False   # video decoder:419
+        cp = f"{p}transformer_cross_attention_layers.{i}."
+        tgt2 = _mha(W, cp + "multihead_attn.", output + query_embed, src[li] + pos[li], src[li], attn_mask, nheads)
+        output = _ln(output + tgt2, W, cp + "norm")
+        sp = f"{p}transformer_self_attention_layers.{i}."
+        qk = output + query_embed
+        tgt2 = _mha(W, sp + "self_attn.", qk, qk, output, None, nheads)
+        output = _ln(output + tgt2, W, sp + "norm")
+        fp = f"{p}transformer_ffn_layers.{i}."
+        tgt2 = F.linear(F.relu(F.linear(output, W[fp + "linear1.weight"], W[fp + "linear1.bias"])),
+                        W[fp + "linear2.weight"], W[fp + "linear2.bias"])
+        output = _ln(output + tgt2, W, fp + "norm")
+        cls, msk, attn_mask = prediction_heads(W, p, output, mask_features, size_list[(i + 1) % 3], nheads)
+        inter.append(msk)
+    if return_intermediate:
+        return cls, msk, inter, output
+    return cls, msk
+
+
+# ----------------------------------------------------------------------------------------------
+# A10  ClipAdapter crops — openvis/modeling/clip_adapter/adapter.py:73-116
+# ----------------------------------------------------------------------------------------------
+def bitmask_boxes(bin_masks):
+    """detectron2 BitMasks.get_bounding_boxes (v0.6 structures/masks.py): [x0, y0, x1+1, y1+1]; zeros if empty.
+    UN-VENDORED -> restated; parity unpinned."""
+    n = bin_masks.shape[0]
+    boxes = torch.zeros(n, 4, dtype=torch.float32)
+    x_any = torch.any(bin_masks, dim=1)
+    y_any = torch.any(bin_masks, dim=2)
+    for idx in range(n):
+        x = torch.where(x_any[idx, :])[0]
+        y = torch.where(y_any[idx, :])[0]
+        if len(x) > 0 and len(y) > 0:
+            boxes[idx, :] = torch.as_tensor([x[0], y[0], x[-1] + 1, y[-1] + 1], dtype=torch.float32)
+    return boxes
+
+
+def roi_align(inp, rois, output_size, spatial_scale=1.0, sampling_ratio=-1, aligned=False):
+    """torchvision.ops.roi_align (0.11, csrc/ops/cpu/roi_align_kernel.cpp) restated; rois [K,5] = (batch, x1,y1,x2,y2).
+    UN-VENDORED -> parity unpinned. Vectorised over the adaptive sampling grid per roi."""
+    K = rois.shape[0]
+    C, H, W = inp.shape[1:]
+    ph, pw = output_size
+    out = inp.new_zeros(K, C, ph, pw)
+    offset = 0.5 if aligned else 0.0
+    for k in range(K):
+        b = int(rois[k, 0])
+        x1, y1, x2, y2 = [float(v) * spatial_scale - offset for v in rois[k, 1:]]
+        rw, rh = x2 - x1, y2 - y1
+        if not aligned:
+            rw, rh = max(rw, 1.0), max(rh, 1.0)
+        bh, bw = rh / ph, rw / pw
+        gh = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rh / ph))
+        gw = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rw / pw))
+        count = max(gh * gw, 1)
+        dt = torch.float64 if inp.dtype == torch.float64 else torch.float32
+        iy = (torch.arange(gh, dtype=dt) + 0.5) * bh / gh
+        ix = (torch.arange(gw, dtype=dt) + 0.5) * bw / gw
+        ys = (y1 + torch.arange(ph, dtype=dt)[:, None] * bh + iy[None, :]).reshape(-1)   # [ph*gh]
+        xs = (x1 + torch.arange(pw, dtype=dt)[:, None] * bw + ix[None, :]).reshape(-1)   # [pw*gw]
+
+        def prep(v, size):
+            bad = (v < -1.0) | (v > size)
+            v = v.clamp(min=0)
+            lo = v.floor().long()
+            hi_edge = lo >= size - 1
+            lo = torch.where(hi_edge, torch.full_like(lo, size - 1), lo)
+            hi = torch.where(hi_edge, lo, lo + 1)
+            v = torch.where(hi_edge, lo.to(v.dtype), v)
+            l = v - lo.to(v.dtype)
+            return lo, hi, l, 1 - l, bad
+
+        ylo, yhi, ly, hy, ybad = prep(ys, H)
+        xlo, xhi, lx, hx, xbad = prep(xs, W)
+        img = inp[b]
+        v1 = img[:, ylo][:, :, xlo]
+        v2 = img[:, ylo][:, :, xhi]
+        v3 = img[:, yhi][:, :, xlo]
+        v4 = img[:, yhi][:, :, xhi]
+        w1 = (hy[:, None] * hx[None, :]).to(inp.dtype)
+        w2 = (hy[:, None] * lx[None, :]).to(inp.dtype)
+        w3 = (ly[:, None] * hx[None, :]).to(inp.dtype)
+        w4 = (ly[:, None] * lx[None, :]).to(inp.dtype)
+        val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4
+        val = val * (~(ybad[:, None] | xbad[None, :])).to(inp.dtype)
+        out[k] = val.view(C, ph, gh, pw, gw).sum(dim=(2, 4)) / count
+    return out
+
+
+def clip_crops(frames, masks, resolution=224):
+    """adapter.py:73-116. frames [T,3,H,W] (raw 0..255, un-padded), masks [T,N,Hp,Wp] (sigmoid probabilities).
+    Returns (regions [M,3,res,res] or None, valid [T,N] bool, boxes [M,4])."""
+    frames = frames.float()
+    bin_masks = masks > 0.5
+    valid = bin_masks.sum(dim=(-1, -2)) > 0
+    if torch.sum(valid) == 0:
+        return None, valid, None
+    valid_bin_masks = bin_masks[valid]
+    valid_masks = masks[valid]
+    sboxes = bitmask_boxes(valid_bin_masks).clone()
+    sboxes[:, 2] = sboxes[:, 2] - sboxes[:, 0]
+    sboxes[:, 3] = sboxes[:, 3] - sboxes[:, 1]
+    sboxes[:, 3] = sboxes[:, 2] = torch.max(sboxes[:, 2], sboxes[:, 3])
+    sboxes[:, 2] = sboxes[:, 0] + sboxes[:, 2]
+    sboxes[:, 3] = sboxes[:, 1] + sboxes[:, 3]
+    ids = torch.nonzero(valid)
+    ind = torch.cat([ids[:, 0:1].float(), sboxes], dim=-1)
+    regions = roi_align(frames, ind, (resolution, resolution))
+    ind = torch.cat([torch.arange(len(sboxes))[:, None].float(), sboxes], dim=-1)
+    mask_regions = roi_align(valid_masks[:, None], ind, (resolution, resolution))
+    regions = mask_regions * regions + (1 - mask_regions) * 0.
+    return regions, valid, sboxes
+
+
+# ----------------------------------------------------------------------------------------------
+# A10  CLIP visual tower (ViT) — third_parties/mask_adapted_clip/mask_adapted_clip/model.py:327-362 with m=None
+#      (identical to openai/CLIP VisionTransformer.forward), blocks model.py:238-268, LayerNorm 223-229, QuickGELU 232-234
+# ----------------------------------------------------------------------------------------------
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def clip_visual(x, W, prefix="clip_adapter.clip_model.visual.", heads=12):
+    p = prefix
+    patch = W[p + "conv1.weight"].shape[-1]
+    x = F.conv2d(x, W[p + "conv1.weight"], None, stride=patch)
+    x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+    cls = W[p + "class_embedding"].to(x.dtype) + torch.zeros(x.shape[0], 1, x.shape[-1], dtype=x.dtype)
+    x = torch.cat([cls, x], dim=1) + W[p + "positional_embedding"]
+    x = _ln(x, W, p + "ln_pre")
+    x = x.permute(1, 0, 2)
+    n_layers = 1 + max(int(k[len(p + "transformer.resblocks."):].split(".")[0]) for k in W
+                       if k.startswith(p + "transformer.resblocks."))
+    for i in range(n_layers):
+        bp = f"{p}transformer.resblocks.{i}."
+        h = _ln(x, W, bp + "ln_1")
+        x = x + _mha(W, bp + "attn.", h, h, h, None, heads)
+        h = _ln(x, W, bp + "ln_2")
+        h = F.linear(h, W[bp + "mlp.c_fc.weight"], W[bp + "mlp.c_fc.bias"])
+        h = h * torch.sigmoid(1.702 * h)
+        x = x + F.linear(h, W[bp + "mlp.c_proj.weight"], W[bp + "mlp.c_proj.bias"])
+    x = x.permute(1, 0, 2)
+    x = _ln(x[:, 0, :], W, p + "ln_post")
+    return x @ W[p + "proj"]
+
+
+def clip_encode_image(regions, W, prefix="clip_adapter.clip_model.visual.", resolution=224, heads=12):
+    """adapter.py:140-144."""
+    image = F.interpolate(regions / 255., (resolution, resolution), mode="bicubic")
+    mean = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+    image = (image - mean) / std
+    feat = clip_visual(image, W, prefix, heads)
+    return feat / feat.norm(dim=-1, keepdim=True)
+
+
+# ----------------------------------------------------------------------------------------------
+# A12 + OpenVIS.open_vocabulary_inference — openvis/openvis.py:110-147 ; A16 inference_video — video_maskformer.py:262-298
+# ----------------------------------------------------------------------------------------------
+def open_vocabulary_inference(masks, frames, text_features, W, part_len=5, temperature=100.0):
+    """masks [Q,T,Hp,Wp] logits (already upsampled); frames [T,3,H,W] uint8; text_features [K,512] unit rows.
+    Returns (probs [Qv,K], masks[valid_query], extras)."""
+    T = frames.shape[0]
+    clip_cls, valid_flag, boxes = [], [], []
+    for idx in range(0, T, part_len):
+        part_frames = frames[idx:idx + part_len]
+        part_masks = masks[:, idx:idx + part_len].sigmoid().transpose(0, 1).contiguous()
+        regions, valid, sb = clip_crops(part_frames, part_masks)
+        if regions is None:
+            logits = torch.empty(0, text_features.shape[0])
+        else:
+            feat = clip_encode_image(regions, W)
+            logits = temperature * feat @ text_features.T                     # adapter.py:146-147
+            boxes.append(sb)
+        clip_cls.append(logits)
+        valid_flag.append(valid)
+    clip_cls = torch.cat(clip_cls)
+    valid_flag = torch.cat(valid_flag)
+    if torch.sum(valid_flag) == 0:
+        return [], [], {}
+    valid_ids = torch.nonzero(valid_flag)
+    valid_query_flag = torch.sum(valid_flag, dim=0) > 0
+    valid_query_ids = torch.nonzero(valid_query_flag)[:, 0]
+    query_clip_cls = [torch.mean(clip_cls[valid_ids[:, 1] == q], dim=0) for q in valid_query_ids]
+    mean_cls = torch.stack(query_clip_cls)
+    probs = mean_cls.softmax(dim=-1)
+    extras = {"crop_logits": clip_cls, "valid": valid_flag, "boxes": torch.cat(boxes) if boxes else None,
+              "query_logits": mean_cls}
+    return probs, masks[valid_query_flag], extras
+
+
+def inference_video(num_queries, num_classes, pred_cls, pred_masks, img_size, out_h, out_w, topk=10):
+    """video_maskformer.py:262-298."""
+    if len(pred_cls) == 0:
+        return {"image_size": (out_h, out_w), "pred_entropys": [], "pred_scores": [], "pred_labels": [],
+                "pred_masks": []}
+    scores = pred_cls
+    labels = torch.arange(num_classes).unsqueeze(0).repeat(num_queries, 1).flatten(0, 1)
+    scores_per_image, topk_indices = scores.flatten(0, 1).topk(topk, sorted=False)
+    labels_per_image = labels[topk_indices]
+    topk_indices = topk_indices // num_classes
+    entropys = torch.sum(-scores[topk_indices] * torch.log(scores[topk_indices]), dim=-1)
+    pm = pred_masks[topk_indices]
+    pm = pm[:, :, : img_size[0], : img_size[1]]
+    pm = F.interpolate(pm, size=(out_h, out_w), mode="bilinear", align_corners=False)
+    masks = pm > 0.
+    return {"image_size": (out_h, out_w), "pred_entropys": entropys.tolist(), "pred_scores": scores_per_image.tolist(),
+            "pred_labels": labels_per_image.tolist(), "pred_masks": [m for m in masks], "rows": topk_indices.tolist()}
+
+
+def openvis_forward(frames, W, text_features, out_hw=None, stages=None):
+    """OpenVIS.forward, eval (openvis/openvis.py:47-108). frames: uint8 [T,3,H,W]."""
+    T = frames.shape[0]
+    images, (H, Wd) = preprocess([f for f in frames])
+    feats = resnet50(images, W)
+    mask_features, _, ms = pixel_decoder(feats, W)
+    cls, pred_masks = video_decoder(ms, mask_features, W)
+    mask_pred = pred_masks[0]                                                # [Q,T,h,w]
+    ih, iw = images.shape[-2:]
+    mask_pred = F.interpolate(mask_pred, size=(ih, iw), mode="bilinear", align_corners=False)   # openvis.py:87-96
+    probs, vmasks, extras = open_vocabulary_inference(mask_pred, frames, text_features, W)
+    oh, ow = out_hw if out_hw is not None else (H, Wd)
+    K = text_features.shape[0]
+    out = inference_video(pred_masks.shape[1], K, probs, vmasks, (H, Wd), oh, ow)
+    if stages is not None:
+        stages.update(dict(images=images, feats=feats, mask_features=mask_features, ms=ms, pred_logits=cls,
+                           pred_masks=pred_masks, probs=probs, **extras))
+    return out

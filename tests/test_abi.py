@@ -4,7 +4,7 @@ import ctypes
 import os
 import re
 
-from conftest import ROOT
+from tests.conftest import ROOT
 from openvis_amd import _lib
 
 

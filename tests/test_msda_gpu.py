@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN
+from tests.conftest import GOLDEN
 from oracle import msda as oracle_msda
 
 pytestmark = pytest.mark.gpu

@@ -2,7 +2,7 @@
 import os
 import re
 
-from conftest import ROOT
+from tests.conftest import ROOT
 
 
 def _sources():

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from tests.conftest import GOLDEN
 from oracle import msda
 
 G = np.load(os.path.join(GOLDEN, "msda.npz"))
