@@ -1,0 +1,255 @@
+// f32 GEMM / implicit-GEMM convolution on the gfx950 matrix cores (exact-f32 MFMA).
+//
+//   C[m,n] = act( sum_k A[m,k] * B[n,k] + bias[n] + R[m,n] )            ("NT": both K-contiguous)
+//
+// Serves every linear layer of the path (torch Linear weights are [out,in] = B[n,k]) and, with the
+// implicit-im2col A loader, every convolution in NHWC (weights pre-permuted to [Cout,KH,KW,Cin]).
+// Replaces the cuDNN/cuBLAS calls behind the reference's nn.Linear / nn.Conv2d modules
+// (e.g. ops/modules/ms_deform_attn.py:98-104, msdeformattn.py:227-235, 287-296; detectron2 ResNet).
+//
+// MI355X mapping
+//  * v_mfma_f32_32x32x2_f32: exact f32 (bit-for-bit an fmaf chain), 64 FLOP/clk/SIMD.  K order is a
+//    free permutation as long as A and B agree, so lane half h = lane>>5 owns the contiguous k range
+//    [16h, 16h+16) of a 32-deep K tile: each lane fetches its 16 operands with 4 ds_read_b128.
+//  * Block tile BMxBN x 32, 256 threads = 4 wavefronts (2x2), each wavefront (BM/2)x(BN/2) built from
+//    32x32 MFMA tiles.  LDS rows are padded to 36 floats (144 B) -> the 16 lanes of a ds_read_b128
+//    group hit 16 distinct 16-B slots of the 256-B bank row (conflict-free).
+//  * Global->LDS goes through registers with the next K tile's dwordx4 loads issued before the
+//    current tile's MFMAs (64 cycles each), so HBM/L2 latency hides under the matrix pipe.
+//  * blockIdx is remapped per XCD (common.h) so the blocks sharing an L2 walk neighbouring M tiles
+//    of the same N panel.
+//  * Epilogue fused: bias, residual add, ReLU / QuickGELU, written as 128-B row segments.
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 32;
+constexpr int LDS_STRIDE = BK + 4;  // floats
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_QUICKGELU = 2 };
+
+struct ConvGeom {
+  int H, W, Cin, OH, OW, KH, KW, stride, pad;
+};
+
+// ---- A-operand loaders: fetch 4 consecutive k of row m as a float4 (zero outside) ----------------
+struct DenseA {
+  const float* A;
+  long long lda;
+  int M, K;
+  bool vec_ok;
+  __device__ __forceinline__ float4 load(int m, int k) const {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < M) {
+      const float* p = A + (long long)m * lda + k;
+      if (vec_ok && k + 3 < K) {
+        v = *reinterpret_cast<const float4*>(p);
+      } else {
+        if (k < K) v.x = p[0];
+        if (k + 1 < K) v.y = p[1];
+        if (k + 2 < K) v.z = p[2];
+        if (k + 3 < K) v.w = p[3];
+      }
+    }
+    return v;
+  }
+};
+
+// Implicit im2col over an NHWC input; k = (kh*KW + kw)*Cin + c, Cin % 4 == 0 (float4 never straddles a pixel).
+struct ConvA {
+  const float* X;
+  ConvGeom g;
+  int M, K;
+  __device__ __forceinline__ float4 load(int m, int k) const {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < M && k < K) {
+      const int ow = m % g.OW;
+      const int t = m / g.OW;
+      const int oh = t % g.OH;
+      const int n = t / g.OH;
+      const int c = k % g.Cin;
+      const int t2 = k / g.Cin;
+      const int kw = t2 % g.KW;
+      const int kh = t2 / g.KW;
+      const int ih = oh * g.stride - g.pad + kh;
+      const int iw = ow * g.stride - g.pad + kw;
+      if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
+        v = *reinterpret_cast<const float4*>(X + (((long long)n * g.H + ih) * g.W + iw) * g.Cin + c);
+    }
+    return v;
+  }
+};
+
+template <int BM, int BN, typename LoaderA>
+__global__ void __launch_bounds__(256)
+gemm_f32_kernel(LoaderA la, const float* __restrict__ B, long long ldb, float* __restrict__ C,
+                long long ldc, int M, int N, int K, const float* __restrict__ bias,
+                const float* __restrict__ R, long long ldr, int act, int tiles_m) {
+  constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 MFMA tiles per wave (2x2 waves)
+  constexpr int A_LD = BM * 8 / 256, B_LD = BN * 8 / 256;  // float4 loads per thread per K tile
+  __shared__ __attribute__((aligned(16))) float As[BM * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_STRIDE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const unsigned bid = ovis::xcd_remap(blockIdx.x, gridDim.x);
+  const int bm = (int)(bid % tiles_m) * BM;   // consecutive blocks of an XCD share the B panel
+  const int bn = (int)(bid / tiles_m) * BN;
+
+  // staging assignment: 8 threads cover one 32-float row; 32 rows per pass
+  const int srow = tid >> 3, scol = (tid & 7) * 4;
+
+  float4 pa[A_LD], pb[B_LD];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) pa[i] = la.load(bm + srow + i * 32, k0 + scol);
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int n = bn + srow + i * 32, k = k0 + scol;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N) {
+        const float* p = B + (long long)n * ldb + k;
+        if (k + 3 < K && ((ldb & 3) == 0)) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (k < K) v.x = p[0];
+          if (k + 1 < K) v.y = p[1];
+          if (k + 2 < K) v.z = p[2];
+          if (k + 3 < K) v.w = p[3];
+        }
+      }
+      pb[i] = v;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i)
+      *reinterpret_cast<float4*>(&As[(srow + i * 32) * LDS_STRIDE + scol]) = pa[i];
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i)
+      *reinterpret_cast<float4*>(&Bs[(srow + i * 32) * LDS_STRIDE + scol]) = pb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int r32 = lane & 31, h = lane >> 5;
+  const int nk = (K + BK - 1) / BK;
+  gload(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();           // previous tile's LDS reads done
+    lstore();
+    __syncthreads();
+    if (kt + 1 < nk) gload((kt + 1) * BK);   // in flight during the MFMAs below
+
+    float4 af[TM][4], bf[TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float* p = &As[(wr * (BM / 2) + i * 32 + r32) * LDS_STRIDE + h * 16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) af[i][q] = *reinterpret_cast<const float4*>(p + q * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float* p = &Bs[(wc * (BN / 2) + j * 32 + r32) * LDS_STRIDE + h * 16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bf[j][q] = *reinterpret_cast<const float4*>(p + q * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float a = e == 0 ? af[i][q].x : e == 1 ? af[i][q].y : e == 2 ? af[i][q].z : af[i][q].w;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float b = e == 0 ? bf[j][q].x : e == 1 ? bf[j][q].y : e == 2 ? bf[j][q].z : bf[j][q].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // epilogue: lane holds column (lane&31); rows (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = bn + wc * (BN / 2) + j * 32 + r32;
+    if (n >= N) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = bm + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < M) {
+          float v = acc[i][j][r] + bv;
+          if (R) v += R[(long long)m * ldr + n];
+          if (act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (act == ACT_QUICKGELU) v = v * (1.f / (1.f + expf(-1.702f * v)));
+          C[(long long)m * ldc + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <typename LoaderA>
+int launch_gemm(LoaderA la, const float* B, long long ldb, float* C, long long ldc, int M, int N, int K,
+                const float* bias, const float* R, long long ldr, int act, hipStream_t stream) {
+  // tile choice: big tiles once the grid still fills 256 CUs, else 64x64 for parallelism
+  const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128);
+  if (blocks128 >= 256) {
+    const int tm = ovis::cdiv(M, 128), tn = ovis::cdiv(N, 128);
+    hipLaunchKernelGGL((gemm_f32_kernel<128, 128, LoaderA>), dim3(tm * tn), dim3(256), 0, stream, la, B, ldb, C,
+                       ldc, M, N, K, bias, R, ldr, act, tm);
+  } else {
+    const int tm = ovis::cdiv(M, 64), tn = ovis::cdiv(N, 64);
+    hipLaunchKernelGGL((gemm_f32_kernel<64, 64, LoaderA>), dim3(tm * tn), dim3(256), 0, stream, la, B, ldb, C,
+                       ldc, M, N, K, bias, R, ldr, act, tm);
+  }
+  return ovis::check_launch("gemm_f32");
+}
+
+}  // namespace
+
+extern "C" int ovis_gemm_nt_f32(const float* A, long long lda, const float* B, long long ldb, float* C,
+                                long long ldc, int M, int N, int K, const float* bias, const float* residual,
+                                long long ldr, int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(A && B && C, "gemm_nt_f32: null pointer");
+  OVIS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt_f32: non-positive size (M=%d N=%d K=%d)", M, N, K);
+  OVIS_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm_nt_f32: leading dimension too small");
+  OVIS_REQUIRE(act >= 0 && act <= 2, "gemm_nt_f32: unknown activation %d", act);
+  OVIS_REQUIRE(!residual || ldr >= N, "gemm_nt_f32: residual leading dimension too small");
+  DenseA la{A, lda, M, K, ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0)};
+  OVIS_REQUIRE(((uintptr_t)B & 15) == 0, "gemm_nt_f32: B must be 16-byte aligned");
+  return launch_gemm(la, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream);
+}
+
+extern "C" int ovis_conv2d_nhwc_f32(const float* x, const float* w, float* y, int N, int H, int W, int Cin,
+                                    int Cout, int KH, int KW, int stride, int pad, const float* bias,
+                                    const float* residual, int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(x && w && y, "conv2d_nhwc_f32: null pointer");
+  OVIS_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
+               "conv2d_nhwc_f32: bad geometry");
+  OVIS_REQUIRE(Cin % 4 == 0, "conv2d_nhwc_f32: Cin (%d) must be a multiple of 4 (pad channels)", Cin);
+  OVIS_REQUIRE((((uintptr_t)x | (uintptr_t)w) & 15) == 0, "conv2d_nhwc_f32: x/w must be 16-byte aligned");
+  OVIS_REQUIRE(act >= 0 && act <= 2, "conv2d_nhwc_f32: unknown activation %d", act);
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  OVIS_REQUIRE(OH > 0 && OW > 0, "conv2d_nhwc_f32: empty output");
+  const long long M = (long long)N * OH * OW;
+  OVIS_REQUIRE(M < (1ll << 31), "conv2d_nhwc_f32: too many output pixels");
+  const int K = KH * KW * Cin;
+  ConvA la{x, ConvGeom{H, W, Cin, OH, OW, KH, KW, stride, pad}, (int)M, K};
+  return launch_gemm(la, w, (long long)K, y, (long long)Cout, (int)M, Cout, K, bias, residual, (long long)Cout, act,
+                     (hipStream_t)stream);
+}

@@ -1,0 +1,312 @@
+// HBM-bound helpers of the path for gfx950: pre-processing, pooling, LayerNorm, GroupNorm (NHWC),
+// broadcast add, sine position encodings.  All are one-pass-per-element kernels with 16-byte
+// accesses; none is reshaped into a GEMM.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- A1: (x - mean)/std, zero pad to [T,Hp,Wp,4] NHWC (4th channel = 0) ---------------------
+// openvis/openvis.py:57-62 + detectron2 ImageList.from_tensors(size_divisibility=32).
+__global__ void __launch_bounds__(256)
+preprocess_kernel(const uint8_t* __restrict__ frames, float* __restrict__ out, int T, int H, int W, int Hp,
+                  int Wp, float m0, float m1, float m2, float s0, float s1, float s2) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)T * Hp * Wp;
+  if (i >= total) return;
+  const int x = (int)(i % Wp);
+  const long long r = i / Wp;
+  const int y = (int)(r % Hp);
+  const int t = (int)(r / Hp);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (y < H && x < W) {
+    const uint8_t* p = frames + ((long long)t * 3 * H + y) * W + x;
+    const long long plane = (long long)H * W;
+    v.x = ((float)p[0] - m0) / s0;
+    v.y = ((float)p[plane] - m1) / s1;
+    v.z = ((float)p[2 * plane] - m2) / s2;
+  }
+  reinterpret_cast<float4*>(out)[i] = v;
+}
+
+// ---- 3x3 / stride 2 / pad 1 max pool, NHWC (detectron2 BasicStem: F.max_pool2d(x, 3, 2, 1)) ---
+__global__ void __launch_bounds__(256)
+maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int OH,
+                    int OW) {
+  const int c4n = C >> 2;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)N * OH * OW * c4n;
+  if (i >= total) return;
+  const int c4 = (int)(i % c4n);
+  long long r = i / c4n;
+  const int ow = (int)(r % OW);
+  r /= OW;
+  const int oh = (int)(r % OH);
+  const int n = (int)(r / OH);
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int ih = oh * 2 - 1 + dy;
+    if (ih < 0 || ih >= H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int iw = ow * 2 - 1 + dx;
+      if (iw < 0 || iw >= W) continue;
+      const float4 v = reinterpret_cast<const float4*>(x + (((long long)n * H + ih) * W + iw) * C)[c4];
+      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+  }
+  reinterpret_cast<float4*>(y)[i] = m;
+}
+
+// ---- LayerNorm over the last dim (C % 4 == 0, C <= 4096): one wavefront per row -----------------
+// y = LN(x + residual) * gamma + beta ; torch.nn.LayerNorm eps inside the sqrt, biased variance.
+template <int MAXV>
+__global__ void __launch_bounds__(256)
+layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
+                 const float* __restrict__ beta, float* __restrict__ y, long long rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = C >> 2;
+  const float4* xp = reinterpret_cast<const float4*>(x + row * C);
+  const float4* rp = res ? reinterpret_cast<const float4*>(res + row * C) : nullptr;
+  float4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = lane + i * 64;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < nv) {
+      v[i] = xp[idx];
+      if (rp) { const float4 r = rp[idx]; v[i].x += r.x; v[i].y += r.y; v[i].z += r.z; v[i].w += r.w; }
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
+  float4* yp = reinterpret_cast<float4*>(y + row * C);
+  const float4* gp = reinterpret_cast<const float4*>(gamma);
+  const float4* bp = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      const float4 g = gp[idx], b = bp[idx];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      yp[idx] = o;
+    }
+  }
+}
+
+// ---- GroupNorm on NHWC (C % 4 == 0, (C/G) % 4 == 0) -------------------------------------------
+// pass 1: per-(n,g) sum / sum of squares accumulated in f64 (block partials -> f64 atomics);
+// pass 2: normalise (+ optional bilinear x2-upsampled addend, + optional ReLU).
+__global__ void __launch_bounds__(256)
+gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int HW, int C, int G, int pix_per_blk) {
+  // grid: (chunks, N). thread -> channel quad cq = tid % (C/4), pixel lane pl = tid / (C/4)
+  const int c4n = C >> 2;
+  const int n = blockIdx.y;
+  const int cq = threadIdx.x % c4n, pl = threadIdx.x / c4n, npl = blockDim.x / c4n;
+  const int p0 = blockIdx.x * pix_per_blk;
+  const int p1 = min(HW, p0 + pix_per_blk);
+  double s = 0.0, q = 0.0;
+  for (int p = p0 + pl; p < p1; p += npl) {
+    const float4 v = reinterpret_cast<const float4*>(x + ((long long)n * HW + p) * C)[cq];
+    s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    q += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+  }
+  const int cpg4 = (C / G) >> 2;           // channel quads per group
+  const int g = cq / cpg4;
+  extern __shared__ double sh[];            // [G][2]
+  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) sh[i] = 0.0;
+  __syncthreads();
+  atomicAdd(&sh[2 * g], s);
+  atomicAdd(&sh[2 * g + 1], q);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) atomicAdd(&stats[(long long)n * 2 * G + i], sh[i]);
+}
+
+__global__ void __launch_bounds__(256)
+gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats, const float* __restrict__ gamma,
+                const float* __restrict__ beta, float* __restrict__ y, int N, int H, int W, int C, int G,
+                float eps, int relu, const float* __restrict__ up, int UH, int UW) {
+  const int c4n = C >> 2;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)N * H * W * c4n;
+  if (i >= total) return;
+  const int cq = (int)(i % c4n);
+  const long long pix = i / c4n;
+  const int n = (int)(pix / ((long long)H * W));
+  const int g = (cq * 4) / (C / G);
+  const double cnt = (double)H * W * (C / G);
+  const double mean_d = stats[((long long)n * G + g) * 2] / cnt;
+  const double var_d = stats[((long long)n * G + g) * 2 + 1] / cnt - mean_d * mean_d;
+  const float mean = (float)mean_d;
+  const float rstd = 1.f / sqrtf((float)var_d + eps);
+  const float4 v = reinterpret_cast<const float4*>(x)[i];
+  const float4 ga = reinterpret_cast<const float4*>(gamma)[cq], be = reinterpret_cast<const float4*>(beta)[cq];
+  float4 o;
+  o.x = (v.x - mean) * rstd * ga.x + be.x;
+  o.y = (v.y - mean) * rstd * ga.y + be.y;
+  o.z = (v.z - mean) * rstd * ga.z + be.z;
+  o.w = (v.w - mean) * rstd * ga.w + be.w;
+  if (up) {
+    // F.interpolate(up, size=(H,W), mode="bilinear", align_corners=False) added to the normalised map
+    const int rem = (int)(pix % ((long long)H * W));
+    const int oy = rem / W, ox = rem % W;
+    const float sy = fmaxf(((float)oy + 0.5f) * ((float)UH / (float)H) - 0.5f, 0.f);
+    const float sx = fmaxf(((float)ox + 0.5f) * ((float)UW / (float)W) - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < UH - 1 ? 1 : 0), x1 = x0 + (x0 < UW - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float4* ub = reinterpret_cast<const float4*>(up + (long long)n * UH * UW * C);
+    const float4 a = ub[((long long)y0 * UW + x0) * c4n + cq], b = ub[((long long)y0 * UW + x1) * c4n + cq];
+    const float4 c = ub[((long long)y1 * UW + x0) * c4n + cq], d = ub[((long long)y1 * UW + x1) * c4n + cq];
+    o.x += hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
+    o.y += hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
+    o.z += hy * (hx * a.z + lx * b.z) + ly * (hx * c.z + lx * d.z);
+    o.w += hy * (hx * a.w + lx * b.w) + ly * (hx * c.w + lx * d.w);
+  }
+  if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+  reinterpret_cast<float4*>(y)[i] = o;
+}
+
+// out[i] = a[i] + b[i % nb]   (float4 granularity)
+__global__ void __launch_bounds__(256)
+add_bcast_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ out,
+                 long long n4, long long nb4) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 x = a[i], y = b[i % nb4];
+  out[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+
+// Sine position encodings (input independent; evaluated once per shape and cached by the host).
+// 2-D: pixel_decoder/position_encoding.py:29-53 -> out[H,W,2*npf] (y half | x half), + optional level embed.
+// 3-D: transformer_decoder/position_encoding.py:135-165 -> out[T,H,W,2*npf] = cat(y,x) + z.
+__global__ void __launch_bounds__(256)
+pe_sine_kernel(float* __restrict__ out, int T, int H, int W, int npf, int three_d, const float* __restrict__ add) {
+  const int C = 2 * npf;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)T * H * W * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  long long r = i / C;
+  const int x = (int)(r % W);
+  r /= W;
+  const int y = (int)(r % H);
+  const int t = (int)(r / H);
+  const float scale = 6.283185307179586f, eps = 1e-6f;
+  const bool is_y = c < npf;
+  const int k = is_y ? c : c - npf;
+  const float e = is_y ? (float)(y + 1) / ((float)H + eps) * scale : (float)(x + 1) / ((float)W + eps) * scale;
+  const float dim_t = powf(10000.f, 2.f * (float)(k / 2) / (float)npf);
+  const float a = e / dim_t;
+  float v = (k & 1) ? cosf(a) : sinf(a);
+  if (three_d) {
+    const float ez = (float)(t + 1) / ((float)T + eps) * scale;
+    const float dz = powf(10000.f, 2.f * (float)(c / 2) / (float)C);
+    const float az = ez / dz;
+    v += (c & 1) ? cosf(az) : sinf(az);
+  }
+  if (add) v += add[c];
+  out[i] = v;
+}
+
+}  // namespace
+
+extern "C" int ovis_preprocess_u8_nhwc4(const uint8_t* frames, float* out, int T, int H, int W, int Hp, int Wp,
+                                        const float* mean3_host, const float* std3_host, ovis_stream_t stream) {
+  OVIS_REQUIRE(frames && out && mean3_host && std3_host, "preprocess: null pointer");
+  OVIS_REQUIRE(T > 0 && H > 0 && W > 0 && Hp >= H && Wp >= W, "preprocess: bad geometry");
+  const long long total = (long long)T * Hp * Wp;
+  hipLaunchKernelGGL(preprocess_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, frames, out,
+                     T, H, W, Hp, Wp, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1],
+                     std3_host[2]);
+  return ovis::check_launch("preprocess");
+}
+
+extern "C" int ovis_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C,
+                                          ovis_stream_t stream) {
+  OVIS_REQUIRE(x && y, "maxpool: null pointer");
+  OVIS_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool: bad geometry (C %% 4 != 0?)");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long long total = (long long)N * OH * OW * (C / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H,
+                     W, C, OH, OW);
+  return ovis::check_launch("maxpool");
+}
+
+extern "C" int ovis_layernorm_f32(const float* x, const float* residual, const float* gamma, const float* beta,
+                                  float* y, long long rows, int C, float eps, ovis_stream_t stream) {
+  OVIS_REQUIRE(x && gamma && beta && y, "layernorm: null pointer");
+  OVIS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 4096, "layernorm: C must be a multiple of 4 and <= 4096");
+  const unsigned grid = ovis::cdiv(rows, 4);
+  const int nv = C / 4;
+  hipStream_t s = (hipStream_t)stream;
+  if (nv <= 64) hipLaunchKernelGGL(layernorm_kernel<1>, dim3(grid), dim3(256), 0, s, x, residual, gamma, beta, y, rows, C, eps);
+  else if (nv <= 256) hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, s, x, residual, gamma, beta, y, rows, C, eps);
+  else hipLaunchKernelGGL(layernorm_kernel<16>, dim3(grid), dim3(256), 0, s, x, residual, gamma, beta, y, rows, C, eps);
+  return ovis::check_launch("layernorm");
+}
+
+extern "C" int ovis_groupnorm_nhwc_f32(const float* x, float* y, const float* gamma, const float* beta,
+                                       double* stats_ws, int N, int H, int W, int C, int G, float eps, int relu,
+                                       const float* up_add, int UH, int UW, ovis_stream_t stream) {
+  OVIS_REQUIRE(x && y && gamma && beta && stats_ws, "groupnorm: null pointer");
+  OVIS_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && G > 0 && C % G == 0 && (C / G) % 4 == 0 && C <= 1024,
+               "groupnorm: need (C/G) %% 4 == 0 and C <= 1024");
+  OVIS_REQUIRE(!up_add || (UH > 0 && UW > 0), "groupnorm: bad upsample source size");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * G * N, s);
+  if (e != hipSuccess) return ovis::fail(OVIS_ELAUNCH, "groupnorm memset: %s", hipGetErrorString(e));
+  const int HW = H * W;
+  const int c4n = C / 4;
+  const int threads = 256 / c4n > 0 ? (256 / c4n) * c4n : c4n;
+  const int pix_per_blk = 128;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(ovis::cdiv(HW, pix_per_blk), N), dim3(threads), sizeof(double) * 2 * G, s, x,
+                     stats_ws, HW, C, G, pix_per_blk);
+  const long long total = (long long)N * HW * c4n;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, s, x, stats_ws, gamma, beta, y, N, H,
+                     W, C, G, eps, relu, up_add, UH, UW);
+  return ovis::check_launch("groupnorm");
+}
+
+extern "C" int ovis_add_bcast_f32(const float* a, const float* b, float* out, long long n, long long nb,
+                                  ovis_stream_t stream) {
+  OVIS_REQUIRE(a && b && out, "add_bcast: null pointer");
+  OVIS_REQUIRE(n > 0 && nb > 0 && n % 4 == 0 && nb % 4 == 0 && n % nb == 0, "add_bcast: sizes must be multiples of 4 and nb | n");
+  hipLaunchKernelGGL(add_bcast_kernel, dim3(ovis::cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b),
+                     reinterpret_cast<float4*>(out), n / 4, nb / 4);
+  return ovis::check_launch("add_bcast");
+}
+
+extern "C" int ovis_pe_sine_f32(float* out, int T, int H, int W, int num_pos_feats, int three_d,
+                                const float* add_c, ovis_stream_t stream) {
+  OVIS_REQUIRE(out, "pe_sine: null pointer");
+  OVIS_REQUIRE(T > 0 && H > 0 && W > 0 && num_pos_feats > 0, "pe_sine: bad geometry");
+  const long long total = (long long)T * H * W * 2 * num_pos_feats;
+  hipLaunchKernelGGL(pe_sine_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, out, T, H, W,
+                     num_pos_feats, three_d, add_c);
+  return ovis::check_launch("pe_sine");
+}

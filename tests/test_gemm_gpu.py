@@ -1,0 +1,70 @@
+"""GPU: f32 MFMA GEMM / implicit-GEMM conv vs a plain torch fp64->fp32 reference of the same op."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(out, ref, tol=2e-5):
+    err = (out.double().cpu() - ref.double()).abs().max().item()
+    scale = ref.double().abs().max().item() + 1e-12
+    assert err / scale < tol, (err, scale)
+
+
+@pytest.mark.parametrize("M,N,K", [(100, 256, 256), (1, 8, 3), (257, 130, 77), (96600 // 5, 288, 256), (1000, 2048, 256),
+                                   (300, 482, 512), (4097, 256, 1024)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_nt(M, N, K, act):
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(M + N + K + act)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = a.double() @ w.double().T + b.double() + r.double()
+    if act == 1:
+        ref = ref.relu()
+    elif act == 2:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    out = ops.gemm_nt(a.cuda(), w.cuda(), b.cuda(), r.cuda(), act)
+    _close(out, ref)
+    out2 = ops.gemm_nt(a.cuda(), w.cuda())
+    _close(out2, a.double() @ w.double().T)
+
+
+def test_gemm_integer_exact_layout():
+    # asymmetric integer data: catches transposed / permuted fragment maps exactly
+    from openvis_amd import ops
+    M, N, K = 133, 97, 70
+    a = (torch.arange(M * K).reshape(M, K) % 13 - 6).float()
+    w = (torch.arange(N * K).reshape(N, K) % 7 - 3).float()
+    out = ops.gemm_nt(a.cuda(), w.cuda()).cpu()
+    assert torch.equal(out, a @ w.T)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(N=2, H=17, W=23, Cin=4, Cout=64, k=7, s=2, p=3),      # stem-like (3 channels padded to 4)
+    dict(N=1, H=12, W=20, Cin=64, Cout=64, k=3, s=1, p=1),
+    dict(N=2, H=12, W=20, Cin=128, Cout=128, k=3, s=2, p=1),
+    dict(N=1, H=9, W=7, Cin=256, Cout=512, k=1, s=2, p=0),
+    dict(N=1, H=46, W=80, Cin=256, Cout=256, k=3, s=1, p=1),
+])
+def test_conv2d_nhwc(cfg):
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(cfg["H"] * cfg["W"])
+    x = torch.randn(cfg["N"], cfg["Cin"], cfg["H"], cfg["W"], generator=g)
+    w = torch.randn(cfg["Cout"], cfg["Cin"], cfg["k"], cfg["k"], generator=g) / (cfg["Cin"] * cfg["k"] ** 2) ** 0.5
+    b = torch.randn(cfg["Cout"], generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=cfg["s"], padding=cfg["p"])
+    res = torch.randn(ref.shape, generator=g)
+    ref = (ref + res.double()).relu()
+    y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), w.permute(0, 2, 3, 1).contiguous().cuda(),
+                        cfg["s"], cfg["p"], b.cuda(), res.permute(0, 2, 3, 1).contiguous().cuda(), 1)
+    _close(y.permute(0, 3, 1, 2), ref)
+
+
+def test_gemm_rejects_cpu_tensors():
+    from openvis_amd import ops, _lib
+    with pytest.raises(_lib.OvisError):
+        ops.gemm_nt(torch.zeros(4, 4), torch.zeros(4, 4))
