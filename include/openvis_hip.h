@@ -99,6 +99,59 @@ int ovis_add_bcast_f32(const float* a, const float* b, float* out, long long n, 
 int ovis_pe_sine_f32(float* out, int T, int H, int W, int num_pos_feats, int three_d, const float* add_c,
                      ovis_stream_t stream);
 
+/* ---- Multi-head attention (flash style, f32 MFMA) ----------------------------------------------
+ * out[b,q,h*D:(h+1)*D] = softmax_k( scale * <Q[b,q,h], K[b,k,h]> , mask ) V[b,k,h]
+ *   Replaces nn.MultiheadAttention's core in video decoder:52-62 (self), 110-122 + 417-426 (masked cross) and
+ *   mask_adapted_clip/model.py:254-263 (ViT); in/out projections are ovis_gemm_nt_f32 calls.
+ *   q/k/v/out: element (b, row, h, d) at ptr[b*bs + row*ld + h*D + d]; D in {32, 64}.
+ *   mask: uint8 [Nq, mask_ld] (1 = blocked), shared by all heads and batches, or NULL;
+ *   row_open: int32 [Nq] = number of unblocked keys per row (rows with 0 are treated as unmasked,
+ *   video decoder:419) or NULL.  nsplit > 1 splits the key range over workgroups (needs
+ *   ovis_attention_workspace_bytes(B,H,Nq,D,nsplit) bytes of workspace). */
+long long ovis_attention_workspace_bytes(int B, int H, int Nq, int D, int nsplit);
+int ovis_attention_f32(const float* q, long long q_bs, int q_ld, const float* k, long long k_bs, int k_ld,
+                       const float* v, long long v_bs, int v_ld, float* out, long long o_bs, int o_ld,
+                       const uint8_t* mask, long long mask_ld, const int* row_open, int B, int H, int Nq, int Nk,
+                       int D, float scale, int nsplit, float* workspace, ovis_stream_t stream);
+
+/* ---- OpenVIS-specific fused stages ---------------------------------------------------------------
+ * Encoder deformable attention with the softmax over L*P and the sampling-location arithmetic fused in
+ *   (ops/modules/ms_deform_attn.py:102-118 + msdeformattn.py:155-168 + cuh:242-304).
+ *   offs_attn [B,S,ld_oa]: first M*L*P*2 columns = sampling_offsets output, next M*L*P = attention_weights
+ *   logits (one fused GEMM); reference points are those of the encoder (valid ratios == 1). L=3, P=4. */
+int ovis_msda_encoder_fused_f32(const float* value, const float* offs_attn, int ld_oa, const int64_t* spatial_shapes,
+                                const int64_t* level_start_index, float* out, int batch, int spatial_size,
+                                int num_heads, int channels, int num_levels, int num_point, ovis_stream_t stream);
+/* mask[q,k] = sigmoid(logits[q,k]) < 0.5 ; row_open[q] = #unblocked (video decoder:465-469, 419). */
+int ovis_attn_mask_from_logits(const float* logits, long long ld, uint8_t* mask, long long mask_ld, int* row_open,
+                               int Q, int Nk, ovis_stream_t stream);
+/* y = mean of the 2x2 centre taps of each s x s cell (== bilinear resize by exactly 1/s, align_corners False). */
+int ovis_center_pool_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, int s, ovis_stream_t stream);
+/* boxes[t,q] = inclusive (x0,y0,x1,y1) of { sigmoid(bilinear_up(masks[q,t]) to Hp x Wp) > 0.5 }, x1 < 0 if empty
+ *   (openvis.py:87-96,118; adapter.py:88-94; detectron2 BitMasks.get_bounding_boxes). masks [Q,T,h,w] logits. */
+int ovis_mask_bbox(const float* masks, int* boxes, int Q, int T, int h, int w, int Hp, int Wp, ovis_stream_t stream);
+/* CLIP crops (adapter.py:96-116,140-143) written as the patch-embedding im2col matrix
+ *   A[(m*G*G + py*G + px), c*ps*ps + iy*ps + ix]; crops int32 [M,6] = (t,q,x0,y0,x1,y1);
+ *   frames uint8 [T,3,H,W] (raw, un-padded); masks [Q,T,h,w] logits; mean/std = CLIP's (HOST, in [0,1] units). */
+int ovis_clip_crop_patches(const uint8_t* frames, const float* masks, const int* crops, float* A, int M, int Q, int T,
+                           int H, int W, int h, int w, int Hp, int Wp, int resolution, int patch,
+                           const float* mean3_host, const float* std3_host, ovis_stream_t stream);
+/* ViT token assembly + ln_pre (model.py:341-343): out [M,L1,C]; patch [M,L1-1,C]; cls [C]; pos [L1,C]. */
+int ovis_vit_embed_ln_f32(const float* patch, const float* cls, const float* pos, const float* gamma, const float* beta,
+                          float* out, int M, int L1, int C, float eps, ovis_stream_t stream);
+/* y[r,:] = x[r,:] / ||x[r,:]|| * scale (adapter.py:118-119,144,146). */
+int ovis_l2norm_rows_f32(const float* x, float* y, long long rows, int C, float scale, ovis_stream_t stream);
+/* probs[q,:] = softmax_K( mean over frames t with slot[t,q] >= 0 of crop_logits[slot[t,q],:] ) (openvis.py:130-141). */
+int ovis_openvis_aggregate_f32(const float* crop_logits, const int* slot, float* probs, int* qvalid, int T, int Q, int K,
+                               ovis_stream_t stream);
+/* top-k over the flattened probabilities of rows row_ids (flat index = i*K + k over the compacted rows) + entropy
+ *   of the selected rows (video_maskformer.py:267-272). */
+int ovis_topk_entropy_f32(const float* probs, const int* row_ids, int nrows, int K, int topk, int* out_idx,
+                          float* out_score, float* out_entropy, ovis_stream_t stream);
+/* final masks of the selected queries (openvis.py:87-96 + video_maskformer.py:273-278): out uint8 [n_sel,T,OH,OW]. */
+int ovis_final_masks_u8(const float* masks, const int* sel_q, uint8_t* out, int n_sel, int Q, int T, int h, int w, int Hp,
+                        int Wp, int H, int W, int OH, int OW, ovis_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,8 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ovis_last_error.restype = ctypes.c_char_p
         _lib.ovis_abi_version.restype = ctypes.c_int
+        if hasattr(_lib, "ovis_attention_workspace_bytes"):
+            _lib.ovis_attention_workspace_bytes.restype = ctypes.c_longlong
     return _lib
 
 

@@ -1,0 +1,97 @@
+"""Config surface of the reference (openvis/config.py:6-166 + detectron2 defaults used by the path), as a small
+yacs-like CfgNode with `_BASE_` yaml inheritance and KEY VALUE overrides (train_net.py:256-282).  Only keys the
+inference path reads get defaults; unknown yaml keys are accepted so the reference's yaml files load unchanged."""
+import copy
+import os
+
+import yaml
+
+
+class CfgNode(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def clone(self):
+        return copy.deepcopy(self)
+
+    def merge(self, other):
+        for k, v in other.items():
+            if isinstance(v, dict) and isinstance(self.get(k), dict):
+                self[k].merge(_to_node(v))
+            else:
+                self[k] = _to_node(v)
+        return self
+
+    def merge_from_file(self, path):
+        with open(path) as f:
+            d = yaml.safe_load(f) or {}
+        base = d.pop("_BASE_", None)
+        if base:
+            self.merge_from_file(os.path.join(os.path.dirname(path), base))
+        return self.merge(d)
+
+    def merge_from_list(self, opts):
+        assert len(opts) % 2 == 0
+        for k, v in zip(opts[0::2], opts[1::2]):
+            node = self
+            parts = k.split(".")
+            for p in parts[:-1]:
+                node = node[p]
+            node[parts[-1]] = yaml.safe_load(v) if isinstance(v, str) else v
+        return self
+
+
+def _to_node(v):
+    if isinstance(v, dict) and not isinstance(v, CfgNode):
+        n = CfgNode()
+        for k, x in v.items():
+            n[k] = _to_node(x)
+        return n
+    return v
+
+
+def get_cfg():
+    """Defaults for the keys the eval path reads (detectron2 defaults + add_*_config of openvis/config.py)."""
+    return _to_node({
+        "MODEL": {
+            "META_ARCHITECTURE": "OpenVIS", "DEVICE": "cuda", "WEIGHTS": "",
+            "PIXEL_MEAN": [123.675, 116.280, 103.530], "PIXEL_STD": [58.395, 57.120, 57.375],
+            "BACKBONE": {"NAME": "build_resnet_backbone", "FREEZE_AT": 0},
+            "RESNETS": {"DEPTH": 50, "STRIDE_IN_1X1": False, "OUT_FEATURES": ["res2", "res3", "res4", "res5"],
+                        "STEM_OUT_CHANNELS": 64, "NORM": "FrozenBN"},
+            "SEM_SEG_HEAD": {"NAME": "MaskFormerHead", "IGNORE_VALUE": 255, "NUM_CLASSES": 1, "LOSS_WEIGHT": 1.0,
+                             "CONVS_DIM": 256, "MASK_DIM": 256, "NORM": "GN",
+                             "PIXEL_DECODER_NAME": "MSDeformAttnPixelDecoder",
+                             "IN_FEATURES": ["res2", "res3", "res4", "res5"],
+                             "DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES": ["res3", "res4", "res5"],
+                             "COMMON_STRIDE": 4, "TRANSFORMER_ENC_LAYERS": 6},
+            "MASK_FORMER": {"TRANSFORMER_DECODER_NAME": "VideoMultiScaleMaskedTransformerDecoder",
+                            "TRANSFORMER_IN_FEATURE": "multi_scale_pixel_decoder", "HIDDEN_DIM": 256,
+                            "NUM_OBJECT_QUERIES": 100, "NHEADS": 8, "DROPOUT": 0.0, "DIM_FEEDFORWARD": 2048,
+                            "ENC_LAYERS": 0, "DEC_LAYERS": 10, "PRE_NORM": False, "ENFORCE_INPUT_PROJ": False,
+                            "SIZE_DIVISIBILITY": 32,
+                            "TEST": {"OBJECT_MASK_THRESHOLD": 0.8, "OVERLAP_THRESHOLD": 0.8, "WINDOW_INFERENCE": False,
+                                     "WINDOW_SIZE": 10}},
+            "CLIP_ADAPTER": {"NAME": "ClipAdapter", "PROMPT_NAME": "vild", "CLIP_MODEL_NAME": "ViT-B/16",
+                             "CLIP_NUM_HEADS": 12, "CLIP_EMBED_DIMS": 512, "MERGE_IDS": [3, 6, 9], "BROKEN_ID": 9,
+                             "CLIP_ENSEMBLE": True, "CLIP_ENSEMBLE_WEIGHT": 0.8, "MASK_PROMPT_DEPTH": 3,
+                             "MASK_PROMPT_FWD": True},
+        },
+        "INPUT": {"SAMPLING_FRAME_NUM": 2, "MIN_SIZE_TEST": 360, "FORMAT": "RGB"},
+        "DATASETS": {"TEST": ["burst_val"]},
+        "SEED": 42,
+    })
+
+
+def build_model(cfg):
+    """detectron2.modeling.build_model: META_ARCH_REGISTRY.get(name)(cfg) via from_config."""
+    from . import openvis  # noqa: F401  (registers the meta-architectures)
+    from .registry import META_ARCH_REGISTRY
+    cls = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)
+    return cls(**cls.from_config(cfg))

@@ -1,0 +1,580 @@
+// OpenVIS-specific HBM/latency-bound stages for gfx950: fused encoder deformable sampling, attention-mask
+// construction, mask -> box -> CLIP crop, ViT token assembly, class aggregation, top-k and final masks.
+// None of these is GEMM-shaped; they are written for coalesced 16-byte traffic and to avoid the
+// full-resolution intermediates the reference materialises ([Q,T,Hp,Wp] fp32 masks, x8-replicated
+// boolean masks, per-mask host loops).
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// bilinear tap set for torch's upsample_bilinear2d(align_corners=False): src = (dst+0.5)*scale-0.5, clamped at 0
+struct Tap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Tap make_tap(int dst, float scale, int in_size) {
+  float s = ((float)dst + 0.5f) * scale - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  Tap t;
+  t.i0 = (int)s;
+  t.i1 = t.i0 + (t.i0 < in_size - 1 ? 1 : 0);
+  t.l1 = s - (float)t.i0;
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+__device__ __forceinline__ float bilerp(const float* p, int w, Tap ty, Tap tx) {
+  const float a = p[(long long)ty.i0 * w + tx.i0], b = p[(long long)ty.i0 * w + tx.i1];
+  const float c = p[(long long)ty.i1 * w + tx.i0], d = p[(long long)ty.i1 * w + tx.i1];
+  return ty.l0 * (tx.l0 * a + tx.l1 * b) + ty.l1 * (tx.l0 * c + tx.l1 * d);
+}
+
+// =================================================================================================
+// Fused encoder K1: softmax(12) + sampling-location arithmetic + deformable sampling.
+//   ops/modules/ms_deform_attn.py:102-118 (offsets/weights views, softmax, loc = ref + off/(W,H), op call)
+//   msdeformattn.py:155-168 (reference points with valid_ratio == 1), cuh:242-304 (sampling).
+// value [B,S,M,D] (M*D == C), oa [B,S,ld_oa]: cols [0, M*L*P*2) offsets (x,y), then M*L*P attention logits.
+// The query token s of level l' at (i,j) has reference point ((j+.5)/W_l', (i+.5)/H_l') on every level.
+// =================================================================================================
+template <int L, int P>
+__global__ void __launch_bounds__(256)
+msda_encoder_fused_kernel(const float* __restrict__ value, const float* __restrict__ oa, int ld_oa,
+                          const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                          float* __restrict__ out, long long n_items, int S, int M, int D) {
+  const unsigned blk = ovis::xcd_remap(blockIdx.x, gridDim.x);
+  const long long item = (long long)blk * blockDim.x + threadIdx.x;
+  if (item >= n_items) return;
+  const int dv = D >> 2;
+  const int cv = (int)(item % dv);
+  const long long sidx = item / dv;              // (b*S + s)*M + m
+  const int m = (int)(sidx % M);
+  const long long bs = sidx / M;                 // b*S + s
+  const int s = (int)(bs % S);
+  const long long b = bs / S;
+  const int qid_stride = M * D;
+
+  int Hs[L], Ws[L], starts[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) { Hs[l] = (int)shapes[2 * l]; Ws[l] = (int)shapes[2 * l + 1]; starts[l] = (int)lsi[l]; }
+  // reference point of this token
+  float refx = 0.f, refy = 0.f;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int e = starts[l] + Hs[l] * Ws[l];
+    if (s >= starts[l] && s < e) {
+      const int rr = s - starts[l];
+      refx = ((float)(rr % Ws[l]) + 0.5f) / (float)Ws[l];
+      refy = ((float)(rr / Ws[l]) + 0.5f) / (float)Hs[l];
+    }
+  }
+  const float* op = oa + bs * ld_oa + m * (L * P * 2);
+  const float* ap = oa + bs * ld_oa + M * L * P * 2 + m * (L * P);
+  float lg[L * P];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < L * P; ++i) { lg[i] = ap[i]; mx = fmaxf(mx, lg[i]); }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < L * P; ++i) { lg[i] = expf(lg[i] - mx); sum += lg[i]; }
+
+  const float* vbase = value + b * (long long)S * qid_stride + m * D + cv * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int H = Hs[l], W = Ws[l];
+    const float* vp = vbase + (long long)starts[l] * qid_stride;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float loc_w = refx + op[(l * P + p) * 2] / (float)W;
+      const float loc_h = refy + op[(l * P + p) * 2 + 1] / (float)H;
+      const float weight = lg[l * P + p] / sum;
+      const float h_im = loc_h * (float)H - 0.5f;
+      const float w_im = loc_w * (float)W - 0.5f;
+      if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
+        const long long h_stride = (long long)W * qid_stride;
+        const float* r0 = vp + h_low * h_stride;
+        const float* r1 = r0 + h_stride;
+        float4 v1 = make_float4(0, 0, 0, 0), v2 = v1, v3 = v1, v4 = v1;
+        if (h_low >= 0 && w_low >= 0) v1 = *reinterpret_cast<const float4*>(r0 + (long long)w_low * qid_stride);
+        if (h_low >= 0 && w_high <= W - 1) v2 = *reinterpret_cast<const float4*>(r0 + (long long)w_high * qid_stride);
+        if (h_high <= H - 1 && w_low >= 0) v3 = *reinterpret_cast<const float4*>(r1 + (long long)w_low * qid_stride);
+        if (h_high <= H - 1 && w_high <= W - 1) v4 = *reinterpret_cast<const float4*>(r1 + (long long)w_high * qid_stride);
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        acc[0] += (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) * weight;
+        acc[1] += (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) * weight;
+        acc[2] += (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) * weight;
+        acc[3] += (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w) * weight;
+      }
+    }
+  }
+  *reinterpret_cast<float4*>(out + sidx * D + cv * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// =================================================================================================
+// Attention mask from (level-resolution) mask logits: blocked = sigmoid(x) < 0.5 (video decoder:465-469),
+// plus per-query count of open keys so that fully blocked rows can be reopened (video decoder:419).
+// =================================================================================================
+__global__ void __launch_bounds__(256)
+attn_mask_kernel(const float* __restrict__ logits, long long ld, uint8_t* __restrict__ mask, long long mask_ld,
+                 int* __restrict__ row_open, int Nk) {
+  const int q = blockIdx.y;
+  const int k0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  int open = 0;
+  if (k0 < Nk) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (k0 + e < Nk) {
+        const float x = logits[(long long)q * ld + k0 + e];
+        const bool blocked = sigmoidf_(x) < 0.5f;
+        bits |= (blocked ? 1u : 0u) << (8 * e);
+        open += blocked ? 0 : 1;
+      }
+    }
+    *reinterpret_cast<unsigned*>(mask + (long long)q * mask_ld + k0) = bits;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) open += __shfl_xor(open, o, 64);
+  if ((threadIdx.x & 63) == 0 && open) atomicAdd(&row_open[q], open);
+}
+
+// mean of the 2x2 centre taps of every s x s cell == F.interpolate(bilinear, align_corners=False) by an exact
+// factor 1/s (s = 2,4,8) — applied to the mask FEATURES (linear), so the intermediate prediction heads only
+// evaluate mask logits at the attention-target resolution (video decoder:463-466).
+__global__ void __launch_bounds__(256)
+center_pool_kernel(const float4* __restrict__ x, float4* __restrict__ y, int N, int H, int W, int c4n, int s) {
+  const int OH = H / s, OW = W / s;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)N * OH * OW * c4n;
+  if (i >= total) return;
+  const int c = (int)(i % c4n);
+  long long r = i / c4n;
+  const int ox = (int)(r % OW);
+  r /= OW;
+  const int oy = (int)(r % OH);
+  const int n = (int)(r / OH);
+  const int y0 = oy * s + s / 2 - 1, x0 = ox * s + s / 2 - 1;
+  const float4* b = x + ((long long)n * H * W) * c4n + c;
+  const float4 p00 = b[((long long)y0 * W + x0) * c4n], p01 = b[((long long)y0 * W + x0 + 1) * c4n];
+  const float4 p10 = b[((long long)(y0 + 1) * W + x0) * c4n], p11 = b[((long long)(y0 + 1) * W + x0 + 1) * c4n];
+  float4 o;
+  o.x = 0.5f * (0.5f * p00.x + 0.5f * p01.x) + 0.5f * (0.5f * p10.x + 0.5f * p11.x);
+  o.y = 0.5f * (0.5f * p00.y + 0.5f * p01.y) + 0.5f * (0.5f * p10.y + 0.5f * p11.y);
+  o.z = 0.5f * (0.5f * p00.z + 0.5f * p01.z) + 0.5f * (0.5f * p10.z + 0.5f * p11.z);
+  o.w = 0.5f * (0.5f * p00.w + 0.5f * p01.w) + 0.5f * (0.5f * p10.w + 0.5f * p11.w);
+  y[i] = o;
+}
+
+// =================================================================================================
+// A9+A10 (first half): bounding boxes of {sigmoid(upsampled mask) > 0.5} without materialising the
+// [Q,T,Hp,Wp] upsampled tensor (openvis.py:87-96,118; adapter.py:88-94; BitMasks.get_bounding_boxes).
+// masks [Q,T,h,w] logits; boxes int32 [T,Q,4] = (x0,y0,x1,y1) inclusive, x1 < 0 if empty.
+// =================================================================================================
+__global__ void bbox_init_kernel(int* boxes, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) boxes[i] = (i & 3) < 2 ? 0x7fffffff : -1;
+}
+
+__device__ __forceinline__ bool mask_on(float x) {
+  // sigmoid(x) > 0.5 evaluated as torch does (fp32); equivalent to x > 0 except for |x| ~ 1e-8
+  return x > 0.f && (x > 1e-6f || sigmoidf_(x) > 0.5f);
+}
+
+__global__ void __launch_bounds__(256)
+mask_bbox_kernel(const float* __restrict__ masks, int* __restrict__ boxes, int Q, int T, int h, int w, int Hp, int Wp,
+                 int rows_per_blk) {
+  const int tq = blockIdx.y;              // t*Q + q
+  const int t = tq / Q, q = tq % Q;
+  const float* mp = masks + ((long long)q * T + t) * h * w;
+  const float sy = (float)h / (float)Hp, sx = (float)w / (float)Wp;
+  const int y_begin = blockIdx.x * rows_per_blk, y_end = min(Hp, y_begin + rows_per_blk);
+  int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
+  for (int y = y_begin; y < y_end; ++y) {
+    const Tap ty = make_tap(y, sy, h);
+    for (int x = threadIdx.x; x < Wp; x += blockDim.x) {
+      const Tap tx = make_tap(x, sx, w);
+      if (mask_on(bilerp(mp, w, ty, tx))) {
+        x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    x0 = min(x0, __shfl_xor(x0, o, 64)); y0 = min(y0, __shfl_xor(y0, o, 64));
+    x1 = max(x1, __shfl_xor(x1, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0 && x1 >= 0) {
+    atomicMin(&boxes[tq * 4 + 0], x0); atomicMin(&boxes[tq * 4 + 1], y0);
+    atomicMax(&boxes[tq * 4 + 2], x1); atomicMax(&boxes[tq * 4 + 3], y1);
+  }
+}
+
+// =================================================================================================
+// A10 (second half): CLIP input crops.  adapter.py:96-116 + 140-143:
+//   square box [x0,y0,x0+s,y0+s], s = max(x1+1-x0, y1+1-y0); roi_align(frame) and roi_align(sigmoid mask)
+//   (torchvision defaults: spatial_scale 1, sampling_ratio -1 -> ceil(s/R) samples per bin and axis, aligned False),
+//   regions = mask_region * region; /255; bicubic to the same size (identity); CLIP mean/std normalise.
+// Output is written directly as the im2col matrix of the ViT patch embedding:
+//   A[(crop*G*G + py*G + px)][c*ps*ps + iy*ps + ix]   (conv1 weight [width,3,ps,ps] flattened).
+// crops int32 [M,6] = (t, q, x0, y0, x1, y1) (inclusive box of the binary mask).
+// =================================================================================================
+__device__ __forceinline__ bool ra_prep(float& v, int size, int& lo, int& hi) {
+  if (v < -1.0f || v > (float)size) return false;
+  if (v <= 0.f) v = 0.f;
+  lo = (int)v;
+  if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; } else hi = lo + 1;
+  return true;
+}
+
+__global__ void __launch_bounds__(256)
+clip_crop_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ masks, const int* __restrict__ crops,
+                 float* __restrict__ A, int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int R, int ps,
+                 float m0, float m1, float m2, float s0, float s1, float s2) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)M * R * R;
+  if (i >= total) return;
+  const int px = (int)(i % R);
+  const int py = (int)((i / R) % R);
+  const int m = (int)(i / ((long long)R * R));
+  const int* cr = crops + m * 6;
+  const int t = cr[0], q = cr[1];
+  const float bx0 = (float)cr[2], by0 = (float)cr[3];
+  const float bw = (float)(cr[4] + 1 - cr[2]), bh = (float)(cr[5] + 1 - cr[3]);
+  const float side = fmaxf(bw, bh);
+  // roi = [bx0, by0, bx0+side, by0+side]
+  const float roi_w = fmaxf(side, 1.f);
+  const float bin = roi_w / (float)R;
+  const int grid = (int)ceilf(roi_w / (float)R);
+  const float count = (float)max(grid * grid, 1);
+  const uint8_t* fp = frames + (long long)t * 3 * H * W;
+  const long long plane = (long long)H * W;
+  const float* mp = masks + ((long long)q * T + t) * h * w;
+  const float usy = (float)h / (float)Hp, usx = (float)w / (float)Wp;
+  float f0 = 0.f, f1 = 0.f, f2 = 0.f, mk = 0.f;
+  for (int iy = 0; iy < grid; ++iy) {
+    const float yy = by0 + (float)py * bin + ((float)iy + .5f) * bin / (float)grid;
+    for (int ix = 0; ix < grid; ++ix) {
+      const float xx = bx0 + (float)px * bin + ((float)ix + .5f) * bin / (float)grid;
+      {  // frame sample (size H x W, un-padded)
+        float y = yy, x = xx; int yl, yh, xl, xh;
+        if (ra_prep(y, H, yl, yh) && ra_prep(x, W, xl, xh)) {
+          const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+          const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+          const long long o1 = (long long)yl * W + xl, o2 = (long long)yl * W + xh, o3 = (long long)yh * W + xl, o4 = (long long)yh * W + xh;
+          f0 += w1 * (float)fp[o1] + w2 * (float)fp[o2] + w3 * (float)fp[o3] + w4 * (float)fp[o4];
+          f1 += w1 * (float)fp[plane + o1] + w2 * (float)fp[plane + o2] + w3 * (float)fp[plane + o3] + w4 * (float)fp[plane + o4];
+          f2 += w1 * (float)fp[2 * plane + o1] + w2 * (float)fp[2 * plane + o2] + w3 * (float)fp[2 * plane + o3] + w4 * (float)fp[2 * plane + o4];
+        }
+      }
+      {  // soft-mask sample (size Hp x Wp): taps are sigmoid(x4 bilinear upsample of the low-res logits)
+        float y = yy, x = xx; int yl, yh, xl, xh;
+        if (ra_prep(y, Hp, yl, yh) && ra_prep(x, Wp, xl, xh)) {
+          const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+          const Tap tyl = make_tap(yl, usy, h), tyh = make_tap(yh, usy, h);
+          const Tap txl = make_tap(xl, usx, w), txh = make_tap(xh, usx, w);
+          const float v1 = sigmoidf_(bilerp(mp, w, tyl, txl)), v2 = sigmoidf_(bilerp(mp, w, tyl, txh));
+          const float v3 = sigmoidf_(bilerp(mp, w, tyh, txl)), v4 = sigmoidf_(bilerp(mp, w, tyh, txh));
+          mk += (hy * hx) * v1 + (hy * lx) * v2 + (ly * hx) * v3 + (ly * lx) * v4;
+        }
+      }
+    }
+  }
+  f0 /= count; f1 /= count; f2 /= count; mk /= count;
+  const float r0 = ((mk * f0) / 255.f - m0) / s0;
+  const float r1 = ((mk * f1) / 255.f - m1) / s1;
+  const float r2 = ((mk * f2) / 255.f - m2) / s2;
+  const int G = R / ps;
+  const long long row = (long long)m * G * G + (py / ps) * G + (px / ps);
+  const int col = (py % ps) * ps + (px % ps);
+  float* ap = A + row * (3 * ps * ps) + col;
+  ap[0] = r0; ap[ps * ps] = r1; ap[2 * ps * ps] = r2;
+}
+
+// ViT token assembly + ln_pre (model.py:341-343): tok[m,0] = cls + pos[0]; tok[m,1+p] = patch[m,p] + pos[1+p]; LN.
+// one wavefront per token; C % 256 == 0 (C = 768 / 1024).
+template <int NV>
+__global__ void __launch_bounds__(256)
+vit_embed_ln_kernel(const float* __restrict__ patch, const float* __restrict__ cls, const float* __restrict__ pos,
+                    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out,
+                    long long n_tok, int L1, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= n_tok) return;
+  const int p = (int)(tok % L1);
+  const long long m = tok / L1;
+  const float4* src = p == 0 ? reinterpret_cast<const float4*>(cls)
+                             : reinterpret_cast<const float4*>(patch + (m * (L1 - 1) + (p - 1)) * C);
+  const float4* pp = reinterpret_cast<const float4*>(pos + (long long)p * C);
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float4 a = src[lane + i * 64], b = pp[lane + i * 64];
+    v[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)C;
+  float qq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+    qq += (a * a + b * b) + (c * c + d * d);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 64);
+  const float rstd = 1.f / sqrtf(qq / (float)C + eps);
+  float4* op = reinterpret_cast<float4*>(out + tok * C);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float4 g = reinterpret_cast<const float4*>(gamma)[lane + i * 64], b = reinterpret_cast<const float4*>(beta)[lane + i * 64];
+    op[lane + i * 64] = make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                                    (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+  }
+}
+
+// y[r,:] = x[r,:] / ||x[r,:]||_2 * scale   (adapter.py:118-119,144,146)
+__global__ void __launch_bounds__(256)
+l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int C, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) { const float v = x[r * C + c]; s += v * v; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float n = sqrtf(s);
+  for (int c = lane; c < C; c += 64) y[r * C + c] = x[r * C + c] / n * scale;
+}
+
+// A12: per-query mean of the crop logits over the frames where the query is valid, then softmax over K
+// (openvis.py:130-141).  slot [T,Q] = crop row or -1.  probs [Q,K]; qvalid [Q].
+__global__ void __launch_bounds__(256)
+openvis_aggregate_kernel(const float* __restrict__ crop_logits, const int* __restrict__ slot, float* __restrict__ probs,
+                         int* __restrict__ qvalid, int T, int Q, int K) {
+  const int q = blockIdx.x;
+  __shared__ float red[256];
+  __shared__ int cnt_s;
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int t = 0; t < T; ++t) c += slot[t * Q + q] >= 0;
+    cnt_s = c;
+    qvalid[q] = c > 0;
+  }
+  __syncthreads();
+  const int cnt = cnt_s;
+  if (cnt == 0) return;
+  float mx = -INFINITY;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const int r = slot[t * Q + q];
+      if (r >= 0) s += crop_logits[(long long)r * K + k];
+    }
+    s = s / (float)cnt;
+    probs[(long long)q * K + k] = s;
+    mx = fmaxf(mx, s);
+  }
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+  mx = red[0];
+  __syncthreads();
+  float sum = 0.f;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const float e = expf(probs[(long long)q * K + k] - mx);
+    probs[(long long)q * K + k] = e;
+    sum += e;
+  }
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  sum = red[0];
+  for (int k = threadIdx.x; k < K; k += blockDim.x) probs[(long long)q * K + k] /= sum;
+}
+
+// A16 (scores): top-k over the flattened [rows*K] probabilities of the valid rows + entropy of the selected rows
+// (video_maskformer.py:267-272).  row_ids [nrows] = rows of `probs` that take part.  Single workgroup.
+__global__ void __launch_bounds__(1024)
+topk_entropy_kernel(const float* __restrict__ probs, const int* __restrict__ row_ids, int nrows, int K, int topk,
+                    int* __restrict__ out_idx, float* __restrict__ out_score, float* __restrict__ out_entropy) {
+  __shared__ float bv[1024];
+  __shared__ long long bi[1024];
+  __shared__ long long chosen[64];
+  const long long total = (long long)nrows * K;
+  for (int j = 0; j < topk; ++j) {
+    float best = -INFINITY;
+    long long besti = -1;
+    for (long long i = threadIdx.x; i < total; i += blockDim.x) {
+      bool taken = false;
+      for (int c = 0; c < j; ++c) taken |= (chosen[c] == i);
+      if (taken) continue;
+      const float v = probs[(long long)row_ids[i / K] * K + (i % K)];
+      if (v > best || (v == best && (besti < 0 || i < besti))) { best = v; besti = i; }
+    }
+    bv[threadIdx.x] = best; bi[threadIdx.x] = besti;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+      if (threadIdx.x < o) {
+        const float v2 = bv[threadIdx.x + o]; const long long i2 = bi[threadIdx.x + o];
+        if (i2 >= 0 && (v2 > bv[threadIdx.x] || (v2 == bv[threadIdx.x] && (bi[threadIdx.x] < 0 || i2 < bi[threadIdx.x])))) {
+          bv[threadIdx.x] = v2; bi[threadIdx.x] = i2;
+        }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { chosen[j] = bi[0]; out_idx[j] = (int)bi[0]; out_score[j] = bv[0]; }
+    __syncthreads();
+  }
+  // entropy of each selected row: -sum p log p
+  for (int j = 0; j < topk; ++j) {
+    const long long row = row_ids[chosen[j] / K];
+    float e = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) { const float p = probs[row * K + k]; e += -p * logf(p); }
+    bv[threadIdx.x] = e;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (threadIdx.x < o) bv[threadIdx.x] += bv[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out_entropy[j] = bv[0];
+    __syncthreads();
+  }
+}
+
+// A16 (masks): for the selected queries: x4 bilinear upsample to the padded size, crop to [H,W], bilinear resize to
+// (OH,OW), threshold > 0 (openvis.py:87-96; video_maskformer.py:273-278). out uint8 [n_sel,T,OH,OW].
+__global__ void __launch_bounds__(256)
+final_masks_kernel(const float* __restrict__ masks, const int* __restrict__ sel_q, uint8_t* __restrict__ out, int n_sel,
+                   int Q, int T, int h, int w, int Hp, int Wp, int H, int W, int OH, int OW) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)n_sel * T * OH * OW;
+  if (i >= total) return;
+  const int ox = (int)(i % OW);
+  long long r = i / OW;
+  const int oy = (int)(r % OH);
+  r /= OH;
+  const int t = (int)(r % T);
+  const int j = (int)(r / T);
+  const float* mp = masks + ((long long)sel_q[j] * T + t) * h * w;
+  const float usy = (float)h / (float)Hp, usx = (float)w / (float)Wp;
+  const Tap oyT = make_tap(oy, (float)H / (float)OH, H), oxT = make_tap(ox, (float)W / (float)OW, W);
+  const Tap ty0 = make_tap(oyT.i0, usy, h), ty1 = make_tap(oyT.i1, usy, h);
+  const Tap tx0 = make_tap(oxT.i0, usx, w), tx1 = make_tap(oxT.i1, usx, w);
+  const float a = bilerp(mp, w, ty0, tx0), b = bilerp(mp, w, ty0, tx1);
+  const float c = bilerp(mp, w, ty1, tx0), d = bilerp(mp, w, ty1, tx1);
+  const float v = oyT.l0 * (oxT.l0 * a + oxT.l1 * b) + oyT.l1 * (oxT.l0 * c + oxT.l1 * d);
+  out[i] = v > 0.f ? 1 : 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int ovis_msda_encoder_fused_f32(const float* value, const float* offs_attn, int ld_oa,
+                                           const int64_t* spatial_shapes, const int64_t* level_start_index, float* out,
+                                           int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                                           int num_point, ovis_stream_t stream) {
+  OVIS_REQUIRE(value && offs_attn && spatial_shapes && level_start_index && out, "msda_encoder_fused: null pointer");
+  OVIS_REQUIRE(batch > 0 && spatial_size > 0 && num_heads > 0 && channels > 0 && channels % 4 == 0,
+               "msda_encoder_fused: bad sizes (channels %% 4)");
+  OVIS_REQUIRE(num_levels == 3 && num_point == 4, "msda_encoder_fused: built for L=3, P=4 (got L=%d P=%d)", num_levels, num_point);
+  OVIS_REQUIRE(ld_oa >= num_heads * num_levels * num_point * 3, "msda_encoder_fused: ld_oa too small");
+  const long long n_items = (long long)batch * spatial_size * num_heads * (channels / 4);
+  hipLaunchKernelGGL((msda_encoder_fused_kernel<3, 4>), dim3(ovis::cdiv(n_items, 256)), dim3(256), 0, (hipStream_t)stream,
+                     value, offs_attn, ld_oa, spatial_shapes, level_start_index, out, n_items, spatial_size, num_heads, channels);
+  return ovis::check_launch("msda_encoder_fused");
+}
+
+extern "C" int ovis_attn_mask_from_logits(const float* logits, long long ld, uint8_t* mask, long long mask_ld,
+                                          int* row_open, int Q, int Nk, ovis_stream_t stream) {
+  OVIS_REQUIRE(logits && mask && row_open, "attn_mask: null pointer");
+  OVIS_REQUIRE(Q > 0 && Nk > 0 && ld >= Nk && mask_ld >= (Nk + 3) / 4 * 4 && mask_ld % 4 == 0, "attn_mask: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(row_open, 0, sizeof(int) * Q, s);
+  if (e != hipSuccess) return ovis::fail(OVIS_ELAUNCH, "attn_mask memset: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(attn_mask_kernel, dim3(ovis::cdiv((Nk + 3) / 4, 256), Q), dim3(256), 0, s, logits, ld, mask, mask_ld,
+                     row_open, Nk);
+  return ovis::check_launch("attn_mask");
+}
+
+extern "C" int ovis_center_pool_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, int s, ovis_stream_t stream) {
+  OVIS_REQUIRE(x && y, "center_pool: null pointer");
+  OVIS_REQUIRE(N > 0 && C % 4 == 0 && s >= 2 && s % 2 == 0 && H % s == 0 && W % s == 0, "center_pool: need even s dividing H, W");
+  const long long total = (long long)N * (H / s) * (W / s) * (C / 4);
+  hipLaunchKernelGGL(center_pool_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), N, H, W, C / 4, s);
+  return ovis::check_launch("center_pool");
+}
+
+extern "C" int ovis_mask_bbox(const float* masks, int* boxes, int Q, int T, int h, int w, int Hp, int Wp, ovis_stream_t stream) {
+  OVIS_REQUIRE(masks && boxes, "mask_bbox: null pointer");
+  OVIS_REQUIRE(Q > 0 && T > 0 && h > 0 && w > 0 && Hp >= h && Wp >= w, "mask_bbox: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bbox_init_kernel, dim3(ovis::cdiv(T * Q * 4, 256)), dim3(256), 0, s, boxes, T * Q * 4);
+  const int rows_per_blk = 32;
+  hipLaunchKernelGGL(mask_bbox_kernel, dim3(ovis::cdiv(Hp, rows_per_blk), T * Q), dim3(256), 0, s, masks, boxes, Q, T, h, w, Hp, Wp,
+                     rows_per_blk);
+  return ovis::check_launch("mask_bbox");
+}
+
+extern "C" int ovis_clip_crop_patches(const uint8_t* frames, const float* masks, const int* crops, float* A, int M, int Q,
+                                      int T, int H, int W, int h, int w, int Hp, int Wp, int resolution, int patch,
+                                      const float* mean3_host, const float* std3_host, ovis_stream_t stream) {
+  OVIS_REQUIRE(frames && masks && crops && A && mean3_host && std3_host, "clip_crop: null pointer");
+  OVIS_REQUIRE(M > 0 && resolution > 0 && patch > 0 && resolution % patch == 0, "clip_crop: bad sizes");
+  const long long total = (long long)M * resolution * resolution;
+  hipLaunchKernelGGL(clip_crop_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, frames, masks, crops, A,
+                     M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, mean3_host[0], mean3_host[1], mean3_host[2],
+                     std3_host[0], std3_host[1], std3_host[2]);
+  return ovis::check_launch("clip_crop");
+}
+
+extern "C" int ovis_vit_embed_ln_f32(const float* patch, const float* cls, const float* pos, const float* gamma,
+                                     const float* beta, float* out, int M, int L1, int C, float eps, ovis_stream_t stream) {
+  OVIS_REQUIRE(patch && cls && pos && gamma && beta && out, "vit_embed_ln: null pointer");
+  OVIS_REQUIRE(M > 0 && L1 > 1 && C > 0 && C % 256 == 0 && C <= 1024, "vit_embed_ln: C must be a multiple of 256, <= 1024");
+  const long long n_tok = (long long)M * L1;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = ovis::cdiv(n_tok, 4);
+  switch (C / 256) {
+    case 1: hipLaunchKernelGGL(vit_embed_ln_kernel<1>, dim3(grid), dim3(256), 0, s, patch, cls, pos, gamma, beta, out, n_tok, L1, C, eps); break;
+    case 2: hipLaunchKernelGGL(vit_embed_ln_kernel<2>, dim3(grid), dim3(256), 0, s, patch, cls, pos, gamma, beta, out, n_tok, L1, C, eps); break;
+    case 3: hipLaunchKernelGGL(vit_embed_ln_kernel<3>, dim3(grid), dim3(256), 0, s, patch, cls, pos, gamma, beta, out, n_tok, L1, C, eps); break;
+    default: hipLaunchKernelGGL(vit_embed_ln_kernel<4>, dim3(grid), dim3(256), 0, s, patch, cls, pos, gamma, beta, out, n_tok, L1, C, eps); break;
+  }
+  return ovis::check_launch("vit_embed_ln");
+}
+
+extern "C" int ovis_l2norm_rows_f32(const float* x, float* y, long long rows, int C, float scale, ovis_stream_t stream) {
+  OVIS_REQUIRE(x && y && rows > 0 && C > 0, "l2norm_rows: bad arguments");
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3(ovis::cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, C, scale);
+  return ovis::check_launch("l2norm_rows");
+}
+
+extern "C" int ovis_openvis_aggregate_f32(const float* crop_logits, const int* slot, float* probs, int* qvalid, int T, int Q,
+                                          int K, ovis_stream_t stream) {
+  OVIS_REQUIRE(crop_logits && slot && probs && qvalid, "openvis_aggregate: null pointer");
+  OVIS_REQUIRE(T > 0 && Q > 0 && K > 0, "openvis_aggregate: bad sizes");
+  hipLaunchKernelGGL(openvis_aggregate_kernel, dim3(Q), dim3(256), 0, (hipStream_t)stream, crop_logits, slot, probs, qvalid, T, Q, K);
+  return ovis::check_launch("openvis_aggregate");
+}
+
+extern "C" int ovis_topk_entropy_f32(const float* probs, const int* row_ids, int nrows, int K, int topk, int* out_idx,
+                                     float* out_score, float* out_entropy, ovis_stream_t stream) {
+  OVIS_REQUIRE(probs && row_ids && out_idx && out_score && out_entropy, "topk_entropy: null pointer");
+  OVIS_REQUIRE(nrows > 0 && K > 0 && topk > 0 && topk <= 64 && (long long)nrows * K >= topk, "topk_entropy: need 0 < topk <= min(64, nrows*K)");
+  hipLaunchKernelGGL(topk_entropy_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, probs, row_ids, nrows, K, topk, out_idx,
+                     out_score, out_entropy);
+  return ovis::check_launch("topk_entropy");
+}
+
+extern "C" int ovis_final_masks_u8(const float* masks, const int* sel_q, uint8_t* out, int n_sel, int Q, int T, int h, int w,
+                                   int Hp, int Wp, int H, int W, int OH, int OW, ovis_stream_t stream) {
+  OVIS_REQUIRE(masks && sel_q && out, "final_masks: null pointer");
+  OVIS_REQUIRE(n_sel > 0 && T > 0 && H <= Hp && W <= Wp && OH > 0 && OW > 0, "final_masks: bad sizes");
+  const long long total = (long long)n_sel * T * OH * OW;
+  hipLaunchKernelGGL(final_masks_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, masks, sel_q, out, n_sel,
+                     Q, T, h, w, Hp, Wp, H, W, OH, OW);
+  return ovis::check_launch("final_masks");
+}

@@ -1,0 +1,82 @@
+"""ResNet backbone (detectron2 `build_resnet_backbone`, configs/openvoc_ytvis_coco/Base.yaml:2-16: DEPTH 50,
+STRIDE_IN_1X1 False, FrozenBN, OUT_FEATURES res2..res5) on the gfx950 kernels.
+
+NHWC activations; every conv is the f32 MFMA implicit GEMM (csrc/gemm_f32.hip) with FrozenBN folded into the
+weights/bias at load time and ReLU / residual-add fused in the epilogue.  State-dict keys are detectron2's
+(`stem.conv1.{weight,norm.*}`, `res{2..5}.{i}.conv{1,2,3}.*`, `shortcut.*`)."""
+import torch
+
+from ... import ops
+from ...registry import BACKBONE_REGISTRY
+
+STAGES = {50: (("res2", 3, 1), ("res3", 4, 2), ("res4", 6, 2), ("res5", 3, 2))}
+
+
+def _fold(sd, p, eps=1e-5, pad_cin_to=None):
+    """conv weight [Cout,Cin,KH,KW] + FrozenBN -> (w' [Cout,KH,KW,Cin] with the BN scale folded in, bias)."""
+    w = sd[p + ".weight"].float()
+    scale = sd[p + ".norm.weight"].float() * (sd[p + ".norm.running_var"].float() + eps).rsqrt()
+    bias = sd[p + ".norm.bias"].float() - sd[p + ".norm.running_mean"].float() * scale
+    w = (w * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1)
+    if pad_cin_to is not None and w.shape[-1] < pad_cin_to:
+        w = torch.nn.functional.pad(w, (0, pad_cin_to - w.shape[-1]))
+    return w.contiguous(), bias.contiguous()
+
+
+class ResNet:
+    size_divisibility = 32
+
+    def __init__(self, depth=50, out_features=("res2", "res3", "res4", "res5")):
+        self.depth = depth
+        self.out_features = tuple(out_features)
+        self.w = {}
+
+    def output_shape(self):
+        ch = {"res2": 256, "res3": 512, "res4": 1024, "res5": 2048}
+        st = {"res2": 4, "res3": 8, "res4": 16, "res5": 32}
+        return {k: dict(channels=ch[k], stride=st[k]) for k in self.out_features}
+
+    def load_state_dict(self, sd, prefix="backbone.", device="cuda"):
+        d = lambda t: t.to(device)
+        self.w["stem"] = tuple(map(d, _fold(sd, prefix + "stem.conv1", pad_cin_to=4)))
+        for name, nblocks, _ in STAGES[self.depth]:
+            for i in range(nblocks):
+                p = f"{prefix}{name}.{i}"
+                for c in ("conv1", "conv2", "conv3", "shortcut"):
+                    if f"{p}.{c}.weight" in sd:
+                        self.w[f"{name}.{i}.{c}"] = tuple(map(d, _fold(sd, f"{p}.{c}")))
+        return self
+
+    def _conv(self, x, key, stride=1, pad=0, residual=None, relu=True):
+        w, b = self.w[key]
+        act = ops.ACT_RELU if relu else ops.ACT_NONE
+        if w.shape[1] == 1 and w.shape[2] == 1 and stride == 1:
+            N, H, W, C = x.shape
+            y = ops.gemm_nt(x.view(-1, C), w.view(w.shape[0], C), b,
+                            residual.view(-1, w.shape[0]) if residual is not None else None, act)
+            return y.view(N, H, W, -1)
+        return ops.conv2d_nhwc(x, w, stride, pad, b, residual, act)
+
+    def forward(self, x):
+        """x: f32 [T,Hp,Wp,4] (normalised, channel 3 zero) -> {res2..res5} NHWC."""
+        x = self._conv(x, "stem", stride=2, pad=3)
+        x = ops.maxpool3x3s2(x)
+        feats = {}
+        for name, nblocks, first_stride in STAGES[self.depth]:
+            for i in range(nblocks):
+                stride = first_stride if i == 0 else 1
+                k = f"{name}.{i}"
+                sc = self._conv(x, k + ".shortcut", stride=stride, relu=False) if (k + ".shortcut") in self.w else x
+                out = self._conv(x, k + ".conv1")
+                out = self._conv(out, k + ".conv2", stride=stride, pad=1)
+                x = self._conv(out, k + ".conv3", residual=sc)            # relu(conv3 + shortcut)
+            if name in self.out_features:
+                feats[name] = x
+        return feats
+
+    __call__ = forward
+
+
+@BACKBONE_REGISTRY.register()
+def build_resnet_backbone(cfg, input_shape=None):
+    return ResNet(cfg.MODEL.RESNETS.DEPTH, cfg.MODEL.RESNETS.OUT_FEATURES)

@@ -1,0 +1,125 @@
+"""ClipAdapter — mirror of openvis/modeling/clip_adapter/adapter.py:34-147 (eval path) on the gfx950 kernels.
+
+forward(frames, text, masks) keeps the reference's meaning, but `masks` are the LOW-RESOLUTION mask logits
+[Q,T,h,w] plus the padded size: the x4 upsample + sigmoid + threshold + bounding box + roi_align + blend +
+CLIP normalisation of openvis.py:87-96,118 / adapter.py:73-116,140-143 are evaluated inside two kernels
+(ovis_mask_bbox, ovis_clip_crop_patches) without materialising [Q,T,Hp,Wp].
+
+dtype: f32 (the oracle's); the reference's GPU path casts crops to fp16 (adapter.py:108-111).
+Text side (adapter.py:121-138): embeddings come from `text_cache` (filled by `set_text_features`); the CLIP text
+tower / tokenizer is a later §8(f) row, so an unknown class name raises instead of being encoded."""
+import numpy as np
+import torch
+
+from ... import ops
+
+PIXEL_MEAN = (0.48145466, 0.4578275, 0.40821073)
+PIXEL_STD = (0.26862954, 0.26130258, 0.27577711)
+
+_CLIP_ARCH = {"ViT-B/16": dict(width=768, layers=12, heads=12, patch=16, resolution=224, embed_dim=512),
+              "ViT-L/14@336px": dict(width=1024, layers=24, heads=16, patch=14, resolution=336, embed_dim=768)}
+
+
+class ClipVisual:
+    """CLIP VisionTransformer.forward (mask_adapted_clip/model.py:327-362 with m=None)."""
+
+    def __init__(self, width, layers, heads, patch, resolution, embed_dim):
+        self.width, self.layers, self.heads, self.patch = width, layers, heads, patch
+        self.input_resolution, self.output_dim = resolution, embed_dim
+        self.w = {}
+
+    def load_state_dict(self, sd, prefix, device):
+        g = lambda k: sd[prefix + k].float().contiguous().to(device)
+        w = self.w
+        cw = g("conv1.weight")
+        w["conv1"] = cw.view(cw.shape[0], -1).contiguous()
+        w["cls"], w["pos"] = g("class_embedding"), g("positional_embedding")
+        for n in ("ln_pre", "ln_post"):
+            w[n + ".w"], w[n + ".b"] = g(n + ".weight"), g(n + ".bias")
+        w["proj_t"] = g("proj").t().contiguous()                   # x @ proj == gemm_nt(x, proj^T)
+        for i in range(self.layers):
+            p = f"transformer.resblocks.{i}."
+            for k in ("attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight", "attn.out_proj.bias",
+                      "ln_1.weight", "ln_1.bias", "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias",
+                      "mlp.c_proj.weight", "mlp.c_proj.bias"):
+                w[f"{i}.{k}"] = g(p + k)
+        return self
+
+    def forward_patches(self, A, M):
+        """A: patch im2col matrix [M*G*G, 3*ps*ps] -> image features [M, embed_dim] (before L2 normalisation)."""
+        w = self.w
+        C, Hh = self.width, self.heads
+        D = C // Hh
+        G = self.input_resolution // self.patch
+        L1 = G * G + 1
+        x = ops.gemm_nt(A, w["conv1"])                                                      # conv1 (no bias)
+        x = ops.vit_embed_ln(x, w["cls"], w["pos"], w["ln_pre.w"], w["ln_pre.b"], M, L1)    # [M,L1,C]
+        for i in range(self.layers):
+            h = ops.layernorm(x, w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"])
+            qkv = ops.gemm_nt(h.view(-1, C), w[f"{i}.attn.in_proj_weight"], w[f"{i}.attn.in_proj_bias"])   # [M*L1,3C]
+            att = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], M, Hh, L1, L1, D, L1 * 3 * C, 3 * C, L1 * 3 * C, 3 * C,
+                                L1 * 3 * C, 3 * C)
+            x = ops.gemm_nt(att.view(-1, C), w[f"{i}.attn.out_proj.weight"], w[f"{i}.attn.out_proj.bias"],
+                            x.view(-1, C)).view(M, L1, C)
+            h = ops.layernorm(x, w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"])
+            f = ops.gemm_nt(h.view(-1, C), w[f"{i}.mlp.c_fc.weight"], w[f"{i}.mlp.c_fc.bias"], None, ops.ACT_QUICKGELU)
+            x = ops.gemm_nt(f, w[f"{i}.mlp.c_proj.weight"], w[f"{i}.mlp.c_proj.bias"], x.view(-1, C)).view(M, L1, C)
+        cls = x[:, 0, :].contiguous()
+        cls = ops.layernorm(cls, w["ln_post.w"], w["ln_post.b"])
+        return ops.gemm_nt(cls, w["proj_t"])
+
+
+class ClipAdapter:
+    def __init__(self, clip_model_name="ViT-B/16", text_templates="vild", arch=None):
+        self.clip_model_name = clip_model_name
+        self.arch = dict(arch or _CLIP_ARCH[clip_model_name])
+        self.visual = ClipVisual(**self.arch)
+        self.input_resolution = self.arch["resolution"]
+        self.templates = text_templates
+        self.text_cache = {}
+
+    def load_state_dict(self, sd, prefix="clip_adapter.", device="cuda"):
+        self.device = device
+        self.visual.load_state_dict(sd, prefix + "clip_model.visual.", device)
+        return self
+
+    # ---- text side -------------------------------------------------------------------------
+    def set_text_features(self, noun_list, feats):
+        """feats [K, embed_dim] unit-norm rows (what encode_text would cache, adapter.py:121-138)."""
+        feats = feats.float().to(self.device)
+        self.text_cache.update(dict(zip(noun_list, feats)))
+
+    def encode_text(self, noun_list):
+        missing = [w for w in noun_list if w not in self.text_cache]
+        if missing:
+            raise NotImplementedError(
+                f"no cached text embedding for {missing[:3]}...: the CLIP text tower is a later §8(f) row; "
+                "call ClipAdapter.set_text_features(class_names, embeddings) first")
+        return torch.stack([self.text_cache[w] for w in noun_list]).contiguous()
+
+    # ---- image side ------------------------------------------------------------------------
+    def preprocess_boxes(self, masks_lowres, Hp, Wp):
+        """valid flags + crop list from the mask logits (adapter.py:86-102). One small D2H copy, as the reference's
+        BitMasks.get_bounding_boxes host loop (adapter.py:94)."""
+        boxes = ops.mask_bbox(masks_lowres, Hp, Wp).cpu().numpy()             # [T,Q,4]
+        valid = boxes[..., 2] >= 0                                            # [T,Q]
+        tq = np.argwhere(valid)                                               # (t, q) lexicographic
+        crops = np.concatenate([tq, boxes[valid]], axis=1).astype(np.int32) if len(tq) else np.zeros((0, 6), np.int32)
+        return valid, crops
+
+    def forward(self, frames, text, masks_lowres, padded_hw):
+        """frames uint8 [T,3,H,W] (device); masks_lowres [Q,T,h,w] logits; returns (sim_logits [M,K] or None, valid [T,Q],
+        crops int32 [M,6])."""
+        Hp, Wp = padded_hw
+        valid, crops = self.preprocess_boxes(masks_lowres, Hp, Wp)
+        if crops.shape[0] == 0:
+            return None, valid, crops
+        crops_d = torch.from_numpy(crops).to(self.device)
+        A = ops.clip_crop_patches(frames, masks_lowres, crops_d, Hp, Wp, self.input_resolution, self.arch["patch"],
+                                  PIXEL_MEAN, PIXEL_STD)
+        feat = self.visual.forward_patches(A, crops.shape[0])
+        text_features = self.encode_text(text)
+        feat = ops.l2norm_rows(feat, 100.0)                                   # normalize, then temperature (:144,146)
+        return ops.gemm_nt(feat, text_features), valid, crops
+
+    __call__ = forward

@@ -1,0 +1,64 @@
+"""MSDeformAttn module — mirror of openvis/modeling/pixel_decoder/ops/modules/ms_deform_attn.py:33-125.
+
+Same constructor arguments, parameter names (sampling_offsets / attention_weights / value_proj / output_proj) and
+forward signature.  Unlike the reference there is NO silent fallback (its bare `except` at :116-121 degrades to the
+slow torch path on any error): every step runs on the HIP kernels or raises."""
+import torch
+
+from ..... import ops
+from ..functions import MSDeformAttnFunction
+
+
+class MSDeformAttn:
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        if d_model % n_heads != 0:
+            raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
+        self.im2col_step = 128
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        self.w = {}
+
+    def load_state_dict(self, sd, prefix="", device="cuda"):
+        g = lambda k: sd[prefix + k].float().contiguous().to(device)
+        for n in ("sampling_offsets", "attention_weights", "value_proj", "output_proj"):
+            self.w[n + ".weight"], self.w[n + ".bias"] = g(n + ".weight"), g(n + ".bias")
+        # one GEMM for [sampling_offsets | attention_weights] (both consume the same query)
+        self.w["oa.weight"] = torch.cat([self.w["sampling_offsets.weight"], self.w["attention_weights.weight"]], 0).contiguous()
+        self.w["oa.bias"] = torch.cat([self.w["sampling_offsets.bias"], self.w["attention_weights.bias"]], 0).contiguous()
+        return self
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        """General (drop-in) path: explicit reference points, un-fused op call (ms_deform_attn.py:82-125)."""
+        N, Len_q, _ = query.shape
+        N, Len_in, _ = input_flatten.shape
+        assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == Len_in
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        value = ops.gemm_nt(input_flatten, self.w["value_proj.weight"], self.w["value_proj.bias"])
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, Len_in, M, self.d_model // M)
+        oa = ops.gemm_nt(query, self.w["oa.weight"], self.w["oa.bias"])
+        off = oa[..., : M * L * P * 2].reshape(N, Len_q, M, L, P, 2)
+        aw = torch.softmax(oa[..., M * L * P * 2:].reshape(N, Len_q, M, L * P), -1).view(N, Len_q, M, L, P)
+        if reference_points.shape[-1] == 2:
+            normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+            loc = reference_points[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            loc = reference_points[:, :, None, :, None, :2] + off / P * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+                reference_points.shape[-1]))
+        out = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
+                                         loc.contiguous(), aw.contiguous(), self.im2col_step)
+        return ops.gemm_nt(out, self.w["output_proj.weight"], self.w["output_proj.bias"])
+
+    def forward_encoder_fused(self, query, src, spatial_shapes, level_start_index, residual):
+        """Encoder fast path: value_proj + fused [offsets|weights] GEMM + fused softmax/location/sampling kernel +
+        output_proj with the residual add fused.  Reference points are the encoder's (msdeformattn.py:155-168)."""
+        value = ops.gemm_nt(src, self.w["value_proj.weight"], self.w["value_proj.bias"])
+        oa = ops.gemm_nt(query, self.w["oa.weight"], self.w["oa.bias"])
+        samp = ops.msda_encoder_fused(value, oa, spatial_shapes, level_start_index, self.n_heads, self.n_levels,
+                                      self.n_points)
+        return ops.gemm_nt(samp, self.w["output_proj.weight"], self.w["output_proj.bias"], residual)
+
+    __call__ = forward

@@ -1,0 +1,2 @@
+from .video_mask2former_transformer_decoder import (  # noqa: F401
+    VideoMultiScaleMaskedTransformerDecoder, build_transformer_decoder)

@@ -1,0 +1,151 @@
+"""VideoMultiScaleMaskedTransformerDecoder — mirror of
+openvis/modeling/transformer_decoder/video_mask2former_transformer_decoder.py:218-471 (eval path, post-norm).
+
+Same constructor arguments / state-dict keys.  MI355X restructuring that does not change results beyond f32 rounding:
+  * the boolean attention mask is built once per layer as uint8 [Q, keys] and shared by the 8 heads (:468 repeats it);
+  * intermediate prediction heads evaluate mask logits only at the attention-target resolution, by pooling the mask
+    FEATURES with the exact 2x2-centre-tap mean that F.interpolate(bilinear, 1/s) applies to the logits (:463-466);
+    only the final head produces full-resolution masks (aux_outputs are training-only, :445-451);
+  * K/V of a level are projected with one GEMM each per layer; scores are never materialised (flash attention)."""
+import torch
+
+from ... import ops
+from ...registry import TRANSFORMER_DECODER_REGISTRY
+
+
+def build_transformer_decoder(cfg, in_channels, mask_classification=True):
+    name = cfg.MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME
+    return TRANSFORMER_DECODER_REGISTRY.get(name).from_config(cfg, in_channels, mask_classification)
+
+
+@TRANSFORMER_DECODER_REGISTRY.register()
+class VideoMultiScaleMaskedTransformerDecoder:
+    def __init__(self, in_channels, mask_classification=True, *, num_classes, hidden_dim, num_queries, nheads,
+                 dim_feedforward, dec_layers, pre_norm, mask_dim, enforce_input_project, num_frames):
+        if pre_norm:
+            raise NotImplementedError("PRE_NORM=True is not used by any reference config")
+        if in_channels != hidden_dim or enforce_input_project:
+            raise NotImplementedError("input_proj conv (in_channels != hidden_dim) is not used by any reference config")
+        self.mask_classification = mask_classification
+        self.num_frames, self.num_heads, self.num_layers = num_frames, nheads, dec_layers
+        self.num_queries, self.hidden_dim, self.num_feature_levels = num_queries, hidden_dim, 3
+        self.w = {}
+        self._pos_cache = {}
+
+    @classmethod
+    def from_config(cls, cfg, in_channels, mask_classification):
+        assert cfg.MODEL.MASK_FORMER.DEC_LAYERS >= 1
+        return cls(in_channels, mask_classification, num_classes=cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES,
+                   hidden_dim=cfg.MODEL.MASK_FORMER.HIDDEN_DIM, num_queries=cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES,
+                   nheads=cfg.MODEL.MASK_FORMER.NHEADS, dim_feedforward=cfg.MODEL.MASK_FORMER.DIM_FEEDFORWARD,
+                   dec_layers=cfg.MODEL.MASK_FORMER.DEC_LAYERS - 1, pre_norm=cfg.MODEL.MASK_FORMER.PRE_NORM,
+                   mask_dim=cfg.MODEL.SEM_SEG_HEAD.MASK_DIM, enforce_input_project=cfg.MODEL.MASK_FORMER.ENFORCE_INPUT_PROJ,
+                   num_frames=cfg.INPUT.SAMPLING_FRAME_NUM)
+
+    def load_state_dict(self, sd, prefix="sem_seg_head.predictor.", device="cuda"):
+        sd = dict(sd)
+        for k in list(sd.keys()):                                   # :224-245 static_query -> query_feat
+            if k.startswith(prefix) and "static_query" in k:
+                sd[k.replace("static_query", "query_feat")] = sd.pop(k)
+        g = lambda k: sd[prefix + k].float().contiguous().to(device)
+        self.device = device
+        C = self.hidden_dim
+        w = self.w
+        for i in range(self.num_layers):
+            cp = f"transformer_cross_attention_layers.{i}."
+            ipw, ipb = g(cp + "multihead_attn.in_proj_weight"), g(cp + "multihead_attn.in_proj_bias")
+            w[f"ca{i}.wq"], w[f"ca{i}.bq"] = ipw[:C].contiguous(), ipb[:C].contiguous()
+            w[f"ca{i}.wk"], w[f"ca{i}.bk"] = ipw[C:2 * C].contiguous(), ipb[C:2 * C].contiguous()
+            w[f"ca{i}.wv"], w[f"ca{i}.bv"] = ipw[2 * C:].contiguous(), ipb[2 * C:].contiguous()
+            w[f"ca{i}.wo"], w[f"ca{i}.bo"] = g(cp + "multihead_attn.out_proj.weight"), g(cp + "multihead_attn.out_proj.bias")
+            w[f"ca{i}.nw"], w[f"ca{i}.nb"] = g(cp + "norm.weight"), g(cp + "norm.bias")
+            sp = f"transformer_self_attention_layers.{i}."
+            ipw, ipb = g(sp + "self_attn.in_proj_weight"), g(sp + "self_attn.in_proj_bias")
+            w[f"sa{i}.wqk"], w[f"sa{i}.bqk"] = ipw[:2 * C].contiguous(), ipb[:2 * C].contiguous()
+            w[f"sa{i}.wv"], w[f"sa{i}.bv"] = ipw[2 * C:].contiguous(), ipb[2 * C:].contiguous()
+            w[f"sa{i}.wo"], w[f"sa{i}.bo"] = g(sp + "self_attn.out_proj.weight"), g(sp + "self_attn.out_proj.bias")
+            w[f"sa{i}.nw"], w[f"sa{i}.nb"] = g(sp + "norm.weight"), g(sp + "norm.bias")
+            fp = f"transformer_ffn_layers.{i}."
+            for k in ("linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias", "norm.weight", "norm.bias"):
+                w[f"ffn{i}.{k}"] = g(fp + k)
+        for k in ("decoder_norm.weight", "decoder_norm.bias", "query_feat.weight", "query_embed.weight", "level_embed.weight"):
+            w[k] = g(k)
+        if self.mask_classification:
+            w["class_embed.weight"], w["class_embed.bias"] = g("class_embed.weight"), g("class_embed.bias")
+        for j in range(3):
+            w[f"mask_embed.{j}.w"], w[f"mask_embed.{j}.b"] = g(f"mask_embed.layers.{j}.weight"), g(f"mask_embed.layers.{j}.bias")
+        self._pos_cache.clear()
+        return self
+
+    def _pos(self, T, H, W):
+        key = (T, H, W)
+        if key not in self._pos_cache:      # PositionEmbeddingSine3D (position_encoding.py:135-165), input independent
+            self._pos_cache[key] = ops.pe_sine(T, H, W, self.hidden_dim // 2, True, None, self.device).view(T * H * W, -1)
+        return self._pos_cache[key]
+
+    def _mask_embed(self, output):
+        w = self.w
+        dec = ops.layernorm(output, w["decoder_norm.weight"], w["decoder_norm.bias"])
+        h = ops.gemm_nt(dec, w["mask_embed.0.w"], w["mask_embed.0.b"], None, ops.ACT_RELU)
+        h = ops.gemm_nt(h, w["mask_embed.1.w"], w["mask_embed.1.b"], None, ops.ACT_RELU)
+        return dec, ops.gemm_nt(h, w["mask_embed.2.w"], w["mask_embed.2.b"])
+
+    @staticmethod
+    def _nsplit(nk):
+        return max(1, min(64, nk // 1024))
+
+    def forward(self, x, mask_features, mask=None):
+        """x: 3 maps [T,H_l,W_l,C] (res5,res4,res3 scale); mask_features [T,h,w,C] (NHWC).
+        Returns {'pred_logits': [1,Q,C+1], 'pred_masks': [1,Q,T,h,w]} (eval: bs = 1, t = T; :381-383)."""
+        w = self.w
+        T, hm, wm, C = mask_features.shape
+        Q, H8 = self.num_queries, self.num_heads
+        D = C // H8
+        src, kin, sizes, pooled = [], [], [], []
+        for i in range(self.num_feature_levels):
+            _, H, W, _ = x[i].shape
+            sizes.append((H, W))
+            s = ops.add_bcast(x[i].reshape(T * H * W, C), w["level_embed.weight"][i].contiguous())   # :401
+            src.append(s)
+            kin.append(ops.add_bcast(s, self._pos(T, H, W)))                                           # memory + pos
+            sc = hm // H
+            pooled.append(ops.center_pool(mask_features, sc).view(T * H * W, C) if sc > 1 else mask_features.view(-1, C))
+        query_embed = w["query_embed.weight"]
+        output = w["query_feat.weight"]
+
+        def head_mask(out, level):
+            _, me = self._mask_embed(out)
+            logits = ops.gemm_nt(me, pooled[level])                       # [Q, T*H_l*W_l]
+            return ops.attn_mask_from_logits(logits)
+
+        amask, row_open = head_mask(output, 0)
+        for i in range(self.num_layers):
+            li = i % self.num_feature_levels
+            Nk = src[li].shape[0]
+            # masked cross-attention (:417-426, CrossAttentionLayer.forward_post :110-122)
+            qp = ops.gemm_nt(ops.add_bcast(output, query_embed), w[f"ca{i}.wq"], w[f"ca{i}.bq"])
+            kp = ops.gemm_nt(kin[li], w[f"ca{i}.wk"], w[f"ca{i}.bk"])
+            vp = ops.gemm_nt(src[li], w[f"ca{i}.wv"], w[f"ca{i}.bv"])
+            att = ops.attention(qp, kp, vp, 1, H8, Q, Nk, D, 0, C, 0, C, 0, C, amask, row_open, self._nsplit(Nk))
+            y = ops.gemm_nt(att.view(Q, C), w[f"ca{i}.wo"], w[f"ca{i}.bo"], output)
+            output = ops.layernorm(y, w[f"ca{i}.nw"], w[f"ca{i}.nb"])
+            # self-attention (:428-432, SelfAttentionLayer.forward_post :52-62)
+            qk = ops.gemm_nt(ops.add_bcast(output, query_embed), w[f"sa{i}.wqk"], w[f"sa{i}.bqk"])   # [Q, 2C] = q | k
+            vv = ops.gemm_nt(output, w[f"sa{i}.wv"], w[f"sa{i}.bv"])
+            att = ops.attention(qk, qk[:, C:], vv, 1, H8, Q, Q, D, 0, 2 * C, 0, 2 * C, 0, C)
+            y = ops.gemm_nt(att.view(Q, C), w[f"sa{i}.wo"], w[f"sa{i}.bo"], output)
+            output = ops.layernorm(y, w[f"sa{i}.nw"], w[f"sa{i}.nb"])
+            # FFN (:434-437, FFNLayer.forward_post :175-179)
+            hdn = ops.gemm_nt(output, w[f"ffn{i}.linear1.weight"], w[f"ffn{i}.linear1.bias"], None, ops.ACT_RELU)
+            y = ops.gemm_nt(hdn, w[f"ffn{i}.linear2.weight"], w[f"ffn{i}.linear2.bias"], output)
+            output = ops.layernorm(y, w[f"ffn{i}.norm.weight"], w[f"ffn{i}.norm.bias"])
+            if i + 1 < self.num_layers:
+                amask, row_open = head_mask(output, (i + 1) % self.num_feature_levels)
+        dec, me = self._mask_embed(output)
+        pred_masks = ops.gemm_nt(me, mask_features.view(-1, C)).view(1, Q, T, hm, wm)   # einsum bqc,btchw->bqthw (:460)
+        out = {"pred_masks": pred_masks, "pred_embeds": dec}
+        if self.mask_classification:
+            out["pred_logits"] = ops.gemm_nt(dec, w["class_embed.weight"], w["class_embed.bias"]).view(1, Q, -1)
+        return out
+
+    __call__ = forward

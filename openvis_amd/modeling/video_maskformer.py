@@ -1,0 +1,82 @@
+"""VideoMaskFormer — mirror of openvis/modeling/video_maskformer.py:23-298 (eval path)."""
+import torch
+
+from .. import ops
+from ..registry import META_ARCH_REGISTRY, BACKBONE_REGISTRY, SEM_SEG_HEADS_REGISTRY
+
+
+def build_backbone(cfg):
+    return BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg)
+
+
+def build_sem_seg_head(cfg, input_shape):
+    return SEM_SEG_HEADS_REGISTRY.get(cfg.MODEL.SEM_SEG_HEAD.NAME).from_config(cfg, input_shape)
+
+
+@META_ARCH_REGISTRY.register()
+class VideoMaskFormer:
+    def __init__(self, *, backbone, sem_seg_head, num_queries, object_mask_threshold, overlap_threshold,
+                 size_divisibility, pixel_mean, pixel_std, num_frames, device="cuda", **unused):
+        self.backbone, self.sem_seg_head = backbone, sem_seg_head
+        self.num_queries = num_queries
+        self.overlap_threshold, self.object_mask_threshold = overlap_threshold, object_mask_threshold
+        self.size_divisibility = size_divisibility if size_divisibility >= 0 else backbone.size_divisibility
+        self.pixel_mean, self.pixel_std = tuple(pixel_mean), tuple(pixel_std)
+        self.num_frames = num_frames
+        self.device = torch.device(device)
+        self.training = False
+
+    @classmethod
+    def from_config(cls, cfg):
+        backbone = build_backbone(cfg)
+        return dict(backbone=backbone, sem_seg_head=build_sem_seg_head(cfg, backbone.output_shape()),
+                    num_queries=cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES,
+                    object_mask_threshold=cfg.MODEL.MASK_FORMER.TEST.OBJECT_MASK_THRESHOLD,
+                    overlap_threshold=cfg.MODEL.MASK_FORMER.TEST.OVERLAP_THRESHOLD,
+                    size_divisibility=cfg.MODEL.MASK_FORMER.SIZE_DIVISIBILITY, pixel_mean=cfg.MODEL.PIXEL_MEAN,
+                    pixel_std=cfg.MODEL.PIXEL_STD, num_frames=cfg.INPUT.SAMPLING_FRAME_NUM)
+
+    def load_state_dict(self, sd):
+        self.backbone.load_state_dict(sd, "backbone.", self.device)
+        self.sem_seg_head.load_state_dict(sd, "sem_seg_head.", self.device)
+        return self
+
+    def eval(self):
+        return self
+
+    def _frames_to_device(self, batched_inputs):
+        """list of T uint8 [3,H,W] -> one uint8 [T,3,H,W] device tensor (single H2D copy; openvis.py:57-60)."""
+        frames = [f for video in batched_inputs for f in video["image"]]
+        x = torch.stack(frames) if not isinstance(frames, torch.Tensor) else frames
+        if x.dtype != torch.uint8:
+            raise TypeError("frames must be uint8 [3,H,W] tensors (ytvis_dataset_mapper.py:293-313)")
+        return x.to(self.device, non_blocking=True).contiguous()
+
+    def preprocess(self, frames_u8):
+        T, _, H, W = frames_u8.shape
+        d = self.size_divisibility
+        Hp, Wp = ((H + d - 1) // d * d, (W + d - 1) // d * d) if d > 1 else (H, W)
+        return ops.preprocess_u8(frames_u8, Hp, Wp, self.pixel_mean, self.pixel_std), (H, W), (Hp, Wp)
+
+    @classmethod
+    def inference_video(cls, num_queries, num_classes, probs, row_ids, pred_masks_lowres, padded_hw, img_size,
+                        output_height, output_width, topk=10):
+        """video_maskformer.py:262-298.  probs [Q,K] (rows of valid queries filled), row_ids = valid query ids."""
+        if row_ids is None or len(row_ids) == 0:
+            return {"image_size": (output_height, output_width), "pred_entropys": [], "pred_scores": [],
+                    "pred_labels": [], "pred_masks": []}
+        dev = probs.device
+        K = probs.shape[1]
+        rid = torch.as_tensor(row_ids, dtype=torch.int32, device=dev)
+        idx, score, ent = ops.topk_entropy(probs, rid, topk)                  # raises if rows*K < topk (as torch.topk)
+        idx_h = idx.cpu().tolist()
+        labels = [i % K for i in idx_h]
+        rows = [i // K for i in idx_h]
+        sel_q = torch.as_tensor([int(row_ids[r]) for r in rows], dtype=torch.int32, device=dev)
+        Q, T, h, w = pred_masks_lowres.shape
+        masks = ops.final_masks(pred_masks_lowres, sel_q, padded_hw[0], padded_hw[1], img_size[0], img_size[1],
+                                output_height, output_width)
+        masks_cpu = masks.cpu().bool()
+        return {"image_size": (output_height, output_width), "pred_entropys": ent.cpu().tolist(),
+                "pred_scores": score.cpu().tolist(), "pred_labels": labels, "pred_masks": [m for m in masks_cpu],
+                "pred_queries": sel_q.cpu().tolist()}

@@ -1,0 +1,76 @@
+"""OpenVIS meta-architecture — mirror of openvis/openvis.py:20-147 (eval path; registered as "OpenVIS").
+
+forward(batched_inputs) takes the reference's input (a list with ONE video dict: "image": list of T uint8 [3,H,W]
+tensors, "dataset_name", optional "height"/"width") and returns the reference's `video_output` dict
+(video_maskformer.py:290-298).  Everything between runs on the gfx950 kernels; the [Q,T,Hp,Wp] upsampled mask
+tensor of openvis.py:87-96 is never materialised (crops and the 10 output masks sample the low-res logits)."""
+import numpy as np
+import torch
+
+from . import ops
+from .catalog import MetadataCatalog
+from .modeling.clip_adapter import build_clip_adapter
+from .modeling.video_maskformer import VideoMaskFormer
+from .registry import META_ARCH_REGISTRY
+
+
+@META_ARCH_REGISTRY.register()
+class OpenVIS(VideoMaskFormer):
+    def __init__(self, *, clip_adapter, **kwargs):
+        super().__init__(**kwargs)
+        self.clip_adapter = clip_adapter
+
+    @classmethod
+    def from_config(cls, cfg):
+        args = VideoMaskFormer.from_config(cfg)
+        assert cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES == 1          # openvis.py:35
+        args["clip_adapter"] = build_clip_adapter(cfg.MODEL.CLIP_ADAPTER)
+        return args
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        self.clip_adapter.load_state_dict(sd, "clip_adapter.", self.device)
+        return self
+
+    def get_class_name_list(self, dataset_name):
+        return [c.strip() for c in MetadataCatalog.get(dataset_name).thing_classes]
+
+    def forward(self, batched_inputs, stages=None):
+        dataset_name = list(set(x["dataset_name"] for x in batched_inputs))[0]
+        class_names = self.get_class_name_list(dataset_name)
+        self.sem_seg_head.num_classes = len(class_names)
+
+        frames = self._frames_to_device(batched_inputs)                       # uint8 [T,3,H,W]
+        images, image_size, padded = self.preprocess(frames)                  # A1
+        features = self.backbone(images)                                      # A2
+        outputs = self.sem_seg_head(features)                                 # A3-A8
+        mask_score = outputs["pred_logits"][0]
+        masks_lowres = outputs["pred_masks"][0]                               # [Q,T,h,w] logits
+
+        probs, row_ids, extras = self.open_vocabulary_inference(mask_score, masks_lowres, frames, class_names, padded)
+        if stages is not None:
+            stages.update(dict(images=images, features=features, pred_masks=outputs["pred_masks"],
+                               pred_logits=outputs["pred_logits"], probs=probs, row_ids=row_ids, **extras))
+        inp = batched_inputs[0]
+        height = inp.get("height", image_size[0])
+        width = inp.get("width", image_size[1])
+        return self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
+                                    height, width)
+
+    __call__ = forward
+
+    def open_vocabulary_inference(self, scores, masks_lowres, frames, class_names, padded_hw):
+        """openvis.py:110-147. The reference walks the clip in chunks of 5 frames (part_len) only to bound memory; the
+        per-(frame,query) crops are independent, so one batch over all T frames gives identical rows in the same
+        (frame, query) order.  Returns (probs [Q,K] with the valid queries' rows filled, valid query ids, extras)."""
+        if len(scores) == 0:
+            return None, None, {}
+        logits, valid, crops = self.clip_adapter(frames, class_names, masks_lowres, padded_hw)
+        if logits is None:                                                    # openvis.py:127-128
+            return None, None, {"valid": valid}
+        T, Q = valid.shape
+        slot = -np.ones((T, Q), np.int32)
+        slot[valid] = np.arange(crops.shape[0], dtype=np.int32)
+        probs, _ = ops.openvis_aggregate(logits, torch.from_numpy(slot).to(self.device))
+        row_ids = np.nonzero(valid.any(axis=0))[0].astype(np.int32)
+        return probs, row_ids, {"crop_logits": logits, "valid": valid, "crops": crops}

@@ -48,3 +48,172 @@ def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE):
     _lib.call("ovis_conv2d_nhwc_f32", x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act,
               _lib.stream_ptr())
     return y
+
+
+# ---------------------------------------------------------------------------------------------
+def _f3(vals):
+    return (ctypes.c_float * 3)(*[float(v) for v in vals])
+
+
+def preprocess_u8(frames, Hp, Wp, mean, std):
+    """frames uint8 [T,3,H,W] -> f32 [T,Hp,Wp,4] normalised, zero padded (openvis.py:57-62)."""
+    _chk(frames)
+    T, _, H, W = frames.shape
+    out = torch.empty((T, Hp, Wp, 4), dtype=torch.float32, device=frames.device)
+    _lib.call("ovis_preprocess_u8_nhwc4", frames, out, T, H, W, Hp, Wp, _f3(mean), _f3(std), _lib.stream_ptr())
+    return out
+
+
+def maxpool3x3s2(x):
+    _chk(x)
+    N, H, W, C = x.shape
+    y = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float32, device=x.device)
+    _lib.call("ovis_maxpool3x3s2_nhwc_f32", x, y, N, H, W, C, _lib.stream_ptr())
+    return y
+
+
+def layernorm(x, gamma, beta, residual=None, eps=1e-5):
+    _chk(x, gamma, beta, residual)
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    _lib.call("ovis_layernorm_f32", x, residual, gamma, beta, y, _ll(x.numel() // C), C, float(eps), _lib.stream_ptr())
+    return y
+
+
+def groupnorm_nhwc(x, gamma, beta, groups=32, eps=1e-5, relu=False, up_add=None):
+    _chk(x, gamma, beta, up_add)
+    N, H, W, C = x.shape
+    y = torch.empty_like(x)
+    ws = torch.empty((N * groups * 2,), dtype=torch.float64, device=x.device)
+    UH, UW = (up_add.shape[1], up_add.shape[2]) if up_add is not None else (0, 0)
+    _lib.call("ovis_groupnorm_nhwc_f32", x, y, gamma, beta, ws, N, H, W, C, groups, float(eps), int(relu), up_add, UH, UW,
+              _lib.stream_ptr())
+    return y
+
+
+def add_bcast(a, b):
+    """a + b with b broadcast over the leading dims of a (b.numel() divides a.numel())."""
+    _chk(a, b)
+    out = torch.empty_like(a)
+    _lib.call("ovis_add_bcast_f32", a, b, out, _ll(a.numel()), _ll(b.numel()), _lib.stream_ptr())
+    return out
+
+
+def pe_sine(T, H, W, npf, three_d, add_c, device):
+    out = torch.empty((T, H, W, 2 * npf), dtype=torch.float32, device=device)
+    _chk(add_c)
+    _lib.call("ovis_pe_sine_f32", out, T, H, W, npf, int(three_d), add_c, _lib.stream_ptr())
+    return out
+
+
+def attention(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, mask=None, row_open=None, nsplit=1):
+    """q/k/v: tensors (possibly column-sliced views of a fused projection) whose element (b,row,h,d) sits at
+    data_ptr + (b*bs + row*ld + h*D + d)*4.  Returns out [B,Nq,H*D]."""
+    for t in (q, k, v):
+        if not t.is_cuda:
+            raise _lib.OvisError("attention needs HIP tensors")
+    out = torch.empty((B, Nq, H * D), dtype=torch.float32, device=q.device)
+    ws = None
+    if nsplit > 1:
+        nbytes = _lib.lib().ovis_attention_workspace_bytes(B, H, Nq, D, nsplit)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=q.device)
+    mask_ld = mask.shape[-1] if mask is not None else 0
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.call("ovis_attention_f32", vp(q), _ll(q_bs), q_ld, vp(k), _ll(k_bs), k_ld, vp(v), _ll(v_bs), v_ld, out,
+              _ll(Nq * H * D), H * D, mask, _ll(mask_ld), row_open, B, H, Nq, Nk, D, float(D) ** -0.5, nsplit, ws,
+              _lib.stream_ptr())
+    return out
+
+
+def msda_encoder_fused(value, oa, shapes, lsi, M=8, L=3, P=4):
+    """value [B,S,C], oa [B,S,M*L*P*3] -> [B,S,C]."""
+    _chk(value, oa, shapes, lsi)
+    B, S, C = value.shape
+    out = torch.empty_like(value)
+    _lib.call("ovis_msda_encoder_fused_f32", value, oa, oa.shape[-1], shapes, lsi, out, B, S, M, C // M, L, P,
+              _lib.stream_ptr())
+    return out
+
+
+def attn_mask_from_logits(logits):
+    """logits [Q,Nk] -> (mask uint8 [Q,Nk4], row_open int32 [Q])."""
+    _chk(logits)
+    Q, Nk = logits.shape
+    ld = (Nk + 3) // 4 * 4
+    mask = torch.empty((Q, ld), dtype=torch.uint8, device=logits.device)
+    row_open = torch.empty((Q,), dtype=torch.int32, device=logits.device)
+    _lib.call("ovis_attn_mask_from_logits", logits, _ll(Nk), mask, _ll(ld), row_open, Q, Nk, _lib.stream_ptr())
+    return mask, row_open
+
+
+def center_pool(x, s):
+    _chk(x)
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // s, W // s, C), dtype=torch.float32, device=x.device)
+    _lib.call("ovis_center_pool_nhwc_f32", x, y, N, H, W, C, s, _lib.stream_ptr())
+    return y
+
+
+def mask_bbox(masks, Hp, Wp):
+    """masks [Q,T,h,w] logits -> int32 [T,Q,4] inclusive boxes at (Hp,Wp) resolution (x1 < 0: empty)."""
+    _chk(masks)
+    Q, T, h, w = masks.shape
+    boxes = torch.empty((T, Q, 4), dtype=torch.int32, device=masks.device)
+    _lib.call("ovis_mask_bbox", masks, boxes, Q, T, h, w, Hp, Wp, _lib.stream_ptr())
+    return boxes
+
+
+def clip_crop_patches(frames, masks, crops, Hp, Wp, resolution, patch, mean, std):
+    _chk(frames, masks, crops)
+    T, _, H, W = frames.shape
+    Q, _, h, w = masks.shape
+    M = crops.shape[0]
+    G = resolution // patch
+    A = torch.empty((M * G * G, 3 * patch * patch), dtype=torch.float32, device=frames.device)
+    _lib.call("ovis_clip_crop_patches", frames, masks, crops, A, M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, _f3(mean),
+              _f3(std), _lib.stream_ptr())
+    return A
+
+
+def vit_embed_ln(patch, cls, pos, gamma, beta, M, L1, eps=1e-5):
+    _chk(patch, cls, pos, gamma, beta)
+    C = cls.numel()
+    out = torch.empty((M, L1, C), dtype=torch.float32, device=patch.device)
+    _lib.call("ovis_vit_embed_ln_f32", patch, cls, pos, gamma, beta, out, M, L1, C, float(eps), _lib.stream_ptr())
+    return out
+
+
+def l2norm_rows(x, scale=1.0):
+    _chk(x)
+    y = torch.empty_like(x)
+    _lib.call("ovis_l2norm_rows_f32", x, y, _ll(x.shape[0]), x.shape[1], float(scale), _lib.stream_ptr())
+    return y
+
+
+def openvis_aggregate(crop_logits, slot):
+    _chk(crop_logits, slot)
+    T, Q = slot.shape
+    K = crop_logits.shape[1]
+    probs = torch.zeros((Q, K), dtype=torch.float32, device=slot.device)
+    qvalid = torch.empty((Q,), dtype=torch.int32, device=slot.device)
+    _lib.call("ovis_openvis_aggregate_f32", crop_logits, slot, probs, qvalid, T, Q, K, _lib.stream_ptr())
+    return probs, qvalid
+
+
+def topk_entropy(probs, row_ids, topk):
+    _chk(probs, row_ids)
+    K = probs.shape[1]
+    idx = torch.empty((topk,), dtype=torch.int32, device=probs.device)
+    score = torch.empty((topk,), dtype=torch.float32, device=probs.device)
+    ent = torch.empty((topk,), dtype=torch.float32, device=probs.device)
+    _lib.call("ovis_topk_entropy_f32", probs, row_ids, row_ids.numel(), K, topk, idx, score, ent, _lib.stream_ptr())
+    return idx, score, ent
+
+
+def final_masks(masks, sel_q, Hp, Wp, H, W, OH, OW):
+    _chk(masks, sel_q)
+    Q, T, h, w = masks.shape
+    n = sel_q.numel()
+    out = torch.empty((n, T, OH, OW), dtype=torch.uint8, device=masks.device)
+    _lib.call("ovis_final_masks_u8", masks, sel_q, out, n, Q, T, h, w, Hp, Wp, H, W, OH, OW, _lib.stream_ptr())
+    return out

@@ -1,0 +1,119 @@
+"""State-dict shape specs (the reference's key names) and a seeded random initialiser.
+There is no network for checkpoints: benchmarks and tests use random-init weights of the named architecture;
+a real checkpoint's state dict loads through the same `load_state_dict` paths."""
+import math
+
+import torch
+
+from .modeling.clip_adapter.adapter import _CLIP_ARCH
+
+
+def resnet50_spec(prefix="backbone."):
+    spec = []
+
+    def conv(p, cout, cin, k):
+        spec.append((p + ".weight", (cout, cin, k, k)))
+        for n in ("weight", "bias", "running_mean", "running_var"):
+            spec.append((f"{p}.norm.{n}", (cout,)))
+
+    conv(prefix + "stem.conv1", 64, 3, 7)
+    cin = 64
+    for name, nblocks, mid, cout in (("res2", 3, 64, 256), ("res3", 4, 128, 512), ("res4", 6, 256, 1024), ("res5", 3, 512, 2048)):
+        for i in range(nblocks):
+            p = f"{prefix}{name}.{i}"
+            if i == 0:
+                conv(p + ".shortcut", cout, cin, 1)
+            conv(p + ".conv1", mid, cin, 1)
+            conv(p + ".conv2", mid, mid, 3)
+            conv(p + ".conv3", cout, mid, 1)
+            cin = cout
+    return spec
+
+
+def pixel_decoder_spec(prefix="sem_seg_head.pixel_decoder.", C=256, layers=6, ffn=1024, M=8, L=3, P=4):
+    s = []
+    for i, cin in enumerate((2048, 1024, 512)):
+        s += [(f"{prefix}input_proj.{i}.0.weight", (C, cin, 1, 1)), (f"{prefix}input_proj.{i}.0.bias", (C,)),
+              (f"{prefix}input_proj.{i}.1.weight", (C,)), (f"{prefix}input_proj.{i}.1.bias", (C,))]
+    s.append((prefix + "transformer.level_embed", (L, C)))
+    for i in range(layers):
+        p = f"{prefix}transformer.encoder.layers.{i}."
+        s += [(p + "self_attn.sampling_offsets.weight", (M * L * P * 2, C)), (p + "self_attn.sampling_offsets.bias", (M * L * P * 2,)),
+              (p + "self_attn.attention_weights.weight", (M * L * P, C)), (p + "self_attn.attention_weights.bias", (M * L * P,)),
+              (p + "self_attn.value_proj.weight", (C, C)), (p + "self_attn.value_proj.bias", (C,)),
+              (p + "self_attn.output_proj.weight", (C, C)), (p + "self_attn.output_proj.bias", (C,)),
+              (p + "norm1.weight", (C,)), (p + "norm1.bias", (C,)),
+              (p + "linear1.weight", (ffn, C)), (p + "linear1.bias", (ffn,)),
+              (p + "linear2.weight", (C, ffn)), (p + "linear2.bias", (C,)),
+              (p + "norm2.weight", (C,)), (p + "norm2.bias", (C,))]
+    s += [(prefix + "mask_features.weight", (C, C, 1, 1)), (prefix + "mask_features.bias", (C,)),
+          (prefix + "adapter_1.weight", (C, 256, 1, 1)), (prefix + "adapter_1.norm.weight", (C,)), (prefix + "adapter_1.norm.bias", (C,)),
+          (prefix + "layer_1.weight", (C, C, 3, 3)), (prefix + "layer_1.norm.weight", (C,)), (prefix + "layer_1.norm.bias", (C,))]
+    return s
+
+
+def video_decoder_spec(prefix="sem_seg_head.predictor.", C=256, layers=9, ffn=2048, Q=100, num_classes=1):
+    s = []
+    for i in range(layers):
+        for kind, attn in (("transformer_cross_attention_layers", "multihead_attn"), ("transformer_self_attention_layers", "self_attn")):
+            p = f"{prefix}{kind}.{i}."
+            s += [(p + attn + ".in_proj_weight", (3 * C, C)), (p + attn + ".in_proj_bias", (3 * C,)),
+                  (p + attn + ".out_proj.weight", (C, C)), (p + attn + ".out_proj.bias", (C,)),
+                  (p + "norm.weight", (C,)), (p + "norm.bias", (C,))]
+        p = f"{prefix}transformer_ffn_layers.{i}."
+        s += [(p + "linear1.weight", (ffn, C)), (p + "linear1.bias", (ffn,)), (p + "linear2.weight", (C, ffn)),
+              (p + "linear2.bias", (C,)), (p + "norm.weight", (C,)), (p + "norm.bias", (C,))]
+    s += [(prefix + "decoder_norm.weight", (C,)), (prefix + "decoder_norm.bias", (C,)),
+          (prefix + "query_feat.weight", (Q, C)), (prefix + "query_embed.weight", (Q, C)), (prefix + "level_embed.weight", (3, C)),
+          (prefix + "class_embed.weight", (num_classes + 1, C)), (prefix + "class_embed.bias", (num_classes + 1,))]
+    for j in range(3):
+        s += [(f"{prefix}mask_embed.layers.{j}.weight", (C, C)), (f"{prefix}mask_embed.layers.{j}.bias", (C,))]
+    return s
+
+
+def clip_visual_spec(prefix="clip_adapter.clip_model.visual.", width=768, layers=12, heads=12, patch=16, resolution=224,
+                     embed_dim=512):
+    G = resolution // patch
+    s = [(prefix + "conv1.weight", (width, 3, patch, patch)), (prefix + "class_embedding", (width,)),
+         (prefix + "positional_embedding", (G * G + 1, width)), (prefix + "ln_pre.weight", (width,)), (prefix + "ln_pre.bias", (width,)),
+         (prefix + "ln_post.weight", (width,)), (prefix + "ln_post.bias", (width,)), (prefix + "proj", (width, embed_dim))]
+    for i in range(layers):
+        p = f"{prefix}transformer.resblocks.{i}."
+        s += [(p + "attn.in_proj_weight", (3 * width, width)), (p + "attn.in_proj_bias", (3 * width,)),
+              (p + "attn.out_proj.weight", (width, width)), (p + "attn.out_proj.bias", (width,)),
+              (p + "ln_1.weight", (width,)), (p + "ln_1.bias", (width,)), (p + "ln_2.weight", (width,)), (p + "ln_2.bias", (width,)),
+              (p + "mlp.c_fc.weight", (4 * width, width)), (p + "mlp.c_fc.bias", (4 * width,)),
+              (p + "mlp.c_proj.weight", (width, 4 * width)), (p + "mlp.c_proj.bias", (width,))]
+    return s
+
+
+def openvis_r50_spec(clip_arch=None, num_queries=100):
+    arch = dict(clip_arch or _CLIP_ARCH["ViT-B/16"])
+    return resnet50_spec() + pixel_decoder_spec() + video_decoder_spec(Q=num_queries) + clip_visual_spec(**arch)
+
+
+def random_init(spec, seed=42):
+    """Seeded random weights with sane scales (fan-in scaled matrices, unit norms, small biases)."""
+    g = torch.Generator().manual_seed(int(seed))
+    sd = {}
+    for key, shape in spec:
+        shape = tuple(shape)
+        if key.endswith("running_var"):
+            t = torch.rand(shape, generator=g) * 0.5 + 0.75
+        elif key.endswith("running_mean"):
+            t = torch.randn(shape, generator=g) * 0.1
+        elif key.endswith("sampling_offsets.bias"):
+            t = torch.randn(shape, generator=g) * 2.0
+        elif key.endswith("sampling_offsets.weight"):
+            t = torch.randn(shape, generator=g) * (0.5 / math.sqrt(shape[-1]))
+        elif "query_feat" in key or "query_embed" in key:
+            t = torch.randn(shape, generator=g)
+        elif len(shape) == 1:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g) if key.endswith("weight") else 0.05 * torch.randn(shape, generator=g)
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            t = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+        sd[key] = t
+    return sd

@@ -459,7 +459,8 @@ def clip_encode_image(regions, W, prefix="clip_adapter.clip_model.visual.", reso
 # ----------------------------------------------------------------------------------------------
 # A12 + OpenVIS.open_vocabulary_inference — openvis/openvis.py:110-147 ; A16 inference_video — video_maskformer.py:262-298
 # ----------------------------------------------------------------------------------------------
-def open_vocabulary_inference(masks, frames, text_features, W, part_len=5, temperature=100.0):
+def open_vocabulary_inference(masks, frames, text_features, W, part_len=5, temperature=100.0, clip_heads=12,
+                              clip_resolution=224):
     """masks [Q,T,Hp,Wp] logits (already upsampled); frames [T,3,H,W] uint8; text_features [K,512] unit rows.
     Returns (probs [Qv,K], masks[valid_query], extras)."""
     T = frames.shape[0]
@@ -467,11 +468,11 @@ def open_vocabulary_inference(masks, frames, text_features, W, part_len=5, tempe
     for idx in range(0, T, part_len):
         part_frames = frames[idx:idx + part_len]
         part_masks = masks[:, idx:idx + part_len].sigmoid().transpose(0, 1).contiguous()
-        regions, valid, sb = clip_crops(part_frames, part_masks)
+        regions, valid, sb = clip_crops(part_frames, part_masks, clip_resolution)
         if regions is None:
             logits = torch.empty(0, text_features.shape[0])
         else:
-            feat = clip_encode_image(regions, W)
+            feat = clip_encode_image(regions, W, resolution=clip_resolution, heads=clip_heads)
             logits = temperature * feat @ text_features.T                     # adapter.py:146-147
             boxes.append(sb)
         clip_cls.append(logits)
@@ -510,7 +511,7 @@ def inference_video(num_queries, num_classes, pred_cls, pred_masks, img_size, ou
             "pred_labels": labels_per_image.tolist(), "pred_masks": [m for m in masks], "rows": topk_indices.tolist()}
 
 
-def openvis_forward(frames, W, text_features, out_hw=None, stages=None):
+def openvis_forward(frames, W, text_features, out_hw=None, stages=None, clip_heads=12, clip_resolution=224):
     """OpenVIS.forward, eval (openvis/openvis.py:47-108). frames: uint8 [T,3,H,W]."""
     T = frames.shape[0]
     images, (H, Wd) = preprocess([f for f in frames])
@@ -520,7 +521,8 @@ def openvis_forward(frames, W, text_features, out_hw=None, stages=None):
     mask_pred = pred_masks[0]                                                # [Q,T,h,w]
     ih, iw = images.shape[-2:]
     mask_pred = F.interpolate(mask_pred, size=(ih, iw), mode="bilinear", align_corners=False)   # openvis.py:87-96
-    probs, vmasks, extras = open_vocabulary_inference(mask_pred, frames, text_features, W)
+    probs, vmasks, extras = open_vocabulary_inference(mask_pred, frames, text_features, W, clip_heads=clip_heads,
+                                                      clip_resolution=clip_resolution)
     oh, ow = out_hw if out_hw is not None else (H, Wd)
     K = text_features.shape[0]
     out = inference_video(pred_masks.shape[1], K, probs, vmasks, (H, Wd), oh, ow)
