@@ -1,0 +1,222 @@
+"""bench.py — OpenVIS R50 720p eval-only throughput on MI355X (BASELINE.json metric, configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU; ranks process independent clips — the OpenVIS
+   offline decoder attends over all frames of a clip, so the path shards by clip with no data-path collective,
+   SURVEY.md §8(e); "scaling": "weak".)
+
+A "step" is one full eval forward of the OpenVIS meta-architecture over one synthetic 5-frame 720p clip
+(uint8 frames already resident in HBM): pre-process -> ResNet-50 -> MSDeformAttn pixel decoder -> 9-layer
+masked-attention decoder -> mask boxes -> CLIP ViT-B/16 on every valid (frame, query) crop -> class aggregation ->
+top-10 -> output masks copied to the host.  Random-init weights of the real architecture (no network for
+checkpoints), 482 synthetic class embeddings (burst_val size).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+T_CLIP, H720, W720, NUM_CLASSES, NUM_QUERIES = 5, 720, 1280, 482, 100
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+PEAK_F16_MFMA_TFLOPS = 2500.0     # same guide: Peak BF16/FP16 MFMA, dense (~2.5 PF)
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_frames(T, H, W, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.rand(T, 3, H, W, generator=g) * 255
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    for t in range(T):
+        for (cy, cx, sy, sx, amp) in ((0.35, 0.3, 0.12, 0.1, 110), (0.6, 0.65, 0.2, 0.15, 90), (0.5, 0.5, 0.4, 0.45, 40)):
+            base[t] = base[t] * 0.7 + amp * torch.exp(-(((yy - (cy + 0.01 * t) * H) / (sy * H)) ** 2 +
+                                                        ((xx - (cx - 0.015 * t) * W) / (sx * W)) ** 2))
+    return base.clamp(0, 255).to(torch.uint8).to(device)
+
+
+def synth_text(K, dim, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randn(1, dim, generator=g)
+    return torch.nn.functional.normalize(base + 0.05 * torch.randn(K, dim, generator=g), dim=-1)
+
+
+def build_model(device, seed=42, clip_precision="fp16"):
+    from openvis_amd import config, weights
+    from openvis_amd.catalog import MetadataCatalog
+    cfg = config.get_cfg()
+    cfg.MODEL.DEVICE = str(device)
+    cfg.MODEL.CLIP_ADAPTER.PRECISION = clip_precision
+    model = config.build_model(cfg)
+    model.device = torch.device(device)
+    sd = weights.random_init(weights.openvis_r50_spec(), seed=seed)
+    model.load_state_dict(sd)
+    names = [f"class_{i}" for i in range(NUM_CLASSES)]
+    MetadataCatalog.get("synthetic_burst_val").set(thing_classes=names)
+    text = synth_text(NUM_CLASSES, 512)
+    model.clip_adapter.set_text_features(names, text)
+    return model, sd, text
+
+
+def _usable_cpus(cap=32):
+    """CPU threads for the oracle leg: affinity mask, cgroup quota and a cap of 32 (beyond that the oracle's small
+    torch ops stop scaling; a 256-thread run on the GPU box's host was ~50x SLOWER than this)."""
+    n = torch.get_num_threads()
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(sd, text, n_crops=4):
+    """The oracle (CPU port of the reference path, oracle/torch_ref.py) on a BOUNDED sample of the 720p workload:
+    one 720x1280 frame; backbone, FPN/mask features, the 9-layer decoder and the x4 mask upsample are run in full,
+    the 6 identical MSDeformAttn encoder layers are timed as t(2 layers) - t(1 layer) and scaled x6, and CLIP
+    ViT-B/16 is timed on `n_crops` crops and scaled to the frame's number of valid crops."""
+    from oracle import torch_ref as TR
+    import torch.nn.functional as F
+    # threads: torch's own default for this host (respects affinity); oversubscribing a quota'd container with
+    # os.cpu_count() threads makes the CPU leg pathologically slow
+    cores = _usable_cpus()
+    torch.set_num_threads(cores)
+    frames = synth_frames(1, H720, W720, 0, "cpu")
+    tm = lambda: time.perf_counter()
+    with torch.no_grad():
+        t0 = tm()
+        images, (H, W) = TR.preprocess([f for f in frames])
+        feats = TR.resnet50(images, sd)
+        t_backbone = tm() - t0
+        t0 = tm()
+        mf, _, ms = TR.pixel_decoder(feats, sd, n_layers=1)
+        t_pd1 = tm() - t0
+        t0 = tm()
+        TR.pixel_decoder(feats, sd, n_layers=2)
+        t_pd2 = tm() - t0
+        t_layer = max(t_pd2 - t_pd1, 0.0)
+        t0 = tm()
+        _, pm = TR.video_decoder(ms, mf, sd)
+        mask_pred = F.interpolate(pm[0], size=images.shape[-2:], mode="bilinear", align_corners=False)
+        part = mask_pred.sigmoid().transpose(0, 1).contiguous()
+        valid = (part > 0.5).sum(dim=(-1, -2)) > 0
+        t_dec = tm() - t0
+        n_valid = int(valid.sum())
+        t0 = tm()
+        regions, v2, _ = TR.clip_crops(frames, part[:, :n_crops])
+        feat = TR.clip_encode_image(regions, sd)
+        _ = 100.0 * feat @ text.T
+        n_done = max(int(v2.sum()), 1)
+        t_clip = (tm() - t0) / n_done
+    sec_per_frame = t_backbone + t_pd1 + 5 * t_layer + t_dec + t_clip * n_valid
+    return {"value": round(1.0 / sec_per_frame, 5), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/torch_ref.py fp32, 1 frame 720x1280: backbone {t_backbone:.1f}s + pixel decoder "
+                      f"(1 layer {t_pd1:.1f}s + 5 x {t_layer:.1f}s) + decoder/upsample {t_dec:.1f}s + CLIP ViT-B/16 "
+                      f"{t_clip:.2f}s/crop (timed on {n_done}) x {n_valid} valid crops = {sec_per_frame:.1f} s/frame"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--clip-precision", default="fp16", choices=["fp16", "fp32"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from openvis_amd import ops
+    model, sd, text = build_model(device, clip_precision=args.clip_precision)
+    # each rank owns its own clips (replicas over clips)
+    clips = [synth_frames(T_CLIP, H720, W720, 1000 * rank + i, device) for i in range(2)]
+    inputs = [[{"image": [f for f in c], "dataset_name": "synthetic_burst_val"}] for c in clips]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    out = None
+    for i in range(args.warmup):
+        out = model(inputs[i % len(inputs)])
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = model(inputs[i % len(inputs)])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream -----------
+    # one extra (untimed) step with per-launch events around every f32-MFMA GEMM launch
+    ops.PROFILE = []
+    st = {}
+    model(inputs[0], stages=st)
+    torch.cuda.synchronize()
+    prof, ops.PROFILE = ops.PROFILE, None
+    agg = {}
+    for name, flops, e0, e1 in prof:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += flops
+        a[2] += e0.elapsed_time(e1) * 1e-3
+    dom = max(agg.items(), key=lambda kv: kv[1][2])
+    n_launch, flops, secs = dom[1]
+    achieved = flops / secs / 1e12
+    peak = PEAK_F16_MFMA_TFLOPS if "f16" in dom[0].split("<")[0] else PEAK_F32_MFMA_TFLOPS
+    roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "launches_per_step": n_launch, "avg_launch_ms": round(secs / n_launch * 1e3, 4),
+                "share_of_step": round(secs / (elapsed / args.steps), 3),
+                "gflop_per_launch": round(flops / n_launch / 1e9, 2),
+                "all_gemm_kernels": {k: {"launches": v[0], "ms": round(v[2] * 1e3, 3), "TFLOPs": round(v[1] / v[2] / 1e12, 1)}
+                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}}
+
+    if rank == 0:
+        frames_total = T_CLIP * args.steps * world
+        n_valid = int(st["valid"].sum()) if "valid" in st else 0
+        line = {
+            "metric": "frames/sec (whole node) OpenVIS R50 720p inference", "value": round(frames_total / elapsed, 3),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16" if model.clip_adapter.precision == "fp16" else "f32", "data": "synthetic",
+            "config": {"workload": "openvis_R50 720p (720x1280 -> 736x1280), 100 queries, 482 classes, 5-frame clips, "
+                                   "ClipAdapter ViT-B/16, random-init weights", "frames_per_step": T_CLIP,
+                       "precision": "backbone/pixel decoder/decoder/masks/logits: exact-f32 MFMA; CLIP ViT GEMM operands: "
+                                    + ("fp16 with f32 accumulation (the reference's GPU CLIP dtype)"
+                                       if model.clip_adapter.precision == "fp16" else "f32"),
+                       "valid_crops_per_clip": n_valid, "parallelism": f"clip-replicas x{world}"},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(sd, text)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,9 @@ int ovis_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, in
  *   msdeformattn.py:139-141,118-122 (norm1/norm2), video decoder:57-60,117-120,175-179, model.py:223-229. */
 int ovis_layernorm_f32(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                        long long rows, int C, float eps, ovis_stream_t stream);
+/* Same, output written as fp16 (operand of the fp16 CLIP GEMMs; statistics and affine in f32). */
+int ovis_layernorm_f32_to_f16(const float* x, const float* residual, const float* gamma, const float* beta, void* y_f16,
+                              long long rows, int C, float eps, ovis_stream_t stream);
 /* GroupNorm(G) on NHWC + optional ReLU + optional "+ bilinear-resized(up_add)" (FPN top-down add):
  *   msdeformattn.py:227-235 (input_proj GN), 276-296 + 369-372 (lateral GN + F.interpolate add, output GN + ReLU).
  *   stats_ws: workspace of 2*G*N doubles. up_add [N,UH,UW,C] or NULL. */
@@ -99,6 +102,15 @@ int ovis_add_bcast_f32(const float* a, const float* b, float* out, long long n, 
 int ovis_pe_sine_f32(float* out, int T, int H, int W, int num_pos_feats, int three_d, const float* add_c,
                      ovis_stream_t stream);
 
+/* ovis_gemm_nt_f16: same contract with fp16 A [M,K] / B [N,K] (K, lda, ldb multiples of 8), f32 accumulation,
+ *   f32 bias / residual, C written as f32 (out_f16 == 0) or fp16.  Used for the CLIP ViT GEMMs only — the reference
+ *   runs CLIP in fp16 on the GPU (adapter.py:108-111; clip.load on cuda). */
+int ovis_gemm_nt_f16(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int M, int N,
+                     int K, const float* bias, const float* residual, long long ldr, int act, int out_f16,
+                     ovis_stream_t stream);
+/* y (fp16) = x (f32), n % 4 == 0 (weights are cast once at load). */
+int ovis_cast_f32_to_f16(const float* x, void* y, long long n, ovis_stream_t stream);
+
 /* ---- Multi-head attention (flash style, f32 MFMA) ----------------------------------------------
  * out[b,q,h*D:(h+1)*D] = softmax_k( scale * <Q[b,q,h], K[b,k,h]> , mask ) V[b,k,h]
  *   Replaces nn.MultiheadAttention's core in video decoder:52-62 (self), 110-122 + 417-426 (masked cross) and
@@ -107,10 +119,11 @@ int ovis_pe_sine_f32(float* out, int T, int H, int W, int num_pos_feats, int thr
  *   mask: uint8 [Nq, mask_ld] (1 = blocked), shared by all heads and batches, or NULL;
  *   row_open: int32 [Nq] = number of unblocked keys per row (rows with 0 are treated as unmasked,
  *   video decoder:419) or NULL.  nsplit > 1 splits the key range over workgroups (needs
- *   ovis_attention_workspace_bytes(B,H,Nq,D,nsplit) bytes of workspace). */
+ *   ovis_attention_workspace_bytes(B,H,Nq,D,nsplit) bytes of workspace).  out_f16 != 0 writes `out` as fp16
+ *   (feeds the fp16 CLIP GEMMs; nsplit must be 1). */
 long long ovis_attention_workspace_bytes(int B, int H, int Nq, int D, int nsplit);
 int ovis_attention_f32(const float* q, long long q_bs, int q_ld, const float* k, long long k_bs, int k_ld,
-                       const float* v, long long v_bs, int v_ld, float* out, long long o_bs, int o_ld,
+                       const float* v, long long v_bs, int v_ld, void* out, long long o_bs, int o_ld, int out_f16,
                        const uint8_t* mask, long long mask_ld, const int* row_open, int B, int H, int Nq, int Nk,
                        int D, float scale, int nsplit, float* workspace, ovis_stream_t stream);
 
@@ -132,9 +145,10 @@ int ovis_center_pool_nhwc_f32(const float* x, float* y, int N, int H, int W, int
 int ovis_mask_bbox(const float* masks, int* boxes, int Q, int T, int h, int w, int Hp, int Wp, ovis_stream_t stream);
 /* CLIP crops (adapter.py:96-116,140-143) written as the patch-embedding im2col matrix
  *   A[(m*G*G + py*G + px), c*ps*ps + iy*ps + ix]; crops int32 [M,6] = (t,q,x0,y0,x1,y1);
- *   frames uint8 [T,3,H,W] (raw, un-padded); masks [Q,T,h,w] logits; mean/std = CLIP's (HOST, in [0,1] units). */
-int ovis_clip_crop_patches(const uint8_t* frames, const float* masks, const int* crops, float* A, int M, int Q, int T,
-                           int H, int W, int h, int w, int Hp, int Wp, int resolution, int patch,
+ *   frames uint8 [T,3,H,W] (raw, un-padded); masks [Q,T,h,w] logits; mean/std = CLIP's (HOST, in [0,1] units);
+ *   A is f32, or fp16 when out_f16 != 0 (the reference feeds CLIP fp16 crops, adapter.py:108-111). */
+int ovis_clip_crop_patches(const uint8_t* frames, const float* masks, const int* crops, void* A, int out_f16, int M,
+                           int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int resolution, int patch,
                            const float* mean3_host, const float* std3_host, ovis_stream_t stream);
 /* ViT token assembly + ln_pre (model.py:341-343): out [M,L1,C]; patch [M,L1-1,C]; cls [C]; pos [L1,C]. */
 int ovis_vit_embed_ln_f32(const float* patch, const float* cls, const float* pos, const float* gamma, const float* beta,

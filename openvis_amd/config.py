@@ -81,7 +81,10 @@ def get_cfg():
             "CLIP_ADAPTER": {"NAME": "ClipAdapter", "PROMPT_NAME": "vild", "CLIP_MODEL_NAME": "ViT-B/16",
                              "CLIP_NUM_HEADS": 12, "CLIP_EMBED_DIMS": 512, "MERGE_IDS": [3, 6, 9], "BROKEN_ID": 9,
                              "CLIP_ENSEMBLE": True, "CLIP_ENSEMBLE_WEIGHT": 0.8, "MASK_PROMPT_DEPTH": 3,
-                             "MASK_PROMPT_FWD": True},
+                             "MASK_PROMPT_FWD": True,
+                             # not a reference key: GEMM operand dtype of the CLIP tower on MI355X ("fp16" as the
+                             # reference's GPU CLIP, or "fp32")
+                             "PRECISION": "fp16"},
         },
         "INPUT": {"SAMPLING_FRAME_NUM": 2, "MIN_SIZE_TEST": 360, "FORMAT": "RGB"},
         "DATASETS": {"TEST": ["burst_val"]},

@@ -31,7 +31,7 @@ struct AttnArgs {
   const float* q; long long q_bs; int q_ld;       // batch stride (elements), row stride
   const float* k; long long k_bs; int k_ld;
   const float* v; long long v_bs; int v_ld;
-  float* out; long long o_bs; int o_ld;
+  void* out; long long o_bs; int o_ld; int out_f16;
   const uint8_t* mask; long long mask_ld;          // [Nq][mask_ld], 1 = blocked; may be null
   const int* row_open;                             // [Nq] number of unblocked keys; may be null
   float* part_o; float* part_ml;                   // split-KV workspace
@@ -87,18 +87,17 @@ flash_attn_f32_kernel(AttnArgs a) {
   constexpr int F4_PER_ROW = D / 4;
   constexpr int NLD = 32 * F4_PER_ROW / 256;
   float4 pk[NLD], pv[NLD];
+  bool okr[NLD];
   auto gload = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / F4_PER_ROW, c4 = idx % F4_PER_ROW;
       const int key = kt + row;
-      pk[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      pv[i] = pk[i];
-      if (key < k_end) {
-        pk[i] = *reinterpret_cast<const float4*>(kp + (long long)key * a.k_ld + c4 * 4);
-        pv[i] = *reinterpret_cast<const float4*>(vp + (long long)key * a.v_ld + c4 * 4);
-      }
+      okr[i] = key < k_end;                         // branch-free: clamped row, select at LDS-store time
+      const int kc = okr[i] ? key : k_begin;
+      pk[i] = *reinterpret_cast<const float4*>(kp + (long long)kc * a.k_ld + c4 * 4);
+      pv[i] = *reinterpret_cast<const float4*>(vp + (long long)kc * a.v_ld + c4 * 4);
     }
   };
   auto lstore = [&]() {
@@ -106,8 +105,11 @@ flash_attn_f32_kernel(AttnArgs a) {
     for (int i = 0; i < NLD; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / F4_PER_ROW, c4 = idx % F4_PER_ROW;
-      *reinterpret_cast<float4*>(&Ks[row * LDK + c4 * 4]) = pk[i];
-      *reinterpret_cast<float4*>(&Vs[row * LDK + c4 * 4]) = pv[i];
+      const bool ok = okr[i];
+      *reinterpret_cast<float4*>(&Ks[row * LDK + c4 * 4]) =
+          make_float4(ok ? pk[i].x : 0.f, ok ? pk[i].y : 0.f, ok ? pk[i].z : 0.f, ok ? pk[i].w : 0.f);
+      *reinterpret_cast<float4*>(&Vs[row * LDK + c4 * 4]) =
+          make_float4(ok ? pv[i].x : 0.f, ok ? pv[i].y : 0.f, ok ? pv[i].z : 0.f, ok ? pv[i].w : 0.f);
     }
   };
 
@@ -195,14 +197,20 @@ flash_attn_f32_kernel(AttnArgs a) {
   if (!wave_active || !q_ok) return;
   if (a.nsplit == 1) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-    float* op = a.out + b * a.o_bs + (long long)qi * a.o_ld + head * D;
+    const long long obase = b * a.o_bs + (long long)qi * a.o_ld + head * D;
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = t * 32 + 8 * g + 4 * h;
-        *reinterpret_cast<float4*>(op + d) =
-            make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+        const float4 r = make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+        if (a.out_f16) {
+          union { _Float16 hh[4]; uint2 u; } pk;
+          pk.hh[0] = (_Float16)r.x; pk.hh[1] = (_Float16)r.y; pk.hh[2] = (_Float16)r.z; pk.hh[3] = (_Float16)r.w;
+          *reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(a.out) + obase + d) = pk.u;
+        } else {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + obase + d) = r;
+        }
       }
   } else {
     const long long slot = ((long long)split * a.B * a.H + bh) * a.Nq + qi;
@@ -255,9 +263,10 @@ extern "C" long long ovis_attention_workspace_bytes(int B, int H, int Nq, int D,
 }
 
 extern "C" int ovis_attention_f32(const float* q, long long q_bs, int q_ld, const float* k, long long k_bs, int k_ld,
-                                  const float* v, long long v_bs, int v_ld, float* out, long long o_bs, int o_ld,
-                                  const uint8_t* mask, long long mask_ld, const int* row_open, int B, int H, int Nq,
-                                  int Nk, int D, float scale, int nsplit, float* workspace, ovis_stream_t stream) {
+                                  const float* v, long long v_bs, int v_ld, void* out, long long o_bs, int o_ld,
+                                  int out_f16, const uint8_t* mask, long long mask_ld, const int* row_open, int B, int H,
+                                  int Nq, int Nk, int D, float scale, int nsplit, float* workspace,
+                                  ovis_stream_t stream) {
   OVIS_REQUIRE(q && k && v && out, "attention: null pointer");
   OVIS_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "attention: non-positive size");
   OVIS_REQUIRE(D == 32 || D == 64, "attention: head dim %d not supported (32 or 64)", D);
@@ -266,13 +275,14 @@ extern "C" int ovis_attention_f32(const float* q, long long q_bs, int q_ld, cons
                "attention: strides must be multiples of 4 floats");
   OVIS_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, "attention: 16-byte alignment");
   OVIS_REQUIRE(nsplit >= 1 && (nsplit == 1 || workspace), "attention: nsplit > 1 needs a workspace");
+  OVIS_REQUIRE(!(out_f16 && nsplit > 1), "attention: fp16 output is only supported with nsplit == 1");
   OVIS_REQUIRE(!mask || mask_ld >= Nk, "attention: mask_ld < Nk");
   int keys_per_split = (Nk + nsplit - 1) / nsplit;
   keys_per_split = (keys_per_split + 31) / 32 * 32;
   nsplit = (Nk + keys_per_split - 1) / keys_per_split;
   AttnArgs a;
   a.q = q; a.q_bs = q_bs; a.q_ld = q_ld; a.k = k; a.k_bs = k_bs; a.k_ld = k_ld; a.v = v; a.v_bs = v_bs; a.v_ld = v_ld;
-  a.out = out; a.o_bs = o_bs; a.o_ld = o_ld; a.mask = mask; a.mask_ld = mask_ld; a.row_open = row_open;
+  a.out = out; a.o_bs = o_bs; a.o_ld = o_ld; a.out_f16 = out_f16; a.mask = mask; a.mask_ld = mask_ld; a.row_open = row_open;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.nsplit = nsplit; a.keys_per_split = keys_per_split; a.scale = scale;
   a.part_o = workspace;
   a.part_ml = workspace ? workspace + (long long)nsplit * B * H * Nq * D : nullptr;
@@ -284,7 +294,7 @@ extern "C" int ovis_attention_f32(const float* q, long long q_bs, int q_ld, cons
   if (rc) return rc;
   if (nsplit > 1) {
     const long long total = (long long)B * H * Nq * D;
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, s, a.part_o, a.part_ml, out, o_bs,
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, s, a.part_o, a.part_ml, (float*)out, o_bs,
                        o_ld, B, H, Nq, D, nsplit);
     rc = ovis::check_launch("attention combine");
   }

@@ -35,25 +35,36 @@ struct ConvGeom {
 };
 
 // ---- A-operand loaders: fetch 4 consecutive k of row m as a float4 (zero outside) ----------------
+// Loads are BRANCH-FREE (clamped address + select): a predicated load compiles to an exec-masked branch with its
+// own s_waitcnt, which serialises the 8 staging loads of a K tile (2x slower GEMM when measured).
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+// dense row-major [M,K]; VEC: K % 4 == 0, lda % 4 == 0 and 16-byte aligned base (a chunk is all-in or all-out)
+template <bool VEC>
 struct DenseA {
   const float* A;
   long long lda;
   int M, K;
-  bool vec_ok;
-  __device__ __forceinline__ float4 load(int m, int k) const {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m < M) {
-      const float* p = A + (long long)m * lda + k;
-      if (vec_ok && k + 3 < K) {
-        v = *reinterpret_cast<const float4*>(p);
-      } else {
-        if (k < K) v.x = p[0];
-        if (k + 1 < K) v.y = p[1];
-        if (k + 2 < K) v.z = p[2];
-        if (k + 3 < K) v.w = p[3];
-      }
+  // raw load from a clamped address; `ok` tells the caller whether to keep it (selected at LDS-store time so the
+  // s_waitcnt for this load lands AFTER the current tile's MFMAs, not right behind the load)
+  __device__ __forceinline__ float4 load(int m, int k, bool& ok) const {
+    if constexpr (VEC) {
+      ok = m < M && k < K;
+      const float* p = A + (ok ? (long long)m * lda + k : 0);
+      return *reinterpret_cast<const float4*>(p);
+    } else {
+      ok = true;
+      const bool okm = m < M;
+      const float* row = A + (okm ? (long long)m * lda : 0);
+      float4 v;
+      v.x = (okm && k < K) ? row[min(k, K - 1)] : 0.f;
+      v.y = (okm && k + 1 < K) ? row[min(k + 1, K - 1)] : 0.f;
+      v.z = (okm && k + 2 < K) ? row[min(k + 2, K - 1)] : 0.f;
+      v.w = (okm && k + 3 < K) ? row[min(k + 3, K - 1)] : 0.f;
+      return v;
     }
-    return v;
   }
 };
 
@@ -62,27 +73,24 @@ struct ConvA {
   const float* X;
   ConvGeom g;
   int M, K;
-  __device__ __forceinline__ float4 load(int m, int k) const {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m < M && k < K) {
-      const int ow = m % g.OW;
-      const int t = m / g.OW;
-      const int oh = t % g.OH;
-      const int n = t / g.OH;
-      const int c = k % g.Cin;
-      const int t2 = k / g.Cin;
-      const int kw = t2 % g.KW;
-      const int kh = t2 / g.KW;
-      const int ih = oh * g.stride - g.pad + kh;
-      const int iw = ow * g.stride - g.pad + kw;
-      if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
-        v = *reinterpret_cast<const float4*>(X + (((long long)n * g.H + ih) * g.W + iw) * g.Cin + c);
-    }
-    return v;
+  __device__ __forceinline__ float4 load(int m, int k, bool& ok) const {
+    const int ow = m % g.OW;
+    const int t = m / g.OW;
+    const int oh = t % g.OH;
+    const int n = t / g.OH;
+    const int c = k % g.Cin;
+    const int t2 = k / g.Cin;
+    const int kw = t2 % g.KW;
+    const int kh = t2 / g.KW;
+    const int ih = oh * g.stride - g.pad + kh;
+    const int iw = ow * g.stride - g.pad + kw;
+    ok = m < M && k < K && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+    const float* p = X + (ok ? (((long long)n * g.H + ih) * g.W + iw) * g.Cin + c : 0);
+    return *reinterpret_cast<const float4*>(p);
   }
 };
 
-template <int BM, int BN, typename LoaderA>
+template <int BM, int BN, typename LoaderA, bool VECB>
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(LoaderA la, const float* __restrict__ B, long long ldb, float* __restrict__ C,
                 long long ldc, int M, int N, int K, const float* __restrict__ bias,
@@ -102,35 +110,22 @@ gemm_f32_kernel(LoaderA la, const float* __restrict__ B, long long ldb, float* _
   // staging assignment: 8 threads cover one 32-float row; 32 rows per pass
   const int srow = tid >> 3, scol = (tid & 7) * 4;
 
+  const DenseA<VECB> lb{B, ldb, N, K};
   float4 pa[A_LD], pb[B_LD];
+  bool oka[A_LD], okb[B_LD];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) pa[i] = la.load(bm + srow + i * 32, k0 + scol);
+    for (int i = 0; i < A_LD; ++i) pa[i] = la.load(bm + srow + i * 32, k0 + scol, oka[i]);
 #pragma unroll
-    for (int i = 0; i < B_LD; ++i) {
-      const int n = bn + srow + i * 32, k = k0 + scol;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < N) {
-        const float* p = B + (long long)n * ldb + k;
-        if (k + 3 < K && ((ldb & 3) == 0)) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (k < K) v.x = p[0];
-          if (k + 1 < K) v.y = p[1];
-          if (k + 2 < K) v.z = p[2];
-          if (k + 3 < K) v.w = p[3];
-        }
-      }
-      pb[i] = v;
-    }
+    for (int i = 0; i < B_LD; ++i) pb[i] = lb.load(bn + srow + i * 32, k0 + scol, okb[i]);
   };
   auto lstore = [&]() {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i)
-      *reinterpret_cast<float4*>(&As[(srow + i * 32) * LDS_STRIDE + scol]) = pa[i];
+      *reinterpret_cast<float4*>(&As[(srow + i * 32) * LDS_STRIDE + scol]) = sel4(oka[i], pa[i]);
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)
-      *reinterpret_cast<float4*>(&Bs[(srow + i * 32) * LDS_STRIDE + scol]) = pb[i];
+      *reinterpret_cast<float4*>(&Bs[(srow + i * 32) * LDS_STRIDE + scol]) = sel4(okb[i], pb[i]);
   };
 
   f32x16 acc[TM][TN];
@@ -184,20 +179,37 @@ gemm_f32_kernel(LoaderA la, const float* __restrict__ B, long long ldb, float* _
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = bn + wc * (BN / 2) + j * 32 + r32;
-    if (n >= N) continue;
-    const float bv = bias ? bias[n] : 0.f;
+    const bool n_ok = n < N;
+    const int nc = n_ok ? n : 0;
+    const float bv = bias ? bias[nc] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      const int m0 = bm + wr * (BM / 2) + i * 32 + 4 * h;
+      float rv[16];
+      if (R) {          // all 16 residual loads issued back to back from clamped addresses (no per-element branch)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (r & 3) + 8 * (r >> 2);
+          rv[r] = R[(long long)(m < M ? m : 0) * ldr + nc];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] += acc[i][j][r] + bv;
+      if (act == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = fmaxf(rv[r], 0.f);
+      } else if (act == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = rv[r] * (1.f / (1.f + expf(-1.702f * rv[r])));
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = bm + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < M) {
-          float v = acc[i][j][r] + bv;
-          if (R) v += R[(long long)m * ldr + n];
-          if (act == ACT_RELU) v = fmaxf(v, 0.f);
-          else if (act == ACT_QUICKGELU) v = v * (1.f / (1.f + expf(-1.702f * v)));
-          C[(long long)m * ldc + n] = v;
-        }
+        const int m = m0 + (r & 3) + 8 * (r >> 2);
+        const float v = rv[r];
+        if (n_ok && m < M) C[(long long)m * ldc + n] = v;
       }
     }
   }
@@ -207,16 +219,20 @@ template <typename LoaderA>
 int launch_gemm(LoaderA la, const float* B, long long ldb, float* C, long long ldc, int M, int N, int K,
                 const float* bias, const float* R, long long ldr, int act, hipStream_t stream) {
   // tile choice: big tiles once the grid still fills 256 CUs, else 64x64 for parallelism
+  const bool vecb = (K % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
   const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128);
-  if (blocks128 >= 256) {
-    const int tm = ovis::cdiv(M, 128), tn = ovis::cdiv(N, 128);
-    hipLaunchKernelGGL((gemm_f32_kernel<128, 128, LoaderA>), dim3(tm * tn), dim3(256), 0, stream, la, B, ldb, C,
-                       ldc, M, N, K, bias, R, ldr, act, tm);
-  } else {
-    const int tm = ovis::cdiv(M, 64), tn = ovis::cdiv(N, 64);
-    hipLaunchKernelGGL((gemm_f32_kernel<64, 64, LoaderA>), dim3(tm * tn), dim3(256), 0, stream, la, B, ldb, C,
-                       ldc, M, N, K, bias, R, ldr, act, tm);
+#define GEMM_LAUNCH(BM_, BN_, VB_)                                                                                  \
+  {                                                                                                                 \
+    const int tm = ovis::cdiv(M, BM_), tn = ovis::cdiv(N, BN_);                                                     \
+    hipLaunchKernelGGL((gemm_f32_kernel<BM_, BN_, LoaderA, VB_>), dim3(tm * tn), dim3(256), 0, stream, la, B, ldb, C, \
+                       ldc, M, N, K, bias, R, ldr, act, tm);                                                        \
   }
+  if (blocks128 >= 256) {
+    if (vecb) GEMM_LAUNCH(128, 128, true) else GEMM_LAUNCH(128, 128, false)
+  } else {
+    if (vecb) GEMM_LAUNCH(64, 64, true) else GEMM_LAUNCH(64, 64, false)
+  }
+#undef GEMM_LAUNCH
   return ovis::check_launch("gemm_f32");
 }
 
@@ -230,9 +246,9 @@ extern "C" int ovis_gemm_nt_f32(const float* A, long long lda, const float* B, l
   OVIS_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm_nt_f32: leading dimension too small");
   OVIS_REQUIRE(act >= 0 && act <= 2, "gemm_nt_f32: unknown activation %d", act);
   OVIS_REQUIRE(!residual || ldr >= N, "gemm_nt_f32: residual leading dimension too small");
-  DenseA la{A, lda, M, K, ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0)};
-  OVIS_REQUIRE(((uintptr_t)B & 15) == 0, "gemm_nt_f32: B must be 16-byte aligned");
-  return launch_gemm(la, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream);
+  const bool veca = (K % 4 == 0) && ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
+  if (veca) return launch_gemm(DenseA<true>{A, lda, M, K}, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream);
+  return launch_gemm(DenseA<false>{A, lda, M, K}, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream);
 }
 
 extern "C" int ovis_conv2d_nhwc_f32(const float* x, const float* w, float* y, int N, int H, int W, int Cin,

@@ -66,10 +66,10 @@ maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int N, i
 
 // ---- LayerNorm over the last dim (C % 4 == 0, C <= 4096): one wavefront per row -----------------
 // y = LN(x + residual) * gamma + beta ; torch.nn.LayerNorm eps inside the sqrt, biased variance.
-template <int MAXV>
+template <int MAXV, bool OUT16>
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
-                 const float* __restrict__ beta, float* __restrict__ y, long long rows, int C, float eps) {
+                 const float* __restrict__ beta, void* __restrict__ yv, long long rows, int C, float eps) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -99,7 +99,8 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, con
     }
   }
   const float rstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
-  float4* yp = reinterpret_cast<float4*>(y + row * C);
+  float4* yp = reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + row * C);
+  uint2* yh = reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(yv) + row * C);
   const float4* gp = reinterpret_cast<const float4*>(gamma);
   const float4* bp = reinterpret_cast<const float4*>(beta);
 #pragma unroll
@@ -112,7 +113,13 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, con
       o.y = (v[i].y - mean) * rstd * g.y + b.y;
       o.z = (v[i].z - mean) * rstd * g.z + b.z;
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
-      yp[idx] = o;
+      if constexpr (OUT16) {
+        union { _Float16 h[4]; uint2 u; } pk;
+        pk.h[0] = (_Float16)o.x; pk.h[1] = (_Float16)o.y; pk.h[2] = (_Float16)o.z; pk.h[3] = (_Float16)o.w;
+        yh[idx] = pk.u;
+      } else {
+        yp[idx] = o;
+      }
     }
   }
 }
@@ -256,17 +263,27 @@ extern "C" int ovis_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H
   return ovis::check_launch("maxpool");
 }
 
-extern "C" int ovis_layernorm_f32(const float* x, const float* residual, const float* gamma, const float* beta,
-                                  float* y, long long rows, int C, float eps, ovis_stream_t stream) {
+template <bool OUT16>
+static int layernorm_launch(const float* x, const float* residual, const float* gamma, const float* beta, void* y,
+                            long long rows, int C, float eps, hipStream_t s) {
   OVIS_REQUIRE(x && gamma && beta && y, "layernorm: null pointer");
   OVIS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 4096, "layernorm: C must be a multiple of 4 and <= 4096");
   const unsigned grid = ovis::cdiv(rows, 4);
   const int nv = C / 4;
-  hipStream_t s = (hipStream_t)stream;
-  if (nv <= 64) hipLaunchKernelGGL(layernorm_kernel<1>, dim3(grid), dim3(256), 0, s, x, residual, gamma, beta, y, rows, C, eps);
-  else if (nv <= 256) hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, s, x, residual, gamma, beta, y, rows, C, eps);
-  else hipLaunchKernelGGL(layernorm_kernel<16>, dim3(grid), dim3(256), 0, s, x, residual, gamma, beta, y, rows, C, eps);
+  if (nv <= 64) hipLaunchKernelGGL((layernorm_kernel<1, OUT16>), dim3(grid), dim3(256), 0, s, x, residual, gamma, beta, y, rows, C, eps);
+  else if (nv <= 256) hipLaunchKernelGGL((layernorm_kernel<4, OUT16>), dim3(grid), dim3(256), 0, s, x, residual, gamma, beta, y, rows, C, eps);
+  else hipLaunchKernelGGL((layernorm_kernel<16, OUT16>), dim3(grid), dim3(256), 0, s, x, residual, gamma, beta, y, rows, C, eps);
   return ovis::check_launch("layernorm");
+}
+
+extern "C" int ovis_layernorm_f32(const float* x, const float* residual, const float* gamma, const float* beta,
+                                  float* y, long long rows, int C, float eps, ovis_stream_t stream) {
+  return layernorm_launch<false>(x, residual, gamma, beta, y, rows, C, eps, (hipStream_t)stream);
+}
+
+extern "C" int ovis_layernorm_f32_to_f16(const float* x, const float* residual, const float* gamma, const float* beta,
+                                         void* y_f16, long long rows, int C, float eps, ovis_stream_t stream) {
+  return layernorm_launch<true>(x, residual, gamma, beta, y_f16, rows, C, eps, (hipStream_t)stream);
 }
 
 extern "C" int ovis_groupnorm_nhwc_f32(const float* x, float* y, const float* gamma, const float* beta,

@@ -231,8 +231,8 @@ __device__ __forceinline__ bool ra_prep(float& v, int size, int& lo, int& hi) {
 
 __global__ void __launch_bounds__(256)
 clip_crop_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ masks, const int* __restrict__ crops,
-                 float* __restrict__ A, int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int R, int ps,
-                 float m0, float m1, float m2, float s0, float s1, float s2) {
+                 void* __restrict__ Av, int out_f16, int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int R,
+                 int ps, float m0, float m1, float m2, float s0, float s1, float s2) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)M * R * R;
   if (i >= total) return;
@@ -289,8 +289,13 @@ clip_crop_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ m
   const int G = R / ps;
   const long long row = (long long)m * G * G + (py / ps) * G + (px / ps);
   const int col = (py % ps) * ps + (px % ps);
-  float* ap = A + row * (3 * ps * ps) + col;
-  ap[0] = r0; ap[ps * ps] = r1; ap[2 * ps * ps] = r2;
+  if (out_f16) {
+    _Float16* ap = reinterpret_cast<_Float16*>(Av) + row * (3 * ps * ps) + col;
+    ap[0] = (_Float16)r0; ap[ps * ps] = (_Float16)r1; ap[2 * ps * ps] = (_Float16)r2;
+  } else {
+    float* ap = reinterpret_cast<float*>(Av) + row * (3 * ps * ps) + col;
+    ap[0] = r0; ap[ps * ps] = r1; ap[2 * ps * ps] = r2;
+  }
 }
 
 // ViT token assembly + ln_pre (model.py:341-343): tok[m,0] = cls + pos[0]; tok[m,1+p] = patch[m,p] + pos[1+p]; LN.
@@ -518,14 +523,14 @@ extern "C" int ovis_mask_bbox(const float* masks, int* boxes, int Q, int T, int 
   return ovis::check_launch("mask_bbox");
 }
 
-extern "C" int ovis_clip_crop_patches(const uint8_t* frames, const float* masks, const int* crops, float* A, int M, int Q,
-                                      int T, int H, int W, int h, int w, int Hp, int Wp, int resolution, int patch,
-                                      const float* mean3_host, const float* std3_host, ovis_stream_t stream) {
+extern "C" int ovis_clip_crop_patches(const uint8_t* frames, const float* masks, const int* crops, void* A, int out_f16,
+                                      int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int resolution,
+                                      int patch, const float* mean3_host, const float* std3_host, ovis_stream_t stream) {
   OVIS_REQUIRE(frames && masks && crops && A && mean3_host && std3_host, "clip_crop: null pointer");
   OVIS_REQUIRE(M > 0 && resolution > 0 && patch > 0 && resolution % patch == 0, "clip_crop: bad sizes");
   const long long total = (long long)M * resolution * resolution;
   hipLaunchKernelGGL(clip_crop_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, frames, masks, crops, A,
-                     M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, mean3_host[0], mean3_host[1], mean3_host[2],
+                     out_f16, M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, mean3_host[0], mean3_host[1], mean3_host[2],
                      std3_host[0], std3_host[1], std3_host[2]);
   return ovis::check_launch("clip_crop");
 }

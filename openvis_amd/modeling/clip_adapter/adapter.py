@@ -5,7 +5,9 @@ forward(frames, text, masks) keeps the reference's meaning, but `masks` are the 
 CLIP normalisation of openvis.py:87-96,118 / adapter.py:73-116,140-143 are evaluated inside two kernels
 (ovis_mask_bbox, ovis_clip_crop_patches) without materialising [Q,T,Hp,Wp].
 
-dtype: f32 (the oracle's); the reference's GPU path casts crops to fp16 (adapter.py:108-111).
+dtype: `precision="fp16"` (default) rounds the ViT GEMM operands to fp16 like the reference's GPU path
+(clip.load on cuda is fp16; crops are .half()'d, adapter.py:108-111) with f32 accumulation, residual stream,
+LayerNorm and softmax; `precision="fp32"` runs the tower on the exact-f32 matrix cores (the oracle's dtype).
 Text side (adapter.py:121-138): embeddings come from `text_cache` (filled by `set_text_features`); the CLIP text
 tower / tokenizer is a later §8(f) row, so an unknown class name raises instead of being encoded."""
 import numpy as np
@@ -23,9 +25,12 @@ _CLIP_ARCH = {"ViT-B/16": dict(width=768, layers=12, heads=12, patch=16, resolut
 class ClipVisual:
     """CLIP VisionTransformer.forward (mask_adapted_clip/model.py:327-362 with m=None)."""
 
-    def __init__(self, width, layers, heads, patch, resolution, embed_dim):
+    def __init__(self, width, layers, heads, patch, resolution, embed_dim, precision="fp16"):
         self.width, self.layers, self.heads, self.patch = width, layers, heads, patch
         self.input_resolution, self.output_dim = resolution, embed_dim
+        if precision not in ("fp16", "fp32"):
+            raise ValueError("precision must be 'fp16' (GEMM operands fp16 like the reference's GPU CLIP) or 'fp32'")
+        self.precision = precision
         self.w = {}
 
     def load_state_dict(self, sd, prefix, device):
@@ -43,6 +48,10 @@ class ClipVisual:
                       "ln_1.weight", "ln_1.bias", "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias",
                       "mlp.c_proj.weight", "mlp.c_proj.bias"):
                 w[f"{i}.{k}"] = g(p + k)
+        if self.precision == "fp16":                                  # GEMM operand copies in fp16 (cast once)
+            for k in ["conv1"] + [f"{i}.{n}" for i in range(self.layers)
+                                  for n in ("attn.in_proj_weight", "attn.out_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight")]:
+                w[k + ".h"] = ops.cast_f16(w[k])
         return self
 
     def forward_patches(self, A, M):
@@ -52,6 +61,8 @@ class ClipVisual:
         D = C // Hh
         G = self.input_resolution // self.patch
         L1 = G * G + 1
+        if self.precision == "fp16":
+            return self._forward_patches_f16(A, M, C, Hh, D, L1)
         x = ops.gemm_nt(A, w["conv1"])                                                      # conv1 (no bias)
         x = ops.vit_embed_ln(x, w["cls"], w["pos"], w["ln_pre.w"], w["ln_pre.b"], M, L1)    # [M,L1,C]
         for i in range(self.layers):
@@ -64,16 +75,40 @@ class ClipVisual:
             h = ops.layernorm(x, w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"])
             f = ops.gemm_nt(h.view(-1, C), w[f"{i}.mlp.c_fc.weight"], w[f"{i}.mlp.c_fc.bias"], None, ops.ACT_QUICKGELU)
             x = ops.gemm_nt(f, w[f"{i}.mlp.c_proj.weight"], w[f"{i}.mlp.c_proj.bias"], x.view(-1, C)).view(M, L1, C)
+        return self._head(x)
+
+    def _head(self, x):
+        w = self.w
         cls = x[:, 0, :].contiguous()
         cls = ops.layernorm(cls, w["ln_post.w"], w["ln_post.b"])
         return ops.gemm_nt(cls, w["proj_t"])
 
+    def _forward_patches_f16(self, A, M, C, Hh, D, L1):
+        """fp16 GEMM operands (activations rounded to fp16 right before each GEMM, weights cast once), f32
+        accumulation; the residual stream, LayerNorm statistics, softmax and the final projection stay f32."""
+        w = self.w
+        x = ops.gemm_nt_f16(A, w["conv1.h"])                                                # f32 out
+        x = ops.vit_embed_ln(x, w["cls"], w["pos"], w["ln_pre.w"], w["ln_pre.b"], M, L1)
+        for i in range(self.layers):
+            h = ops.layernorm(x, w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"], out_f16=True)
+            qkv = ops.gemm_nt_f16(h.view(-1, C), w[f"{i}.attn.in_proj_weight.h"], w[f"{i}.attn.in_proj_bias"])   # f32
+            att = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], M, Hh, L1, L1, D, L1 * 3 * C, 3 * C, L1 * 3 * C, 3 * C,
+                                L1 * 3 * C, 3 * C, out_f16=True)
+            x = ops.gemm_nt_f16(att.view(-1, C), w[f"{i}.attn.out_proj.weight.h"], w[f"{i}.attn.out_proj.bias"],
+                                x.view(-1, C)).view(M, L1, C)
+            h = ops.layernorm(x, w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"], out_f16=True)
+            f = ops.gemm_nt_f16(h.view(-1, C), w[f"{i}.mlp.c_fc.weight.h"], w[f"{i}.mlp.c_fc.bias"], None,
+                                ops.ACT_QUICKGELU, out_f16=True)
+            x = ops.gemm_nt_f16(f, w[f"{i}.mlp.c_proj.weight.h"], w[f"{i}.mlp.c_proj.bias"], x.view(-1, C)).view(M, L1, C)
+        return self._head(x)
+
 
 class ClipAdapter:
-    def __init__(self, clip_model_name="ViT-B/16", text_templates="vild", arch=None):
+    def __init__(self, clip_model_name="ViT-B/16", text_templates="vild", arch=None, precision="fp16"):
         self.clip_model_name = clip_model_name
         self.arch = dict(arch or _CLIP_ARCH[clip_model_name])
-        self.visual = ClipVisual(**self.arch)
+        self.precision = precision
+        self.visual = ClipVisual(**self.arch, precision=precision)
         self.input_resolution = self.arch["resolution"]
         self.templates = text_templates
         self.text_cache = {}
@@ -116,7 +151,7 @@ class ClipAdapter:
             return None, valid, crops
         crops_d = torch.from_numpy(crops).to(self.device)
         A = ops.clip_crop_patches(frames, masks_lowres, crops_d, Hp, Wp, self.input_resolution, self.arch["patch"],
-                                  PIXEL_MEAN, PIXEL_STD)
+                                  PIXEL_MEAN, PIXEL_STD, out_f16=(self.precision == "fp16"))
         feat = self.visual.forward_patches(A, crops.shape[0])
         text_features = self.encode_text(text)
         feat = ops.l2norm_rows(feat, 100.0)                                   # normalize, then temperature (:144,146)

@@ -11,6 +11,32 @@ from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_QUICKGELU = 0, 1, 2
 
+# bench.py sets this to a list to time every MFMA GEMM launch with HIP events on the launch stream:
+# entries are (kernel name, algorithmic flops, start event, end event).
+PROFILE = None
+
+
+def _gemm_variant(M, N, loader):
+    big = ((M + 127) // 128) * ((N + 127) // 128) >= 256       # mirrors launch_gemm() in csrc/gemm_f32.hip
+    return f"gemm_f32_kernel<{'128,128' if big else '64,64'},{loader}>"
+
+
+class _Prof:
+    def __init__(self, name, flops):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+
 
 def _ll(v):
     return ctypes.c_longlong(int(v))
@@ -32,9 +58,35 @@ def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None):
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     r2 = residual.reshape(-1, N) if residual is not None else None
-    _lib.call("ovis_gemm_nt_f32", a2, _ll(K), w, _ll(w.stride(0)), out, _ll(N), M, N, K, bias, r2, _ll(N), act,
-              _lib.stream_ptr())
+    with _Prof(_gemm_variant(M, N, "DenseA"), 2.0 * M * N * K):
+        _lib.call("ovis_gemm_nt_f32", a2, _ll(K), w, _ll(w.stride(0)), out, _ll(N), M, N, K, bias, r2, _ll(N), act,
+                  _lib.stream_ptr())
     return out.view(*a.shape[:-1], N)
+
+
+def gemm_nt_f16(a, w, bias=None, residual=None, act=ACT_NONE, out_f16=False):
+    """fp16 a [...,K] x fp16 w [N,K] -> f32 (or fp16) [...,N]; f32 accumulation / bias / residual."""
+    K = a.shape[-1]
+    N = w.shape[0]
+    a2 = a.reshape(-1, K)
+    _chk(a2, w, bias, residual)
+    if a2.dtype != torch.float16 or w.dtype != torch.float16:
+        raise _lib.OvisError("gemm_nt_f16 needs fp16 operands")
+    M = a2.shape[0]
+    out = torch.empty((M, N), dtype=torch.float16 if out_f16 else torch.float32, device=a.device)
+    r2 = residual.reshape(-1, N) if residual is not None else None
+    big = ((M + 127) // 128) * ((N + 127) // 128) >= 128
+    with _Prof(f"gemm_f16_kernel<{'128,128' if big else '64,64'},{'f16' if out_f16 else 'f32'}>", 2.0 * M * N * K):
+        _lib.call("ovis_gemm_nt_f16", a2, _ll(K), w, _ll(w.stride(0)), out, _ll(N), M, N, K, bias, r2, _ll(N), act,
+                  int(out_f16), _lib.stream_ptr())
+    return out.view(*a.shape[:-1], N)
+
+
+def cast_f16(x):
+    _chk(x)
+    y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    _lib.call("ovis_cast_f32_to_f16", x, y, _ll(x.numel()), _lib.stream_ptr())
+    return y
 
 
 def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE):
@@ -45,8 +97,9 @@ def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE):
     OH = (H + 2 * pad - KH) // stride + 1
     OW = (W + 2 * pad - KW) // stride + 1
     y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device)
-    _lib.call("ovis_conv2d_nhwc_f32", x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act,
-              _lib.stream_ptr())
+    with _Prof(_gemm_variant(N * OH * OW, Cout, "ConvA"), 2.0 * N * OH * OW * Cout * KH * KW * Cin):
+        _lib.call("ovis_conv2d_nhwc_f32", x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act,
+                  _lib.stream_ptr())
     return y
 
 
@@ -72,11 +125,12 @@ def maxpool3x3s2(x):
     return y
 
 
-def layernorm(x, gamma, beta, residual=None, eps=1e-5):
+def layernorm(x, gamma, beta, residual=None, eps=1e-5, out_f16=False):
     _chk(x, gamma, beta, residual)
     C = x.shape[-1]
-    y = torch.empty_like(x)
-    _lib.call("ovis_layernorm_f32", x, residual, gamma, beta, y, _ll(x.numel() // C), C, float(eps), _lib.stream_ptr())
+    y = torch.empty(x.shape, dtype=torch.float16 if out_f16 else torch.float32, device=x.device)
+    _lib.call("ovis_layernorm_f32_to_f16" if out_f16 else "ovis_layernorm_f32", x, residual, gamma, beta, y,
+              _ll(x.numel() // C), C, float(eps), _lib.stream_ptr())
     return y
 
 
@@ -106,13 +160,14 @@ def pe_sine(T, H, W, npf, three_d, add_c, device):
     return out
 
 
-def attention(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, mask=None, row_open=None, nsplit=1):
+def attention(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, mask=None, row_open=None, nsplit=1,
+              out_f16=False):
     """q/k/v: tensors (possibly column-sliced views of a fused projection) whose element (b,row,h,d) sits at
     data_ptr + (b*bs + row*ld + h*D + d)*4.  Returns out [B,Nq,H*D]."""
     for t in (q, k, v):
         if not t.is_cuda:
             raise _lib.OvisError("attention needs HIP tensors")
-    out = torch.empty((B, Nq, H * D), dtype=torch.float32, device=q.device)
+    out = torch.empty((B, Nq, H * D), dtype=torch.float16 if out_f16 else torch.float32, device=q.device)
     ws = None
     if nsplit > 1:
         nbytes = _lib.lib().ovis_attention_workspace_bytes(B, H, Nq, D, nsplit)
@@ -120,8 +175,8 @@ def attention(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, mask
     mask_ld = mask.shape[-1] if mask is not None else 0
     vp = lambda t: ctypes.c_void_p(t.data_ptr())
     _lib.call("ovis_attention_f32", vp(q), _ll(q_bs), q_ld, vp(k), _ll(k_bs), k_ld, vp(v), _ll(v_bs), v_ld, out,
-              _ll(Nq * H * D), H * D, mask, _ll(mask_ld), row_open, B, H, Nq, Nk, D, float(D) ** -0.5, nsplit, ws,
-              _lib.stream_ptr())
+              _ll(Nq * H * D), H * D, int(out_f16), mask, _ll(mask_ld), row_open, B, H, Nq, Nk, D, float(D) ** -0.5,
+              nsplit, ws, _lib.stream_ptr())
     return out
 
 
@@ -163,15 +218,16 @@ def mask_bbox(masks, Hp, Wp):
     return boxes
 
 
-def clip_crop_patches(frames, masks, crops, Hp, Wp, resolution, patch, mean, std):
+def clip_crop_patches(frames, masks, crops, Hp, Wp, resolution, patch, mean, std, out_f16=False):
     _chk(frames, masks, crops)
     T, _, H, W = frames.shape
     Q, _, h, w = masks.shape
     M = crops.shape[0]
     G = resolution // patch
-    A = torch.empty((M * G * G, 3 * patch * patch), dtype=torch.float32, device=frames.device)
-    _lib.call("ovis_clip_crop_patches", frames, masks, crops, A, M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, _f3(mean),
-              _f3(std), _lib.stream_ptr())
+    A = torch.empty((M * G * G, 3 * patch * patch), dtype=torch.float16 if out_f16 else torch.float32,
+                    device=frames.device)
+    _lib.call("ovis_clip_crop_patches", frames, masks, crops, A, int(out_f16), M, Q, T, H, W, h, w, Hp, Wp, resolution,
+              patch, _f3(mean), _f3(std), _lib.stream_ptr())
     return A
 
 

@@ -1,0 +1,194 @@
+"""GPU: individual HIP kernels vs plain torch references of the same op (fp64/fp32 on CPU)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(out, ref):
+    return (out.double().cpu() - ref.double()).abs().max().item() / (ref.double().abs().max().item() + 1e-12)
+
+
+@pytest.mark.parametrize("M,N,K", [(197 * 3, 768, 768), (1000, 3072, 768), (130, 96, 64), (4000, 2304, 768)])
+@pytest.mark.parametrize("out_f16", [False, True])
+def test_gemm_f16(M, N, K, out_f16):
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).half()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).half()
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = a.double() @ w.double().T + b.double() + r.double()
+    ref = ref * torch.sigmoid(1.702 * ref)
+    out = ops.gemm_nt_f16(a.cuda(), w.cuda(), b.cuda(), r.cuda(), ops.ACT_QUICKGELU, out_f16=out_f16)
+    assert out.dtype == (torch.float16 if out_f16 else torch.float32)
+    assert _rel(out, ref) < (2e-3 if out_f16 else 2e-5)
+
+
+def test_gemm_f16_integer_exact():
+    from openvis_amd import ops
+    M, N, K = 150, 70, 128
+    a = (torch.arange(M * K).reshape(M, K) % 13 - 6).half()
+    w = (torch.arange(N * K).reshape(N, K) % 7 - 3).half()
+    out = ops.gemm_nt_f16(a.cuda(), w.cuda()).cpu()
+    assert torch.equal(out, a.float() @ w.float().T)
+
+
+def _attn_ref(q, k, v, mask=None):
+    # q [B,Nq,H,D] ...; mask bool [Nq,Nk] True = blocked (rows fully blocked -> unmasked)
+    s = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) / math.sqrt(q.shape[-1])
+    if mask is not None:
+        m = mask.clone()
+        m[m.all(-1)] = False
+        s = s.masked_fill(m[None, None], float("-inf"))
+    return torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), v.double()).flatten(2)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D,nsplit,masked", [
+    (1, 8, 100, 4600, 32, 4, True), (1, 8, 100, 100, 32, 1, False), (3, 12, 197, 197, 64, 1, False),
+    (1, 8, 100, 1000, 32, 1, True), (2, 4, 37, 333, 64, 3, False), (1, 8, 100, 73600 // 8, 32, 8, True)])
+def test_attention(B, H, Nq, Nk, D, nsplit, masked):
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(Nq * Nk)
+    C = H * D
+    q = torch.randn(B, Nq, C, generator=g)
+    kv = torch.randn(B, Nk, 2 * C, generator=g)
+    mask = None
+    if masked:
+        logits = torch.randn(Nq, Nk, generator=g) + 1.0
+        logits[3] = -5.0           # a fully blocked row -> must be treated as unmasked
+        logits[7, : Nk // 2] = -5.0
+        mask = torch.sigmoid(logits) < 0.5
+    ref = _attn_ref(q.view(B, Nq, H, D), kv[..., :C].reshape(B, Nk, H, D), kv[..., C:].reshape(B, Nk, H, D), mask)
+    qd, kvd = q.cuda(), kv.cuda()
+    md = ro = None
+    if masked:
+        md, ro = ops.attn_mask_from_logits(logits.cuda())
+        assert torch.equal(md[:, :Nk].cpu().bool(), mask)
+        assert torch.equal(ro.cpu(), (~mask).sum(-1).int())
+    out = ops.attention(qd, kvd, kvd[..., C:], B, H, Nq, Nk, D, Nq * C, C, Nk * 2 * C, 2 * C, Nk * 2 * C, 2 * C, md, ro, nsplit)
+    assert _rel(out, ref) < 2e-5
+    if nsplit == 1:
+        out16 = ops.attention(qd, kvd, kvd[..., C:], B, H, Nq, Nk, D, Nq * C, C, Nk * 2 * C, 2 * C, Nk * 2 * C, 2 * C, md, ro, 1,
+                              out_f16=True)
+        assert out16.dtype == torch.float16 and _rel(out16, ref) < 2e-3
+
+
+def test_layernorm_groupnorm_maxpool():
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for C in (256, 768, 2048):
+        x = torch.randn(333, C, generator=g) * 3 + 1
+        r = torch.randn(333, C, generator=g)
+        w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        ref = F.layer_norm((x + r).double(), (C,), w.double(), b.double())
+        assert _rel(ops.layernorm(x.cuda(), w.cuda(), b.cuda(), r.cuda()), ref) < 1e-5
+        assert _rel(ops.layernorm(x.cuda(), w.cuda(), b.cuda(), r.cuda(), out_f16=True), ref) < 2e-3
+    x = torch.randn(2, 256, 23, 40, generator=g) * 2 + 0.5
+    up = torch.randn(2, 256, 12, 20, generator=g)
+    w, b = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    ref = F.group_norm(x.double(), 32, w.double(), b.double()) + F.interpolate(up.double(), size=(23, 40), mode="bilinear",
+                                                                                align_corners=False)
+    y = ops.groupnorm_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), w.cuda(), b.cuda(),
+                           up_add=up.permute(0, 2, 3, 1).contiguous().cuda())
+    assert _rel(y.permute(0, 3, 1, 2), ref) < 1e-5
+    y = ops.groupnorm_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), w.cuda(), b.cuda(), relu=True)
+    assert _rel(y.permute(0, 3, 1, 2), F.group_norm(x.double(), 32, w.double(), b.double()).relu()) < 1e-5
+    x = torch.randn(2, 64, 37, 51, generator=g)
+    y = ops.maxpool3x3s2(x.permute(0, 2, 3, 1).contiguous().cuda())
+    assert torch.equal(y.permute(0, 3, 1, 2).cpu(), F.max_pool2d(x, 3, 2, 1))
+
+
+def test_position_encodings_and_pool():
+    from openvis_amd import ops
+    from oracle import torch_ref as TR
+    pe2 = ops.pe_sine(1, 23, 40, 128, False, None, "cuda").cpu()
+    assert (pe2[0].permute(2, 0, 1) - TR.pe_sine_2d(1, 23, 40)[0]).abs().max() < 2e-5
+    pe3 = ops.pe_sine(5, 12, 20, 128, True, None, "cuda").cpu()
+    assert (pe3.permute(0, 3, 1, 2) - TR.pe_sine_3d(1, 5, 12, 20)[0]).abs().max() < 2e-5
+    x = torch.randn(2, 16, 24, 8)
+    for s in (2, 4, 8):
+        ref = F.interpolate(x.permute(0, 3, 1, 2), size=(16 // s, 24 // s), mode="bilinear", align_corners=False)
+        assert (ops.center_pool(x.cuda(), s).permute(0, 3, 1, 2).cpu() - ref).abs().max() < 1e-6
+
+
+def test_msda_encoder_fused_matches_unfused_oracle():
+    from openvis_amd import ops
+    from oracle import torch_ref as TR
+    g = torch.Generator().manual_seed(11)
+    sizes = [(4, 7), (8, 14), (15, 27)]
+    shapes = torch.tensor(sizes)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    B = 2
+    value = torch.randn(B, S, 256, generator=g)
+    oa = torch.randn(B, S, 288, generator=g)
+    oa[..., :192] *= 3.0
+    off = oa[..., :192].reshape(B, S, 8, 3, 4, 2)
+    aw = oa[..., 192:].reshape(B, S, 8, 12).softmax(-1).view(B, S, 8, 3, 4)
+    ref_pts = TR.encoder_reference_points(sizes).expand(B, -1, -1, -1)
+    norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()
+    loc = ref_pts[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    ref = TR.msda_torch(value.view(B, S, 8, 32).double(), shapes, lsi, loc.double(), aw.double())
+    out = ops.msda_encoder_fused(value.cuda(), oa.cuda(), shapes.cuda(), lsi.cuda())
+    assert _rel(out, ref) < 1e-5
+
+
+def test_mask_bbox_crop_and_final_masks_vs_oracle():
+    from openvis_amd import ops
+    from oracle import torch_ref as TR
+    g = torch.Generator().manual_seed(3)
+    Q, T, h, w, H, W = 6, 2, 12, 16, 45, 60
+    Hp, Wp = 48, 64
+    masks = torch.randn(Q, T, h, w, generator=g) * 2 - 1.0
+    masks[1] = -3.0                                              # never valid
+    frames = (torch.rand(T, 3, H, W, generator=g) * 255).to(torch.uint8)
+    up = F.interpolate(masks, size=(Hp, Wp), mode="bilinear", align_corners=False)
+    part = up.sigmoid().transpose(0, 1).contiguous()
+    regions, valid, sboxes = TR.clip_crops(frames, part, 32)
+    boxes = ops.mask_bbox(masks.cuda(), Hp, Wp).cpu().numpy()
+    assert np.array_equal(boxes[..., 2] >= 0, valid.numpy())
+    tq = np.argwhere(valid.numpy())
+    crops = np.concatenate([tq, boxes[valid.numpy()]], 1).astype(np.int32)
+    side = np.maximum(crops[:, 4] + 1 - crops[:, 2], crops[:, 5] + 1 - crops[:, 3])
+    assert np.array_equal(np.stack([crops[:, 2], crops[:, 3], crops[:, 2] + side, crops[:, 3] + side], 1), sboxes.numpy())
+    A = ops.clip_crop_patches(frames.cuda(), masks.cuda(), torch.from_numpy(crops).cuda(), Hp, Wp, 32, 16, TR.CLIP_MEAN,
+                              TR.CLIP_STD).cpu()
+    mean = torch.tensor(TR.CLIP_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(TR.CLIP_STD).view(1, 3, 1, 1)
+    img = (regions / 255. - mean) / std                         # [M,3,32,32]
+    ref_A = img.unfold(2, 16, 16).unfold(3, 16, 16).permute(0, 2, 3, 1, 4, 5).reshape(-1, 3 * 256)
+    assert (A - ref_A).abs().max() < 2e-4
+    sel = torch.tensor([0, 2, 5], dtype=torch.int32)
+    for (OH, OW) in ((H, W), (90, 120)):
+        out = ops.final_masks(masks.cuda(), sel.cuda(), Hp, Wp, H, W, OH, OW).cpu().bool()
+        ref = F.interpolate(up[sel.long()][:, :, :H, :W], size=(OH, OW), mode="bilinear", align_corners=False) > 0
+        assert (out == ref).float().mean() > 0.9995
+
+
+def test_aggregate_topk():
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(9)
+    T, Q, K = 3, 10, 17
+    valid = torch.rand(T, Q, generator=g) > 0.4
+    valid[:, 4] = False
+    M = int(valid.sum())
+    logits = torch.randn(M, K, generator=g) * 2
+    slot = -torch.ones(T, Q, dtype=torch.int32)
+    slot[valid] = torch.arange(M, dtype=torch.int32)
+    probs, qv = ops.openvis_aggregate(logits.cuda(), slot.cuda())
+    ids = torch.nonzero(valid)
+    vq = torch.nonzero(valid.any(0))[:, 0]
+    ref = torch.stack([logits[ids[:, 1] == q].mean(0) for q in vq]).softmax(-1)
+    assert torch.equal(qv.cpu().bool(), valid.any(0))
+    assert (probs.cpu()[vq] - ref).abs().max() < 1e-6
+    idx, score, ent = ops.topk_entropy(probs, vq.int().cuda(), 10)
+    rs, ri = ref.flatten().topk(10)
+    assert set(idx.cpu().tolist()) == set(ri.tolist())
+    ent_ref = {int(i): float((-ref[i // K] * ref[i // K].log()).sum()) for i in ri}
+    for i, e in zip(idx.cpu().tolist(), ent.cpu().tolist()):
+        assert abs(e - ent_ref[i]) < 1e-5

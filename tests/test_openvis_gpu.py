@@ -22,8 +22,8 @@ def _frames(seed=0):
     return base.to(torch.uint8)
 
 
-@pytest.fixture(scope="module")
-def case():
+@pytest.fixture(scope="module", params=["fp32", "fp16"])
+def case(request):
     from openvis_amd import config, weights
     from openvis_amd.catalog import MetadataCatalog
     from openvis_amd.modeling.clip_adapter.adapter import ClipAdapter
@@ -34,7 +34,7 @@ def case():
     sd = weights.random_init(spec, seed=7)
     cfg = config.get_cfg()
     model = config.build_model(cfg)
-    model.clip_adapter = ClipAdapter("tiny", arch=CLIP_ARCH)
+    model.clip_adapter = ClipAdapter("tiny", arch=CLIP_ARCH, precision=request.param)
     model.load_state_dict(sd)
     names = [f"class_{i}" for i in range(K)]
     MetadataCatalog.get("synthetic_val").set(thing_classes=names)
@@ -52,7 +52,16 @@ def case():
     with torch.no_grad():
         out_ref = TR.openvis_forward(frames, sd, text, stages=st_ref, clip_heads=CLIP_ARCH["heads"],
                                      clip_resolution=CLIP_ARCH["resolution"])
-    return dict(out_gpu=out_gpu, out_ref=out_ref, st_gpu=st_gpu, st_ref=st_ref)
+    return dict(out_gpu=out_gpu, out_ref=out_ref, st_gpu=st_gpu, st_ref=st_ref, precision=request.param)
+
+
+def _report(case, key, val):
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    path = "gpurun_out/parity_report.json"
+    d = json.load(open(path)) if os.path.exists(path) else {}
+    d.setdefault(case["precision"], {})[key] = val
+    json.dump(d, open(path, "w"), indent=1)
 
 
 def _rel(a, b):
@@ -79,6 +88,7 @@ def test_a3_a8_masks(case):
     agree = ((g > 0) == (r > 0)).float().mean().item()
     inter = ((g > 0) & (r > 0)).sum().item()
     union = ((g > 0) | (r > 0)).sum().item()
+    _report(case, "pred_masks", dict(rel_err=_rel(g, r), sign_agree=agree, iou=inter / max(union, 1)))
     assert agree > 0.999 and inter / max(union, 1) > 0.999, (agree, inter / max(union, 1))
 
 
@@ -108,8 +118,13 @@ def test_a12_clip_logits_and_probs(case):
     ir = {tuple(x): i for i, x in enumerate(np.argwhere(vr))}
     common = [k for k in ig if k in ir]
     d = np.array([np.abs(lg[ig[k]] - lr[ir[k]]).max() for k in common])
-    # cosine logits x100: north-star tolerance 1e-3 on the cosine -> 1e-1 on the x100 logits; report the tight fraction
-    assert np.median(d) < 1e-2 and (d < 1e-1).mean() > 0.97, (np.median(d), (d < 1e-1).mean())
+    # cosine logits x100: north-star tolerance 1e-3 on the cosine -> 1e-1 on the x100 logits.
+    # fp32 tower: ~1e-3 on the logits; fp16 GEMM operands (the reference's GPU dtype): within the 1e-1 bound.
+    _report(case, "clip_logit_abs_err", dict(median=float(np.median(d)), p99=float(np.quantile(d, 0.99)), max=float(d.max())))
+    if case["precision"] == "fp32":
+        assert np.median(d) < 1e-2 and (d < 1e-1).mean() > 0.97, (np.median(d), (d < 1e-1).mean())
+    else:
+        assert np.median(d) < 5e-2 and (d < 1e-1).mean() > 0.9, (np.median(d), (d < 1e-1).mean())
 
 
 def test_a16_video_output(case):
@@ -120,8 +135,11 @@ def test_a16_video_output(case):
     sr = {(rows_ref[r], l): (s, e) for r, l, s, e in zip(orf["rows"], orf["pred_labels"], orf["pred_scores"], orf["pred_entropys"])}
     common = set(sg) & set(sr)
     assert len(common) >= 8, (sorted(sg), sorted(sr))                   # top-10 as a set keyed by (query, label)
+    tol_s, tol_e = (2e-3, 2e-2) if case["precision"] == "fp32" else (2e-2, 1e-1)
+    _report(case, "top10", dict(common=len(common), max_score_err=max(abs(sg[k][0] - sr[k][0]) for k in common),
+                                max_entropy_err=max(abs(sg[k][1] - sr[k][1]) for k in common)))
     for k in common:
-        assert abs(sg[k][0] - sr[k][0]) < 2e-3 and abs(sg[k][1] - sr[k][1]) < 2e-2
+        assert abs(sg[k][0] - sr[k][0]) < tol_s and abs(sg[k][1] - sr[k][1]) < tol_e
     # masks of the common detections
     mg = {(q, l): m for q, l, m in zip(og["pred_queries"], og["pred_labels"], og["pred_masks"])}
     mr = {(rows_ref[r], l): m for r, l, m in zip(orf["rows"], orf["pred_labels"], orf["pred_masks"])}
