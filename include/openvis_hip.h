@@ -127,6 +127,12 @@ int ovis_attention_f32(const float* q, long long q_bs, int q_ld, const float* k,
                        const uint8_t* mask, long long mask_ld, const int* row_open, int B, int H, int Nq, int Nk,
                        int D, float scale, int nsplit, float* workspace, ovis_stream_t stream);
 
+/* fp16-operand variant for the CLIP ViT tower (no mask, no split): q/k/v/out fp16, f32 softmax + accumulation, D = 64.
+ *   element (b,row,h,d) at ptr[b*bs + row*ld + h*D + d] (strides in halfs, multiples of 8). */
+int ovis_attention_f16(const void* q, long long q_bs, int q_ld, const void* k, long long k_bs, int k_ld, const void* v,
+                       long long v_bs, int v_ld, void* out, long long o_bs, int o_ld, int B, int H, int Nq, int Nk,
+                       int D, float scale, ovis_stream_t stream);
+
 /* ---- OpenVIS-specific fused stages ---------------------------------------------------------------
  * Encoder deformable attention with the softmax over L*P and the sampling-location arithmetic fused in
  *   (ops/modules/ms_deform_attn.py:102-118 + msdeformattn.py:155-168 + cuh:242-304).

@@ -1,0 +1,187 @@
+// fp16-operand flash attention for the CLIP ViT tower (197 x 197 tokens, heads x 64) on gfx950.
+//
+// Replaces the nn.MultiheadAttention core of mask_adapted_clip/model.py:254-263 on the fp16 CLIP path (the reference's
+// GPU CLIP runs in fp16).  Same structure as attention_f32.hip — transposed scores S^T = K Q^T so one query lives on a
+// lane and P is directly the B operand of O^T += V^T P^T — with v_mfma_f32_32x32x16_f16 (f32 accumulate, f32 softmax):
+//   * K tile [32 keys][64] fp16 in LDS, rows padded to 144 B, fragments by ds_read_b128 (conflict-free);
+//   * V tile [32 keys][64] fp16 in LDS, rows padded to 192 B, consumed TRANSPOSED with ds_read_b64_tr_b16
+//     (gfx950 hardware transpose read): a 16-lane group fetches a 4-key x 16-d block and each lane receives the
+//     4 keys of its own d column — exactly the k-order in which the accumulator registers hold P
+//     (register r of lane-half h  <->  key (r&3) + 8(r>>2) + 4h), so P never leaves registers.
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+
+struct AttnH {
+  const _Float16* q; long long q_bs; int q_ld;
+  const _Float16* k; long long k_bs; int k_ld;
+  const _Float16* v; long long v_bs; int v_ld;
+  _Float16* out; long long o_bs; int o_ld;
+  int B, H, Nq, Nk;
+  float scale;
+};
+
+__device__ __forceinline__ f16x4 tr_read(const _Float16* lds_ptr) {
+  const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(const_cast<_Float16*>(lds_ptr)));
+  return __builtin_bit_cast(f16x4, r);
+}
+
+__global__ void __launch_bounds__(256)
+flash_attn_f16_kernel(AttnH a) {
+  constexpr int D = 64;
+  constexpr int KROW = D + 8;    // halfs -> 144 B rows (ds_read_b128, conflict-free)
+  constexpr int VROW = D + 32;   // halfs -> 192 B rows (4 rows x 64 B of a tr-read group tile the 64 banks)
+  __shared__ __attribute__((aligned(16))) _Float16 Ks[32 * KROW];
+  __shared__ __attribute__((aligned(16))) _Float16 Vs[32 * VROW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const int qi = q0 + r32;
+  const bool wave_active = q0 < a.Nq;
+  const bool q_ok = qi < a.Nq;
+
+  const _Float16* qp = a.q + b * a.q_bs + (long long)head * D;
+  const _Float16* kp = a.k + b * a.k_bs + (long long)head * D;
+  const _Float16* vp = a.v + b * a.v_bs + (long long)head * D;
+
+  // Q fragments (B operand of S^T = K Q^T): lane (q = r32, half h), step s holds d = 16s + 8h .. +8
+  f16x8 qf[D / 16];
+#pragma unroll
+  for (int s = 0; s < D / 16; ++s) {
+    const uint4 t = *reinterpret_cast<const uint4*>(qp + (long long)(q_ok ? qi : 0) * a.q_ld + 16 * s + 8 * h);
+    const uint4 z = make_uint4(q_ok ? t.x : 0u, q_ok ? t.y : 0u, q_ok ? t.z : 0u, q_ok ? t.w : 0u);
+    qf[s] = __builtin_bit_cast(f16x8, z);
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // staging: thread -> (key row = tid/8, 16-byte chunk = tid%8)
+  const int srow = tid >> 3, sch = tid & 7;
+  uint4 pk, pv;
+  bool okr;
+  auto gload = [&](int kt) {
+    const int key = kt + srow;
+    okr = key < a.Nk;
+    const int kc = okr ? key : 0;
+    pk = *reinterpret_cast<const uint4*>(kp + (long long)kc * a.k_ld + sch * 8);
+    pv = *reinterpret_cast<const uint4*>(vp + (long long)kc * a.v_ld + sch * 8);
+  };
+  auto lstore = [&]() {
+    *reinterpret_cast<uint4*>(&Ks[srow * KROW + sch * 8]) = make_uint4(okr ? pk.x : 0u, okr ? pk.y : 0u, okr ? pk.z : 0u, okr ? pk.w : 0u);
+    *reinterpret_cast<uint4*>(&Vs[srow * VROW + sch * 8]) = make_uint4(okr ? pv.x : 0u, okr ? pv.y : 0u, okr ? pv.z : 0u, okr ? pv.w : 0u);
+  };
+
+  // transposed-read addressing: group g = lane>>4 fetches block rows key0+q (q = (lane&15)>>2), cols dcol0 + 4p (p = lane&3)
+  const int g = lane >> 4, li = lane & 15;
+  const int tr_off = (li >> 2) * VROW + 16 * (g & 1) + 4 * (li & 3);   // + key0*VROW + t*32
+
+  const float scale_log2e = a.scale * 1.4426950408889634f;
+  gload(0);
+  for (int kt = 0; kt < a.Nk; kt += 32) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (kt + 32 < a.Nk) gload(kt + 32);
+    if (!wave_active) continue;
+
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < D / 16; ++st) {
+      const f16x8 kk = *reinterpret_cast<const f16x8*>(&Ks[r32 * KROW + 16 * st + 8 * h]);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kk, qf[st], s, 0, 0, 0);
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float x = key < a.Nk ? s[r] * scale_log2e : -INFINITY;
+      s[r] = x;
+      mt = fmaxf(mt, x);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);       // finite: every tile holds at least one valid key
+    const float alpha = exp2f(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = exp2f(s[r] - m_new);
+      s[r] = p;
+      ps += p;
+    }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+
+    // O^T += V^T P^T : step sp covers keys 16sp..16sp+15; lane-half h element j <-> key 16sp + 4h + (j&3) + 8(j>>2)
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      f16x8 pb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pb[j] = (_Float16)s[8 * sp + j];
+      const int key0a = 16 * sp + 4 * h, key0b = key0a + 8;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f16x4 va = tr_read(&Vs[key0a * VROW + t * 32 + tr_off]);
+        const f16x4 vb = tr_read(&Vs[key0b * VROW + t * 32 + tr_off]);
+        f16x8 av;
+        av[0] = va[0]; av[1] = va[1]; av[2] = va[2]; av[3] = va[3];
+        av[4] = vb[0]; av[5] = vb[1]; av[6] = vb[2]; av[7] = vb[3];
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, pb, o[t], 0, 0, 0);
+      }
+    }
+  }
+
+  if (!wave_active || !q_ok) return;
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+  _Float16* op = a.out + b * a.o_bs + (long long)qi * a.o_ld + head * D;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d = t * 32 + 8 * g4 + 4 * h;
+      f16x4 r;
+      r[0] = (_Float16)(o[t][4 * g4] * inv); r[1] = (_Float16)(o[t][4 * g4 + 1] * inv);
+      r[2] = (_Float16)(o[t][4 * g4 + 2] * inv); r[3] = (_Float16)(o[t][4 * g4 + 3] * inv);
+      *reinterpret_cast<f16x4*>(op + d) = r;
+    }
+}
+
+}  // namespace
+
+extern "C" int ovis_attention_f16(const void* q, long long q_bs, int q_ld, const void* k, long long k_bs, int k_ld,
+                                  const void* v, long long v_bs, int v_ld, void* out, long long o_bs, int o_ld, int B,
+                                  int H, int Nq, int Nk, int D, float scale, ovis_stream_t stream) {
+  OVIS_REQUIRE(q && k && v && out, "attention_f16: null pointer");
+  OVIS_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "attention_f16: non-positive size");
+  OVIS_REQUIRE(D == 64, "attention_f16: head dim %d not supported (64)", D);
+  OVIS_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && v_ld % 8 == 0 && o_ld % 4 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 &&
+                   v_bs % 8 == 0 && o_bs % 4 == 0,
+               "attention_f16: strides must be multiples of 8 halfs");
+  OVIS_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)out & 7) == 0,
+               "attention_f16: q/k/v must be 16-byte aligned");
+  AttnH a;
+  a.q = (const _Float16*)q; a.q_bs = q_bs; a.q_ld = q_ld; a.k = (const _Float16*)k; a.k_bs = k_bs; a.k_ld = k_ld;
+  a.v = (const _Float16*)v; a.v_bs = v_bs; a.v_ld = v_ld; a.out = (_Float16*)out; a.o_bs = o_bs; a.o_ld = o_ld;
+  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+  hipLaunchKernelGGL(flash_attn_f16_kernel, dim3(ovis::cdiv(Nq, 128), B * H), dim3(256), 0, (hipStream_t)stream, a);
+  return ovis::check_launch("attention_f16");
+}

@@ -91,9 +91,10 @@ class ClipVisual:
         x = ops.vit_embed_ln(x, w["cls"], w["pos"], w["ln_pre.w"], w["ln_pre.b"], M, L1)
         for i in range(self.layers):
             h = ops.layernorm(x, w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"], out_f16=True)
-            qkv = ops.gemm_nt_f16(h.view(-1, C), w[f"{i}.attn.in_proj_weight.h"], w[f"{i}.attn.in_proj_bias"])   # f32
-            att = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], M, Hh, L1, L1, D, L1 * 3 * C, 3 * C, L1 * 3 * C, 3 * C,
-                                L1 * 3 * C, 3 * C, out_f16=True)
+            qkv = ops.gemm_nt_f16(h.view(-1, C), w[f"{i}.attn.in_proj_weight.h"], w[f"{i}.attn.in_proj_bias"],
+                                  out_f16=True)
+            att = ops.attention_f16(qkv, qkv[:, C:], qkv[:, 2 * C:], M, Hh, L1, L1, D, L1 * 3 * C, 3 * C, L1 * 3 * C,
+                                    3 * C, L1 * 3 * C, 3 * C)
             x = ops.gemm_nt_f16(att.view(-1, C), w[f"{i}.attn.out_proj.weight.h"], w[f"{i}.attn.out_proj.bias"],
                                 x.view(-1, C)).view(M, L1, C)
             h = ops.layernorm(x, w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"], out_f16=True)

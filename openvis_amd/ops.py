@@ -180,6 +180,18 @@ def attention(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, mask
     return out
 
 
+def attention_f16(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld):
+    """fp16 q/k/v views (element (b,row,h,d) at data_ptr + (b*bs + row*ld + h*D + d)*2) -> fp16 out [B,Nq,H*D]."""
+    for t in (q, k, v):
+        if not (t.is_cuda and t.dtype == torch.float16):
+            raise _lib.OvisError("attention_f16 needs fp16 HIP tensors")
+    out = torch.empty((B, Nq, H * D), dtype=torch.float16, device=q.device)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.call("ovis_attention_f16", vp(q), _ll(q_bs), q_ld, vp(k), _ll(k_bs), k_ld, vp(v), _ll(v_bs), v_ld, out,
+              _ll(Nq * H * D), H * D, B, H, Nq, Nk, D, float(D) ** -0.5, _lib.stream_ptr())
+    return out
+
+
 def msda_encoder_fused(value, oa, shapes, lsi, M=8, L=3, P=4):
     """value [B,S,C], oa [B,S,M*L*P*3] -> [B,S,C]."""
     _chk(value, oa, shapes, lsi)

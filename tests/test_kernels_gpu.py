@@ -29,9 +29,9 @@ def test_gemm_f16(M, N, K, out_f16):
     assert _rel(out, ref) < (2e-3 if out_f16 else 2e-5)
 
 
-def test_gemm_f16_integer_exact():
+@pytest.mark.parametrize("M,N,K", [(150, 70, 128), (2001, 1027, 128), (4099, 768, 192)])   # small-tile, LDS-DMA paths
+def test_gemm_f16_integer_exact(M, N, K):
     from openvis_amd import ops
-    M, N, K = 150, 70, 128
     a = (torch.arange(M * K).reshape(M, K) % 13 - 6).half()
     w = (torch.arange(N * K).reshape(N, K) % 7 - 3).half()
     out = ops.gemm_nt_f16(a.cuda(), w.cuda()).cpu()
@@ -76,6 +76,31 @@ def test_attention(B, H, Nq, Nk, D, nsplit, masked):
         out16 = ops.attention(qd, kvd, kvd[..., C:], B, H, Nq, Nk, D, Nq * C, C, Nk * 2 * C, 2 * C, Nk * 2 * C, 2 * C, md, ro, 1,
                               out_f16=True)
         assert out16.dtype == torch.float16 and _rel(out16, ref) < 2e-3
+
+
+@pytest.mark.parametrize("B,H,N", [(3, 12, 197), (2, 4, 64), (1, 16, 577), (5, 2, 33)])
+def test_attention_f16(B, H, N):
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(N)
+    D, C = 64, H * 64
+    qkv = (torch.randn(B * N, 3 * C, generator=g)).half()
+    q, k, v = [qkv[:, i * C:(i + 1) * C].float().reshape(B, N, H, D) for i in range(3)]
+    ref = _attn_ref(q, k, v)
+    qd = qkv.cuda()
+    out = ops.attention_f16(qd, qd[:, C:], qd[:, 2 * C:], B, H, N, N, D, N * 3 * C, 3 * C, N * 3 * C, 3 * C, N * 3 * C, 3 * C)
+    assert out.dtype == torch.float16 and _rel(out, ref) < 3e-3
+    # exact-integer layout check: one-hot attention (huge logit on key (7q+3) % N) must copy that V row exactly
+    vi = torch.randint(-8, 9, (B, N, H, D)).float()
+    idx = (7 * torch.arange(N) + 3) % N
+    # keys: make key idx[q] the (near-)unique maximiser for query q via a +-1 code
+    code = torch.randn(N, D, generator=g).sign()
+    qi = code[None, :, None, :].expand(B, N, H, D).clone() * 4.0
+    ki = torch.zeros(B, N, H, D)
+    ki[:, idx] = qi                                                # key idx[q] == query q's code -> score 16*D/8 >> others
+    x = torch.cat([qi.reshape(B * N, C), ki.reshape(B * N, C), vi.reshape(B * N, C)], 1).half().cuda()
+    out = ops.attention_f16(x, x[:, C:], x[:, 2 * C:], B, H, N, N, D, N * 3 * C, 3 * C, N * 3 * C, 3 * C, N * 3 * C, 3 * C)
+    ref = _attn_ref(qi, ki, vi)
+    assert _rel(out, ref) < 3e-3
 
 
 def test_layernorm_groupnorm_maxpool():
