@@ -20,6 +20,7 @@
 //    of the same N panel.
 //  * Epilogue fused: bias, residual add, ReLU / QuickGELU, written as 128-B row segments.
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -94,7 +95,7 @@ template <int BM, int BN, typename LoaderA, bool VECB>
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(LoaderA la, const float* __restrict__ B, long long ldb, float* __restrict__ C,
                 long long ldc, int M, int N, int K, const float* __restrict__ bias,
-                const float* __restrict__ R, long long ldr, int act, int tiles_m) {
+                const float* __restrict__ R, long long ldr, int act, int tiles_n) {
   constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 MFMA tiles per wave (2x2 waves)
   constexpr int A_LD = BM * 8 / 256, B_LD = BN * 8 / 256;  // float4 loads per thread per K tile
   __shared__ __attribute__((aligned(16))) float As[BM * LDS_STRIDE];
@@ -104,8 +105,10 @@ gemm_f32_kernel(LoaderA la, const float* __restrict__ B, long long ldb, float* _
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const unsigned bid = ovis::xcd_remap(blockIdx.x, gridDim.x);
-  const int bm = (int)(bid % tiles_m) * BM;   // consecutive blocks of an XCD share the B panel
-  const int bn = (int)(bid / tiles_m) * BN;
+  // N-tile index fastest: the blocks an XCD runs concurrently share their A tile (same bm) and the few B tiles, so
+  // A is fetched from HBM/MALL once instead of once per N tile (bm-fastest order measured MALL-bound at ~5 TB/s)
+  const int bn = (int)(bid % tiles_n) * BN;
+  const int bm = (int)(bid / tiles_n) * BM;
 
   // staging assignment: 8 threads cover one 32-float row; 32 rows per pass
   const int srow = tid >> 3, scol = (tid & 7) * 4;
@@ -168,50 +171,22 @@ gemm_f32_kernel(LoaderA la, const float* __restrict__ B, long long ldb, float* _
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             const float b = e == 0 ? bf[j][q].x : e == 1 ? bf[j][q].y : e == 2 ? bf[j][q].z : bf[j][q].w;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[i][j], 0, 0, 0);   // roles swapped: lane = row m
           }
         }
       }
     }
   }
 
-  // epilogue: lane holds column (lane&31); rows (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // epilogue (roles swapped): lane holds output row m = tile row r32; registers hold columns 8g + 4h + e
+  const bool vec_ok = ((ldc & 3) == 0) && (!R || (ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                      (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = bn + wc * (BN / 2) + j * 32 + r32;
-    const bool n_ok = n < N;
-    const int nc = n_ok ? n : 0;
-    const float bv = bias ? bias[nc] : 0.f;
+  for (int i = 0; i < TM; ++i) {
+    const long long m = bm + wr * (BM / 2) + i * 32 + r32;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int m0 = bm + wr * (BM / 2) + i * 32 + 4 * h;
-      float rv[16];
-      if (R) {          // all 16 residual loads issued back to back from clamped addresses (no per-element branch)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + (r & 3) + 8 * (r >> 2);
-          rv[r] = R[(long long)(m < M ? m : 0) * ldr + nc];
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) rv[r] += acc[i][j][r] + bv;
-      if (act == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = fmaxf(rv[r], 0.f);
-      } else if (act == 2) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = rv[r] * (1.f / (1.f + expf(-1.702f * rv[r])));
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (r & 3) + 8 * (r >> 2);
-        const float v = rv[r];
-        if (n_ok && m < M) C[(long long)m * ldc + n] = v;
-      }
-    }
+    for (int j = 0; j < TN; ++j)
+      ovis::epilogue_tile<false>(acc[i][j], m, m < M, bn + wc * (BN / 2) + j * 32, h, N, C, ldc, bias, R, ldr, act, vec_ok);
   }
 }
 
@@ -225,7 +200,7 @@ int launch_gemm(LoaderA la, const float* B, long long ldb, float* C, long long l
   {                                                                                                                 \
     const int tm = ovis::cdiv(M, BM_), tn = ovis::cdiv(N, BN_);                                                     \
     hipLaunchKernelGGL((gemm_f32_kernel<BM_, BN_, LoaderA, VB_>), dim3(tm * tn), dim3(256), 0, stream, la, B, ldb, C, \
-                       ldc, M, N, K, bias, R, ldr, act, tm);                                                        \
+                       ldc, M, N, K, bias, R, ldr, act, tn);                                                        \
   }
   if (blocks128 >= 256) {
     if (vecb) GEMM_LAUNCH(128, 128, true) else GEMM_LAUNCH(128, 128, false)

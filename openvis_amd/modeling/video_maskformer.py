@@ -76,7 +76,12 @@ class VideoMaskFormer:
         Q, T, h, w = pred_masks_lowres.shape
         masks = ops.final_masks(pred_masks_lowres, sel_q, padded_hw[0], padded_hw[1], img_size[0], img_size[1],
                                 output_height, output_width)
-        masks_cpu = masks.cpu().bool()
+        # D2H of the 10 output masks (video_maskformer.py:283): pinned staging buffer from torch's caching host
+        # allocator + one async copy; uint8 {0,1} is re-viewed as bool (no host-side conversion pass).
+        host = torch.empty(masks.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(masks, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        masks_cpu = host.view(torch.bool)
         return {"image_size": (output_height, output_width), "pred_entropys": ent.cpu().tolist(),
                 "pred_scores": score.cpu().tolist(), "pred_labels": labels, "pred_masks": [m for m in masks_cpu],
                 "pred_queries": sel_q.cpu().tolist()}

@@ -13,7 +13,8 @@ def _rel(out, ref):
     return (out.double().cpu() - ref.double()).abs().max().item() / (ref.double().abs().max().item() + 1e-12)
 
 
-@pytest.mark.parametrize("M,N,K", [(197 * 3, 768, 768), (1000, 3072, 768), (130, 96, 64), (4000, 2304, 768)])
+@pytest.mark.parametrize("M,N,K", [(197 * 3, 768, 768), (1000, 3072, 768), (130, 96, 64), (4000, 2304, 768),
+                                   (16389, 4100, 256), (40000, 768, 3072)])     # the last two take the 256x256 ring kernel
 @pytest.mark.parametrize("out_f16", [False, True])
 def test_gemm_f16(M, N, K, out_f16):
     from openvis_amd import ops
@@ -29,13 +30,15 @@ def test_gemm_f16(M, N, K, out_f16):
     assert _rel(out, ref) < (2e-3 if out_f16 else 2e-5)
 
 
-@pytest.mark.parametrize("M,N,K", [(150, 70, 128), (2001, 1027, 128), (4099, 768, 192)])   # small-tile, LDS-DMA paths
+@pytest.mark.parametrize("M,N,K", [(150, 70, 128), (2001, 1027, 128), (4099, 768, 192), (8200, 2060, 96),
+                                   (16384, 4096, 32)])                          # small-tile, LDS-DMA 128 and 256-ring paths
 def test_gemm_f16_integer_exact(M, N, K):
     from openvis_amd import ops
     a = (torch.arange(M * K).reshape(M, K) % 13 - 6).half()
     w = (torch.arange(N * K).reshape(N, K) % 7 - 3).half()
-    out = ops.gemm_nt_f16(a.cuda(), w.cuda()).cpu()
-    assert torch.equal(out, a.float() @ w.float().T)
+    out = ops.gemm_nt_f16(a.cuda(), w.cuda())
+    ref = (a.cuda().float() @ w.cuda().float().T)      # exact in f32 for these small integers
+    assert torch.equal(out, ref)
 
 
 def _attn_ref(q, k, v, mask=None):
