@@ -134,28 +134,22 @@ def main():
     ap.add_argument("--clip-precision", default="fp16", choices=["fp16", "fp32"])
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
+    from openvis_amd import distributed as D
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, world, local_rank = D.init_from_env("nccl")              # "nccl" is RCCL on ROCm
     device = torch.device("cuda", local_rank)
 
     from openvis_amd import ops
     model, sd, text = build_model(device, clip_precision=args.clip_precision)
-    # each rank owns its own clips (replicas over clips)
-    clips = [synth_frames(T_CLIP, H720, W720, 1000 * rank + i, device) for i in range(2)]
+    # clip-level sharding (InferenceSampler layout): a global list of 2*world clips, each rank owns a contiguous shard
+    my_clips = D.inference_shard(2 * world, rank, world)
+    clips = [synth_frames(T_CLIP, H720, W720, 1000 + i, device) for i in my_clips]
     inputs = [[{"image": [f for f in c], "dataset_name": "synthetic_burst_val"}] for c in clips]
 
     def sync_all():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
 
     out = None
     for i in range(args.warmup):
@@ -166,10 +160,7 @@ def main():
         out = model(inputs[i % len(inputs)])
     sync_all()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.max_over_ranks(elapsed, device)
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream -----------
     # one extra (untimed) step with per-launch events around every f32-MFMA GEMM launch
@@ -215,7 +206,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(sd, text)
         print(json.dumps(line))
-    if dist is not None:
+    if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

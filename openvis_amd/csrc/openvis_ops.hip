@@ -10,6 +10,10 @@
 namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// hardware exp2 / rcp sigmoid for the soft-mask crop values (rel. error ~1e-6; never feeds a threshold)
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 // bilinear tap set for torch's upsample_bilinear2d(align_corners=False): src = (dst+0.5)*scale-0.5, clamped at 0
 struct Tap { int i0, i1; float l0, l1; };
@@ -254,30 +258,48 @@ clip_crop_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ m
   const float* mp = masks + ((long long)q * T + t) * h * w;
   const float usy = (float)h / (float)Hp, usx = (float)w / (float)Wp;
   float f0 = 0.f, f1 = 0.f, f2 = 0.f, mk = 0.f;
+  const float step = bin / (float)grid;
   for (int iy = 0; iy < grid; ++iy) {
-    const float yy = by0 + (float)py * bin + ((float)iy + .5f) * bin / (float)grid;
+    const float yy = by0 + (float)py * bin + ((float)iy + .5f) * step;
+    // everything that depends on the sample row only (frame rows, mask rows + their low-res taps)
+    float yf = yy; int fyl, fyh;
+    const bool fy_ok = ra_prep(yf, H, fyl, fyh);
+    const float fly = yf - (float)fyl, fhy = 1.f - fly;
+    float ym = yy; int myl, myh;
+    const bool my_ok = ra_prep(ym, Hp, myl, myh);
+    const float mly = ym - (float)myl, mhy = 1.f - mly;
+    const Tap tyl = make_tap(myl, usy, h), tyh = make_tap(myh, usy, h);
+    const float* rl0 = mp + (long long)tyl.i0 * w; const float* rl1 = mp + (long long)tyl.i1 * w;
+    const float* rh0 = mp + (long long)tyh.i0 * w; const float* rh1 = mp + (long long)tyh.i1 * w;
+    const uint8_t* fr0 = fp + (long long)fyl * W; const uint8_t* fr1 = fp + (long long)fyh * W;
     for (int ix = 0; ix < grid; ++ix) {
-      const float xx = bx0 + (float)px * bin + ((float)ix + .5f) * bin / (float)grid;
+      const float xx = bx0 + (float)px * bin + ((float)ix + .5f) * step;
       {  // frame sample (size H x W, un-padded)
-        float y = yy, x = xx; int yl, yh, xl, xh;
-        if (ra_prep(y, H, yl, yh) && ra_prep(x, W, xl, xh)) {
-          const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
-          const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-          const long long o1 = (long long)yl * W + xl, o2 = (long long)yl * W + xh, o3 = (long long)yh * W + xl, o4 = (long long)yh * W + xh;
-          f0 += w1 * (float)fp[o1] + w2 * (float)fp[o2] + w3 * (float)fp[o3] + w4 * (float)fp[o4];
-          f1 += w1 * (float)fp[plane + o1] + w2 * (float)fp[plane + o2] + w3 * (float)fp[plane + o3] + w4 * (float)fp[plane + o4];
-          f2 += w1 * (float)fp[2 * plane + o1] + w2 * (float)fp[2 * plane + o2] + w3 * (float)fp[2 * plane + o3] + w4 * (float)fp[2 * plane + o4];
+        float x = xx; int xl, xh;
+        if (fy_ok && ra_prep(x, W, xl, xh)) {
+          const float lx = x - (float)xl, hx = 1.f - lx;
+          const float w1 = fhy * hx, w2 = fhy * lx, w3 = fly * hx, w4 = fly * lx;
+          f0 += w1 * (float)fr0[xl] + w2 * (float)fr0[xh] + w3 * (float)fr1[xl] + w4 * (float)fr1[xh];
+          f1 += w1 * (float)fr0[plane + xl] + w2 * (float)fr0[plane + xh] + w3 * (float)fr1[plane + xl] + w4 * (float)fr1[plane + xh];
+          f2 += w1 * (float)fr0[2 * plane + xl] + w2 * (float)fr0[2 * plane + xh] + w3 * (float)fr1[2 * plane + xl] + w4 * (float)fr1[2 * plane + xh];
         }
       }
       {  // soft-mask sample (size Hp x Wp): taps are sigmoid(x4 bilinear upsample of the low-res logits)
-        float y = yy, x = xx; int yl, yh, xl, xh;
-        if (ra_prep(y, Hp, yl, yh) && ra_prep(x, Wp, xl, xh)) {
-          const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
-          const Tap tyl = make_tap(yl, usy, h), tyh = make_tap(yh, usy, h);
+        float x = xx; int xl, xh;
+        if (my_ok && ra_prep(x, Wp, xl, xh)) {
+          const float lx = x - (float)xl, hx = 1.f - lx;
           const Tap txl = make_tap(xl, usx, w), txh = make_tap(xh, usx, w);
-          const float v1 = sigmoidf_(bilerp(mp, w, tyl, txl)), v2 = sigmoidf_(bilerp(mp, w, tyl, txh));
-          const float v3 = sigmoidf_(bilerp(mp, w, tyh, txl)), v4 = sigmoidf_(bilerp(mp, w, tyh, txh));
-          mk += (hy * hx) * v1 + (hy * lx) * v2 + (ly * hx) * v3 + (ly * lx) * v4;
+          // the four up-sampled logits share their low-res rows; same operation order as bilerp()
+          const float a_ll = rl0[txl.i0], b_ll = rl0[txl.i1], c_ll = rl1[txl.i0], d_ll = rl1[txl.i1];
+          const float a_lh = rl0[txh.i0], b_lh = rl0[txh.i1], c_lh = rl1[txh.i0], d_lh = rl1[txh.i1];
+          const float a_hl = rh0[txl.i0], b_hl = rh0[txl.i1], c_hl = rh1[txl.i0], d_hl = rh1[txl.i1];
+          const float a_hh = rh0[txh.i0], b_hh = rh0[txh.i1], c_hh = rh1[txh.i0], d_hh = rh1[txh.i1];
+          const float u1 = tyl.l0 * (txl.l0 * a_ll + txl.l1 * b_ll) + tyl.l1 * (txl.l0 * c_ll + txl.l1 * d_ll);
+          const float u2 = tyl.l0 * (txh.l0 * a_lh + txh.l1 * b_lh) + tyl.l1 * (txh.l0 * c_lh + txh.l1 * d_lh);
+          const float u3 = tyh.l0 * (txl.l0 * a_hl + txl.l1 * b_hl) + tyh.l1 * (txl.l0 * c_hl + txl.l1 * d_hl);
+          const float u4 = tyh.l0 * (txh.l0 * a_hh + txh.l1 * b_hh) + tyh.l1 * (txh.l0 * c_hh + txh.l1 * d_hh);
+          mk += (mhy * hx) * fast_sigmoid(u1) + (mhy * lx) * fast_sigmoid(u2) + (mly * hx) * fast_sigmoid(u3) +
+                (mly * lx) * fast_sigmoid(u4);
         }
       }
     }
