@@ -45,12 +45,13 @@ def synth_text(K, dim, seed=1):
     return torch.nn.functional.normalize(base + 0.05 * torch.randn(K, dim, generator=g), dim=-1)
 
 
-def build_model(device, seed=42, clip_precision="fp16"):
+def build_model(device, seed=42, clip_precision="fp16", precision="mixed"):
     from openvis_amd import config, weights
     from openvis_amd.catalog import MetadataCatalog
     cfg = config.get_cfg()
     cfg.MODEL.DEVICE = str(device)
     cfg.MODEL.CLIP_ADAPTER.PRECISION = clip_precision
+    cfg.MODEL.PRECISION = precision
     model = config.build_model(cfg)
     model.device = torch.device(device)
     sd = weights.random_init(weights.openvis_r50_spec(), seed=seed)
@@ -132,6 +133,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clip-precision", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--precision", default="mixed", choices=["mixed", "fp32"],
+                    help="dense-path policy: mixed = the reference's autocast policy, fp32 = exact f32 everywhere")
     args = ap.parse_args()
 
     from openvis_amd import distributed as D
@@ -140,7 +143,7 @@ def main():
     device = torch.device("cuda", local_rank)
 
     from openvis_amd import ops
-    model, sd, text = build_model(device, clip_precision=args.clip_precision)
+    model, sd, text = build_model(device, clip_precision=args.clip_precision, precision=args.precision)
     # clip-level sharding (InferenceSampler layout): a global list of 2*world clips, each rank owns a contiguous shard
     my_clips = D.inference_shard(2 * world, rank, world)
     clips = [synth_frames(T_CLIP, H720, W720, 1000 + i, device) for i in my_clips]
@@ -194,10 +197,13 @@ def main():
             "metric": "frames/sec (whole node) OpenVIS R50 720p inference", "value": round(frames_total / elapsed, 3),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16" if model.clip_adapter.precision == "fp16" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16" if (model.clip_adapter.precision == "fp16" or args.precision == "mixed") else "f32", "data": "synthetic",
             "config": {"workload": "openvis_R50 720p (720x1280 -> 736x1280), 100 queries, 482 classes, 5-frame clips, "
                                    "ClipAdapter ViT-B/16, random-init weights", "frames_per_step": T_CLIP,
-                       "precision": "backbone/pixel decoder/decoder/masks/logits: exact-f32 MFMA; CLIP ViT GEMM operands: "
+                       "precision": ("reference autocast policy: backbone + decoder GEMM operands fp16 / f32 accumulate, "
+                                     "pixel decoder + logits exact-f32 MFMA; " if args.precision == "mixed" else
+                                     "backbone/pixel decoder/decoder/masks/logits: exact-f32 MFMA; ")
+                                    + "CLIP ViT GEMM operands: "
                                     + ("fp16 with f32 accumulation (the reference's GPU CLIP dtype)"
                                        if model.clip_adapter.precision == "fp16" else "f32"),
                        "valid_crops_per_clip": n_valid, "parallelism": f"clip-replicas x{world}"},

@@ -108,6 +108,16 @@ int ovis_pe_sine_f32(float* out, int T, int H, int W, int num_pos_feats, int thr
 int ovis_gemm_nt_f16(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int M, int N,
                      int K, const float* bias, const float* residual, long long ldr, int act, int out_f16,
                      ovis_stream_t stream);
+/* "autocast" variants: f32 activations rounded to fp16 while staged into LDS, fp16 weights (cast once at load), f32
+ *   accumulation / bias / residual / output.  The arithmetic of the reference's GPU path for the backbone convolutions
+ *   and the decoder's Linear / einsum under torch.cuda.amp.autocast (train_net.py:241); the pixel decoder stays f32
+ *   (msdeformattn.py:329).  K % 8 == 0 (conv: KH*KW*Cin % 8 == 0). */
+int ovis_gemm_nt_f32a_f16w(const float* A, long long lda, const void* B16, long long ldb, float* C, long long ldc, int M,
+                           int N, int K, const float* bias, const float* residual, long long ldr, int act,
+                           ovis_stream_t stream);
+int ovis_conv2d_nhwc_f32a_f16w(const float* x, const void* w16, float* y, int N, int H, int W, int Cin, int Cout, int KH,
+                               int KW, int stride, int pad, const float* bias, const float* residual, int act,
+                               ovis_stream_t stream);
 /* y (fp16) = x (f32), n % 4 == 0 (weights are cast once at load). */
 int ovis_cast_f32_to_f16(const float* x, void* y, long long n, ovis_stream_t stream);
 

@@ -61,6 +61,10 @@ def get_cfg():
     return _to_node({
         "MODEL": {
             "META_ARCHITECTURE": "OpenVIS", "DEVICE": "cuda", "WEIGHTS": "",
+            # not a reference key — MI355X arithmetic policy of the dense path:
+            #   "mixed" = the reference's own GPU policy (autocast: backbone + decoder GEMM operands fp16 with f32
+            #             accumulation; pixel decoder forced f32, msdeformattn.py:329),  "fp32" = exact f32 everywhere.
+            "PRECISION": "mixed",
             "PIXEL_MEAN": [123.675, 116.280, 103.530], "PIXEL_STD": [58.395, 57.120, 57.375],
             "BACKBONE": {"NAME": "build_resnet_backbone", "FREEZE_AT": 0},
             "RESNETS": {"DEPTH": 50, "STRIDE_IN_1X1": False, "OUT_FEATURES": ["res2", "res3", "res4", "res5"],

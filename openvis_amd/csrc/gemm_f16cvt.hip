@@ -1,0 +1,171 @@
+// f32-activation x fp16-weight GEMM / implicit-GEMM convolution with fp16 MFMA operands and f32 accumulation.
+//
+//   C[m,n] (f32) = act( sum_k fp16(A[m,k]) * B16[n,k] + bias[n] + R[m,n] )
+//
+// This is the "autocast" arithmetic of the reference's GPU path: under torch.cuda.amp.autocast (train_net.py:241)
+// the backbone convolutions and the decoder's Linear / einsum run with fp16 operands and f32 accumulation, while the
+// pixel decoder is forced to f32 (msdeformattn.py:329).  Activations stay f32 in HBM (no other kernel changes);
+// they are rounded to fp16 while being staged into LDS, weights are cast once at load.
+// Same tiling as gemm_f16.hip's register-staged kernel: 128x128x64 (or 64x64x64) tile, v_mfma_f32_32x32x16_f16,
+// K-permuted fragments, rows padded to 144 B, operand roles swapped for the vectorised epilogue (gemm_epilogue.h).
+#include "common.h"
+#include "gemm_epilogue.h"
+#include "gemm_loaders.h"
+
+namespace {
+
+using ovis::ConvA;
+using ovis::ConvGeom;
+using ovis::DenseA;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+constexpr int BKH = 64;
+constexpr int LDS_ROW = BKH + 8;
+
+__device__ __forceinline__ uint4 cvt8(bool ok0, float4 a, bool ok1, float4 b) {
+  union { _Float16 h[8]; uint4 u; } o;
+  o.h[0] = (_Float16)(ok0 ? a.x : 0.f); o.h[1] = (_Float16)(ok0 ? a.y : 0.f);
+  o.h[2] = (_Float16)(ok0 ? a.z : 0.f); o.h[3] = (_Float16)(ok0 ? a.w : 0.f);
+  o.h[4] = (_Float16)(ok1 ? b.x : 0.f); o.h[5] = (_Float16)(ok1 ? b.y : 0.f);
+  o.h[6] = (_Float16)(ok1 ? b.z : 0.f); o.h[7] = (_Float16)(ok1 ? b.w : 0.f);
+  return o.u;
+}
+
+template <int BM, int BN, typename LoaderA>
+__global__ void __launch_bounds__(256)
+gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, float* __restrict__ C, long long ldc,
+                   int M, int N, int K, const float* __restrict__ bias, const float* __restrict__ R, long long ldr,
+                   int act, int tiles_n) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A_LD = BM * 8 / 256, B_LD = BN * 8 / 256;   // 8-element chunks per thread per K tile
+  __shared__ __attribute__((aligned(16))) _Float16 As[BM * LDS_ROW];
+  __shared__ __attribute__((aligned(16))) _Float16 Bs[BN * LDS_ROW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const unsigned bid = ovis::xcd_remap(blockIdx.x, gridDim.x);
+  const int bn = (int)(bid % tiles_n) * BN;
+  const int bm = (int)(bid / tiles_n) * BM;
+  const int srow = tid >> 3, scol = (tid & 7) * 8;
+
+  float4 pa[A_LD][2];
+  bool oka[A_LD][2];
+  uint4 pb[B_LD];
+  bool okb[B_LD];
+  auto gload = [&](int k0) {
+    const int k = k0 + scol;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      pa[i][0] = la.load(bm + srow + i * 32, k, oka[i][0]);
+      pa[i][1] = la.load(bm + srow + i * 32, k + 4, oka[i][1]);
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int n = bn + srow + i * 32;
+      okb[i] = n < N && k < K;
+      pb[i] = *reinterpret_cast<const uint4*>(B + (okb[i] ? (long long)n * ldb + k : 0));
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i)
+      *reinterpret_cast<uint4*>(&As[(srow + i * 32) * LDS_ROW + scol]) = cvt8(oka[i][0], pa[i][0], oka[i][1], pa[i][1]);
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i)
+      *reinterpret_cast<uint4*>(&Bs[(srow + i * 32) * LDS_ROW + scol]) =
+          make_uint4(okb[i] ? pb[i].x : 0u, okb[i] ? pb[i].y : 0u, okb[i] ? pb[i].z : 0u, okb[i] ? pb[i].w : 0u);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int r32 = lane & 31, h = lane >> 5;
+  const int nk = (K + BKH - 1) / BKH;
+  gload(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (kt + 1 < nk) gload((kt + 1) * BKH);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      f16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(&As[(wr * (BM / 2) + i * 32 + r32) * LDS_ROW + h * 32 + s * 8]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(&Bs[(wc * (BN / 2) + j * 32 + r32) * LDS_ROW + h * 32 + s * 8]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // roles swapped
+    }
+  }
+
+  const bool vec_ok = ((ldc & 3) == 0) && (!R || (ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                      (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const long long m = bm + wr * (BM / 2) + i * 32 + r32;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      ovis::epilogue_tile<false>(acc[i][j], m, m < M, bn + wc * (BN / 2) + j * 32, h, N, C, ldc, bias, R, ldr, act, vec_ok);
+  }
+}
+
+template <typename LoaderA>
+int launch(LoaderA la, const _Float16* B, long long ldb, float* C, long long ldc, int M, int N, int K, const float* bias,
+           const float* R, long long ldr, int act, hipStream_t stream) {
+  const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128);
+  if (blocks128 >= 256) {
+    const int tm = ovis::cdiv(M, 128), tn = ovis::cdiv(N, 128);
+    hipLaunchKernelGGL((gemm_f16cvt_kernel<128, 128, LoaderA>), dim3(tm * tn), dim3(256), 0, stream, la, B, ldb, C, ldc, M, N,
+                       K, bias, R, ldr, act, tn);
+  } else {
+    const int tm = ovis::cdiv(M, 64), tn = ovis::cdiv(N, 64);
+    hipLaunchKernelGGL((gemm_f16cvt_kernel<64, 64, LoaderA>), dim3(tm * tn), dim3(256), 0, stream, la, B, ldb, C, ldc, M, N, K,
+                       bias, R, ldr, act, tn);
+  }
+  return ovis::check_launch("gemm_f16cvt");
+}
+
+}  // namespace
+
+extern "C" int ovis_gemm_nt_f32a_f16w(const float* A, long long lda, const void* B16, long long ldb, float* C, long long ldc,
+                                      int M, int N, int K, const float* bias, const float* residual, long long ldr,
+                                      int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(A && B16 && C, "gemm_nt_f32a_f16w: null pointer");
+  OVIS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt_f32a_f16w: non-positive size");
+  OVIS_REQUIRE(K % 8 == 0 && lda % 4 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && ldc >= N,
+               "gemm_nt_f32a_f16w: need K %% 8 == 0, lda %% 4 == 0, ldb %% 8 == 0");
+  OVIS_REQUIRE((((uintptr_t)A | (uintptr_t)B16) & 15) == 0, "gemm_nt_f32a_f16w: A/B must be 16-byte aligned");
+  OVIS_REQUIRE(act >= 0 && act <= 2, "gemm_nt_f32a_f16w: unknown activation %d", act);
+  OVIS_REQUIRE(!residual || ldr >= N, "gemm_nt_f32a_f16w: residual leading dimension too small");
+  return launch(DenseA<true>{A, lda, M, K}, (const _Float16*)B16, ldb, C, ldc, M, N, K, bias, residual, ldr, act,
+                (hipStream_t)stream);
+}
+
+extern "C" int ovis_conv2d_nhwc_f32a_f16w(const float* x, const void* w16, float* y, int N, int H, int W, int Cin, int Cout,
+                                          int KH, int KW, int stride, int pad, const float* bias, const float* residual,
+                                          int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(x && w16 && y, "conv2d_nhwc_f32a_f16w: null pointer");
+  OVIS_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
+               "conv2d_nhwc_f32a_f16w: bad geometry");
+  OVIS_REQUIRE(Cin % 4 == 0 && (KH * KW * Cin) % 8 == 0, "conv2d_nhwc_f32a_f16w: need Cin %% 4 == 0 and KH*KW*Cin %% 8 == 0");
+  OVIS_REQUIRE((((uintptr_t)x | (uintptr_t)w16) & 15) == 0, "conv2d_nhwc_f32a_f16w: x/w must be 16-byte aligned");
+  OVIS_REQUIRE(act >= 0 && act <= 2, "conv2d_nhwc_f32a_f16w: unknown activation %d", act);
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  OVIS_REQUIRE(OH > 0 && OW > 0, "conv2d_nhwc_f32a_f16w: empty output");
+  const long long M = (long long)N * OH * OW;
+  OVIS_REQUIRE(M < (1ll << 31), "conv2d_nhwc_f32a_f16w: too many output pixels");
+  const int K = KH * KW * Cin;
+  ConvA la{x, ConvGeom{H, W, Cin, OH, OW, KH, KW, stride, pad}, (int)M, K};
+  return launch(la, (const _Float16*)w16, (long long)K, y, (long long)Cout, (int)M, Cout, K, bias, residual, (long long)Cout,
+                act, (hipStream_t)stream);
+}

@@ -1,0 +1,67 @@
+// A-operand loaders shared by the f32 and the f32->fp16-converting GEMM kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ovis {
+
+struct ConvGeom {
+  int H, W, Cin, OH, OW, KH, KW, stride, pad;
+};
+
+// ---- A-operand loaders: fetch 4 consecutive k of row m as a float4 (zero outside) ----------------
+// Loads are BRANCH-FREE (clamped address + select): a predicated load compiles to an exec-masked branch with its
+// own s_waitcnt, which serialises the 8 staging loads of a K tile (2x slower GEMM when measured).
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+// dense row-major [M,K]; VEC: K % 4 == 0, lda % 4 == 0 and 16-byte aligned base (a chunk is all-in or all-out)
+template <bool VEC>
+struct DenseA {
+  const float* A;
+  long long lda;
+  int M, K;
+  // raw load from a clamped address; `ok` tells the caller whether to keep it (selected at LDS-store time so the
+  // s_waitcnt for this load lands AFTER the current tile's MFMAs, not right behind the load)
+  __device__ __forceinline__ float4 load(int m, int k, bool& ok) const {
+    if constexpr (VEC) {
+      ok = m < M && k < K;
+      const float* p = A + (ok ? (long long)m * lda + k : 0);
+      return *reinterpret_cast<const float4*>(p);
+    } else {
+      ok = true;
+      const bool okm = m < M;
+      const float* row = A + (okm ? (long long)m * lda : 0);
+      float4 v;
+      v.x = (okm && k < K) ? row[min(k, K - 1)] : 0.f;
+      v.y = (okm && k + 1 < K) ? row[min(k + 1, K - 1)] : 0.f;
+      v.z = (okm && k + 2 < K) ? row[min(k + 2, K - 1)] : 0.f;
+      v.w = (okm && k + 3 < K) ? row[min(k + 3, K - 1)] : 0.f;
+      return v;
+    }
+  }
+};
+
+// Implicit im2col over an NHWC input; k = (kh*KW + kw)*Cin + c, Cin % 4 == 0 (float4 never straddles a pixel).
+struct ConvA {
+  const float* X;
+  ConvGeom g;
+  int M, K;
+  __device__ __forceinline__ float4 load(int m, int k, bool& ok) const {
+    const int ow = m % g.OW;
+    const int t = m / g.OW;
+    const int oh = t % g.OH;
+    const int n = t / g.OH;
+    const int c = k % g.Cin;
+    const int t2 = k / g.Cin;
+    const int kw = t2 % g.KW;
+    const int kh = t2 / g.KW;
+    const int ih = oh * g.stride - g.pad + kh;
+    const int iw = ow * g.stride - g.pad + kw;
+    ok = m < M && k < K && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+    const float* p = X + (ok ? (((long long)n * g.H + ih) * g.W + iw) * g.Cin + c : 0);
+    return *reinterpret_cast<const float4*>(p);
+  }
+};
+
+}  // namespace ovis

@@ -26,10 +26,14 @@ def _fold(sd, p, eps=1e-5, pad_cin_to=None):
 class ResNet:
     size_divisibility = 32
 
-    def __init__(self, depth=50, out_features=("res2", "res3", "res4", "res5")):
+    def __init__(self, depth=50, out_features=("res2", "res3", "res4", "res5"), precision="fp16"):
         self.depth = depth
         self.out_features = tuple(out_features)
+        # "fp16": conv operands rounded to fp16, f32 accumulation (= the reference under autocast, train_net.py:241);
+        # "fp32": exact-f32 MFMA.  Activations are f32 in HBM either way.
+        self.precision = precision
         self.w = {}
+        self.w16 = {}
 
     def output_shape(self):
         ch = {"res2": 256, "res3": 512, "res4": 1024, "res5": 2048}
@@ -45,17 +49,20 @@ class ResNet:
                 for c in ("conv1", "conv2", "conv3", "shortcut"):
                     if f"{p}.{c}.weight" in sd:
                         self.w[f"{name}.{i}.{c}"] = tuple(map(d, _fold(sd, f"{p}.{c}")))
+        self.w16 = {k: ops.cast_f16(v[0]) for k, v in self.w.items()} if self.precision == "fp16" else {}
         return self
 
     def _conv(self, x, key, stride=1, pad=0, residual=None, relu=True):
         w, b = self.w[key]
+        w16 = self.w16.get(key)
         act = ops.ACT_RELU if relu else ops.ACT_NONE
         if w.shape[1] == 1 and w.shape[2] == 1 and stride == 1:
             N, H, W, C = x.shape
             y = ops.gemm_nt(x.view(-1, C), w.view(w.shape[0], C), b,
-                            residual.view(-1, w.shape[0]) if residual is not None else None, act)
+                            residual.view(-1, w.shape[0]) if residual is not None else None, act,
+                            w16=w16.view(w.shape[0], C) if w16 is not None else None)
             return y.view(N, H, W, -1)
-        return ops.conv2d_nhwc(x, w, stride, pad, b, residual, act)
+        return ops.conv2d_nhwc(x, w, stride, pad, b, residual, act, w16=w16)
 
     def forward(self, x):
         """x: f32 [T,Hp,Wp,4] (normalised, channel 3 zero) -> {res2..res5} NHWC."""
@@ -79,4 +86,5 @@ class ResNet:
 
 @BACKBONE_REGISTRY.register()
 def build_resnet_backbone(cfg, input_shape=None):
-    return ResNet(cfg.MODEL.RESNETS.DEPTH, cfg.MODEL.RESNETS.OUT_FEATURES)
+    return ResNet(cfg.MODEL.RESNETS.DEPTH, cfg.MODEL.RESNETS.OUT_FEATURES,
+                  precision="fp32" if cfg.MODEL.get("PRECISION", "mixed") == "fp32" else "fp16")

@@ -21,7 +21,7 @@ def build_transformer_decoder(cfg, in_channels, mask_classification=True):
 @TRANSFORMER_DECODER_REGISTRY.register()
 class VideoMultiScaleMaskedTransformerDecoder:
     def __init__(self, in_channels, mask_classification=True, *, num_classes, hidden_dim, num_queries, nheads,
-                 dim_feedforward, dec_layers, pre_norm, mask_dim, enforce_input_project, num_frames):
+                 dim_feedforward, dec_layers, pre_norm, mask_dim, enforce_input_project, num_frames, precision="fp16"):
         if pre_norm:
             raise NotImplementedError("PRE_NORM=True is not used by any reference config")
         if in_channels != hidden_dim or enforce_input_project:
@@ -29,7 +29,11 @@ class VideoMultiScaleMaskedTransformerDecoder:
         self.mask_classification = mask_classification
         self.num_frames, self.num_heads, self.num_layers = num_frames, nheads, dec_layers
         self.num_queries, self.hidden_dim, self.num_feature_levels = num_queries, hidden_dim, 3
+        # "fp16": Linear / einsum operands rounded to fp16 with f32 accumulation (the reference decoder runs under
+        # autocast, train_net.py:241); LayerNorm, softmax, residuals f32.  "fp32": exact-f32 MFMA everywhere.
+        self.precision = precision
         self.w = {}
+        self.h = {}
         self._pos_cache = {}
 
     @classmethod
@@ -40,7 +44,8 @@ class VideoMultiScaleMaskedTransformerDecoder:
                    nheads=cfg.MODEL.MASK_FORMER.NHEADS, dim_feedforward=cfg.MODEL.MASK_FORMER.DIM_FEEDFORWARD,
                    dec_layers=cfg.MODEL.MASK_FORMER.DEC_LAYERS - 1, pre_norm=cfg.MODEL.MASK_FORMER.PRE_NORM,
                    mask_dim=cfg.MODEL.SEM_SEG_HEAD.MASK_DIM, enforce_input_project=cfg.MODEL.MASK_FORMER.ENFORCE_INPUT_PROJ,
-                   num_frames=cfg.INPUT.SAMPLING_FRAME_NUM)
+                   num_frames=cfg.INPUT.SAMPLING_FRAME_NUM,
+                   precision="fp32" if cfg.MODEL.get("PRECISION", "mixed") == "fp32" else "fp16")
 
     def load_state_dict(self, sd, prefix="sem_seg_head.predictor.", device="cuda"):
         sd = dict(sd)
@@ -75,7 +80,13 @@ class VideoMultiScaleMaskedTransformerDecoder:
         for j in range(3):
             w[f"mask_embed.{j}.w"], w[f"mask_embed.{j}.b"] = g(f"mask_embed.layers.{j}.weight"), g(f"mask_embed.layers.{j}.bias")
         self._pos_cache.clear()
+        self.h = {k: ops.cast_f16(v) for k, v in w.items() if v.dim() == 2 and v.shape[1] % 8 == 0 and
+                  (k.split(".")[-1].startswith("w") or k.endswith("weight")) and "query" not in k and "level_embed" not in k} \
+            if self.precision == "fp16" else {}
         return self
+
+    def _mm(self, x, wk, bk=None, residual=None, act=ops.ACT_NONE):
+        return ops.gemm_nt(x, self.w[wk], self.w[bk] if bk else None, residual, act, w16=self.h.get(wk))
 
     def _pos(self, T, H, W):
         key = (T, H, W)
@@ -86,9 +97,9 @@ class VideoMultiScaleMaskedTransformerDecoder:
     def _mask_embed(self, output):
         w = self.w
         dec = ops.layernorm(output, w["decoder_norm.weight"], w["decoder_norm.bias"])
-        h = ops.gemm_nt(dec, w["mask_embed.0.w"], w["mask_embed.0.b"], None, ops.ACT_RELU)
-        h = ops.gemm_nt(h, w["mask_embed.1.w"], w["mask_embed.1.b"], None, ops.ACT_RELU)
-        return dec, ops.gemm_nt(h, w["mask_embed.2.w"], w["mask_embed.2.b"])
+        h = self._mm(dec, "mask_embed.0.w", "mask_embed.0.b", None, ops.ACT_RELU)
+        h = self._mm(h, "mask_embed.1.w", "mask_embed.1.b", None, ops.ACT_RELU)
+        return dec, self._mm(h, "mask_embed.2.w", "mask_embed.2.b")
 
     @staticmethod
     def _nsplit(nk):
@@ -110,12 +121,14 @@ class VideoMultiScaleMaskedTransformerDecoder:
             kin.append(ops.add_bcast(s, self._pos(T, H, W)))                                           # memory + pos
             sc = hm // H
             pooled.append(ops.center_pool(mask_features, sc).view(T * H * W, C) if sc > 1 else mask_features.view(-1, C))
+        f16 = self.precision == "fp16"
+        pooled16 = [ops.cast_f16(p) for p in pooled] if f16 else [None] * len(pooled)       # einsum operands under autocast
         query_embed = w["query_embed.weight"]
         output = w["query_feat.weight"]
 
         def head_mask(out, level):
             _, me = self._mask_embed(out)
-            logits = ops.gemm_nt(me, pooled[level])                       # [Q, T*H_l*W_l]
+            logits = ops.gemm_nt(me, pooled[level], w16=pooled16[level])   # [Q, T*H_l*W_l]
             return ops.attn_mask_from_logits(logits)
 
         amask, row_open = head_mask(output, 0)
@@ -123,26 +136,27 @@ class VideoMultiScaleMaskedTransformerDecoder:
             li = i % self.num_feature_levels
             Nk = src[li].shape[0]
             # masked cross-attention (:417-426, CrossAttentionLayer.forward_post :110-122)
-            qp = ops.gemm_nt(ops.add_bcast(output, query_embed), w[f"ca{i}.wq"], w[f"ca{i}.bq"])
-            kp = ops.gemm_nt(kin[li], w[f"ca{i}.wk"], w[f"ca{i}.bk"])
-            vp = ops.gemm_nt(src[li], w[f"ca{i}.wv"], w[f"ca{i}.bv"])
+            qp = self._mm(ops.add_bcast(output, query_embed), f"ca{i}.wq", f"ca{i}.bq")
+            kp = self._mm(kin[li], f"ca{i}.wk", f"ca{i}.bk")
+            vp = self._mm(src[li], f"ca{i}.wv", f"ca{i}.bv")
             att = ops.attention(qp, kp, vp, 1, H8, Q, Nk, D, 0, C, 0, C, 0, C, amask, row_open, self._nsplit(Nk))
-            y = ops.gemm_nt(att.view(Q, C), w[f"ca{i}.wo"], w[f"ca{i}.bo"], output)
+            y = self._mm(att.view(Q, C), f"ca{i}.wo", f"ca{i}.bo", output)
             output = ops.layernorm(y, w[f"ca{i}.nw"], w[f"ca{i}.nb"])
             # self-attention (:428-432, SelfAttentionLayer.forward_post :52-62)
-            qk = ops.gemm_nt(ops.add_bcast(output, query_embed), w[f"sa{i}.wqk"], w[f"sa{i}.bqk"])   # [Q, 2C] = q | k
-            vv = ops.gemm_nt(output, w[f"sa{i}.wv"], w[f"sa{i}.bv"])
+            qk = self._mm(ops.add_bcast(output, query_embed), f"sa{i}.wqk", f"sa{i}.bqk")   # [Q, 2C] = q | k
+            vv = self._mm(output, f"sa{i}.wv", f"sa{i}.bv")
             att = ops.attention(qk, qk[:, C:], vv, 1, H8, Q, Q, D, 0, 2 * C, 0, 2 * C, 0, C)
-            y = ops.gemm_nt(att.view(Q, C), w[f"sa{i}.wo"], w[f"sa{i}.bo"], output)
+            y = self._mm(att.view(Q, C), f"sa{i}.wo", f"sa{i}.bo", output)
             output = ops.layernorm(y, w[f"sa{i}.nw"], w[f"sa{i}.nb"])
             # FFN (:434-437, FFNLayer.forward_post :175-179)
-            hdn = ops.gemm_nt(output, w[f"ffn{i}.linear1.weight"], w[f"ffn{i}.linear1.bias"], None, ops.ACT_RELU)
-            y = ops.gemm_nt(hdn, w[f"ffn{i}.linear2.weight"], w[f"ffn{i}.linear2.bias"], output)
+            hdn = self._mm(output, f"ffn{i}.linear1.weight", f"ffn{i}.linear1.bias", None, ops.ACT_RELU)
+            y = self._mm(hdn, f"ffn{i}.linear2.weight", f"ffn{i}.linear2.bias", output)
             output = ops.layernorm(y, w[f"ffn{i}.norm.weight"], w[f"ffn{i}.norm.bias"])
             if i + 1 < self.num_layers:
                 amask, row_open = head_mask(output, (i + 1) % self.num_feature_levels)
         dec, me = self._mask_embed(output)
-        pred_masks = ops.gemm_nt(me, mask_features.view(-1, C)).view(1, Q, T, hm, wm)   # einsum bqc,btchw->bqthw (:460)
+        mf2 = mask_features.view(-1, C)
+        pred_masks = ops.gemm_nt(me, mf2, w16=ops.cast_f16(mf2) if f16 else None).view(1, Q, T, hm, wm)   # einsum (:460)
         out = {"pred_masks": pred_masks, "pred_embeds": dec}
         if self.mask_classification:
             out["pred_logits"] = ops.gemm_nt(dec, w["class_embed.weight"], w["class_embed.bias"]).view(1, Q, -1)

@@ -48,16 +48,23 @@ def _chk(*ts):
             raise _lib.OvisError("openvis_amd ops need contiguous HIP device tensors (no CPU fallback)")
 
 
-def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None):
-    """out[m,n] = act(sum_k a[m,k] w[n,k] + bias[n] + residual[m,n]); a [...,K] -> out [...,N]."""
+def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None):
+    """out[m,n] = act(sum_k a[m,k] w[n,k] + bias[n] + residual[m,n]); a [...,K] -> out [...,N].
+    w16 (an fp16 copy of w) selects the autocast arithmetic: operands rounded to fp16, f32 accumulation."""
     K = a.shape[-1]
     N = w.shape[0]
     a2 = a.reshape(-1, K)
-    _chk(a2, w, bias, residual)
+    _chk(a2, w, bias, residual, w16)
     M = a2.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     r2 = residual.reshape(-1, N) if residual is not None else None
+    if w16 is not None and K % 8 == 0:
+        big = ((M + 127) // 128) * ((N + 127) // 128) >= 256
+        with _Prof(f"gemm_f16cvt_kernel<{'128,128' if big else '64,64'},DenseA>", 2.0 * M * N * K):
+            _lib.call("ovis_gemm_nt_f32a_f16w", a2, _ll(K), w16, _ll(K), out, _ll(N), M, N, K, bias, r2, _ll(N), act,
+                      _lib.stream_ptr())
+        return out.view(*a.shape[:-1], N)
     with _Prof(_gemm_variant(M, N, "DenseA"), 2.0 * M * N * K):
         _lib.call("ovis_gemm_nt_f32", a2, _ll(K), w, _ll(w.stride(0)), out, _ll(N), M, N, K, bias, r2, _ll(N), act,
                   _lib.stream_ptr())
@@ -89,14 +96,20 @@ def cast_f16(x):
     return y
 
 
-def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE):
-    """x [N,H,W,Cin], w [Cout,KH,KW,Cin] -> [N,OH,OW,Cout]."""
-    _chk(x, w, bias, residual)
+def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE, w16=None):
+    """x [N,H,W,Cin], w [Cout,KH,KW,Cin] -> [N,OH,OW,Cout]. w16: fp16 copy of w -> autocast arithmetic."""
+    _chk(x, w, bias, residual, w16)
     N, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
     OH = (H + 2 * pad - KH) // stride + 1
     OW = (W + 2 * pad - KW) // stride + 1
     y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device)
+    if w16 is not None and (KH * KW * Cin) % 8 == 0:
+        big = ((N * OH * OW + 127) // 128) * ((Cout + 127) // 128) >= 256
+        with _Prof(f"gemm_f16cvt_kernel<{'128,128' if big else '64,64'},ConvA>", 2.0 * N * OH * OW * Cout * KH * KW * Cin):
+            _lib.call("ovis_conv2d_nhwc_f32a_f16w", x, w16, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act,
+                      _lib.stream_ptr())
+        return y
     with _Prof(_gemm_variant(N * OH * OW, Cout, "ConvA"), 2.0 * N * OH * OW * Cout * KH * KW * Cin):
         _lib.call("ovis_conv2d_nhwc_f32", x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act,
                   _lib.stream_ptr())

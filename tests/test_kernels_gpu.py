@@ -41,6 +41,33 @@ def test_gemm_f16_integer_exact(M, N, K):
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("M,N,K", [(100, 256, 256), (96600 // 5, 256, 256), (40000, 512, 2048), (777, 130, 264)])
+def test_gemm_f32a_f16w(M, N, K):
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(M)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = (a.half().double() @ w.half().double().T + b.double() + r.double()).relu()    # fp16-rounded operands, exact sum
+    wd = w.cuda()
+    out = ops.gemm_nt(a.cuda(), wd, b.cuda(), r.cuda(), ops.ACT_RELU, w16=ops.cast_f16(wd))
+    assert _rel(out, ref) < 2e-5
+
+
+def test_conv_f32a_f16w():
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(2)
+    for (N, H, W, Cin, Cout, k, s_, p_) in [(2, 23, 40, 64, 64, 3, 1, 1), (1, 46, 80, 128, 256, 3, 2, 1), (2, 12, 20, 256, 512, 1, 2, 0)]:
+        x = torch.randn(N, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+        b = torch.randn(Cout, generator=g)
+        ref = F.conv2d(x.half().double(), w.half().double(), b.double(), stride=s_, padding=p_).relu()
+        wd = w.permute(0, 2, 3, 1).contiguous().cuda()
+        y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), wd, s_, p_, b.cuda(), None, ops.ACT_RELU, w16=ops.cast_f16(wd))
+        assert _rel(y.permute(0, 3, 1, 2), ref) < 2e-5
+
+
 def _attn_ref(q, k, v, mask=None):
     # q [B,Nq,H,D] ...; mask bool [Nq,Nk] True = blocked (rows fully blocked -> unmasked)
     s = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) / math.sqrt(q.shape[-1])

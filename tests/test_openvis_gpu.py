@@ -22,7 +22,10 @@ def _frames(seed=0):
     return base.to(torch.uint8)
 
 
-@pytest.fixture(scope="module", params=["fp32", "fp16"])
+# (dense-path policy, CLIP tower operand dtype): all-f32 parity mode, f32 dense + fp16 CLIP, and the reference's own
+# autocast policy ("mixed": backbone + decoder GEMM operands fp16 / f32 accumulate, pixel decoder f32, CLIP fp16)
+@pytest.fixture(scope="module", params=[("fp32", "fp32"), ("fp32", "fp16"), ("mixed", "fp16")],
+                ids=["f32", "f32+clip16", "mixed"])
 def case(request):
     from openvis_amd import config, weights
     from openvis_amd.catalog import MetadataCatalog
@@ -32,9 +35,11 @@ def case(request):
     spec = (weights.resnet50_spec() + weights.pixel_decoder_spec() + weights.video_decoder_spec() +
             weights.clip_visual_spec(**CLIP_ARCH))
     sd = weights.random_init(spec, seed=7)
+    policy, clip_prec = request.param
     cfg = config.get_cfg()
+    cfg.MODEL.PRECISION = policy
     model = config.build_model(cfg)
-    model.clip_adapter = ClipAdapter("tiny", arch=CLIP_ARCH, precision=request.param)
+    model.clip_adapter = ClipAdapter("tiny", arch=CLIP_ARCH, precision=clip_prec)
     model.load_state_dict(sd)
     names = [f"class_{i}" for i in range(K)]
     MetadataCatalog.get("synthetic_val").set(thing_classes=names)
@@ -52,7 +57,8 @@ def case(request):
     with torch.no_grad():
         out_ref = TR.openvis_forward(frames, sd, text, stages=st_ref, clip_heads=CLIP_ARCH["heads"],
                                      clip_resolution=CLIP_ARCH["resolution"])
-    return dict(out_gpu=out_gpu, out_ref=out_ref, st_gpu=st_gpu, st_ref=st_ref, precision=request.param)
+    return dict(out_gpu=out_gpu, out_ref=out_ref, st_gpu=st_gpu, st_ref=st_ref, precision=clip_prec, policy=policy,
+                tag=f"{policy}+clip_{clip_prec}")
 
 
 def _report(case, key, val):
@@ -60,7 +66,7 @@ def _report(case, key, val):
     os.makedirs("gpurun_out", exist_ok=True)
     path = "gpurun_out/parity_report.json"
     d = json.load(open(path)) if os.path.exists(path) else {}
-    d.setdefault(case["precision"], {})[key] = val
+    d.setdefault(case["tag"], {})[key] = val
     json.dump(d, open(path, "w"), indent=1)
 
 
@@ -75,16 +81,17 @@ def test_a1_preprocess(case):
 
 
 def test_a2_backbone(case):
+    tol = 1e-4 if case["policy"] == "fp32" else 5e-3                     # f32 exact-MFMA vs fp16-operand autocast policy
     for k in ("res2", "res3", "res4", "res5"):
         g = case["st_gpu"]["features"][k].permute(0, 3, 1, 2).cpu()
-        assert _rel(g, case["st_ref"]["feats"][k]) < 1e-4, k             # f32, different summation order / folded BN
+        assert _rel(g, case["st_ref"]["feats"][k]) < tol, k              # different summation order / folded BN
 
 
 def test_a3_a8_masks(case):
     g = case["st_gpu"]["pred_masks"].cpu()
     r = case["st_ref"]["pred_masks"]
     assert g.shape == r.shape
-    assert _rel(g, r) < 5e-3
+    assert _rel(g, r) < (5e-3 if case["policy"] == "fp32" else 3e-2)
     agree = ((g > 0) == (r > 0)).float().mean().item()
     inter = ((g > 0) & (r > 0)).sum().item()
     union = ((g > 0) | (r > 0)).sum().item()
@@ -121,7 +128,10 @@ def test_a12_clip_logits_and_probs(case):
     # cosine logits x100: north-star tolerance 1e-3 on the cosine -> 1e-1 on the x100 logits.
     # fp32 tower: ~1e-3 on the logits; fp16 GEMM operands (the reference's GPU dtype): within the 1e-1 bound.
     _report(case, "clip_logit_abs_err", dict(median=float(np.median(d)), p99=float(np.quantile(d, 0.99)), max=float(d.max())))
-    if case["precision"] == "fp32":
+    if case["policy"] != "fp32":
+        # crops follow masks that differ in a few boundary pixels: bound the bulk, report the tail
+        assert np.median(d) < 5e-2 and (d < 2e-1).mean() > 0.9, (np.median(d), (d < 2e-1).mean())
+    elif case["precision"] == "fp32":
         assert np.median(d) < 1e-2 and (d < 1e-1).mean() > 0.97, (np.median(d), (d < 1e-1).mean())
     else:
         assert np.median(d) < 5e-2 and (d < 1e-1).mean() > 0.9, (np.median(d), (d < 1e-1).mean())
@@ -135,7 +145,7 @@ def test_a16_video_output(case):
     sr = {(rows_ref[r], l): (s, e) for r, l, s, e in zip(orf["rows"], orf["pred_labels"], orf["pred_scores"], orf["pred_entropys"])}
     common = set(sg) & set(sr)
     assert len(common) >= 8, (sorted(sg), sorted(sr))                   # top-10 as a set keyed by (query, label)
-    tol_s, tol_e = (2e-3, 2e-2) if case["precision"] == "fp32" else (2e-2, 1e-1)
+    tol_s, tol_e = (2e-3, 2e-2) if (case["precision"] == "fp32" and case["policy"] == "fp32") else (2e-2, 1e-1)
     _report(case, "top10", dict(common=len(common), max_score_err=max(abs(sg[k][0] - sr[k][0]) for k in common),
                                 max_entropy_err=max(abs(sg[k][1] - sr[k][1]) for k in common)))
     for k in common:
