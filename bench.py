@@ -182,8 +182,20 @@ def main():
     n_launch, flops, secs = dom[1]
     achieved = flops / secs / 1e12
     peak = PEAK_F16_MFMA_TFLOPS if "f16" in dom[0].split("<")[0] else PEAK_F32_MFMA_TFLOPS
+    # HBM traffic of that kernel from the committed PMC passes of this same command (tools/pmc_traffic.py:
+    # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs); null if no summary is committed
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_bench.json")))["kernels"]
+        key = dom[0].replace("<true>", "ILb1E").replace("<false>", "ILb0E").split("<")[0]
+        for k, v in pmc.items():
+            if dom[0].split("<")[0] in k and (("ILb1E" in k) == ("<true>" in dom[0]) or "ILb" not in k):
+                traffic = v["hbm_bytes_per_launch"]
+                break
+    except Exception:
+        traffic = None
     roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "launches_per_step": n_launch, "avg_launch_ms": round(secs / n_launch * 1e3, 4),
                 "share_of_step": round(secs / (elapsed / args.steps), 3),
                 "gflop_per_launch": round(flops / n_launch / 1e9, 2),

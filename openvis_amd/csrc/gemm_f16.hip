@@ -216,74 +216,66 @@ gemm_f16_glds_kernel(const _Float16* __restrict__ A, long long lda, const _Float
   }
 }
 
-// ---- 256x256 tile, 8 wavefronts, 4-stage LDS-DMA ring with counted vmcnt (K % 32 == 0) ----------------------------
+// ---- 256x256 tile, 8 wavefronts, 2-stage LDS-DMA double buffer of 64-deep K steps (K % 64 == 0) -------------------
 // The 128x128 kernels above move 1 byte per 64 flop through L2 (>9 TB/s at 600 TF): tile-size bound.  This kernel
-// doubles the arithmetic intensity (128 flop/B) and keeps THREE 32-deep K stages of LDS-DMA in flight across raw
-// s_barriers (s_waitcnt vmcnt(8) — never 0 in the steady state), so DMA latency (~1-1.5 us under load) hides behind
-// 3 x 1024 MFMA cycles per SIMD.  512 threads = 8 waves as 2(M) x 4(N), each 128x64 = 4x2 MFMA 32x32 tiles
-// (128 accumulator registers), one workgroup per CU, 4 x 32 KB stages = 128 KB LDS.
-// Stage image: 256 A rows then 256 B rows of 64 B; the 16-B chunk index is XOR-swizzled with (row>>2)&3 on the DMA
-// source address and on the fragment read (ds_read_b128 groups then cover 16 distinct slots of a 256-B bank row).
+// doubles the arithmetic intensity (128 flop/B).  A stage holds a 64-deep K step so every DMA'd row segment is one
+// FULL 128-byte cache line (a first version with 32-deep stages issued two half-line L2 requests per line and measured
+// 1.7x the necessary L2 traffic).  512 threads = 8 waves as 2(M) x 4(N), each 128x64 = 4x2 MFMA 32x32 tiles
+// (128 accumulator registers), one workgroup per CU, 2 x 64 KB stages = 128 KB LDS.  Per stage and SIMD there are
+// 2 x 32 MFMAs (2048 cycles) between two barriers; the next stage's DMA is issued at the top of the stage and its
+// fragments are software-pipelined one MFMA step ahead, with the DMA issue interleaved among the MFMAs.
+// Stage image: 256 A rows then 256 B rows of 128 B; the 16-B chunk index is XOR-swizzled with (row>>1)&7 on the DMA
+// source address and on the fragment read (conflict-free ds_read_b128, SQ_LDS_BANK_CONFLICT == 0).
 template <bool OUT_F16>
 __global__ void __launch_bounds__(512)
 gemm_f16_256_kernel(const _Float16* __restrict__ A, long long lda, const _Float16* __restrict__ B, long long ldb,
                     void* __restrict__ Cv, long long ldc, int M, int N, int K, const float* __restrict__ bias,
-                    const float* __restrict__ R, long long ldr, int act, int tiles_n) {
-  constexpr int BM = 256, BN = 256, BKS = 32;                  // halfs per stage along K
-  constexpr int STAGE = (BM + BN) * BKS;                       // halfs per stage (32 KB)
-  constexpr int NST = 4;
-  __shared__ __attribute__((aligned(16))) _Float16 lds[NST * STAGE];
+                    const float* __restrict__ R, long long ldr, int act, int tiles_n, int n_tiles) {
+  constexpr int BM = 256, BN = 256, BKS = 64;                  // halfs per stage along K
+  constexpr int STAGE = (BM + BN) * BKS;                       // halfs per stage (64 KB)
+  __shared__ __attribute__((aligned(16))) _Float16 lds[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;                     // 2 x 4 waves
-  const unsigned bid = ovis::xcd_remap(blockIdx.x, gridDim.x);
-  const int bn = (int)(bid % tiles_n) * BN;   // N-tile fastest (A tile shared through the XCD's L2), see gemm_f32.hip
-  const int bm = (int)(bid / tiles_n) * BM;
+  // PERSISTENT: gridDim.x workgroups (one per CU) walk the tile list; the 32 workgroups of an XCD (blockIdx % 8) take
+  // 32 consecutive tiles per round (N-tile fastest), so they share their A tiles / the B panel through that XCD's L2.
+  const int nblk = gridDim.x;
+  int tile = (int)ovis::xcd_remap(blockIdx.x, nblk);
 
-  // DMA: wave w, instruction i copies the 16-row block (4w + i) of the 32 blocks of a stage (0-15: A, 16-31: B)
-  const int lrow = lane >> 2, pch = lane & 3;
-  const int lch = pch ^ ((lrow >> 2) & 3);
-  const _Float16* src[4];
+  const int lrow = lane >> 3, pch = lane & 7;
+  const _Float16* src[8];
+  auto set_src = [&](int t) {
+    const int bn_ = (t % tiles_n) * BN, bm_ = (t / tiles_n) * BM;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int blk = wave * 4 + i;
-    if (blk < 16) src[i] = A + (long long)min(bm + blk * 16 + lrow, M - 1) * lda + lch * 8;
-    else src[i] = B + (long long)min(bn + (blk - 16) * 16 + lrow, N - 1) * ldb + lch * 8;
-  }
-  auto dma = [&](int stage, int k0) {
-    _Float16* base = lds + stage * STAGE + wave * 4 * 16 * BKS;
+    for (int i = 0; i < 8; ++i) {
+      const int blk = wave * 8 + i;                            // 8-row block of the stage (0-31: A, 32-63: B)
+      const int row = (blk & 31) * 8 + lrow;
+      const int lch = pch ^ ((row >> 1) & 7);
+      if (blk < 32) src[i] = A + (long long)min(bm_ + row, M - 1) * lda + lch * 8;
+      else src[i] = B + (long long)min(bn_ + row, N - 1) * ldb + lch * 8;
+    }
+  };
+  auto dma = [&](int slot, int k0) {
+    _Float16* base = lds + slot * STAGE + wave * 8 * 8 * BKS;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + k0),
-                                       (__attribute__((address_space(3))) void*)(base + i * 16 * BKS), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(base + i * 8 * BKS), 16, 0, 0);
   };
 
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int r32 = lane & 31, h = lane >> 5;
-  // fragment offsets (halfs) inside a stage; step s reads logical chunk 2s + h at physical (2s+h) ^ ((row>>2)&3)
   int aoff[4], boff[2];
-  const int sw = (r32 >> 2) & 3;                               // tile row bases are multiples of 32 -> depends on r32 only
+  const int sw = (r32 >> 1) & 7;                               // tile row bases are multiples of 32
 #pragma unroll
   for (int i = 0; i < 4; ++i) aoff[i] = (wr * 128 + i * 32 + r32) * BKS;
 #pragma unroll
   for (int j = 0; j < 2; ++j) boff[j] = BM * BKS + (wc * 64 + j * 32 + r32) * BKS;
-  const int c0 = ((0 + h) ^ sw) << 3, c1 = ((2 + h) ^ sw) << 3;
+  int coff[4];                                                 // step s reads logical chunk 2s + h
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) coff[s4] = ((2 * s4 + h) ^ sw) << 3;
 
-  const int nk = K / BKS;
-  dma(0, 0);
-  if (nk > 1) dma(1, BKS);
-  if (nk > 2) dma(2, 2 * BKS);
-  // Software pipeline over the two 16-deep MFMA steps of every stage: the fragments of the NEXT step are fetched
-  // from LDS before the MFMAs of the current step are issued, and the stage hand-over (counted vmcnt + raw barrier)
-  // sits between step 0 and step 1, so neither LDS latency, LDS-DMA issue nor the barrier drain the matrix pipe.
+  f32x16 acc[4][2];
   auto ldfrag = [&](const _Float16* st, int cc, f16x8 (&af)[4], f16x8 (&bf)[2]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const f16x8*>(st + aoff[i] + cc);
@@ -297,36 +289,68 @@ gemm_f16_256_kernel(const _Float16* __restrict__ A, long long lda, const _Float1
       for (int j = 0; j < 2; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // roles swapped
   };
-  f16x8 a0[4], b0[2], a1[4], b1[2];
-  if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  ldfrag(lds, c0, a0, b0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const _Float16* st = lds + (kt & 3) * STAGE;
-    ldfrag(st, c1, a1, b1);                                   // step-1 fragments of this stage
-    if (kt + 3 < nk) dma((kt + 3) & 3, (kt + 3) * BKS);       // ring slot (kt-1)&3: every wave passed its barrier
-    mma(a0, b0);
-    if (kt + 1 < nk) {
-      if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                           // stage kt+1 landed for everyone; stage kt fully read
-      ldfrag(lds + ((kt + 1) & 3) * STAGE, c0, a0, b0);       // step-0 fragments of the next stage
-    }
-    mma(a1, b1);
-  }
 
   const bool vec_ok = ((ldc & 3) == 0) && (!R || (ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cv) & 15) == 0) &&
                       (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
+  const int nk = K / BKS;
+  f16x8 a0[4], b0[2], a1[4], b1[2];
+  int g = 0;                                                   // running stage counter: LDS slot = g & 1
+  if (tile < n_tiles) { set_src(tile); dma(0, 0); }
+  while (tile < n_tiles) {
+    const int bn = (tile % tiles_n) * BN, bm = (tile / tiles_n) * BM;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long long m = bm + wr * 128 + i * 32 + r32;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      ovis::epilogue_tile<OUT_F16>(acc[i][j], m, m < M, bn + wc * 64 + j * 32, h, N, Cv, ldc, bias, R, ldr, act, vec_ok);
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this tile's first stage (issued during the previous epilogue)
+    __builtin_amdgcn_s_barrier();
+    ldfrag(lds + (g & 1) * STAGE, coff[0], a0, b0);
+    for (int kt = 0; kt + 1 < nk; ++kt, ++g) {                 // all stages but the last: prefetch the next K step
+      const _Float16* st = lds + (g & 1) * STAGE;
+      dma((g + 1) & 1, (kt + 1) * BKS);
+      ldfrag(st, coff[1], a1, b1);
+      mma(a0, b0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {                            // 1 MFMA : 1 DMA piece
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      ldfrag(st, coff[2], a0, b0);
+      mma(a1, b1);
+      ldfrag(st, coff[3], a1, b1);
+      mma(a0, b0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // own pieces of the next stage landed
+      __builtin_amdgcn_s_barrier();                           // ... everyone's; and this stage is fully read
+      ldfrag(lds + ((g + 1) & 1) * STAGE, coff[0], a0, b0);
+      mma(a1, b1);
+    }
+    {                                                          // last stage: prefetch the NEXT TILE's first stage instead
+      const _Float16* st = lds + (g & 1) * STAGE;
+      const int next = tile + nblk;
+      if (next < n_tiles) { set_src(next); dma((g + 1) & 1, 0); }
+      ldfrag(st, coff[1], a1, b1);
+      mma(a0, b0);
+      ldfrag(st, coff[2], a0, b0);
+      mma(a1, b1);
+      ldfrag(st, coff[3], a1, b1);
+      mma(a0, b0);
+      mma(a1, b1);
+      ++g;
+    }
+    // epilogue: stores overlap the next tile's first-stage DMA (slot g&1); the slot just read is not rewritten before
+    // the barrier at the top of the next tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long m = bm + wr * 128 + i * 32 + r32;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        ovis::epilogue_tile<OUT_F16>(acc[i][j], m, m < M, bn + wc * 64 + j * 32, h, N, Cv, ldc, bias, R, ldr, act, vec_ok);
+    }
+    tile += nblk;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 __global__ void __launch_bounds__(256)
@@ -356,10 +380,11 @@ extern "C" int ovis_gemm_nt_f16(const void* A, long long lda, const void* B, lon
   hipStream_t s = (hipStream_t)stream;
   const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128);
   const long long blocks256 = (long long)ovis::cdiv(M, 256) * ovis::cdiv(N, 256);
-  if (blocks256 >= 256 && K % 32 == 0) {
+  if (blocks256 >= 256 && K % 64 == 0) {
     const int tm = ovis::cdiv(M, 256), tn = ovis::cdiv(N, 256);
-    if (out_f16) hipLaunchKernelGGL((gemm_f16_256_kernel<true>), dim3(tm * tn), dim3(512), 0, s, a, lda, b, ldb, C, ldc, M, N, K, bias, residual, ldr, act, tn);
-    else hipLaunchKernelGGL((gemm_f16_256_kernel<false>), dim3(tm * tn), dim3(512), 0, s, a, lda, b, ldb, C, ldc, M, N, K, bias, residual, ldr, act, tn);
+    const int grid = 256;                                       // one persistent workgroup per CU (MI355X: 256 CUs)
+    if (out_f16) hipLaunchKernelGGL((gemm_f16_256_kernel<true>), dim3(grid), dim3(512), 0, s, a, lda, b, ldb, C, ldc, M, N, K, bias, residual, ldr, act, tn, tm * tn);
+    else hipLaunchKernelGGL((gemm_f16_256_kernel<false>), dim3(grid), dim3(512), 0, s, a, lda, b, ldb, C, ldc, M, N, K, bias, residual, ldr, act, tn, tm * tn);
   } else if (blocks128 >= 128 && K % BKH == 0) {
     const int tm = ovis::cdiv(M, 128), tn = ovis::cdiv(N, 128);
     if (out_f16) hipLaunchKernelGGL((gemm_f16_glds_kernel<true>), dim3(tm * tn), dim3(256), 0, s, a, lda, b, ldb, C, ldc, M, N, K, bias, residual, ldr, act, tn);
