@@ -66,6 +66,11 @@ int ovis_msda_forward_f64(const double* value, const int64_t* spatial_shapes,
 int ovis_gemm_nt_f32(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc,
                      int M, int N, int K, const float* bias, const float* residual, long long ldr, int act,
                      ovis_stream_t stream);
+/* Batched form (independent problems z = 0..batch-1: A + z*a_bs, B + z*b_bs, C + z*c_bs; no residual): the per-frame
+ *   mask einsum "bqc,bchw->bqhw" of the frame decoders (frame_mask2former_transformer_decoder.py:139-154). */
+int ovis_gemm_nt_f32_batched(const float* A, long long lda, long long a_bs, const float* B, long long ldb,
+                             long long b_bs, float* C, long long ldc, long long c_bs, int batch, int M, int N, int K,
+                             const float* bias, int act, ovis_stream_t stream);
 /* ovis_conv2d_nhwc_f32: y[n,oh,ow,co] = act( conv(x, w) + bias[co] + residual[n,oh,ow,co] ), implicit GEMM.
  *   x [N,H,W,Cin] (Cin % 4 == 0), w [Cout,KH,KW,Cin] (the reference's [Cout,Cin,KH,KW] weight permuted once
  *   at load), y/residual [N,OH,OW,Cout]; square stride/zero padding as nn.Conv2d. */
@@ -115,6 +120,9 @@ int ovis_gemm_nt_f16(const void* A, long long lda, const void* B, long long ldb,
 int ovis_gemm_nt_f32a_f16w(const float* A, long long lda, const void* B16, long long ldb, float* C, long long ldc, int M,
                            int N, int K, const float* bias, const float* residual, long long ldr, int act,
                            ovis_stream_t stream);
+int ovis_gemm_nt_f32a_f16w_batched(const float* A, long long lda, long long a_bs, const void* B16, long long ldb,
+                                   long long b_bs, float* C, long long ldc, long long c_bs, int batch, int M, int N,
+                                   int K, const float* bias, int act, ovis_stream_t stream);
 int ovis_conv2d_nhwc_f32a_f16w(const float* x, const void* w16, float* y, int N, int H, int W, int Cin, int Cout, int KH,
                                int KW, int stride, int pad, const float* bias, const float* residual, int act,
                                ovis_stream_t stream);
@@ -126,7 +134,9 @@ int ovis_cast_f32_to_f16(const float* x, void* y, long long n, ovis_stream_t str
  *   Replaces nn.MultiheadAttention's core in video decoder:52-62 (self), 110-122 + 417-426 (masked cross) and
  *   mask_adapted_clip/model.py:254-263 (ViT); in/out projections are ovis_gemm_nt_f32 calls.
  *   q/k/v/out: element (b, row, h, d) at ptr[b*bs + row*ld + h*D + d]; D in {32, 64}.
- *   mask: uint8 [Nq, mask_ld] (1 = blocked), shared by all heads and batches, or NULL;
+ *   mask: uint8 [Nq, mask_ld] (1 = blocked), shared by all heads, or NULL; mask_bs = 0: shared by all batches (the
+ *   offline video decoder), otherwise batch b uses mask + b*mask_bs and row_open + b*Nq (per-frame decoders,
+ *   frame_mask2former_transformer_decoder.py:85-94);
  *   row_open: int32 [Nq] = number of unblocked keys per row (rows with 0 are treated as unmasked,
  *   video decoder:419) or NULL.  nsplit > 1 splits the key range over workgroups (needs
  *   ovis_attention_workspace_bytes(B,H,Nq,D,nsplit) bytes of workspace).  out_f16 != 0 writes `out` as fp16
@@ -134,8 +144,8 @@ int ovis_cast_f32_to_f16(const float* x, void* y, long long n, ovis_stream_t str
 long long ovis_attention_workspace_bytes(int B, int H, int Nq, int D, int nsplit);
 int ovis_attention_f32(const float* q, long long q_bs, int q_ld, const float* k, long long k_bs, int k_ld,
                        const float* v, long long v_bs, int v_ld, void* out, long long o_bs, int o_ld, int out_f16,
-                       const uint8_t* mask, long long mask_ld, const int* row_open, int B, int H, int Nq, int Nk,
-                       int D, float scale, int nsplit, float* workspace, ovis_stream_t stream);
+                       const uint8_t* mask, long long mask_ld, long long mask_bs, const int* row_open, int B, int H,
+                       int Nq, int Nk, int D, float scale, int nsplit, float* workspace, ovis_stream_t stream);
 
 /* fp16-operand variant for the CLIP ViT tower (no mask, no split): q/k/v/out fp16, f32 softmax + accumulation, D = 64.
  *   element (b,row,h,d) at ptr[b*bs + row*ld + h*D + d] (strides in halfs, multiples of 8). */
@@ -181,6 +191,20 @@ int ovis_topk_entropy_f32(const float* probs, const int* row_ids, int nrows, int
 /* final masks of the selected queries (openvis.py:87-96 + video_maskformer.py:273-278): out uint8 [n_sel,T,OH,OW]. */
 int ovis_final_masks_u8(const float* masks, const int* sel_q, uint8_t* out, int n_sel, int Q, int T, int h, int w, int Hp,
                         int Wp, int H, int W, int OH, int OW, ovis_stream_t stream);
+
+/* ---- A14: temporal instance linker (MinVIS tracker) ----------------------------------------------
+ * indices[t, i] = index of the frame-t query assigned to tracked slot i by the Hungarian chain of
+ *   openvis/modeling/minvis.py:28-72 (cost 1 - cosine, scipy.optimize.linear_sum_assignment on target x current,
+ *   targets of frame t = frame t-1's embeddings in their assigned order; frame 0 is matched against itself).
+ *   embeds f32 [T,Q,C]; indices int32 [T,Q]; workspace ovis_hungarian_link_workspace_bytes(Q,C) bytes.
+ *   One launch for the whole chain (the reference does one GPU->CPU sync + scipy call per frame). */
+long long ovis_hungarian_link_workspace_bytes(int Q, int C);
+int ovis_hungarian_link_f32(const float* embeds, int* indices, float* workspace, int T, int Q, int C,
+                            ovis_stream_t stream);
+/* out[b, m, :] = src[b, idx[b, m], :] (openvis/utils/index.py:4-18 batch_index) with explicit strides (in floats):
+ *   element row (b, n) of src starts at src + b*src_bs + n*src_rs; len floats per row (len % 4 == 0). */
+int ovis_batch_index_rows_f32(const float* src, long long src_bs, long long src_rs, const int* idx, float* out,
+                              long long out_bs, long long out_rs, int B, int M, long long len, ovis_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -39,8 +39,9 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ovis_last_error.restype = ctypes.c_char_p
         _lib.ovis_abi_version.restype = ctypes.c_int
-        if hasattr(_lib, "ovis_attention_workspace_bytes"):
-            _lib.ovis_attention_workspace_bytes.restype = ctypes.c_longlong
+        for fn in ("ovis_attention_workspace_bytes", "ovis_hungarian_link_workspace_bytes"):
+            if hasattr(_lib, fn):
+                getattr(_lib, fn).restype = ctypes.c_longlong
     return _lib
 
 

@@ -33,6 +33,7 @@ struct AttnArgs {
   const float* v; long long v_bs; int v_ld;
   void* out; long long o_bs; int o_ld; int out_f16;
   const uint8_t* mask; long long mask_ld;          // [Nq][mask_ld], 1 = blocked; may be null
+  long long mask_bs;                               // batch stride of mask (bytes) / of row_open (x Nq); 0 = shared
   const int* row_open;                             // [Nq] number of unblocked keys; may be null
   float* part_o; float* part_ml;                   // split-KV workspace
   int B, H, Nq, Nk, nsplit, keys_per_split;
@@ -70,8 +71,9 @@ flash_attn_f32_kernel(AttnArgs a) {
     qf[i * 4 + 0] = t.x; qf[i * 4 + 1] = t.y; qf[i * 4 + 2] = t.z; qf[i * 4 + 3] = t.w;
   }
 
-  const bool use_mask = a.mask != nullptr && q_ok && (a.row_open == nullptr || a.row_open[qi] > 0);
-  const uint8_t* mrow = a.mask ? a.mask + (long long)(q_ok ? qi : 0) * a.mask_ld : nullptr;
+  const int* ropen = a.row_open ? a.row_open + (a.mask_bs ? (long long)b * a.Nq : 0) : nullptr;
+  const bool use_mask = a.mask != nullptr && q_ok && (ropen == nullptr || ropen[qi] > 0);
+  const uint8_t* mrow = a.mask ? a.mask + b * a.mask_bs + (long long)(q_ok ? qi : 0) * a.mask_ld : nullptr;
 
   f32x16 o[DT];
 #pragma unroll
@@ -264,9 +266,9 @@ extern "C" long long ovis_attention_workspace_bytes(int B, int H, int Nq, int D,
 
 extern "C" int ovis_attention_f32(const float* q, long long q_bs, int q_ld, const float* k, long long k_bs, int k_ld,
                                   const float* v, long long v_bs, int v_ld, void* out, long long o_bs, int o_ld,
-                                  int out_f16, const uint8_t* mask, long long mask_ld, const int* row_open, int B, int H,
-                                  int Nq, int Nk, int D, float scale, int nsplit, float* workspace,
-                                  ovis_stream_t stream) {
+                                  int out_f16, const uint8_t* mask, long long mask_ld, long long mask_bs,
+                                  const int* row_open, int B, int H, int Nq, int Nk, int D, float scale, int nsplit,
+                                  float* workspace, ovis_stream_t stream) {
   OVIS_REQUIRE(q && k && v && out, "attention: null pointer");
   OVIS_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "attention: non-positive size");
   OVIS_REQUIRE(D == 32 || D == 64, "attention: head dim %d not supported (32 or 64)", D);
@@ -282,7 +284,7 @@ extern "C" int ovis_attention_f32(const float* q, long long q_bs, int q_ld, cons
   nsplit = (Nk + keys_per_split - 1) / keys_per_split;
   AttnArgs a;
   a.q = q; a.q_bs = q_bs; a.q_ld = q_ld; a.k = k; a.k_bs = k_bs; a.k_ld = k_ld; a.v = v; a.v_bs = v_bs; a.v_ld = v_ld;
-  a.out = out; a.o_bs = o_bs; a.o_ld = o_ld; a.out_f16 = out_f16; a.mask = mask; a.mask_ld = mask_ld; a.row_open = row_open;
+  a.out = out; a.o_bs = o_bs; a.o_ld = o_ld; a.out_f16 = out_f16; a.mask = mask; a.mask_ld = mask_ld; a.mask_bs = mask_bs; a.row_open = row_open;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.nsplit = nsplit; a.keys_per_split = keys_per_split; a.scale = scale;
   a.part_o = workspace;
   a.part_ml = workspace ? workspace + (long long)nsplit * B * H * Nq * D : nullptr;

@@ -36,12 +36,18 @@ template <int BM, int BN, typename LoaderA>
 __global__ void __launch_bounds__(256)
 gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, float* __restrict__ C, long long ldc,
                    int M, int N, int K, const float* __restrict__ bias, const float* __restrict__ R, long long ldr,
-                   int act, int tiles_n) {
+                   int act, int tiles_n, long long a_bs, long long b_bs, long long c_bs) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_LD = BM * 8 / 256, B_LD = BN * 8 / 256;   // 8-element chunks per thread per K tile
   __shared__ __attribute__((aligned(16))) _Float16 As[BM * LDS_ROW];
   __shared__ __attribute__((aligned(16))) _Float16 Bs[BN * LDS_ROW];
 
+  if (gridDim.y > 1) {   // batched: independent problems along blockIdx.y
+    la.advance((long long)blockIdx.y * a_bs);
+    B += (long long)blockIdx.y * b_bs;
+    C += (long long)blockIdx.y * c_bs;
+    if (R) R += (long long)blockIdx.y * c_bs;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const unsigned bid = ovis::xcd_remap(blockIdx.x, gridDim.x);
@@ -121,16 +127,17 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, fl
 
 template <typename LoaderA>
 int launch(LoaderA la, const _Float16* B, long long ldb, float* C, long long ldc, int M, int N, int K, const float* bias,
-           const float* R, long long ldr, int act, hipStream_t stream) {
-  const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128);
+           const float* R, long long ldr, int act, hipStream_t stream, int batch = 1, long long a_bs = 0, long long b_bs = 0,
+           long long c_bs = 0) {
+  const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128) * batch;
   if (blocks128 >= 256) {
     const int tm = ovis::cdiv(M, 128), tn = ovis::cdiv(N, 128);
-    hipLaunchKernelGGL((gemm_f16cvt_kernel<128, 128, LoaderA>), dim3(tm * tn), dim3(256), 0, stream, la, B, ldb, C, ldc, M, N,
-                       K, bias, R, ldr, act, tn);
+    hipLaunchKernelGGL((gemm_f16cvt_kernel<128, 128, LoaderA>), dim3(tm * tn, batch), dim3(256), 0, stream, la, B, ldb, C, ldc,
+                       M, N, K, bias, R, ldr, act, tn, a_bs, b_bs, c_bs);
   } else {
     const int tm = ovis::cdiv(M, 64), tn = ovis::cdiv(N, 64);
-    hipLaunchKernelGGL((gemm_f16cvt_kernel<64, 64, LoaderA>), dim3(tm * tn), dim3(256), 0, stream, la, B, ldb, C, ldc, M, N, K,
-                       bias, R, ldr, act, tn);
+    hipLaunchKernelGGL((gemm_f16cvt_kernel<64, 64, LoaderA>), dim3(tm * tn, batch), dim3(256), 0, stream, la, B, ldb, C, ldc, M,
+                       N, K, bias, R, ldr, act, tn, a_bs, b_bs, c_bs);
   }
   return ovis::check_launch("gemm_f16cvt");
 }
@@ -149,6 +156,19 @@ extern "C" int ovis_gemm_nt_f32a_f16w(const float* A, long long lda, const void*
   OVIS_REQUIRE(!residual || ldr >= N, "gemm_nt_f32a_f16w: residual leading dimension too small");
   return launch(DenseA<true>{A, lda, M, K}, (const _Float16*)B16, ldb, C, ldc, M, N, K, bias, residual, ldr, act,
                 (hipStream_t)stream);
+}
+
+extern "C" int ovis_gemm_nt_f32a_f16w_batched(const float* A, long long lda, long long a_bs, const void* B16, long long ldb,
+                                              long long b_bs, float* C, long long ldc, long long c_bs, int batch, int M,
+                                              int N, int K, const float* bias, int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(A && B16 && C, "gemm_nt_f32a_f16w_batched: null pointer");
+  OVIS_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0, "gemm_nt_f32a_f16w_batched: non-positive size");
+  OVIS_REQUIRE(K % 8 == 0 && lda % 4 == 0 && ldb % 8 == 0 && a_bs % 4 == 0 && b_bs % 8 == 0 && lda >= K && ldb >= K &&
+                   ldc >= N && (((uintptr_t)A | (uintptr_t)B16) & 15) == 0,
+               "gemm_nt_f32a_f16w_batched: alignment (K %% 8, lda %% 4, ldb %% 8, strides, 16-byte pointers)");
+  OVIS_REQUIRE(act >= 0 && act <= 2, "gemm_nt_f32a_f16w_batched: unknown activation %d", act);
+  return launch(DenseA<true>{A, lda, M, K}, (const _Float16*)B16, ldb, C, ldc, M, N, K, bias, nullptr, 0, act,
+                (hipStream_t)stream, batch, a_bs, b_bs, c_bs);
 }
 
 extern "C" int ovis_conv2d_nhwc_f32a_f16w(const float* x, const void* w16, float* y, int N, int H, int W, int Cin, int Cout,

@@ -41,12 +41,19 @@ template <int BM, int BN, typename LoaderA, bool VECB>
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(LoaderA la, const float* __restrict__ B, long long ldb, float* __restrict__ C,
                 long long ldc, int M, int N, int K, const float* __restrict__ bias,
-                const float* __restrict__ R, long long ldr, int act, int tiles_n) {
+                const float* __restrict__ R, long long ldr, int act, int tiles_n, long long a_bs, long long b_bs,
+                long long c_bs) {
   constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 MFMA tiles per wave (2x2 waves)
   constexpr int A_LD = BM * 8 / 256, B_LD = BN * 8 / 256;  // float4 loads per thread per K tile
   __shared__ __attribute__((aligned(16))) float As[BM * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_STRIDE];
 
+  if (gridDim.y > 1) {   // batched: independent problems along blockIdx.y
+    la.advance((long long)blockIdx.y * a_bs);
+    B += (long long)blockIdx.y * b_bs;
+    C += (long long)blockIdx.y * c_bs;
+    if (R) R += (long long)blockIdx.y * c_bs;
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -138,15 +145,16 @@ gemm_f32_kernel(LoaderA la, const float* __restrict__ B, long long ldb, float* _
 
 template <typename LoaderA>
 int launch_gemm(LoaderA la, const float* B, long long ldb, float* C, long long ldc, int M, int N, int K,
-                const float* bias, const float* R, long long ldr, int act, hipStream_t stream) {
+                const float* bias, const float* R, long long ldr, int act, hipStream_t stream, int batch = 1,
+                long long a_bs = 0, long long b_bs = 0, long long c_bs = 0) {
   // tile choice: big tiles once the grid still fills 256 CUs, else 64x64 for parallelism
   const bool vecb = (K % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
-  const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128);
+  const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128) * batch;
 #define GEMM_LAUNCH(BM_, BN_, VB_)                                                                                  \
   {                                                                                                                 \
     const int tm = ovis::cdiv(M, BM_), tn = ovis::cdiv(N, BN_);                                                     \
-    hipLaunchKernelGGL((gemm_f32_kernel<BM_, BN_, LoaderA, VB_>), dim3(tm * tn), dim3(256), 0, stream, la, B, ldb, C, \
-                       ldc, M, N, K, bias, R, ldr, act, tn);                                                        \
+    hipLaunchKernelGGL((gemm_f32_kernel<BM_, BN_, LoaderA, VB_>), dim3(tm * tn, batch), dim3(256), 0, stream, la, B,  \
+                       ldb, C, ldc, M, N, K, bias, R, ldr, act, tn, a_bs, b_bs, c_bs);                              \
   }
   if (blocks128 >= 256) {
     if (vecb) GEMM_LAUNCH(128, 128, true) else GEMM_LAUNCH(128, 128, false)
@@ -170,6 +178,20 @@ extern "C" int ovis_gemm_nt_f32(const float* A, long long lda, const float* B, l
   const bool veca = (K % 4 == 0) && ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
   if (veca) return launch_gemm(DenseA<true>{A, lda, M, K}, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream);
   return launch_gemm(DenseA<false>{A, lda, M, K}, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream);
+}
+
+extern "C" int ovis_gemm_nt_f32_batched(const float* A, long long lda, long long a_bs, const float* B, long long ldb,
+                                        long long b_bs, float* C, long long ldc, long long c_bs, int batch, int M, int N,
+                                        int K, const float* bias, int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(A && B && C, "gemm_nt_f32_batched: null pointer");
+  OVIS_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0, "gemm_nt_f32_batched: non-positive size");
+  OVIS_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm_nt_f32_batched: leading dimension too small");
+  OVIS_REQUIRE(act >= 0 && act <= 2, "gemm_nt_f32_batched: unknown activation %d", act);
+  OVIS_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && a_bs % 4 == 0 && b_bs % 4 == 0 &&
+                   (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
+               "gemm_nt_f32_batched: K, lda, ldb, strides must be multiples of 4 and pointers 16-byte aligned");
+  return launch_gemm(DenseA<true>{A, lda, M, K}, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, act, (hipStream_t)stream,
+                     batch, a_bs, b_bs, c_bs);
 }
 
 extern "C" int ovis_conv2d_nhwc_f32(const float* x, const float* w, float* y, int N, int H, int W, int Cin,

@@ -21,6 +21,7 @@ struct DenseA {
   const float* A;
   long long lda;
   int M, K;
+  __device__ __forceinline__ void advance(long long elems) { A += elems; }   // batched GEMM: blockIdx.y * a_bs
   // raw load from a clamped address; `ok` tells the caller whether to keep it (selected at LDS-store time so the
   // s_waitcnt for this load lands AFTER the current tile's MFMAs, not right behind the load)
   __device__ __forceinline__ float4 load(int m, int k, bool& ok) const {
@@ -47,6 +48,7 @@ struct ConvA {
   const float* X;
   ConvGeom g;
   int M, K;
+  __device__ __forceinline__ void advance(long long) {}
   __device__ __forceinline__ float4 load(int m, int k, bool& ok) const {
     const int ow = m % g.OW;
     const int t = m / g.OW;

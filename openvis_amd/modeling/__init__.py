@@ -1,2 +1,2 @@
 from . import backbone, pixel_decoder, transformer_decoder, clip_adapter  # noqa: F401
-from . import mask_former_head, video_maskformer  # noqa: F401  (registers MaskFormerHead / VideoMaskFormer)
+from . import mask_former_head, video_maskformer, minvis  # noqa: F401  (registers MaskFormerHead / VideoMaskFormer / MinVIS)

@@ -1,0 +1,62 @@
+"""MinVIS — mirror of openvis/modeling/minvis.py:75-368 (eval path): frame decoder outputs + Hungarian tracker.
+
+`post_processing` (minvis.py:320-338) runs the whole T-frame Hungarian chain in one kernel launch
+(csrc/linker.hip) and applies the per-frame permutation with one gather kernel per tensor; the reference syncs to the
+CPU and calls scipy once per frame (minvis.py:33-41)."""
+import torch
+
+from .. import ops
+from ..registry import META_ARCH_REGISTRY
+from .video_maskformer import VideoMaskFormer
+
+
+def batch_video_match_via_embeds(pred_embeds):
+    """pred_embeds [1,T,Q,C] -> (indices int32 [1,T,Q], permuted embeds [1,T,Q,C]) (minvis.py:44-72)."""
+    assert pred_embeds.shape[0] == 1, "eval path: one video per call"
+    _, T, Q, C = pred_embeds.shape
+    emb = pred_embeds.view(T, Q, C).contiguous()
+    idx = ops.hungarian_link(emb)
+    out = torch.empty_like(emb)
+    ops.batch_index_rows(emb, idx, out, Q * C, C, Q * C, C, C)
+    return idx.view(1, T, Q), out.view(1, T, Q, C)
+
+
+@META_ARCH_REGISTRY.register()
+class MinVIS(VideoMaskFormer):
+    def __init__(self, *, window_inference=False, window_size=10, **kwargs):
+        super().__init__(**kwargs)
+        if window_inference:
+            raise NotImplementedError("window inference (minvis.py:340-362) is a later §8(f) row; 288 GB HBM keeps "
+                                      "whole clips resident")
+        self.window_inference, self.window_size = window_inference, window_size
+
+    @classmethod
+    def from_config(cls, cfg):
+        args = VideoMaskFormer.from_config(cfg)
+        args["window_inference"] = cfg.MODEL.MASK_FORMER.TEST.WINDOW_INFERENCE
+        args["window_size"] = cfg.MODEL.MASK_FORMER.TEST.WINDOW_SIZE
+        return args
+
+    def post_processing(self, outputs):
+        """Reorder per-frame logits and masks by the tracker's assignment (minvis.py:320-338)."""
+        idx, _ = batch_video_match_via_embeds(outputs["pred_embeds"])
+        _, T, Q = idx.shape
+        idx2 = idx.view(T, Q)
+        masks = outputs["pred_masks"][0]                                 # [Q,T,h,w]
+        n = masks.shape[2] * masks.shape[3]
+        out_masks = torch.empty_like(masks)
+        # batch = frame t, rows = queries: element (t, q) of a [Q,T,...] tensor sits at q*T*n + t*n
+        ops.batch_index_rows(masks, idx2, out_masks, n, T * n, n, T * n, n)
+        out = dict(outputs)
+        out["pred_masks"] = out_masks.unsqueeze(0)
+        if "pred_logits" in outputs:
+            lg = outputs["pred_logits"][0].contiguous()                  # [T,Q,K]
+            K = lg.shape[-1]
+            if K % 4 == 0:
+                lo = torch.empty_like(lg)
+                ops.batch_index_rows(lg, idx2, lo, Q * K, K, Q * K, K, K)
+            else:                                                        # tiny / odd K (class-agnostic 2 logits): plain gather
+                lo = torch.gather(lg, 1, idx2.long().unsqueeze(-1).expand(-1, -1, K))
+            out["pred_logits"] = lo.unsqueeze(0)
+        out["indices"] = idx
+        return out

@@ -74,3 +74,41 @@ class OpenVIS(VideoMaskFormer):
         probs, _ = ops.openvis_aggregate(logits, torch.from_numpy(slot).to(self.device))
         row_ids = np.nonzero(valid.any(axis=0))[0].astype(np.int32)
         return probs, row_ids, {"crop_logits": logits, "valid": valid, "crops": crops}
+
+
+@META_ARCH_REGISTRY.register()
+class OpenVISOnline(OpenVIS):
+    """openvis/openvis.py:150-281: per-frame decoder + MinVIS tracker, then the same masked-crop CLIP classification.
+    (The reference chunks CLIP crops by 10 frames instead of 5 only to bound memory, openvis.py:247.)"""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        from .modeling.minvis import MinVIS
+        self._post = MinVIS.post_processing
+
+    @classmethod
+    def from_config(cls, cfg):
+        if cfg.MODEL.MASK_FORMER.TEST.WINDOW_INFERENCE:
+            raise NotImplementedError("window inference is a later §8(f) row")
+        return OpenVIS.from_config(cfg)
+
+    def forward(self, batched_inputs, stages=None):
+        dataset_name = batched_inputs[0]["dataset_name"]
+        class_names = self.get_class_name_list(dataset_name)
+        self.sem_seg_head.num_classes = len(class_names)
+        frames = self._frames_to_device(batched_inputs)
+        images, image_size, padded = self.preprocess(frames)
+        features = self.backbone(images)
+        outputs = self._post(self, self.sem_seg_head(features))            # tracker re-ordering (minvis.py:320-338)
+        masks_lowres = outputs["pred_masks"][0]
+        probs, row_ids, extras = self.open_vocabulary_inference(outputs["pred_logits"][0], masks_lowres, frames,
+                                                                class_names, padded)
+        if stages is not None:
+            stages.update(dict(images=images, features=features, pred_masks=outputs["pred_masks"],
+                               pred_embeds=outputs["pred_embeds"], indices=outputs["indices"], probs=probs,
+                               row_ids=row_ids, **extras))
+        inp = batched_inputs[0]
+        return self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
+                                    inp.get("height", image_size[0]), inp.get("width", image_size[1]))
+
+    __call__ = forward

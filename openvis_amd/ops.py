@@ -96,6 +96,41 @@ def gemm_nt_f16(a, w, bias=None, residual=None, act=ACT_NONE, out_f16=False):
     return out.view(*a.shape[:-1], N)
 
 
+def gemm_nt_batched(a, b, out, batch, M, N, K, lda, a_bs, ldb, b_bs, ldc, c_bs, bias=None, act=ACT_NONE, b16=None):
+    """batch independent problems out_z = a_z b_z^T (pointer + z*stride, strides in elements); b16: fp16 copy of b
+    (same strides) selects the autocast arithmetic.  Tensors give the base pointers only."""
+    for t in (a, b, out, b16):
+        if t is not None and not t.is_cuda:
+            raise _lib.OvisError("gemm_nt_batched needs HIP tensors")
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    if b16 is not None and K % 8 == 0:
+        _lib.call("ovis_gemm_nt_f32a_f16w_batched", vp(a), _ll(lda), _ll(a_bs), vp(b16), _ll(ldb), _ll(b_bs), vp(out), _ll(ldc),
+                  _ll(c_bs), batch, M, N, K, bias, act, _lib.stream_ptr())
+    else:
+        _lib.call("ovis_gemm_nt_f32_batched", vp(a), _ll(lda), _ll(a_bs), vp(b), _ll(ldb), _ll(b_bs), vp(out), _ll(ldc),
+                  _ll(c_bs), batch, M, N, K, bias, act, _lib.stream_ptr())
+    return out
+
+
+def hungarian_link(embeds):
+    """embeds f32 [T,Q,C] -> int32 indices [T,Q] (minvis.py:28-72 chain)."""
+    _chk(embeds)
+    T, Q, C = embeds.shape
+    idx = torch.empty((T, Q), dtype=torch.int32, device=embeds.device)
+    ws = torch.empty((_lib.lib().ovis_hungarian_link_workspace_bytes(Q, C) // 4,), dtype=torch.float32, device=embeds.device)
+    _lib.call("ovis_hungarian_link_f32", embeds, idx, ws, T, Q, C, _lib.stream_ptr())
+    return idx
+
+
+def batch_index_rows(src, idx, out, src_bs, src_rs, out_bs, out_rs, length):
+    """out[b,m,:] = src[b, idx[b,m], :] with explicit element strides (see include/openvis_hip.h)."""
+    B, M = idx.shape
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.call("ovis_batch_index_rows_f32", vp(src), _ll(src_bs), _ll(src_rs), idx, vp(out), _ll(out_bs), _ll(out_rs), B, M,
+              _ll(length), _lib.stream_ptr())
+    return out
+
+
 def cast_f16(x):
     _chk(x)
     y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
@@ -181,7 +216,7 @@ def pe_sine(T, H, W, npf, three_d, add_c, device):
 
 
 def attention(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, mask=None, row_open=None, nsplit=1,
-              out_f16=False):
+              out_f16=False, mask_per_batch=False):
     """q/k/v: tensors (possibly column-sliced views of a fused projection) whose element (b,row,h,d) sits at
     data_ptr + (b*bs + row*ld + h*D + d)*4.  Returns out [B,Nq,H*D]."""
     for t in (q, k, v):
@@ -193,10 +228,11 @@ def attention(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, mask
         nbytes = _lib.lib().ovis_attention_workspace_bytes(B, H, Nq, D, nsplit)
         ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=q.device)
     mask_ld = mask.shape[-1] if mask is not None else 0
+    mask_bs = Nq * mask_ld if (mask is not None and mask_per_batch) else 0      # mask [B*Nq, ld] when per batch
     vp = lambda t: ctypes.c_void_p(t.data_ptr())
     _lib.call("ovis_attention_f32", vp(q), _ll(q_bs), q_ld, vp(k), _ll(k_bs), k_ld, vp(v), _ll(v_bs), v_ld, out,
-              _ll(Nq * H * D), H * D, int(out_f16), mask, _ll(mask_ld), row_open, B, H, Nq, Nk, D, float(D) ** -0.5,
-              nsplit, ws, _lib.stream_ptr())
+              _ll(Nq * H * D), H * D, int(out_f16), mask, _ll(mask_ld), _ll(mask_bs), row_open, B, H, Nq, Nk, D,
+              float(D) ** -0.5, nsplit, ws, _lib.stream_ptr())
     return out
 
 

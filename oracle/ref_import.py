@@ -139,6 +139,10 @@ def install():
     _mod("detectron2.utils.comm", get_local_rank=lambda: 0, synchronize=lambda: None,
          get_world_size=lambda: 1, get_rank=lambda: 0)
     _mod("detectron2.utils.memory", retry_if_cuda_oom=lambda f: f)
+    _mod("detectron2.projects")
+    _mod("detectron2.projects.point_rend")
+    _mod("detectron2.projects.point_rend.point_features", get_uncertain_point_coords_with_randomness=None,
+         point_sample=None)                                  # training-only helpers (criterion / matcher)
     _mod("detectron2.structures", ImageList=None, BitMasks=None, Boxes=None, Instances=None)
     _mod("detectron2.data", MetadataCatalog=None)
 

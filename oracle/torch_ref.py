@@ -530,3 +530,107 @@ def openvis_forward(frames, W, text_features, out_hw=None, stages=None, clip_hea
         stages.update(dict(images=images, feats=feats, mask_features=mask_features, ms=ms, pred_logits=cls,
                            pred_masks=pred_masks, probs=probs, **extras))
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# A7 (frame variant)  FrameMultiScaleMaskedTransformerDecoder — transformer_decoder/frame_mask2former_transformer_decoder.py:52-154
+# ----------------------------------------------------------------------------------------------
+def frame_prediction_heads(W, p, output, mask_features, target_size, nheads=8, with_class=True):
+    """frame decoder:139-154. output [Q,bt,C]; mask_features [bt,C,H,W]."""
+    dec = _ln(output, W, p + "decoder_norm").transpose(0, 1)
+    outputs_class = F.linear(dec, W[p + "class_embed.weight"], W[p + "class_embed.bias"]) if with_class else None
+    mask_embed = _mlp3(dec, W, p + "mask_embed.")
+    outputs_mask = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features)
+    am = F.interpolate(outputs_mask, size=target_size, mode="bilinear", align_corners=False)
+    am = (am.sigmoid().flatten(2).unsqueeze(1).repeat(1, nheads, 1, 1).flatten(0, 1) < 0.5).bool()
+    return outputs_class, outputs_mask, am
+
+
+def frame_decoder(ms_feats, mask_features, W, prefix="sem_seg_head.predictor.", n_layers=9, nheads=8):
+    """eval: bs = 1, every frame decoded independently. Returns dict with pred_logits [1,T,Q,C+1],
+    pred_masks [1,Q,T,h,w], pred_embeds [1,T,Q,C]."""
+    p = prefix
+    src, pos, size_list = [], [], []
+    for i in range(3):
+        h, w = ms_feats[i].shape[-2:]
+        size_list.append((h, w))
+        pos.append(pe_sine_2d(ms_feats[i].shape[0], h, w).flatten(2).permute(2, 0, 1))
+        src.append((ms_feats[i].flatten(2) + W[p + "level_embed.weight"][i][None, :, None]).permute(2, 0, 1))
+    bs = src[0].shape[1]
+    query_embed = W[p + "query_embed.weight"].unsqueeze(1).repeat(1, bs, 1)
+    output = W[p + "query_feat.weight"].unsqueeze(1).repeat(1, bs, 1)
+    cls, msk, attn_mask = frame_prediction_heads(W, p, output, mask_features, size_list[0], nheads)
+    for i in range(n_layers):
+        li = i % 3
+        attn_mask[torch.where(attn_mask.sum(-1) == attn_mask.shape[-1])] = False
+        cp = f"{p}transformer_cross_attention_layers.{i}."
+        tgt2 = _mha(W, cp + "multihead_attn.", output + query_embed, src[li] + pos[li], src[li], attn_mask, nheads)
+        output = _ln(output + tgt2, W, cp + "norm")
+        sp = f"{p}transformer_self_attention_layers.{i}."
+        qk = output + query_embed
+        tgt2 = _mha(W, sp + "self_attn.", qk, qk, output, None, nheads)
+        output = _ln(output + tgt2, W, sp + "norm")
+        fp = f"{p}transformer_ffn_layers.{i}."
+        tgt2 = F.linear(F.relu(F.linear(output, W[fp + "linear1.weight"], W[fp + "linear1.bias"])),
+                        W[fp + "linear2.weight"], W[fp + "linear2.bias"])
+        output = _ln(output + tgt2, W, fp + "norm")
+        cls, msk, attn_mask = frame_prediction_heads(W, p, output, mask_features, size_list[(i + 1) % 3], nheads)
+    pred_embeds = _ln(output, W, p + "decoder_norm")                                  # [Q, T, C]
+    return {"pred_logits": cls.unsqueeze(0), "pred_masks": msk.permute(1, 0, 2, 3).unsqueeze(0),
+            "pred_embeds": pred_embeds.permute(1, 0, 2).unsqueeze(0)}
+
+
+# ----------------------------------------------------------------------------------------------
+# A14  MinVIS tracker — openvis/modeling/minvis.py:28-72, 320-338 (scipy.optimize.linear_sum_assignment)
+# ----------------------------------------------------------------------------------------------
+def match_via_embeds(tgt_embeds, cur_embeds):
+    from scipy.optimize import linear_sum_assignment
+    cur_embeds = cur_embeds / cur_embeds.norm(dim=1)[:, None]
+    tgt_embeds = tgt_embeds / tgt_embeds.norm(dim=1)[:, None]
+    cos_sim = torch.mm(cur_embeds, tgt_embeds.transpose(0, 1))
+    C = 1.0 * (1 - cos_sim)
+    indices = linear_sum_assignment(C.transpose(0, 1))[1]
+    return indices.tolist()
+
+
+def video_match_via_embeds(embeds):
+    """embeds [T,Q,C] -> (indices [T,Q] long, permuted embeds [T,Q,C])."""
+    last = embeds[0]
+    idx_list, out = [], []
+    for i in range(embeds.shape[0]):
+        indices = match_via_embeds(last, embeds[i])
+        last = embeds[i][indices]
+        idx_list.append(indices)
+        out.append(last)
+    return torch.tensor(idx_list), torch.stack(out)
+
+
+def minvis_post_processing(outputs):
+    """minvis.py:320-338 for bs = 1: reorder per-frame logits / masks by the tracker's indices."""
+    idx, _ = video_match_via_embeds(outputs["pred_embeds"][0])
+    T = idx.shape[0]
+    ar = torch.arange(T)[:, None]
+    out = dict(outputs)
+    out["pred_logits"] = outputs["pred_logits"][0][ar, idx].unsqueeze(0)                                  # [1,T,Q,C]
+    out["pred_masks"] = outputs["pred_masks"][0].transpose(0, 1)[ar, idx].transpose(0, 1).unsqueeze(0)    # [1,Q,T,h,w]
+    out["indices"] = idx
+    return out
+
+
+def openvis_online_forward(frames, W, text_features, out_hw=None, stages=None, clip_heads=12, clip_resolution=224):
+    """OpenVISOnline.forward, eval (openvis/openvis.py:176-281); part_len = 10."""
+    images, (H, Wd) = preprocess([f for f in frames])
+    feats = resnet50(images, W)
+    mask_features, _, ms = pixel_decoder(feats, W)
+    out = minvis_post_processing(frame_decoder(ms, mask_features, W))
+    mask_pred = out["pred_masks"][0]
+    ih, iw = images.shape[-2:]
+    mask_pred = F.interpolate(mask_pred, size=(ih, iw), mode="bilinear", align_corners=False)
+    probs, vmasks, extras = open_vocabulary_inference(mask_pred, frames, text_features, W, part_len=10,
+                                                      clip_heads=clip_heads, clip_resolution=clip_resolution)
+    oh, ow = out_hw if out_hw is not None else (H, Wd)
+    res = inference_video(out["pred_masks"].shape[1], text_features.shape[0], probs, vmasks, (H, Wd), oh, ow)
+    if stages is not None:
+        stages.update(dict(images=images, feats=feats, pred_masks=out["pred_masks"], pred_embeds=out["pred_embeds"],
+                           indices=out["indices"], probs=probs, **extras))
+    return res
