@@ -137,6 +137,9 @@ int ovis_cast_f32_to_f16(const float* x, void* y, long long n, ovis_stream_t str
  *   mask: uint8 [Nq, mask_ld] (1 = blocked), shared by all heads, or NULL; mask_bs = 0: shared by all batches (the
  *   offline video decoder), otherwise batch b uses mask + b*mask_bs and row_open + b*Nq (per-frame decoders,
  *   frame_mask2former_transformer_decoder.py:85-94);
+ *   bias: optional additive f32 bias added to the scaled scores before the softmax, element (b,h,q,k) at
+ *   bias[b*bias_bs + h*bias_hs + q*bias_ld + k], rows padded to a multiple of 4 floats (the SideAdapter's attention
+ *   bias, clip_adapter/side_adapter.py:70-78, 237-270), or NULL;
  *   row_open: int32 [Nq] = number of unblocked keys per row (rows with 0 are treated as unmasked,
  *   video decoder:419) or NULL.  nsplit > 1 splits the key range over workgroups (needs
  *   ovis_attention_workspace_bytes(B,H,Nq,D,nsplit) bytes of workspace).  out_f16 != 0 writes `out` as fp16
@@ -144,8 +147,9 @@ int ovis_cast_f32_to_f16(const float* x, void* y, long long n, ovis_stream_t str
 long long ovis_attention_workspace_bytes(int B, int H, int Nq, int D, int nsplit);
 int ovis_attention_f32(const float* q, long long q_bs, int q_ld, const float* k, long long k_bs, int k_ld,
                        const float* v, long long v_bs, int v_ld, void* out, long long o_bs, int o_ld, int out_f16,
-                       const uint8_t* mask, long long mask_ld, long long mask_bs, const int* row_open, int B, int H,
-                       int Nq, int Nk, int D, float scale, int nsplit, float* workspace, ovis_stream_t stream);
+                       const uint8_t* mask, long long mask_ld, long long mask_bs, const int* row_open, const float* bias,
+                       long long bias_bs, long long bias_hs, int bias_ld, int B, int H, int Nq, int Nk, int D,
+                       float scale, int nsplit, float* workspace, ovis_stream_t stream);
 
 /* fp16-operand variant for the CLIP ViT tower (no mask, no split): q/k/v/out fp16, f32 softmax + accumulation, D = 64.
  *   element (b,row,h,d) at ptr[b*bs + row*ld + h*D + d] (strides in halfs, multiples of 8). */
@@ -191,6 +195,21 @@ int ovis_topk_entropy_f32(const float* probs, const int* row_ids, int nrows, int
 /* final masks of the selected queries (openvis.py:87-96 + video_maskformer.py:273-278): out uint8 [n_sel,T,OH,OW]. */
 int ovis_final_masks_u8(const float* masks, const int* sel_q, uint8_t* out, int n_sel, int Q, int T, int h, int w, int Hp,
                         int Wp, int H, int W, int OH, int OW, ovis_stream_t stream);
+
+/* ---- A13: SideAdapter (SAN / BriVIS) helpers -------------------------------------------------------
+ * Front image path (side_adapter.py:150-153): F.interpolate(frames/255, (R,R), "bicubic") of the raw frames zero-padded
+ *   from (H,W) to (Hp,Wp), CLIP mean/std normalisation, written as the patch-embedding im2col matrix
+ *   A[(t*G*G + py*G + px), c*ps*ps + iy*ps + ix] (f32, or fp16 when out_f16 != 0). frames uint8 [T,3,H,W]. */
+int ovis_san_front_patches(const uint8_t* frames, void* A, int out_f16, int T, int H, int W, int Hp, int Wp,
+                           int resolution, int patch, const float* mean3_host, const float* std3_host,
+                           ovis_stream_t stream);
+/* F.adaptive_max_pool2d over N planes [H,W] -> [OH,OW] (side_adapter.py:244, downsample2d(method="max")). */
+int ovis_adaptive_maxpool2d_f32(const float* x, float* y, long long N, int H, int W, int OH, int OW, ovis_stream_t stream);
+/* Additive attention bias of the back blocks (side_adapter.py:253-265): pooled [BN,Q,L] -> out [BN, Q+1+L, ld]. */
+int ovis_san_attn_bias_f32(const float* pooled, float* out, long long BN, int Q, int L, int ld, ovis_stream_t stream);
+/* dst [N,H,W,C] += bilinear_resize(src [N,h,w,C], (H,W)), align_corners False (msdeformattn.py:338-344). */
+int ovis_bilinear_resize_add_nhwc_f32(float* dst, const float* src, int N, int H, int W, int C, int h, int w,
+                                      ovis_stream_t stream);
 
 /* ---- A14: temporal instance linker (MinVIS tracker) ----------------------------------------------
  * indices[t, i] = index of the frame-t query assigned to tracked slot i by the Hungarian chain of

@@ -34,6 +34,7 @@ struct AttnArgs {
   void* out; long long o_bs; int o_ld; int out_f16;
   const uint8_t* mask; long long mask_ld;          // [Nq][mask_ld], 1 = blocked; may be null
   long long mask_bs;                               // batch stride of mask (bytes) / of row_open (x Nq); 0 = shared
+  const float* bias; long long bias_bs, bias_hs; int bias_ld;   // additive f32 bias [B][H][Nq][bias_ld]; may be null
   const int* row_open;                             // [Nq] number of unblocked keys; may be null
   float* part_o; float* part_ml;                   // split-KV workspace
   int B, H, Nq, Nk, nsplit, keys_per_split;
@@ -75,6 +76,8 @@ flash_attn_f32_kernel(AttnArgs a) {
   const bool use_mask = a.mask != nullptr && q_ok && (ropen == nullptr || ropen[qi] > 0);
   const uint8_t* mrow = a.mask ? a.mask + b * a.mask_bs + (long long)(q_ok ? qi : 0) * a.mask_ld : nullptr;
 
+  const float* brow = a.bias ? a.bias + b * a.bias_bs + head * a.bias_hs + (long long)(q_ok ? qi : 0) * a.bias_ld : nullptr;
+
   f32x16 o[DT];
 #pragma unroll
   for (int t = 0; t < DT; ++t)
@@ -115,7 +118,6 @@ flash_attn_f32_kernel(AttnArgs a) {
     }
   };
 
-  const float scale_log2e = a.scale * 1.4426950408889634f;
   if (k_begin < k_end) gload(k_begin);
   for (int kt = k_begin; kt < k_end; kt += 32) {
     __syncthreads();
@@ -152,11 +154,16 @@ flash_attn_f32_kernel(AttnArgs a) {
             if (key0 + e < a.Nk) mbits |= (unsigned)mrow[key0 + e] << (8 * e);
         }
       }
+      float bq[4] = {0.f, 0.f, 0.f, 0.f};
+      if (brow && key0 < k_end) {                 // bias_ld % 4 == 0 and padded: a float4 never leaves the row
+        const float4 bb = *reinterpret_cast<const float4*>(brow + key0);
+        bq[0] = bb.x; bq[1] = bb.y; bq[2] = bb.z; bq[3] = bb.w;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
         const bool blocked = (key0 + e >= k_end) || ((mbits >> (8 * e)) & 0xffu);
-        const float x = blocked ? -INFINITY : s[r] * scale_log2e;
+        const float x = blocked ? -INFINITY : (s[r] * a.scale + bq[e]) * 1.4426950408889634f;
         s[r] = x;
         mt = fmaxf(mt, x);
       }
@@ -267,7 +274,8 @@ extern "C" long long ovis_attention_workspace_bytes(int B, int H, int Nq, int D,
 extern "C" int ovis_attention_f32(const float* q, long long q_bs, int q_ld, const float* k, long long k_bs, int k_ld,
                                   const float* v, long long v_bs, int v_ld, void* out, long long o_bs, int o_ld,
                                   int out_f16, const uint8_t* mask, long long mask_ld, long long mask_bs,
-                                  const int* row_open, int B, int H, int Nq, int Nk, int D, float scale, int nsplit,
+                                  const int* row_open, const float* bias, long long bias_bs, long long bias_hs,
+                                  int bias_ld, int B, int H, int Nq, int Nk, int D, float scale, int nsplit,
                                   float* workspace, ovis_stream_t stream) {
   OVIS_REQUIRE(q && k && v && out, "attention: null pointer");
   OVIS_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "attention: non-positive size");
@@ -279,12 +287,16 @@ extern "C" int ovis_attention_f32(const float* q, long long q_bs, int q_ld, cons
   OVIS_REQUIRE(nsplit >= 1 && (nsplit == 1 || workspace), "attention: nsplit > 1 needs a workspace");
   OVIS_REQUIRE(!(out_f16 && nsplit > 1), "attention: fp16 output is only supported with nsplit == 1");
   OVIS_REQUIRE(!mask || mask_ld >= Nk, "attention: mask_ld < Nk");
+  OVIS_REQUIRE(!bias || (bias_ld % 4 == 0 && bias_ld >= (Nk + 3) / 4 * 4 && bias_bs % 4 == 0 && bias_hs % 4 == 0 &&
+                         ((uintptr_t)bias & 15) == 0),
+               "attention: bias rows must be padded to a multiple of 4 floats and 16-byte aligned");
   int keys_per_split = (Nk + nsplit - 1) / nsplit;
   keys_per_split = (keys_per_split + 31) / 32 * 32;
   nsplit = (Nk + keys_per_split - 1) / keys_per_split;
   AttnArgs a;
   a.q = q; a.q_bs = q_bs; a.q_ld = q_ld; a.k = k; a.k_bs = k_bs; a.k_ld = k_ld; a.v = v; a.v_bs = v_bs; a.v_ld = v_ld;
   a.out = out; a.o_bs = o_bs; a.o_ld = o_ld; a.out_f16 = out_f16; a.mask = mask; a.mask_ld = mask_ld; a.mask_bs = mask_bs; a.row_open = row_open;
+  a.bias = bias; a.bias_bs = bias_bs; a.bias_hs = bias_hs; a.bias_ld = bias_ld;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.nsplit = nsplit; a.keys_per_split = keys_per_split; a.scale = scale;
   a.part_o = workspace;
   a.part_ml = workspace ? workspace + (long long)nsplit * B * H * Nq * D : nullptr;

@@ -54,54 +54,59 @@ class ClipVisual:
                 w[k + ".h"] = ops.cast_f16(w[k])
         return self
 
+    def embed(self, A, M):
+        """patch im2col matrix [M*G*G, 3*ps*ps] (f32 or fp16) -> ln_pre(tokens) f32 [M, G*G+1, C] (model.py:328-343)."""
+        w = self.w
+        G = self.input_resolution // self.patch
+        x = ops.gemm_nt_f16(A, w["conv1.h"]) if self.precision == "fp16" else ops.gemm_nt(A, w["conv1"])   # conv1, no bias
+        return ops.vit_embed_ln(x, w["cls"], w["pos"], w["ln_pre.w"], w["ln_pre.b"], M, G * G + 1)
+
+    def run_blocks(self, x, i0, i1, attn_bias=None):
+        """resblocks[i0:i1] on x f32 [B, L, C] (model.py:238-268); attn_bias: additive f32 [B, heads, L, ld] (SideAdapter).
+        fp16 policy: GEMM operands rounded to fp16 (weights cast once), f32 accumulation / residual stream / LayerNorm /
+        softmax; fp32 policy: exact-f32 MFMA."""
+        w = self.w
+        B, L, C = x.shape
+        Hh = self.heads
+        D = C // Hh
+        f16 = self.precision == "fp16"
+        for i in range(i0, i1):
+            h = ops.layernorm(x, w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"], out_f16=f16)
+            if f16 and attn_bias is None:
+                qkv = ops.gemm_nt_f16(h.view(-1, C), w[f"{i}.attn.in_proj_weight.h"], w[f"{i}.attn.in_proj_bias"], out_f16=True)
+                att = ops.attention_f16(qkv, qkv[:, C:], qkv[:, 2 * C:], B, Hh, L, L, D, L * 3 * C, 3 * C, L * 3 * C, 3 * C,
+                                        L * 3 * C, 3 * C)
+            else:
+                if f16:
+                    qkv = ops.gemm_nt_f16(h.view(-1, C), w[f"{i}.attn.in_proj_weight.h"], w[f"{i}.attn.in_proj_bias"])
+                else:
+                    qkv = ops.gemm_nt(h.view(-1, C), w[f"{i}.attn.in_proj_weight"], w[f"{i}.attn.in_proj_bias"])
+                att = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B, Hh, L, L, D, L * 3 * C, 3 * C, L * 3 * C, 3 * C,
+                                    L * 3 * C, 3 * C, bias=attn_bias, out_f16=f16)
+            if f16:
+                x = ops.gemm_nt_f16(att.view(-1, C), w[f"{i}.attn.out_proj.weight.h"], w[f"{i}.attn.out_proj.bias"],
+                                    x.view(-1, C)).view(B, L, C)
+                h = ops.layernorm(x, w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"], out_f16=True)
+                f = ops.gemm_nt_f16(h.view(-1, C), w[f"{i}.mlp.c_fc.weight.h"], w[f"{i}.mlp.c_fc.bias"], None,
+                                    ops.ACT_QUICKGELU, out_f16=True)
+                x = ops.gemm_nt_f16(f, w[f"{i}.mlp.c_proj.weight.h"], w[f"{i}.mlp.c_proj.bias"], x.view(-1, C)).view(B, L, C)
+            else:
+                x = ops.gemm_nt(att.view(-1, C), w[f"{i}.attn.out_proj.weight"], w[f"{i}.attn.out_proj.bias"],
+                                x.view(-1, C)).view(B, L, C)
+                h = ops.layernorm(x, w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"])
+                f = ops.gemm_nt(h.view(-1, C), w[f"{i}.mlp.c_fc.weight"], w[f"{i}.mlp.c_fc.bias"], None, ops.ACT_QUICKGELU)
+                x = ops.gemm_nt(f, w[f"{i}.mlp.c_proj.weight"], w[f"{i}.mlp.c_proj.bias"], x.view(-1, C)).view(B, L, C)
+        return x
+
+    def head(self, tok):
+        """ln_post + projection of token rows [N, C] -> [N, embed_dim] (model.py:358-361), exact f32."""
+        w = self.w
+        return ops.gemm_nt(ops.layernorm(tok, w["ln_post.w"], w["ln_post.b"]), w["proj_t"])
+
     def forward_patches(self, A, M):
         """A: patch im2col matrix [M*G*G, 3*ps*ps] -> image features [M, embed_dim] (before L2 normalisation)."""
-        w = self.w
-        C, Hh = self.width, self.heads
-        D = C // Hh
-        G = self.input_resolution // self.patch
-        L1 = G * G + 1
-        if self.precision == "fp16":
-            return self._forward_patches_f16(A, M, C, Hh, D, L1)
-        x = ops.gemm_nt(A, w["conv1"])                                                      # conv1 (no bias)
-        x = ops.vit_embed_ln(x, w["cls"], w["pos"], w["ln_pre.w"], w["ln_pre.b"], M, L1)    # [M,L1,C]
-        for i in range(self.layers):
-            h = ops.layernorm(x, w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"])
-            qkv = ops.gemm_nt(h.view(-1, C), w[f"{i}.attn.in_proj_weight"], w[f"{i}.attn.in_proj_bias"])   # [M*L1,3C]
-            att = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], M, Hh, L1, L1, D, L1 * 3 * C, 3 * C, L1 * 3 * C, 3 * C,
-                                L1 * 3 * C, 3 * C)
-            x = ops.gemm_nt(att.view(-1, C), w[f"{i}.attn.out_proj.weight"], w[f"{i}.attn.out_proj.bias"],
-                            x.view(-1, C)).view(M, L1, C)
-            h = ops.layernorm(x, w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"])
-            f = ops.gemm_nt(h.view(-1, C), w[f"{i}.mlp.c_fc.weight"], w[f"{i}.mlp.c_fc.bias"], None, ops.ACT_QUICKGELU)
-            x = ops.gemm_nt(f, w[f"{i}.mlp.c_proj.weight"], w[f"{i}.mlp.c_proj.bias"], x.view(-1, C)).view(M, L1, C)
-        return self._head(x)
-
-    def _head(self, x):
-        w = self.w
-        cls = x[:, 0, :].contiguous()
-        cls = ops.layernorm(cls, w["ln_post.w"], w["ln_post.b"])
-        return ops.gemm_nt(cls, w["proj_t"])
-
-    def _forward_patches_f16(self, A, M, C, Hh, D, L1):
-        """fp16 GEMM operands (activations rounded to fp16 right before each GEMM, weights cast once), f32
-        accumulation; the residual stream, LayerNorm statistics, softmax and the final projection stay f32."""
-        w = self.w
-        x = ops.gemm_nt_f16(A, w["conv1.h"])                                                # f32 out
-        x = ops.vit_embed_ln(x, w["cls"], w["pos"], w["ln_pre.w"], w["ln_pre.b"], M, L1)
-        for i in range(self.layers):
-            h = ops.layernorm(x, w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"], out_f16=True)
-            qkv = ops.gemm_nt_f16(h.view(-1, C), w[f"{i}.attn.in_proj_weight.h"], w[f"{i}.attn.in_proj_bias"],
-                                  out_f16=True)
-            att = ops.attention_f16(qkv, qkv[:, C:], qkv[:, 2 * C:], M, Hh, L1, L1, D, L1 * 3 * C, 3 * C, L1 * 3 * C,
-                                    3 * C, L1 * 3 * C, 3 * C)
-            x = ops.gemm_nt_f16(att.view(-1, C), w[f"{i}.attn.out_proj.weight.h"], w[f"{i}.attn.out_proj.bias"],
-                                x.view(-1, C)).view(M, L1, C)
-            h = ops.layernorm(x, w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"], out_f16=True)
-            f = ops.gemm_nt_f16(h.view(-1, C), w[f"{i}.mlp.c_fc.weight.h"], w[f"{i}.mlp.c_fc.bias"], None,
-                                ops.ACT_QUICKGELU, out_f16=True)
-            x = ops.gemm_nt_f16(f, w[f"{i}.mlp.c_proj.weight.h"], w[f"{i}.mlp.c_proj.bias"], x.view(-1, C)).view(M, L1, C)
-        return self._head(x)
+        x = self.run_blocks(self.embed(A, M), 0, self.layers)
+        return self.head(x[:, 0, :].contiguous())
 
 
 class ClipAdapter:

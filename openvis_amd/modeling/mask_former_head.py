@@ -18,7 +18,7 @@ class MaskFormerHead:
     def from_config(cls, cfg, input_shape):
         tif = cfg.MODEL.MASK_FORMER.TRANSFORMER_IN_FEATURE
         if tif != "multi_scale_pixel_decoder":
-            raise NotImplementedError(f"TRANSFORMER_IN_FEATURE={tif} is a later §8 row (SAN / BriVIS)")
+            raise NotImplementedError(f"TRANSFORMER_IN_FEATURE={tif} is not used by the eval configs of the path")
         return cls({k: v for k, v in input_shape.items() if k in cfg.MODEL.SEM_SEG_HEAD.IN_FEATURES},
                    ignore_value=cfg.MODEL.SEM_SEG_HEAD.IGNORE_VALUE, num_classes=cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES,
                    pixel_decoder=build_pixel_decoder(cfg, input_shape), loss_weight=cfg.MODEL.SEM_SEG_HEAD.LOSS_WEIGHT,

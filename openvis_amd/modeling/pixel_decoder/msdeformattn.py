@@ -107,8 +107,6 @@ class MSDeformAttnPixelDecoder:
 
     def forward_features(self, features, extra_features=None):
         """features: {res2..res5} NHWC f32.  Returns (mask_features [T,h,w,C], out[0], multi_scale_features[3])."""
-        if extra_features is not None:
-            raise NotImplementedError("SAN extra-feature injection (msdeformattn.py:338-344) is a later §8 row")
         w = self.w
         srcs, shapes_list = [], []
         for idx, f in enumerate(self.transformer_in_features[::-1]):                   # res5, res4, res3
@@ -116,6 +114,12 @@ class MSDeformAttnPixelDecoder:
             T, H, W, C = x.shape
             y = ops.gemm_nt(x.view(-1, C), w[f"input_proj.{idx}.w"], w[f"input_proj.{idx}.b"]).view(T, H, W, -1)
             y = ops.groupnorm_nhwc(y, w[f"input_proj.{idx}.gn_w"], w[f"input_proj.{idx}.gn_b"])
+            if extra_features is not None:                                             # SAN injection (:338-344)
+                ex = extra_features[idx]
+                if ex.shape[1:3] == (H, W):
+                    y = ops.add_bcast(y, ex.contiguous())
+                else:
+                    ops.bilinear_resize_add(y, ex.contiguous())
             srcs.append(y.view(T, H * W, -1))
             shapes_list.append((H, W))
         pos, shapes, lsi = self._pos(shapes_list)

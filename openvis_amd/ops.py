@@ -112,6 +112,44 @@ def gemm_nt_batched(a, b, out, batch, M, N, K, lda, a_bs, ldb, b_bs, ldc, c_bs, 
     return out
 
 
+def san_front_patches(frames, Hp, Wp, resolution, patch, mean, std, out_f16=False):
+    _chk(frames)
+    T, _, H, W = frames.shape
+    G = resolution // patch
+    A = torch.empty((T * G * G, 3 * patch * patch), dtype=torch.float16 if out_f16 else torch.float32, device=frames.device)
+    _lib.call("ovis_san_front_patches", frames, A, int(out_f16), T, H, W, Hp, Wp, resolution, patch, _f3(mean), _f3(std),
+              _lib.stream_ptr())
+    return A
+
+
+def adaptive_maxpool2d(x, OH, OW):
+    """x [..., H, W] -> [..., OH, OW]."""
+    _chk(x)
+    H, W = x.shape[-2:]
+    y = torch.empty((*x.shape[:-2], OH, OW), dtype=torch.float32, device=x.device)
+    _lib.call("ovis_adaptive_maxpool2d_f32", x, y, _ll(x.numel() // (H * W)), H, W, OH, OW, _lib.stream_ptr())
+    return y
+
+
+def san_attn_bias(pooled, Q, L):
+    """pooled [B,n,Q,L] -> additive bias [B,n,Q+1+L,ld] (rows padded to a multiple of 4)."""
+    _chk(pooled)
+    B, n = pooled.shape[:2]
+    S = Q + 1 + L
+    ld = (S + 3) // 4 * 4
+    out = torch.empty((B, n, S, ld), dtype=torch.float32, device=pooled.device)
+    _lib.call("ovis_san_attn_bias_f32", pooled, out, _ll(B * n), Q, L, ld, _lib.stream_ptr())
+    return out
+
+
+def bilinear_resize_add(dst, src):
+    """dst [N,H,W,C] += bilinear_resize(src [N,h,w,C]) in place."""
+    _chk(dst, src)
+    N, H, W, C = dst.shape
+    _lib.call("ovis_bilinear_resize_add_nhwc_f32", dst, src, N, H, W, C, src.shape[1], src.shape[2], _lib.stream_ptr())
+    return dst
+
+
 def hungarian_link(embeds):
     """embeds f32 [T,Q,C] -> int32 indices [T,Q] (minvis.py:28-72 chain)."""
     _chk(embeds)
@@ -216,7 +254,7 @@ def pe_sine(T, H, W, npf, three_d, add_c, device):
 
 
 def attention(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, mask=None, row_open=None, nsplit=1,
-              out_f16=False, mask_per_batch=False):
+              out_f16=False, mask_per_batch=False, bias=None):
     """q/k/v: tensors (possibly column-sliced views of a fused projection) whose element (b,row,h,d) sits at
     data_ptr + (b*bs + row*ld + h*D + d)*4.  Returns out [B,Nq,H*D]."""
     for t in (q, k, v):
@@ -230,8 +268,14 @@ def attention(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, mask
     mask_ld = mask.shape[-1] if mask is not None else 0
     mask_bs = Nq * mask_ld if (mask is not None and mask_per_batch) else 0      # mask [B*Nq, ld] when per batch
     vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    if bias is not None:                      # additive f32 bias [B,H,Nq,ld]
+        _chk(bias)
+        b_ld = bias.shape[-1]
+        b_args = (bias, _ll(H * Nq * b_ld), _ll(Nq * b_ld), b_ld)
+    else:
+        b_args = (None, _ll(0), _ll(0), 0)
     _lib.call("ovis_attention_f32", vp(q), _ll(q_bs), q_ld, vp(k), _ll(k_bs), k_ld, vp(v), _ll(v_bs), v_ld, out,
-              _ll(Nq * H * D), H * D, int(out_f16), mask, _ll(mask_ld), _ll(mask_bs), row_open, B, H, Nq, Nk, D,
+              _ll(Nq * H * D), H * D, int(out_f16), mask, _ll(mask_ld), _ll(mask_bs), row_open, *b_args, B, H, Nq, Nk, D,
               float(D) ** -0.5, nsplit, ws, _lib.stream_ptr())
     return out
 

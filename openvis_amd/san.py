@@ -1,0 +1,75 @@
+"""SANOnline meta-architecture — mirror of openvis/san.py:146-283 (eval path; registered as "SANOnline").
+
+CLIP front blocks feed the pixel decoder, the side-adapter frame decoder predicts masks + per-head attention biases,
+the CLIP back blocks classify every query with [SOS] tokens, the MinVIS tracker links queries over time."""
+import numpy as np
+import torch
+
+from . import ops
+from .catalog import MetadataCatalog
+from .modeling.clip_adapter.side_adapter import SideAdapter
+from .modeling.minvis import MinVIS
+from .registry import META_ARCH_REGISTRY
+
+
+@META_ARCH_REGISTRY.register()
+class SANOnline(MinVIS):
+    def __init__(self, *, clip_adapter, **kwargs):
+        super().__init__(**kwargs)
+        self.clip_adapter = clip_adapter
+
+    @classmethod
+    def from_config(cls, cfg):
+        args = MinVIS.from_config(cfg)
+        args["clip_adapter"] = SideAdapter(cfg.MODEL.CLIP_ADAPTER.CLIP_MODEL_NAME, broken_idx=cfg.MODEL.CLIP_ADAPTER.BROKEN_ID,
+                                           merge_ids=cfg.MODEL.CLIP_ADAPTER.MERGE_IDS,
+                                           num_queries=cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES,
+                                           precision=cfg.MODEL.CLIP_ADAPTER.get("PRECISION", "fp16"))
+        return args
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        self.clip_adapter.load_state_dict(sd, "clip_adapter.", self.device)
+        return self
+
+    def get_class_name_list(self, dataset_name):
+        return [c.strip() for c in MetadataCatalog.get(dataset_name).thing_classes]
+
+    def image_outputs(self, frames, class_names):
+        """frames uint8 [T,3,H,W] -> per-frame head outputs incl. pred_logits [1,T,Q,K+1] (san.py:211-231)."""
+        images, image_size, padded = self.preprocess(frames)
+        mg_feats, clip_tokens = self.clip_adapter.front_encode_image(frames, padded)          # san.py:221
+        text_feats = self.clip_adapter.encode_text(class_names)                               # san.py:222
+        features = self.backbone(images)
+        outputs = self.sem_seg_head(features, extra_feats=mg_feats)
+        clip_feats = self.clip_adapter.post_encode_image(clip_tokens, outputs["class_attn_biases"][0])   # san.py:230
+        outputs["pred_logits"] = self.clip_adapter.cal_sim_logits(text_feats, clip_feats).unsqueeze(0)   # [1,T,Q,K+1]
+        outputs["clip_tokens"], outputs["text_feats"] = clip_tokens, text_feats
+        return outputs, images, image_size, padded
+
+    def classify(self, pred_logits):
+        """mean over frames, softmax, drop the background column (san.py:257,264-265) -> probs [Q,K]."""
+        lg = pred_logits[0]                                                                   # [T,Q,K+1]
+        T, Q, K1 = lg.shape
+        slot = torch.arange(T * Q, dtype=torch.int32, device=lg.device).view(T, Q)           # every (t,q) is valid
+        probs, _ = ops.openvis_aggregate(lg.reshape(T * Q, K1).contiguous(), slot)
+        return probs[:, :-1].contiguous()
+
+    def forward(self, batched_inputs, stages=None):
+        dataset_name = list(set(x["dataset_name"] for x in batched_inputs))[0]
+        class_names = self.get_class_name_list(dataset_name)
+        self.sem_seg_head.num_classes = len(class_names)
+        frames = self._frames_to_device(batched_inputs)
+        outputs, images, image_size, padded = self.image_outputs(frames, class_names)
+        outputs = self.post_processing(outputs)                                               # tracker (minvis.py:320-338)
+        probs = self.classify(outputs["pred_logits"])
+        masks_lowres = outputs["pred_masks"][0]
+        if stages is not None:
+            stages.update(dict(images=images, pred_masks=outputs["pred_masks"], pred_logits=outputs["pred_logits"],
+                               indices=outputs["indices"], probs=probs, class_attn_biases=outputs["class_attn_biases"]))
+        inp = batched_inputs[0]
+        row_ids = np.arange(self.num_queries, dtype=np.int32)
+        return self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
+                                    inp.get("height", image_size[0]), inp.get("width", image_size[1]))
+
+    __call__ = forward

@@ -203,7 +203,56 @@ def gen_frame_decoder_and_tracker():
     print("wrote frame_decoder_tracker.npz", out["pred_masks"].shape, idx.shape)
 
 
-GENERATORS = {"msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual,
+SAN_CLIP = dict(embed_dim=64, image_resolution=64, vision_layers=4, vision_width=256, vision_patch_size=16,
+                mask_prompt_depth=0, context_length=8, vocab_size=64, transformer_width=64, transformer_heads=2,
+                transformer_layers=1)
+
+
+def gen_side_adapter():
+    """Reference SideAdapter.front_encode_image / post_encode_image / cal_sim_logits (side_adapter.py:147-235) and
+    SideAdapterFrameMultiScaleMaskedTransformerDecoder.forward (side-frame decoder:57-169) on a tiny CLIP."""
+    from tests._synth import synth_inputs, synth_weights, spec_of
+    from oracle import torch_ref as TR
+    sa = R.ref("openvis.modeling.clip_adapter.side_adapter")
+    mac = R.ref("mask_adapted_clip.model")
+    sa.build_clip_model = lambda name: mac.CLIP(**SAN_CLIP)          # clip.load() needs the network
+    Q, T = 12, 2
+    ad = sa.SideAdapter("tiny", out_dims=256, broken_idx=3, merge_ids=[1, 2, 3], num_queries=Q, text_templates=["{}"]).eval()
+    spec_ad = _load_synth(ad, 131)
+    frames = (synth_inputs([(T, 3, 96, 128)], 132)[0].sigmoid() * 255).floor()      # raw padded frames 0..255
+    sfd = R.ref("openvis.modeling.transformer_decoder.side_adapter_frame_mask2former_transformer_decoder")
+    dec = sfd.SideAdapterFrameMultiScaleMaskedTransformerDecoder(
+        clip_heads=4, mask_classification=True, in_channels=256, num_classes=1, hidden_dim=256, num_queries=Q, nheads=8,
+        dim_feedforward=2048, dec_layers=9, pre_norm=False, mask_dim=256, enforce_input_project=False, num_frames=T).eval()
+    spec_dec = _load_synth(dec, 133)
+    Wd = synth_weights(spec_dec, 133, "sem_seg_head.predictor.")
+    for s_ms in range(134, 234, 10):                                   # stable seed (see gen_frame_decoder_and_tracker)
+        ms = synth_inputs([(T, 256, 3, 4), (T, 256, 6, 8), (T, 256, 12, 16)], s_ms)
+        mf = synth_inputs([(T, 256, 24, 32)], s_ms + 1)[0]
+        with torch.no_grad():
+            out = dec(ms, mf)
+            mine = TR.side_frame_decoder(ms, mf, Wd, clip_heads=4)
+        if (out["pred_masks"] - mine["pred_masks"]).abs().max() < 1e-3:
+            break
+    else:
+        raise RuntimeError("no stable seed found")
+    print("side-frame decoder fixture uses input seed", s_ms)
+    text = torch.nn.functional.normalize(synth_inputs([(5, 64)], 136)[0], dim=-1)
+    with torch.no_grad():
+        mg, bk = ad.front_encode_image(frames)
+        biases = out["class_attn_biases"].flatten(0, 1)                # [T, n, Q, ha, wa]
+        sos = ad.post_encode_image(bk, biases)
+        tf = torch.cat([text, torch.nn.functional.normalize(ad.bg_embed, dim=-1)], dim=0)
+        logits = ad.cal_sim_logits(tf, sos)
+    np.savez_compressed(os.path.join(GOLD, "side_adapter.npz"), spec_ad=_spec_arrays(spec_ad), spec_dec=_spec_arrays(spec_dec),
+                        seeds=np.array([131, 132, 133, s_ms, s_ms + 1, 136]), mg0=mg[0].numpy(), mg1=mg[1].numpy(),
+                        mg2=mg[2].numpy(), bk_cls=bk[0].numpy(), bk_pix=bk[1].numpy(), sos=sos.numpy(),
+                        logits=logits.numpy(), class_attn_biases=out["class_attn_biases"].numpy(),
+                        pred_masks=out["pred_masks"].numpy(), pred_embeds=out["pred_embeds"].numpy())
+    print("wrote side_adapter.npz", sos.shape, logits.shape, out["class_attn_biases"].shape)
+
+
+GENERATORS = {"msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "san": gen_side_adapter, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual,
               "pe": gen_position_encodings}
 
 if __name__ == "__main__":

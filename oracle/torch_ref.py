@@ -200,7 +200,8 @@ def encoder_reference_points(shapes_list):
     return ref[:, :, None].expand(-1, -1, len(shapes_list), -1)
 
 
-def pixel_decoder(feats, W, prefix="sem_seg_head.pixel_decoder.", n_layers=6, return_intermediate=False):
+def pixel_decoder(feats, W, prefix="sem_seg_head.pixel_decoder.", n_layers=6, return_intermediate=False,
+                  extra_features=None):
     """feats: dict res2..res5 (fp32 NCHW) -> (mask_features, out[0], multi_scale_features[3])."""
     p = prefix
     srcs, poss = [], []
@@ -209,6 +210,11 @@ def pixel_decoder(feats, W, prefix="sem_seg_head.pixel_decoder.", n_layers=6, re
         y = F.conv2d(x, W[f"{p}input_proj.{idx}.0.weight"], W[f"{p}input_proj.{idx}.0.bias"])
         srcs.append(_gn(y, W, f"{p}input_proj.{idx}.1"))
         poss.append(pe_sine_2d(x.shape[0], x.shape[2], x.shape[3]))
+        if extra_features is not None:                                          # msdeformattn.py:338-344 (SAN)
+            ex = extra_features[idx]
+            if ex.shape[-2:] != x.shape[-2:]:
+                ex = F.interpolate(ex, size=x.shape[-2:], mode="bilinear", align_corners=False)
+            srcs[-1] = srcs[-1] + ex
     # MSDeformAttnTransformerEncoderOnly.forward: msdeformattn.py:76-104
     shapes_list = [(s.shape[2], s.shape[3]) for s in srcs]
     src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
@@ -634,3 +640,137 @@ def openvis_online_forward(frames, W, text_features, out_hw=None, stages=None, c
         stages.update(dict(images=images, feats=feats, pred_masks=out["pred_masks"], pred_embeds=out["pred_embeds"],
                            indices=out["indices"], probs=probs, **extras))
     return res
+
+
+# ----------------------------------------------------------------------------------------------
+# A13  SideAdapter — openvis/modeling/clip_adapter/side_adapter.py:147-270 (state-dict prefix clip_adapter.)
+# ----------------------------------------------------------------------------------------------
+def _clip_block(x, W, bp, heads, attn_mask=None):
+    """BiasedResidualAttentionBlock.forward (side_adapter.py:70-78; blocks model.py:238-268), x [L,N,C]."""
+    h = _ln(x, W, bp + "ln_1")
+    x = x + _mha(W, bp + "attn.", h, h, h, attn_mask, heads)
+    h = _ln(x, W, bp + "ln_2")
+    h = F.linear(h, W[bp + "mlp.c_fc.weight"], W[bp + "mlp.c_fc.bias"])
+    h = h * torch.sigmoid(1.702 * h)
+    return x + F.linear(h, W[bp + "mlp.c_proj.weight"], W[bp + "mlp.c_proj.bias"])
+
+
+def san_front_encode_image(x, W, prefix="clip_adapter.", broken_idx=9, merge_ids=(3, 6, 9), resolution=224):
+    """side_adapter.py:147-174. x: raw padded frames [T,3,Hp,Wp] (0..255 float). Returns (mg_feats[3] [T,256,g,g],
+    (cls [1,T,C], pix [T,C,g,g]))."""
+    v = prefix + "clip_model.visual."
+    heads = W[v + "proj"].shape[0] // 64
+    x = F.interpolate(x / 255., (resolution, resolution), mode="bicubic")
+    mean = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+    x = (x - mean) / std
+    patch = W[v + "conv1.weight"].shape[-1]
+    x = F.conv2d(x, W[v + "conv1.weight"], None, stride=patch)
+    b, _, h, w = x.shape
+    x = x.reshape(b, x.shape[1], -1).permute(0, 2, 1).contiguous()
+    cls = W[v + "class_embedding"] + torch.zeros(b, 1, x.shape[-1])
+    x = torch.cat([cls, x], dim=1) + W[v + "positional_embedding"]       # grid == pos-embed grid: resize is the identity
+    x = _ln(x, W, v + "ln_pre").permute(1, 0, 2).contiguous()
+    outs = [(x[0:1], x[1:].permute(1, 2, 0).reshape(b, -1, h, w).contiguous())]
+    for i in range(broken_idx):
+        x = _clip_block(x, W, f"{v}transformer.resblocks.{i}.", heads)
+        outs.append((x[0:1], x[1:].permute(1, 2, 0).reshape(b, -1, h, w).contiguous()))
+    mg = [f[1] for i, f in enumerate(outs) if i in merge_ids]
+    mg = [F.conv2d(f, W[f"{prefix}attn_projs.{i}.weight"], W[f"{prefix}attn_projs.{i}.bias"]) for i, f in enumerate(mg)]
+    return mg, outs[-1]
+
+
+def san_build_attn_bias(attn_bias, num_heads, target_shape):
+    """side_adapter.py:237-270 for one bias tensor [B,n,Q,H,W] -> [B*num_heads, Q+1+L, Q+1+L]."""
+    b, num_head, num_sos, h, w = attn_bias.shape
+    ab = F.adaptive_max_pool2d(attn_bias.reshape(b, num_head * num_sos, h, w), output_size=target_shape)
+    ab = ab.reshape(b, num_head, num_sos, *target_shape)
+    if num_head == 1:
+        ab = ab.repeat(1, num_heads, 1, 1, 1)
+    ab = ab.reshape(b * num_heads, num_sos, -1)
+    L = ab.shape[-1]
+    nb = ab.new_zeros(num_sos + 1 + L, num_sos + 1 + L)
+    nb[:, :num_sos] = -100
+    nb[:num_sos, num_sos] = -100
+    nb[torch.arange(num_sos), torch.arange(num_sos)] = 0
+    nb = nb[None, ...].expand(b * num_heads, -1, -1).clone()
+    nb[..., :num_sos, -L:] = ab
+    return nb
+
+
+def san_post_encode_image(feats, attn_bias, W, prefix="clip_adapter.", broken_idx=9, num_sos=100):
+    """side_adapter.py:176-209. feats = (cls [1,T,C], pix [T,C,g,g]); attn_bias [T,n,Q,H,W] -> sos feats [T,Q,E] (unit rows)."""
+    v = prefix + "clip_model.visual."
+    heads = W[v + "proj"].shape[0] // 64
+    cls_token, pix = feats
+    n, c, h, w = pix.shape
+    x = torch.cat([cls_token, pix.reshape(n, c, -1).permute(2, 0, 1)])
+    sos = cls_token.repeat(num_sos, 1, 1)
+    n_layers = 1 + max(int(k[len(v + "transformer.resblocks."):].split(".")[0]) for k in W if k.startswith(v + "transformer.resblocks."))
+    bias = san_build_attn_bias(attn_bias, heads, (h, w))
+    x = torch.cat([sos, x], dim=0)
+    for i in range(broken_idx, n_layers):
+        x = _clip_block(x, W, f"{v}transformer.resblocks.{i}.", heads, bias)
+    sos = x[:num_sos].permute(1, 0, 2)
+    sos = _ln(sos, W, v + "ln_post") @ W[v + "proj"]
+    return F.normalize(sos, dim=-1)
+
+
+def san_text_with_bg(text_features, W, prefix="clip_adapter."):
+    """encode_text(w_bg=True) tail (side_adapter.py:228-231): append the normalised learned background embedding."""
+    return torch.cat([text_features, F.normalize(W[prefix + "bg_embed"], dim=-1)], dim=0)
+
+
+def san_cal_sim_logits(text_feats, image_feats, W, prefix="clip_adapter."):
+    return W[prefix + "clip_model.logit_scale"].exp() * image_feats @ text_feats.T      # side_adapter.py:234-235
+
+
+# side-adapter frame decoder — transformer_decoder/side_adapter_frame_mask2former_transformer_decoder.py:57-169
+def side_frame_decoder(ms_feats, mask_features, W, prefix="sem_seg_head.predictor.", n_layers=9, nheads=8, clip_heads=12):
+    p = prefix
+    bt, c = mask_features.shape[:2]
+    af = F.interpolate(mask_features, scale_factor=0.25, mode="bilinear", align_corners=False)
+    ha, wa = af.shape[-2:]
+    for j in range(3):
+        af = F.conv2d(af, W[f"{p}attn_mlp.layers.{j}.weight"], W[f"{p}attn_mlp.layers.{j}.bias"])
+        if j < 2:
+            af = F.relu(af)
+    af = af.reshape(bt, clip_heads, c, ha, wa)
+    src, pos, size_list = [], [], []
+    for i in range(3):
+        h, w = ms_feats[i].shape[-2:]
+        size_list.append((h, w))
+        pos.append(pe_sine_2d(ms_feats[i].shape[0], h, w).flatten(2).permute(2, 0, 1))
+        src.append((ms_feats[i].flatten(2) + W[p + "level_embed.weight"][i][None, :, None]).permute(2, 0, 1))
+    bs = src[0].shape[1]
+    query_embed = W[p + "query_embed.weight"].unsqueeze(1).repeat(1, bs, 1)
+    output = W[p + "query_feat.weight"].unsqueeze(1).repeat(1, bs, 1)
+
+    def heads(out, target):
+        dec = _ln(out, W, p + "decoder_norm").transpose(0, 1)
+        attn_embed = _mlp3(dec, W, p + "attn_embed.")
+        mask_embed = _mlp3(dec, W, p + "mask_embed.")
+        biases = torch.einsum("bqc,bnchw->bnqhw", attn_embed, af)
+        masks = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features)
+        am = F.interpolate(masks, size=target, mode="bilinear", align_corners=False)
+        am = (am.sigmoid().flatten(2).unsqueeze(1).repeat(1, nheads, 1, 1).flatten(0, 1) < 0.5).bool()
+        return biases, masks, am
+
+    biases, msk, attn_mask = heads(output, size_list[0])
+    for i in range(n_layers):
+        li = i % 3
+        attn_mask[torch.where(attn_mask.sum(-1) == attn_mask.shape[-1])] = False
+        cp = f"{p}transformer_cross_attention_layers.{i}."
+        tgt2 = _mha(W, cp + "multihead_attn.", output + query_embed, src[li] + pos[li], src[li], attn_mask, nheads)
+        output = _ln(output + tgt2, W, cp + "norm")
+        sp = f"{p}transformer_self_attention_layers.{i}."
+        qk = output + query_embed
+        output = _ln(output + _mha(W, sp + "self_attn.", qk, qk, output, None, nheads), W, sp + "norm")
+        fp = f"{p}transformer_ffn_layers.{i}."
+        tgt2 = F.linear(F.relu(F.linear(output, W[fp + "linear1.weight"], W[fp + "linear1.bias"])),
+                        W[fp + "linear2.weight"], W[fp + "linear2.bias"])
+        output = _ln(output + tgt2, W, fp + "norm")
+        biases, msk, attn_mask = heads(output, size_list[(i + 1) % 3])
+    pred_embeds = _ln(output, W, p + "decoder_norm")
+    return {"class_attn_biases": biases.unsqueeze(0), "pred_masks": msk.permute(1, 0, 2, 3).unsqueeze(0),
+            "pred_embeds": pred_embeds.permute(1, 0, 2).unsqueeze(0), "attn_feats": af, "mask_feats": mask_features}

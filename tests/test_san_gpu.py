@@ -1,0 +1,77 @@
+"""GPU: SideAdapter (A13), side-adapter frame decoder and SANOnline vs the reference goldens / oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import GOLDEN
+from tests.test_oracle_path import load_san_case
+
+pytestmark = pytest.mark.gpu
+
+ARCH = dict(width=256, layers=4, heads=4, patch=16, resolution=64, embed_dim=64)
+nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_side_adapter_matches_reference(precision):
+    from openvis_amd.modeling.clip_adapter.side_adapter import SideAdapter
+    g, Wd, frames, ms, mf, text = load_san_case()
+    Q = g["sos"].shape[1]
+    ad = SideAdapter("tiny", broken_idx=3, merge_ids=[1, 2, 3], num_queries=Q, arch=ARCH, precision=precision)
+    ad.load_state_dict(Wd, "clip_adapter.", "cuda")
+    fu8 = frames.to(torch.uint8).cuda()                          # golden frames are integer valued 0..255
+    mg, tok = ad.front_encode_image(fu8, (96, 128))
+    tol = 2e-4 if precision == "fp32" else 2e-2
+    for i in range(3):
+        assert np.abs(mg[i].permute(0, 3, 1, 2).cpu().numpy() - g[f"mg{i}"]).max() < tol * max(1.0, np.abs(g[f"mg{i}"]).max())
+    assert np.abs(tok[:, 0].cpu().numpy() - g["bk_cls"][0]).max() < tol * 5
+    pix = tok[:, 1:].permute(0, 2, 1).reshape(tok.shape[0], -1, 4, 4).cpu().numpy()
+    assert np.abs(pix - g["bk_pix"]).max() < tol * 5
+    biases = torch.from_numpy(g["class_attn_biases"][0]).cuda()
+    sos = ad.post_encode_image(tok, biases)
+    assert np.abs(sos.cpu().numpy() - g["sos"]).max() < (1e-4 if precision == "fp32" else 5e-3)     # unit vectors
+    ad.set_text_features([f"c{i}" for i in range(5)], text)
+    logits = ad.cal_sim_logits(ad.encode_text([f"c{i}" for i in range(5)]), sos)
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < (2e-3 if precision == "fp32" else 1e-1)
+
+
+def test_side_frame_decoder_matches_reference():
+    from openvis_amd.modeling.transformer_decoder import SideAdapterFrameMultiScaleMaskedTransformerDecoder as Dec
+    g, Wd, frames, ms, mf, text = load_san_case()
+    T, Q = g["pred_masks"].shape[2], g["pred_masks"].shape[1]
+    dec = Dec(4, True, in_channels=256, num_classes=1, hidden_dim=256, num_queries=Q, nheads=8, dim_feedforward=2048,
+              dec_layers=9, pre_norm=False, mask_dim=256, enforce_input_project=False, num_frames=T, precision="fp32")
+    dec.load_state_dict(Wd, "sem_seg_head.predictor.", "cuda")
+    out = dec([nhwc(m) for m in ms], nhwc(mf))
+    pm = out["pred_masks"].cpu().numpy()
+    assert np.abs(pm - g["pred_masks"]).max() < 3e-3
+    assert ((pm > 0) == (g["pred_masks"] > 0)).mean() > 0.9999
+    cab = out["class_attn_biases"].cpu().numpy()
+    assert np.abs(cab - g["class_attn_biases"]).max() < 3e-3 * max(1.0, np.abs(g["class_attn_biases"]).max())
+    assert np.abs(out["pred_embeds"].cpu().numpy() - g["pred_embeds"]).max() < 3e-4
+
+
+def test_san_kernels_vs_torch():
+    from openvis_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 2, 5, 23, 40, generator=g)
+    ref = F.adaptive_max_pool2d(x.flatten(0, 2), (14, 14)).view(3, 2, 5, 14, 14)
+    assert torch.equal(ops.adaptive_maxpool2d(x.cuda(), 14, 14).cpu(), ref)
+    fr = (torch.rand(2, 3, 45, 61, generator=g) * 255).to(torch.uint8)
+    pad = torch.zeros(2, 3, 64, 64)
+    pad[:, :, :45, :61] = fr.float()
+    r = F.interpolate(pad / 255., (32, 32), mode="bicubic")
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(1, 3, 1, 1)
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(1, 3, 1, 1)
+    r = (r - mean) / std
+    refA = r.unfold(2, 16, 16).unfold(3, 16, 16).permute(0, 2, 3, 1, 4, 5).reshape(-1, 768)
+    A = ops.san_front_patches(fr.cuda(), 64, 64, 32, 16, mean.flatten().tolist(), std.flatten().tolist()).cpu()
+    assert (A - refA).abs().max() < 2e-5
+    dst = torch.randn(2, 23, 40, 256, generator=g)
+    src = torch.randn(2, 14, 14, 256, generator=g)
+    ref = dst + F.interpolate(src.permute(0, 3, 1, 2), size=(23, 40), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    out = ops.bilinear_resize_add(dst.clone().cuda(), src.cuda()).cpu()
+    assert (out - ref).abs().max() < 1e-5
