@@ -1,0 +1,82 @@
+"""BriVIS meta-architecture — mirror of openvis/brivis.py:26-265 (eval path, WINDOW_INFERENCE False; registered "BriVIS").
+
+SANOnline per-frame outputs -> Hungarian linker over the per-frame query embeddings -> TemporalInstanceResampler ->
+mask / attention-bias heads -> CLIP back blocks -> per-query logits averaged over time.
+
+Frame sharding (BASELINE.json configs[3]): everything up to the per-frame query embeddings is
+independent per frame, so ranks own contiguous frame blocks; ONE RCCL all-gather of the [t_local,Q,256] embeddings
+precedes the linker + temporal resampler (replicated: deterministic, tiny), prediction heads and the CLIP back pass run
+on the local frames only, and ONE all-reduce of the per-frame logit sums gives every rank the same classification."""
+import numpy as np
+import torch
+
+from . import ops
+from . import distributed as D
+from .modeling.minvis import batch_video_match_via_embeds
+from .modeling.resampler import TemporalInstanceResampler
+from .registry import META_ARCH_REGISTRY
+from .san import SANOnline
+
+
+@META_ARCH_REGISTRY.register()
+class BriVIS(SANOnline):
+    def __init__(self, *, resampler=None, **kwargs):
+        super().__init__(**kwargs)
+        self.resampler = resampler or TemporalInstanceResampler(hidden_dim=256, feed_dim=2048, nheads=8, nlayers=6)
+
+    @classmethod
+    def from_config(cls, cfg):
+        args = SANOnline.from_config(cfg)
+        args["resampler"] = TemporalInstanceResampler(
+            hidden_dim=256, feed_dim=2048, nheads=8, nlayers=6,                        # hard-coded, brivis.py:47
+            precision="fp32" if cfg.MODEL.get("PRECISION", "mixed") == "fp32" else "fp16")
+        return args
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        self.resampler.load_state_dict(sd, "resampler.", self.device)
+        return self
+
+    def forward(self, batched_inputs, stages=None, frame_range=None):
+        """frame_range=(begin, end): this rank's contiguous frame block of the clip (frame-sharded mode; requires an
+        initialised process group). Default: all frames on this rank."""
+        dataset_name = list(set(x["dataset_name"] for x in batched_inputs))[0]
+        class_names = self.get_class_name_list(dataset_name)
+        self.sem_seg_head.num_classes = len(class_names)
+        all_frames = [f for video in batched_inputs for f in video["image"]]
+        T_total = len(all_frames)
+        b0, b1 = frame_range if frame_range is not None else (0, T_total)
+        frames = self._frames_to_device([{"image": all_frames[b0:b1]}])
+        io, images, image_size, padded = self.image_outputs(frames, class_names)          # brivis.py:149-171
+        emb_local = io["pred_embeds"][0]                                                   # [t_local,Q,C]
+        emb = D.all_gather_frames(emb_local, T_total) if frame_range is not None else emb_local   # C5: the one exchange
+        idx, frame_embeds = batch_video_match_via_embeds(emb.unsqueeze(0))                 # brivis.py:173
+        x = self.resampler.temporal(frame_embeds[0])                                       # [T,Q,C], replicated
+        n = self.clip_adapter.num_heads
+        pred_masks, biases, emb_out = self.resampler.prediction_heads(x[b0:b1], io["mask_feats"], io["attn_feats"], n)
+        clip_feats = self.clip_adapter.post_encode_image(io["clip_tokens"], biases)        # resampler.py:313
+        logits = self.clip_adapter.cal_sim_logits(io["text_feats"], clip_feats)            # [t_local,Q,K+1]
+        probs = self.classify_sharded(logits, T_total, frame_range is not None)            # brivis.py:247-252
+        if stages is not None:
+            stages.update(dict(pred_masks=pred_masks.unsqueeze(0), pred_logits=logits.unsqueeze(0), indices=idx, probs=probs,
+                               pred_embeds=emb_out))
+        inp = batched_inputs[0]
+        row_ids = np.arange(self.num_queries, dtype=np.int32)
+        return self.inference_video(self.num_queries, len(class_names), probs, row_ids, pred_masks, padded, image_size,
+                                    inp.get("height", image_size[0]), inp.get("width", image_size[1]))
+
+    __call__ = forward
+
+    def classify_sharded(self, logits, T_total, sharded):
+        """softmax(mean over ALL frames of the logits)[:, :-1]; sharded: per-rank frame sums are all-reduced."""
+        if not sharded:
+            return self.classify(logits.unsqueeze(0))
+        t, Q, K1 = logits.shape
+        # sum over local frames (mean x t) -> all-reduce -> / T_total -> softmax: re-use the aggregate kernel on the sums
+        slot = torch.arange(t * Q, dtype=torch.int32, device=logits.device).view(t, Q)
+        _ = slot
+        local_sum = logits.sum(dim=0)                                                     # [Q,K+1] (tiny reduction)
+        total = D.all_reduce_sum(local_sum) / float(T_total)
+        one = torch.arange(Q, dtype=torch.int32, device=logits.device).view(1, Q)
+        probs, _ = ops.openvis_aggregate(total.contiguous(), one)
+        return probs[:, :-1].contiguous()

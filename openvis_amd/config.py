@@ -98,7 +98,7 @@ def get_cfg():
 
 def build_model(cfg):
     """detectron2.modeling.build_model: META_ARCH_REGISTRY.get(name)(cfg) via from_config."""
-    from . import openvis, san  # noqa: F401  (registers the meta-architectures)
+    from . import openvis, san, brivis  # noqa: F401  (registers the meta-architectures)
     from .registry import META_ARCH_REGISTRY
     cls = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)
     return cls(**cls.from_config(cfg))

@@ -254,13 +254,15 @@ def pe_sine(T, H, W, npf, three_d, add_c, device):
 
 
 def attention(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, mask=None, row_open=None, nsplit=1,
-              out_f16=False, mask_per_batch=False, bias=None):
+              out_f16=False, mask_per_batch=False, bias=None, out=None, o_bs=None, o_ld=None):
     """q/k/v: tensors (possibly column-sliced views of a fused projection) whose element (b,row,h,d) sits at
     data_ptr + (b*bs + row*ld + h*D + d)*4.  Returns out [B,Nq,H*D]."""
     for t in (q, k, v):
         if not t.is_cuda:
             raise _lib.OvisError("attention needs HIP tensors")
-    out = torch.empty((B, Nq, H * D), dtype=torch.float16 if out_f16 else torch.float32, device=q.device)
+    if out is None:
+        out = torch.empty((B, Nq, H * D), dtype=torch.float16 if out_f16 else torch.float32, device=q.device)
+        o_bs, o_ld = Nq * H * D, H * D
     ws = None
     if nsplit > 1:
         nbytes = _lib.lib().ovis_attention_workspace_bytes(B, H, Nq, D, nsplit)
@@ -275,7 +277,7 @@ def attention(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, mask
     else:
         b_args = (None, _ll(0), _ll(0), 0)
     _lib.call("ovis_attention_f32", vp(q), _ll(q_bs), q_ld, vp(k), _ll(k_bs), k_ld, vp(v), _ll(v_bs), v_ld, out,
-              _ll(Nq * H * D), H * D, int(out_f16), mask, _ll(mask_ld), _ll(mask_bs), row_open, *b_args, B, H, Nq, Nk, D,
+              _ll(o_bs), o_ld, int(out_f16), mask, _ll(mask_ld), _ll(mask_bs), row_open, *b_args, B, H, Nq, Nk, D,
               float(D) ** -0.5, nsplit, ws, _lib.stream_ptr())
     return out
 

@@ -87,6 +87,55 @@ def clip_visual_spec(prefix="clip_adapter.clip_model.visual.", width=768, layers
     return s
 
 
+def side_adapter_spec(prefix="clip_adapter.", out_dims=256, n_merge=3, **arch):
+    arch = dict(arch or _CLIP_ARCH["ViT-B/16"])
+    s = clip_visual_spec(prefix + "clip_model.visual.", **arch)
+    s.append((prefix + "clip_model.logit_scale", ()))
+    for i in range(n_merge):
+        s += [(f"{prefix}attn_projs.{i}.weight", (out_dims, arch["width"], 1, 1)), (f"{prefix}attn_projs.{i}.bias", (out_dims,))]
+    s.append((prefix + "bg_embed", (1, arch["embed_dim"])))
+    return s
+
+
+def side_decoder_spec(prefix="sem_seg_head.predictor.", C=256, clip_heads=12, Q=100):
+    s = [kv for kv in video_decoder_spec(prefix, C=C, Q=Q) if "class_embed" not in kv[0]]
+    for j in range(3):
+        s += [(f"{prefix}attn_embed.layers.{j}.weight", (C, C)), (f"{prefix}attn_embed.layers.{j}.bias", (C,))]
+    for j, co in enumerate((C, C, C * clip_heads)):
+        s += [(f"{prefix}attn_mlp.layers.{j}.weight", (co, C, 1, 1)), (f"{prefix}attn_mlp.layers.{j}.bias", (co,))]
+    return s
+
+
+def resampler_spec(prefix="resampler.", C=256, layers=6, ffn=2048):
+    s = []
+    for i in range(layers):
+        p = f"{prefix}long_aggregate_layers.{i}."
+        s += [(p + "self_attn.in_proj_weight", (3 * C, C)), (p + "self_attn.in_proj_bias", (3 * C,)),
+              (p + "self_attn.out_proj.weight", (C, C)), (p + "self_attn.out_proj.bias", (C,)),
+              (p + "norm.weight", (C,)), (p + "norm.bias", (C,))]
+        p = f"{prefix}short_aggregate_layers.{i}."
+        s += [(p + "0.weight", (C, C, 5)), (p + "0.bias", (C,)), (p + "2.weight", (C, C, 3)), (p + "2.bias", (C,))]
+        s += [(f"{prefix}aggregate_norms.{i}.weight", (C,)), (f"{prefix}aggregate_norms.{i}.bias", (C,))]
+        p = f"{prefix}transformer_ffn_layers.{i}."
+        s += [(p + "linear1.weight", (ffn, C)), (p + "linear1.bias", (ffn,)), (p + "linear2.weight", (C, ffn)),
+              (p + "linear2.bias", (C,)), (p + "norm.weight", (C,)), (p + "norm.bias", (C,))]
+    s += [(prefix + "decode_norm.weight", (C,)), (prefix + "decode_norm.bias", (C,))]
+    for nm in ("attn_embed", "mask_embed"):
+        for j in range(3):
+            s += [(f"{prefix}{nm}.layers.{j}.weight", (C, C)), (f"{prefix}{nm}.layers.{j}.bias", (C,))]
+    return s
+
+
+def san_r50_spec(clip_arch=None, num_queries=100):
+    arch = dict(clip_arch or _CLIP_ARCH["ViT-B/16"])
+    return (resnet50_spec() + pixel_decoder_spec() + side_decoder_spec(clip_heads=arch["width"] // 64, Q=num_queries) +
+            side_adapter_spec(**arch))
+
+
+def brivis_r50_spec(clip_arch=None, num_queries=100):
+    return san_r50_spec(clip_arch, num_queries) + resampler_spec()
+
+
 def openvis_r50_spec(clip_arch=None, num_queries=100):
     arch = dict(clip_arch or _CLIP_ARCH["ViT-B/16"])
     return resnet50_spec() + pixel_decoder_spec() + video_decoder_spec(Q=num_queries) + clip_visual_spec(**arch)
@@ -98,7 +147,9 @@ def random_init(spec, seed=42):
     sd = {}
     for key, shape in spec:
         shape = tuple(shape)
-        if key.endswith("running_var"):
+        if key.endswith("logit_scale"):
+            t = torch.tensor(math.log(1 / 0.07))
+        elif key.endswith("running_var"):
             t = torch.rand(shape, generator=g) * 0.5 + 0.75
         elif key.endswith("running_mean"):
             t = torch.randn(shape, generator=g) * 0.1

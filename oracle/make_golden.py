@@ -252,7 +252,34 @@ def gen_side_adapter():
     print("wrote side_adapter.npz", sos.shape, logits.shape, out["class_attn_biases"].shape)
 
 
-GENERATORS = {"msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "san": gen_side_adapter, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual,
+def gen_resampler():
+    """Reference TemporalInstanceResampler.forward (resampler.py:244-316) with a stub adapter (the CLIP pass of its
+    prediction heads is covered by the side_adapter fixture)."""
+    from tests._synth import synth_inputs
+    rs = R.ref("openvis.modeling.resampler")
+    m = rs.TemporalInstanceResampler(hidden_dim=256, feed_dim=2048, nheads=8, nlayers=6).eval()
+    spec = _load_synth(m, 141)
+    T, Q, n = 5, 9, 2
+    fe = synth_inputs([(1, T, Q, 256)], 142)[0]
+    mf = synth_inputs([(T, 256, 8, 12)], 143)[0]
+    af = synth_inputs([(T, n, 256, 2, 3)], 144)[0]
+
+    class _Adapter:                                   # records the biases, returns them pooled as fake "logits"
+        def post_encode_image(self, bk, biases):
+            self.biases = biases
+            return biases.mean(dim=(1, 3, 4))[..., None]
+        def cal_sim_logits(self, text, feats):
+            return feats
+    ad = _Adapter()
+    with torch.no_grad():
+        out = m(fe, mf, af, ad, None, None)
+    np.savez_compressed(os.path.join(GOLD, "resampler.npz"), spec=_spec_arrays(spec), seeds=np.array([141, 142, 143, 144]),
+                        dims=np.array([T, Q, n]), pred_masks=out["pred_masks"].numpy(), pred_embeds=out["pred_embeds"].numpy(),
+                        last_biases=ad.biases.numpy())
+    print("wrote resampler.npz", out["pred_masks"].shape, ad.biases.shape)
+
+
+GENERATORS = {"msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "san": gen_side_adapter, "resampler": gen_resampler, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual,
               "pe": gen_position_encodings}
 
 if __name__ == "__main__":

@@ -774,3 +774,88 @@ def side_frame_decoder(ms_feats, mask_features, W, prefix="sem_seg_head.predicto
     pred_embeds = _ln(output, W, p + "decoder_norm")
     return {"class_attn_biases": biases.unsqueeze(0), "pred_masks": msk.permute(1, 0, 2, 3).unsqueeze(0),
             "pred_embeds": pred_embeds.permute(1, 0, 2).unsqueeze(0), "attn_feats": af, "mask_feats": mask_features}
+
+
+def san_online_image_outputs(frames, W, text_features, broken_idx=9, merge_ids=(3, 6, 9), resolution=224, clip_heads=12,
+                             num_queries=100):
+    """SANOnline.forward up to the per-frame logits (san.py:211-231). frames uint8 [T,3,H,W]; text_features [K,E]."""
+    images, (H, Wd) = preprocess([f for f in frames])
+    Hp, Wp = images.shape[-2:]
+    ori = torch.zeros(frames.shape[0], 3, Hp, Wp)
+    ori[:, :, :H, :Wd] = frames.float()                                   # ImageList.from_tensors(ori_images): zero pad
+    mg, bk = san_front_encode_image(ori, W, broken_idx=broken_idx, merge_ids=merge_ids, resolution=resolution)
+    tf = san_text_with_bg(text_features, W)
+    feats = resnet50(images, W)
+    mask_features, _, ms = pixel_decoder(feats, W, extra_features=mg)
+    out = side_frame_decoder(ms, mask_features, W, clip_heads=clip_heads)
+    sos = san_post_encode_image(bk, out["class_attn_biases"][0], W, broken_idx=broken_idx, num_sos=num_queries)
+    out["pred_logits"] = san_cal_sim_logits(tf, sos, W).unsqueeze(0)       # [1,T,Q,K+1]
+    out.update(images=images, image_size=(H, Wd), clip_bk=bk, text_feats=tf)
+    return out
+
+
+def san_online_forward(frames, W, text_features, out_hw=None, stages=None, **kw):
+    """SANOnline.forward, eval (san.py:177-283)."""
+    out = san_online_image_outputs(frames, W, text_features, **kw)
+    images, (H, Wd) = out["images"], out["image_size"]
+    out = minvis_post_processing(out)
+    cls = out["pred_logits"].mean(dim=1)[0]
+    probs = F.softmax(cls, dim=-1)[:, :-1]
+    mask_pred = F.interpolate(out["pred_masks"][0], size=images.shape[-2:], mode="bilinear", align_corners=False)
+    oh, ow = out_hw if out_hw is not None else (H, Wd)
+    res = inference_video(mask_pred.shape[0], text_features.shape[0], probs, mask_pred, (H, Wd), oh, ow)
+    if stages is not None:
+        stages.update(dict(pred_masks=out["pred_masks"], pred_logits=out["pred_logits"], indices=out["indices"], probs=probs))
+    return res
+
+
+# ----------------------------------------------------------------------------------------------
+# A15  TemporalInstanceResampler — openvis/modeling/resampler.py:244-316 (state-dict prefix resampler.)
+# ----------------------------------------------------------------------------------------------
+def resampler_forward(frame_embeds, W, prefix="resampler.", n_layers=6, nheads=8):
+    """frame_embeds [1,T,Q,C] (tracker order) -> temporal_tgt after the 6 layers as [T,Q,C] (before decode_norm).
+    Only the last prediction head is consumed at eval (resampler.py:294-296), see brivis_forward."""
+    p = prefix
+    _, t, q, c = frame_embeds.shape
+    x = frame_embeds[0]                                                   # 't (b q) c' with b = 1
+    for i in range(n_layers):
+        lp = f"{p}long_aggregate_layers.{i}."
+        x = _ln(x + _mha(W, lp + "self_attn.", x, x, x, None, nheads), W, lp + "norm")     # attention over T per query
+        s = x.permute(1, 2, 0)                                            # (q, c, t)
+        sp = f"{p}short_aggregate_layers.{i}."
+        y = F.conv1d(F.pad(s, (2, 2), mode="replicate"), W[sp + "0.weight"], W[sp + "0.bias"])
+        y = F.conv1d(F.pad(F.relu(y), (1, 1), mode="replicate"), W[sp + "2.weight"], W[sp + "2.bias"])
+        x = _ln((y + s).transpose(1, 2), W, f"{p}aggregate_norms.{i}").permute(1, 0, 2)
+        fp = f"{p}transformer_ffn_layers.{i}."
+        x = _ln(x + F.linear(F.relu(F.linear(x, W[fp + "linear1.weight"], W[fp + "linear1.bias"])),
+                             W[fp + "linear2.weight"], W[fp + "linear2.bias"]), W, fp + "norm")
+    return x
+
+
+def resampler_heads(x, mask_feats, attn_feats, W, prefix="resampler."):
+    """forward_prediction_heads (resampler.py:304-316) without the CLIP pass: x [T,Q,C] -> (masks [T,Q,h,w], biases [T,n,Q,ha,wa])."""
+    out = _ln(x, W, prefix + "decode_norm")
+    masks = torch.einsum("bqc,bchw->bqhw", _mlp3(out, W, prefix + "mask_embed."), mask_feats)
+    biases = torch.einsum("bqc,bnchw->bnqhw", _mlp3(out, W, prefix + "attn_embed."), attn_feats)
+    return masks, biases, out
+
+
+def brivis_forward(frames, W, text_features, out_hw=None, stages=None, **kw):
+    """BriVIS.forward, eval, WINDOW_INFERENCE False (brivis.py:131-176, 201-211, 242-265)."""
+    num_queries = kw.get("num_queries", 100)
+    io = san_online_image_outputs(frames, W, text_features, **kw)
+    images, (H, Wd) = io["images"], io["image_size"]
+    idx, frame_embeds = video_match_via_embeds(io["pred_embeds"][0])                     # brivis.py:173
+    x = resampler_forward(frame_embeds.unsqueeze(0), W)
+    masks, biases, emb = resampler_heads(x, io["mask_feats"], io["attn_feats"], W)
+    sos = san_post_encode_image(io["clip_bk"], biases, W, broken_idx=kw.get("broken_idx", 9), num_sos=num_queries)
+    logits = san_cal_sim_logits(io["text_feats"], sos, W)                                # [T,Q,K+1]
+    probs = F.softmax(logits.mean(dim=0), dim=-1)[:, :-1]                                # brivis.py:247-252
+    pred_masks = masks.permute(1, 0, 2, 3)                                               # [Q,T,h,w]
+    mask_pred = F.interpolate(pred_masks, size=images.shape[-2:], mode="bilinear", align_corners=False)
+    oh, ow = out_hw if out_hw is not None else (H, Wd)
+    res = inference_video(num_queries, text_features.shape[0], probs, mask_pred, (H, Wd), oh, ow)
+    if stages is not None:
+        stages.update(dict(pred_masks=pred_masks.unsqueeze(0), pred_logits=logits.unsqueeze(0), indices=idx, probs=probs,
+                           pred_embeds=emb))
+    return res
