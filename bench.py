@@ -45,16 +45,27 @@ def synth_text(K, dim, seed=1):
     return torch.nn.functional.normalize(base + 0.05 * torch.randn(K, dim, generator=g), dim=-1)
 
 
-def build_model(device, seed=42, clip_precision="fp16", precision="mixed"):
+MODELS = {   # --model: (META_ARCHITECTURE, decoder, weight spec)
+    "openvis": ("OpenVIS", "VideoMultiScaleMaskedTransformerDecoder", "openvis_r50_spec"),
+    "openvis_online": ("OpenVISOnline", "FrameMultiScaleMaskedTransformerDecoder", "openvis_r50_spec"),
+    "san_online": ("SANOnline", "SideAdapterFrameMultiScaleMaskedTransformerDecoder", "san_r50_spec"),
+    "brivis": ("BriVIS", "SideAdapterFrameMultiScaleMaskedTransformerDecoder", "brivis_r50_spec"),
+}
+
+
+def build_model(device, seed=42, clip_precision="fp16", precision="mixed", model_name="openvis"):
     from openvis_amd import config, weights
     from openvis_amd.catalog import MetadataCatalog
+    arch, decoder, spec_fn = MODELS[model_name]
     cfg = config.get_cfg()
     cfg.MODEL.DEVICE = str(device)
+    cfg.MODEL.META_ARCHITECTURE = arch
+    cfg.MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME = decoder
     cfg.MODEL.CLIP_ADAPTER.PRECISION = clip_precision
     cfg.MODEL.PRECISION = precision
     model = config.build_model(cfg)
     model.device = torch.device(device)
-    sd = weights.random_init(weights.openvis_r50_spec(), seed=seed)
+    sd = weights.random_init(getattr(weights, spec_fn)(), seed=seed)
     model.load_state_dict(sd)
     names = [f"class_{i}" for i in range(NUM_CLASSES)]
     MetadataCatalog.get("synthetic_burst_val").set(thing_classes=names)
@@ -133,6 +144,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clip-precision", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--model", default="openvis", choices=sorted(MODELS),
+                    help="default openvis = the BASELINE.json headline (configs[1]); san_online = configs[2]; brivis = "
+                         "configs[3] (one clip of --frames frames, frame-sharded over the ranks, strong scaling)")
+    ap.add_argument("--frames", type=int, default=0, help="frames per clip (default 5; brivis: 36)")
     ap.add_argument("--precision", default="mixed", choices=["mixed", "fp32"],
                     help="dense-path policy: mixed = the reference's autocast policy, fp32 = exact f32 everywhere")
     args = ap.parse_args()
@@ -143,11 +158,22 @@ def main():
     device = torch.device("cuda", local_rank)
 
     from openvis_amd import ops
-    model, sd, text = build_model(device, clip_precision=args.clip_precision, precision=args.precision)
-    # clip-level sharding (InferenceSampler layout): a global list of 2*world clips, each rank owns a contiguous shard
-    my_clips = D.inference_shard(2 * world, rank, world)
-    clips = [synth_frames(T_CLIP, H720, W720, 1000 + i, device) for i in my_clips]
+    model, sd, text = build_model(device, clip_precision=args.clip_precision, precision=args.precision, model_name=args.model)
+    frame_sharded = args.model == "brivis" and world > 1
+    T = args.frames or (36 if args.model == "brivis" else T_CLIP)
+    fwd_kw = {}
+    if frame_sharded:
+        # ONE clip, contiguous frame blocks per rank, all-gather of query embeddings before the linker
+        fr = D.inference_shard(T, rank, world)
+        fwd_kw = {"frame_range": (fr.start, fr.stop)}
+        clips = [synth_frames(T, H720, W720, 1000 + i, device) for i in range(2)]
+    else:
+        # clip-level sharding (InferenceSampler layout): 2*world clips, each rank owns a contiguous shard
+        my_clips = D.inference_shard(2 * world, rank, world)
+        clips = [synth_frames(T, H720, W720, 1000 + i, device) for i in my_clips]
     inputs = [[{"image": [f for f in c], "dataset_name": "synthetic_burst_val"}] for c in clips]
+    _model = model
+    model = (lambda inp, **kw: _model(inp, **fwd_kw, **kw)) if fwd_kw else _model
 
     def sync_all():
         torch.cuda.synchronize()
@@ -203,25 +229,29 @@ def main():
                                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}}
 
     if rank == 0:
-        frames_total = T_CLIP * args.steps * world
+        frames_total = T * args.steps * (1 if frame_sharded else world)
         n_valid = int(st["valid"].sum()) if "valid" in st else 0
         line = {
-            "metric": "frames/sec (whole node) OpenVIS R50 720p inference", "value": round(frames_total / elapsed, 3),
+            "metric": ("frames/sec (whole node) OpenVIS R50 720p inference" if args.model == "openvis" else
+                       f"frames/sec (whole node) {args.model} R50 720p inference"), "value": round(frames_total / elapsed, 3),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16" if (model.clip_adapter.precision == "fp16" or args.precision == "mixed") else "f32", "data": "synthetic",
-            "config": {"workload": "openvis_R50 720p (720x1280 -> 736x1280), 100 queries, 482 classes, 5-frame clips, "
-                                   "ClipAdapter ViT-B/16, random-init weights", "frames_per_step": T_CLIP,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong" if frame_sharded else "weak",
+            "vs_baseline": None, "dtype": "f16" if (_model.clip_adapter.precision == "fp16" or args.precision == "mixed") else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model}_R50 720p (720x1280 -> 736x1280), 100 queries, 482 classes, {T}-frame clips, "
+                                   + ("ClipAdapter" if args.model.startswith("openvis") else "SideAdapter")
+                                   + " ViT-B/16, random-init weights", "frames_per_step": T,
                        "precision": ("reference autocast policy: backbone + decoder GEMM operands fp16 / f32 accumulate, "
                                      "pixel decoder + logits exact-f32 MFMA; " if args.precision == "mixed" else
                                      "backbone/pixel decoder/decoder/masks/logits: exact-f32 MFMA; ")
                                     + "CLIP ViT GEMM operands: "
                                     + ("fp16 with f32 accumulation (the reference's GPU CLIP dtype)"
-                                       if model.clip_adapter.precision == "fp16" else "f32"),
-                       "valid_crops_per_clip": n_valid, "parallelism": f"clip-replicas x{world}"},
+                                       if _model.clip_adapter.precision == "fp16" else "f32"),
+                       "valid_crops_per_clip": n_valid,
+                       "parallelism": (f"frame-sharded x{world} + RCCL all-gather" if frame_sharded else f"clip-replicas x{world}")},
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.model == "openvis":
             line["cpu_baseline"] = cpu_baseline(sd, text)
         print(json.dumps(line))
     if world > 1:

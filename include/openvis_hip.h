@@ -215,9 +215,11 @@ int ovis_bilinear_resize_add_nhwc_f32(float* dst, const float* src, int N, int H
  * indices[t, i] = index of the frame-t query assigned to tracked slot i by the Hungarian chain of
  *   openvis/modeling/minvis.py:28-72 (cost 1 - cosine, scipy.optimize.linear_sum_assignment on target x current,
  *   targets of frame t = frame t-1's embeddings in their assigned order; frame 0 is matched against itself).
- *   embeds f32 [T,Q,C]; indices int32 [T,Q]; workspace ovis_hungarian_link_workspace_bytes(Q,C) bytes.
- *   One launch for the whole chain (the reference does one GPU->CPU sync + scipy call per frame). */
-long long ovis_hungarian_link_workspace_bytes(int Q, int C);
+ *   embeds f32 [T,Q,C] (Q % 4 == 0, C % 4 == 0); indices int32 [T,Q]; workspace of
+ *   ovis_hungarian_link_workspace_bytes(T,Q,C) bytes.  Three launches for the whole chain: row normalisation, one batched
+ *   GEMM for every frame-to-frame cosine matrix, one single-wavefront Jonker-Volgenant chain (the reference does one
+ *   GPU->CPU sync + scipy call per frame). */
+long long ovis_hungarian_link_workspace_bytes(int T, int Q, int C);
 int ovis_hungarian_link_f32(const float* embeds, int* indices, float* workspace, int T, int Q, int C,
                             ovis_stream_t stream);
 /* out[b, m, :] = src[b, idx[b, m], :] (openvis/utils/index.py:4-18 batch_index) with explicit strides (in floats):

@@ -3,137 +3,131 @@
 // Replaces openvis/modeling/minvis.py:28-72 (match_via_embeds / batch_video_match_via_embeds): for t = 0..T-1,
 //   cost[i][j] = 1 - <tgt_i/|tgt_i|, cur_j/|cur_j|>,  tgt = embeds[t-1][indices[t-1]] (tgt = embeds[0] for t = 0),
 //   indices[t] = column assignment of scipy.optimize.linear_sum_assignment(cost) (rows = targets, cols = current).
-// The reference syncs to the host and calls scipy once per frame; here the whole chain over T runs in ONE launch of
-// one workgroup (the chain is inherently sequential in T and the 100x100 problems are tiny), so there is no
-// GPU->CPU round trip per frame.  The assignment is the Jonker-Volgenant shortest-augmenting-path algorithm in the
+// The reference syncs to the host and calls scipy once per frame; here all frame-to-frame cosine matrices come from ONE
+// batched MFMA GEMM and the whole sequential assignment chain over T runs in ONE single-wavefront launch, so there is
+// no GPU->CPU round trip per frame.  The assignment is the Jonker-Volgenant shortest-augmenting-path algorithm in the
 // form scipy uses (rectangular_lsap.cpp: dual variables u, v; ties prefer an unassigned column), in f64 like scipy.
 // Also here: the row gather that applies the permutation to per-frame tensors (utils/index.py:4-18 batch_index).
 #include "common.h"
 
 namespace {
 
-constexpr int LNK_THREADS = 256;
+// ---- stage 1 (parallel): L2-normalise every embedding row ---------------------------------------------------------
+__global__ void __launch_bounds__(256)
+normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float ss = 0.f;
+  for (int c = lane; c < C; c += 64) { const float v = x[r * C + c]; ss += v * v; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float nrm = sqrtf(ss);
+  for (int c = lane; c < C; c += 64) y[r * C + c] = x[r * C + c] / nrm;
+}
 
-struct ArgMin { double v; int j; int free_col; };
-
-__device__ __forceinline__ bool better(double v, int j, int fr, double bv, int bj, int bfr) {
-  // smaller value; ties: a column that is still unassigned first (scipy), then the lower column index
+// ---- stage 3 (sequential chain, ONE wavefront): Jonker-Volgenant per frame on cost = 1 - G_t[prev[i]][j] -----------
+// G_t = En_{t-1} En_t^T (G_0 = En_0 En_0^T) comes from one batched MFMA GEMM (stage 2).  A single 64-lane wavefront
+// owns the whole chain: lane l owns columns l, l+64, ...; the arg-min over columns is 6 cross-lane shuffles, and the
+// only synchronisation is the (single-wave, i.e. free) workgroup barrier that orders LDS traffic.
+__device__ __forceinline__ bool lnk_better(double v, int j, int fr, double bv, int bj, int bfr) {
+  // smaller value; ties: a still-unassigned column first (scipy's rule), then the lower column index
   if (v < bv) return true;
   if (v > bv) return false;
   if (fr != bfr) return fr > bfr;
   return j < bj;
 }
 
-__global__ void __launch_bounds__(LNK_THREADS)
-hungarian_link_kernel(const float* __restrict__ embeds, int* __restrict__ indices, float* __restrict__ cost_ws,
-                      float* __restrict__ norm_ws, int T, int Q, int C) {
-  extern __shared__ double sh[];
-  double* u = sh;                        // [Q]
-  double* v = u + Q;                     // [Q]
-  double* spc = v + Q;                   // shortest path costs [Q]
-  int* path = reinterpret_cast<int*>(spc + Q);   // [Q]
-  int* col4row = path + Q;               // [Q]
-  int* row4col = col4row + Q;            // [Q]
-  int* in_sr = row4col + Q;              // [Q]
-  int* in_sc = in_sr + Q;                // [Q]
-  __shared__ double red_v[LNK_THREADS / 64];
-  __shared__ int red_j[LNK_THREADS / 64], red_f[LNK_THREADS / 64];
-  __shared__ int s_i, s_sink;
-  __shared__ double s_min;
-  const int tid = threadIdx.x;
+// NC = columns per lane (Q <= 64 NC); G_LDS: the frame's Q x Q cosine matrix is staged in LDS (Q*Q*4 bytes) so that the
+// latency-bound inner loop never waits on L2.
+template <int NC, bool G_LDS>
+__global__ void __launch_bounds__(64)
+hungarian_chain_kernel(const float* __restrict__ G, int ldg, int* __restrict__ indices, int T, int Q) {
+  extern __shared__ double shd[];
+  double* u = shd;                                    // [Q] row duals
+  int* path = reinterpret_cast<int*>(u + Q);          // [Q] column -> predecessor row
+  int* col4row = path + Q;                            // [Q]
+  int* row4col = col4row + Q;                         // [Q]
+  int* prev = row4col + Q;                            // [Q] previous frame's assignment (row permutation of G)
+  float* Gs = reinterpret_cast<float*>(prev + Q);     // [Q*ldg] (G_LDS only)
+  const int lane = threadIdx.x;
 
   for (int t = 0; t < T; ++t) {
-    const float* cur = embeds + (long long)t * Q * C;
-    // normalised copies: norm_ws[0:Q*C] = target rows, norm_ws[Q*C:2*Q*C] = current rows
-    float* tn = norm_ws;
-    float* cn = norm_ws + (long long)Q * C;
-    for (int r = tid; r < 2 * Q; r += LNK_THREADS) {
-      const bool is_t = r < Q;
-      const int q = is_t ? r : r - Q;
-      const float* src = is_t ? (t == 0 ? cur + (long long)q * C
-                                        : embeds + ((long long)(t - 1) * Q + indices[(t - 1) * Q + q]) * C)
-                              : cur + (long long)q * C;
-      float ss = 0.f;
-      for (int c = 0; c < C; ++c) ss += src[c] * src[c];
-      const float nrm = sqrtf(ss);
-      float* dst = (is_t ? tn : cn) + (long long)q * C;
-      for (int c = 0; c < C; ++c) dst[c] = src[c] / nrm;
+    const float* Gt = G + (long long)t * Q * ldg;
+    if (G_LDS) {
+      const float4* g4 = reinterpret_cast<const float4*>(Gt);
+      for (int e = lane; e < Q * ldg / 4; e += 64) reinterpret_cast<float4*>(Gs)[e] = g4[e];
     }
-    __threadfence_block();
-    __syncthreads();
-    // cost[i][j] = 1 - <tn_i, cn_j>
-    for (int e = tid; e < Q * Q; e += LNK_THREADS) {
-      const int i = e / Q, j = e % Q;
-      const float* a = tn + (long long)i * C;
-      const float* b = cn + (long long)j * C;
-      float d = 0.f;
-      for (int c = 0; c < C; ++c) d = fmaf(a[c], b[c], d);
-      cost_ws[e] = 1.0f - d;
+    const float* Gc = G_LDS ? Gs : Gt;
+    double v[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[c] = 0.0;
+    for (int q = lane; q < Q; q += 64) {
+      u[q] = 0.0; col4row[q] = -1; row4col[q] = -1;
+      prev[q] = (t == 0) ? q : indices[(t - 1) * Q + q];
     }
-    for (int q = tid; q < Q; q += LNK_THREADS) { u[q] = 0.0; v[q] = 0.0; col4row[q] = -1; row4col[q] = -1; }
-    __threadfence_block();
     __syncthreads();
-
     for (int cur_row = 0; cur_row < Q; ++cur_row) {
-      for (int q = tid; q < Q; q += LNK_THREADS) { spc[q] = INFINITY; in_sr[q] = 0; in_sc[q] = 0; }
-      if (tid == 0) { s_i = cur_row; s_sink = -1; s_min = 0.0; }
-      __syncthreads();
-      while (s_sink < 0) {
-        const int i = s_i;
-        const double min_val = s_min;
-        if (tid == 0) in_sr[i] = 1;
+      unsigned in_sc = 0;                               // bit c: column lane + 64c is in the tree
+      double spc[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) spc[c] = INFINITY;
+      int i = cur_row, sink = -1;
+      double min_val = 0.0;
+      while (sink < 0) {
+        const double ui = u[i];
+        const float* crow = Gc + prev[i] * ldg;
         double bv = INFINITY; int bj = -1, bf = 0;
-        for (int j = tid; j < Q; j += LNK_THREADS) {
-          if (!in_sc[j]) {
-            const double r = min_val + (double)cost_ws[i * Q + j] - u[i] - v[j];
-            if (r < spc[j]) { path[j] = i; spc[j] = r; }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int j = lane + 64 * c;
+          if (j < Q && !((in_sc >> c) & 1u)) {
+            const double r = min_val + (double)(1.0f - crow[j]) - ui - v[c];
+            if (r < spc[c]) { spc[c] = r; path[j] = i; }
             const int fr = row4col[j] < 0;
-            if (bj < 0 || better(spc[j], j, fr, bv, bj, bf)) { bv = spc[j]; bj = j; bf = fr; }
+            if (bj < 0 || lnk_better(spc[c], j, fr, bv, bj, bf)) { bv = spc[c]; bj = j; bf = fr; }
           }
         }
-        // workgroup arg-min
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
           const double ov = __shfl_xor(bv, o, 64);
           const int oj = __shfl_xor(bj, o, 64), of = __shfl_xor(bf, o, 64);
-          if (oj >= 0 && (bj < 0 || better(ov, oj, of, bv, bj, bf))) { bv = ov; bj = oj; bf = of; }
+          if (oj >= 0 && (bj < 0 || lnk_better(ov, oj, of, bv, bj, bf))) { bv = ov; bj = oj; bf = of; }
         }
-        if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_j[tid >> 6] = bj; red_f[tid >> 6] = bf; }
-        __syncthreads();
-        if (tid == 0) {
-          for (int w = 1; w < LNK_THREADS / 64; ++w)
-            if (red_j[w] >= 0 && (bj < 0 || better(red_v[w], red_j[w], red_f[w], bv, bj, bf))) { bv = red_v[w]; bj = red_j[w]; bf = red_f[w]; }
-          s_min = bv;
-          in_sc[bj] = 1;
-          if (row4col[bj] < 0) s_sink = bj; else s_i = row4col[bj];
+        min_val = bv;
+        if ((bj & 63) == lane) in_sc |= 1u << (bj >> 6);
+        const int r4c = row4col[bj];
+        if (r4c < 0) sink = bj; else i = r4c;
+      }
+      // dual update, column-wise: the rows of the tree are cur_row and row4col[j] of every scanned column j, so
+      //   v[j] -= min_val - spc[j],  u[row4col[j]] += min_val - spc[j]  (sink: spc == min_val, no row),  u[cur_row] += min_val
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int j = lane + 64 * c;
+        if (j < Q && ((in_sc >> c) & 1u)) {
+          const double d = min_val - spc[c];
+          v[c] -= d;
+          const int r4c = row4col[j];
+          if (r4c >= 0 && j != sink) u[r4c] += d;
         }
-        __syncthreads();
       }
-      // dual update (rectangular_lsap.cpp: u[curRow] += minVal; SR rows; SC cols)
-      const double min_val = s_min;
-      for (int q = tid; q < Q; q += LNK_THREADS) {
-        if (q == cur_row) u[q] += min_val;
-        else if (in_sr[q]) u[q] += min_val - spc[col4row[q]];
-      }
+      if (lane == 0) u[cur_row] += min_val;
       __syncthreads();
-      for (int q = tid; q < Q; q += LNK_THREADS)
-        if (in_sc[q]) v[q] -= min_val - spc[q];
-      // augment along the path
-      if (tid == 0) {
-        int j = s_sink;
+      if (lane == 0) {                                  // augment along the alternating path
+        int j = sink;
         while (true) {
-          const int i = path[j];
-          row4col[j] = i;
-          const int tmp = col4row[i];
-          col4row[i] = j;
+          const int pi = path[j];
+          row4col[j] = pi;
+          const int tmp = col4row[pi];
+          col4row[pi] = j;
           j = tmp;
-          if (i == cur_row) break;
+          if (pi == cur_row) break;
         }
       }
       __syncthreads();
     }
-    for (int q = tid; q < Q; q += LNK_THREADS) indices[t * Q + q] = col4row[q];
-    __threadfence_block();
+    for (int q = lane; q < Q; q += 64) indices[t * Q + q] = col4row[q];
+    __threadfence();
     __syncthreads();
   }
 }
@@ -154,18 +148,41 @@ batch_index_rows_kernel(const float* __restrict__ src, long long src_bs, long lo
 
 }  // namespace
 
-extern "C" long long ovis_hungarian_link_workspace_bytes(int Q, int C) {
-  return ((long long)Q * Q + 2ll * Q * C) * sizeof(float);
+extern "C" int ovis_gemm_nt_f32_batched(const float* A, long long lda, long long a_bs, const float* B, long long ldb,
+                                        long long b_bs, float* C, long long ldc, long long c_bs, int batch, int M, int N,
+                                        int K, const float* bias, int act, ovis_stream_t stream);
+
+extern "C" long long ovis_hungarian_link_workspace_bytes(int T, int Q, int C) {
+  const long long qp = (Q + 3) / 4 * 4;                       // G rows padded to a multiple of 4 floats
+  return ((long long)T * Q * C + (long long)T * Q * qp) * sizeof(float);
 }
 
 extern "C" int ovis_hungarian_link_f32(const float* embeds, int* indices, float* workspace, int T, int Q, int C,
                                        ovis_stream_t stream) {
   OVIS_REQUIRE(embeds && indices && workspace, "hungarian_link: null pointer");
-  OVIS_REQUIRE(T > 0 && Q > 0 && C > 0 && Q <= 1024, "hungarian_link: bad sizes (Q <= 1024)");
-  const size_t shmem = sizeof(double) * 3 * Q + sizeof(int) * 5 * Q;
-  hipLaunchKernelGGL(hungarian_link_kernel, dim3(1), dim3(LNK_THREADS), shmem, (hipStream_t)stream, embeds, indices, workspace,
-                     workspace + (long long)Q * Q, T, Q, C);
-  return ovis::check_launch("hungarian_link");
+  OVIS_REQUIRE(T > 0 && Q > 0 && C > 0 && Q <= 1024 && C % 4 == 0, "hungarian_link: need Q <= 1024 and C %% 4 == 0");
+  hipStream_t s = (hipStream_t)stream;
+  float* En = workspace;                                      // [T,Q,C] unit rows
+  float* G = workspace + (long long)T * Q * C;                // [T,Q,ldg]: G_t = En_{t-1} En_t^T, G_0 = En_0 En_0^T
+  const int ldg = (Q + 3) / 4 * 4;
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3(ovis::cdiv((long long)T * Q, 4)), dim3(256), 0, s, embeds, En, (long long)T * Q, C);
+  int rc = ovis::check_launch("hungarian_link normalize");
+  if (rc) return rc;
+  rc = ovis_gemm_nt_f32_batched(En, C, 0, En, C, 0, G, ldg, 0, 1, Q, Q, C, nullptr, 0, stream);
+  if (rc) return rc;
+  if (T > 1) {
+    rc = ovis_gemm_nt_f32_batched(En, C, (long long)Q * C, En + (long long)Q * C, C, (long long)Q * C, G + (long long)Q * ldg, ldg,
+                                  (long long)Q * ldg, T - 1, Q, Q, C, nullptr, 0, stream);
+    if (rc) return rc;
+  }
+  const size_t base = sizeof(double) * Q + sizeof(int) * 4 * Q;
+  if (Q <= 112)        // 112*112*4 = 50 KB of LDS for the staged cosine matrix
+    hipLaunchKernelGGL((hungarian_chain_kernel<2, true>), dim3(1), dim3(64), base + sizeof(float) * Q * ldg, s, G, ldg, indices, T, Q);
+  else if (Q <= 256)
+    hipLaunchKernelGGL((hungarian_chain_kernel<4, false>), dim3(1), dim3(64), base, s, G, ldg, indices, T, Q);
+  else
+    hipLaunchKernelGGL((hungarian_chain_kernel<16, false>), dim3(1), dim3(64), base, s, G, ldg, indices, T, Q);
+  return ovis::check_launch("hungarian_link chain");
 }
 
 extern "C" int ovis_batch_index_rows_f32(const float* src, long long src_bs, long long src_rs, const int* idx, float* out,

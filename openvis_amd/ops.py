@@ -155,7 +155,7 @@ def hungarian_link(embeds):
     _chk(embeds)
     T, Q, C = embeds.shape
     idx = torch.empty((T, Q), dtype=torch.int32, device=embeds.device)
-    ws = torch.empty((_lib.lib().ovis_hungarian_link_workspace_bytes(Q, C) // 4,), dtype=torch.float32, device=embeds.device)
+    ws = torch.empty((_lib.lib().ovis_hungarian_link_workspace_bytes(T, Q, C) // 4,), dtype=torch.float32, device=embeds.device)
     _lib.call("ovis_hungarian_link_f32", embeds, idx, ws, T, Q, C, _lib.stream_ptr())
     return idx
 
