@@ -320,6 +320,109 @@ clip_crop_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ m
   }
 }
 
+// Tiled variant: one workgroup = one TY x TX tile of output bins of one crop.  The source pixels a tile can touch form a
+// small rectangle of the frame; it is staged ONCE in LDS as (packed RGB bytes, soft-mask value = sigmoid of the x4
+// up-sampled logit), so every up-sampled logit / sigmoid is evaluated once per source pixel instead of once per tap
+// (~3x fewer) and the 4 x grid^2 taps of a bin become LDS reads.  Arithmetic per bin is the same as clip_crop_kernel.
+template <int TY, int TX>
+__global__ void __launch_bounds__(TY * TX)
+clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ masks, const int* __restrict__ crops,
+                       void* __restrict__ Av, int out_f16, int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp,
+                       int R, int ps, int PRmax, int PWmax, float m0, float m1, float m2, float s0, float s1, float s2) {
+  extern __shared__ uint2 patch[];                      // [PR][PW]: .x = r | g<<8 | b<<16, .y = bits of the soft mask
+  const int tiles_x = R / TX, tiles_y = R / TY;
+  const int tid = threadIdx.x;
+  const int tx_i = blockIdx.x % tiles_x, ty_i = (blockIdx.x / tiles_x) % tiles_y;
+  const int m = blockIdx.x / (tiles_x * tiles_y);
+  const int px = tx_i * TX + tid % TX, py = ty_i * TY + tid / TX;
+  const int* cr = crops + m * 6;
+  const int t = cr[0], q = cr[1];
+  const float bx0 = (float)cr[2], by0 = (float)cr[3];
+  const float bw = (float)(cr[4] + 1 - cr[2]), bh = (float)(cr[5] + 1 - cr[3]);
+  const float roi_w = fmaxf(fmaxf(bw, bh), 1.f);
+  const float bin = roi_w / (float)R;
+  const int grid = (int)ceilf(roi_w / (float)R);
+  const float count = (float)max(grid * grid, 1);
+  const float step = bin / (float)grid;
+  const uint8_t* fp = frames + (long long)t * 3 * H * W;
+  const long long plane = (long long)H * W;
+  const float* mp = masks + ((long long)q * T + t) * h * w;
+  const float usy = (float)h / (float)Hp, usx = (float)w / (float)Wp;
+
+  // source rectangle of this tile: sample coordinates are monotone in (bin index, sample index)
+  const float y_first = by0 + (float)(ty_i * TY) * bin + .5f * step;
+  const float y_last = by0 + (float)(ty_i * TY + TY - 1) * bin + ((float)(grid - 1) + .5f) * step;
+  const float x_first = bx0 + (float)(tx_i * TX) * bin + .5f * step;
+  const float x_last = bx0 + (float)(tx_i * TX + TX - 1) * bin + ((float)(grid - 1) + .5f) * step;
+  const int ylo = min(max((int)floorf(fmaxf(y_first, 0.f)) - 1, 0), Hp - 1);
+  const int xlo = min(max((int)floorf(fmaxf(x_first, 0.f)) - 1, 0), Wp - 1);
+  const int yhi = min((int)floorf(fmaxf(y_last, 0.f)) + 1, Hp - 1);
+  const int xhi = min((int)floorf(fmaxf(x_last, 0.f)) + 1, Wp - 1);
+  const int PR = min(max(yhi - ylo + 1, 1), PRmax), PW = min(max(xhi - xlo + 1, 1), PWmax);
+
+  for (int idx = tid; idx < PR * PW; idx += TY * TX) {
+    const int r = idx / PW, c = idx - r * PW;
+    const int y = ylo + r, x = xlo + c;
+    const float soft = fast_sigmoid(bilerp(mp, w, make_tap(y, usy, h), make_tap(x, usx, w)));
+    unsigned rgb = 0u;
+    if (y < H && x < W) {
+      const long long o = (long long)y * W + x;
+      rgb = (unsigned)fp[o] | ((unsigned)fp[plane + o] << 8) | ((unsigned)fp[2 * plane + o] << 16);
+    }
+    patch[idx] = make_uint2(rgb, __float_as_uint(soft));
+  }
+  __syncthreads();
+
+  float f0 = 0.f, f1 = 0.f, f2 = 0.f, mk = 0.f;
+  for (int iy = 0; iy < grid; ++iy) {
+    const float yy = by0 + (float)py * bin + ((float)iy + .5f) * step;
+    float yf = yy; int fyl, fyh;
+    const bool fy_ok = ra_prep(yf, H, fyl, fyh);
+    const float fly = yf - (float)fyl, fhy = 1.f - fly;
+    float ym = yy; int myl, myh;
+    const bool my_ok = ra_prep(ym, Hp, myl, myh);
+    const float mly = ym - (float)myl, mhy = 1.f - mly;
+    const uint2* fr0 = patch + (fyl - ylo) * PW - xlo; const uint2* fr1 = patch + (fyh - ylo) * PW - xlo;
+    const uint2* mr0 = patch + (myl - ylo) * PW - xlo; const uint2* mr1 = patch + (myh - ylo) * PW - xlo;
+    for (int ix = 0; ix < grid; ++ix) {
+      const float xx = bx0 + (float)px * bin + ((float)ix + .5f) * step;
+      {
+        float x = xx; int xl, xh;
+        if (fy_ok && ra_prep(x, W, xl, xh)) {
+          const float lx = x - (float)xl, hx = 1.f - lx;
+          const float w1 = fhy * hx, w2 = fhy * lx, w3 = fly * hx, w4 = fly * lx;
+          const unsigned a = fr0[xl].x, b = fr0[xh].x, c = fr1[xl].x, d = fr1[xh].x;
+          f0 += w1 * (float)(a & 255u) + w2 * (float)(b & 255u) + w3 * (float)(c & 255u) + w4 * (float)(d & 255u);
+          f1 += w1 * (float)((a >> 8) & 255u) + w2 * (float)((b >> 8) & 255u) + w3 * (float)((c >> 8) & 255u) + w4 * (float)((d >> 8) & 255u);
+          f2 += w1 * (float)(a >> 16) + w2 * (float)(b >> 16) + w3 * (float)(c >> 16) + w4 * (float)(d >> 16);
+        }
+      }
+      {
+        float x = xx; int xl, xh;
+        if (my_ok && ra_prep(x, Wp, xl, xh)) {
+          const float lx = x - (float)xl, hx = 1.f - lx;
+          mk += (mhy * hx) * __uint_as_float(mr0[xl].y) + (mhy * lx) * __uint_as_float(mr0[xh].y) +
+                (mly * hx) * __uint_as_float(mr1[xl].y) + (mly * lx) * __uint_as_float(mr1[xh].y);
+        }
+      }
+    }
+  }
+  f0 /= count; f1 /= count; f2 /= count; mk /= count;
+  const float r0 = ((mk * f0) / 255.f - m0) / s0;
+  const float r1 = ((mk * f1) / 255.f - m1) / s1;
+  const float r2 = ((mk * f2) / 255.f - m2) / s2;
+  const int G = R / ps;
+  const long long row = (long long)m * G * G + (py / ps) * G + (px / ps);
+  const int col = (py % ps) * ps + (px % ps);
+  if (out_f16) {
+    _Float16* ap = reinterpret_cast<_Float16*>(Av) + row * (3 * ps * ps) + col;
+    ap[0] = (_Float16)r0; ap[ps * ps] = (_Float16)r1; ap[2 * ps * ps] = (_Float16)r2;
+  } else {
+    float* ap = reinterpret_cast<float*>(Av) + row * (3 * ps * ps) + col;
+    ap[0] = r0; ap[ps * ps] = r1; ap[2 * ps * ps] = r2;
+  }
+}
+
 // ViT token assembly + ln_pre (model.py:341-343): tok[m,0] = cls + pos[0]; tok[m,1+p] = patch[m,p] + pos[1+p]; LN.
 // one wavefront per token; C % 256 == 0 (C = 768 / 1024).
 template <int NV>
@@ -550,10 +653,31 @@ extern "C" int ovis_clip_crop_patches(const uint8_t* frames, const float* masks,
                                       int patch, const float* mean3_host, const float* std3_host, ovis_stream_t stream) {
   OVIS_REQUIRE(frames && masks && crops && A && mean3_host && std3_host, "clip_crop: null pointer");
   OVIS_REQUIRE(M > 0 && resolution > 0 && patch > 0 && resolution % patch == 0, "clip_crop: bad sizes");
-  const long long total = (long long)M * resolution * resolution;
-  hipLaunchKernelGGL(clip_crop_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, frames, masks, crops, A,
-                     out_f16, M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, mean3_host[0], mean3_host[1], mean3_host[2],
-                     std3_host[0], std3_host[1], std3_host[2]);
+  // tile the output bins when the source rectangle of a tile fits in LDS (boxes never exceed the padded frame)
+  const float bin_max = (float)(Hp > Wp ? Hp : Wp) / (float)resolution;
+  auto args = [&](int ty) { return (int)ceilf((float)ty * bin_max) + 4; };
+  const int p16 = args(16), p8 = args(8);
+  if (resolution % 16 == 0 && (size_t)p16 * p16 * 8 <= 76 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      OVIS_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&clip_crop_tiled_kernel<16, 16>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 76 * 1024) == hipSuccess,
+                   "clip_crop: cannot raise the dynamic LDS limit");
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((clip_crop_tiled_kernel<16, 16>), dim3((unsigned)((long long)M * (resolution / 16) * (resolution / 16))), dim3(256),
+                       (size_t)p16 * p16 * 8, (hipStream_t)stream, frames, masks, crops, A, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
+                       resolution, patch, p16, p16, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
+  } else if (resolution % 8 == 0 && (size_t)p8 * p8 * 8 <= 64 * 1024) {
+    hipLaunchKernelGGL((clip_crop_tiled_kernel<8, 8>), dim3((unsigned)((long long)M * (resolution / 8) * (resolution / 8))), dim3(64),
+                       (size_t)p8 * p8 * 8, (hipStream_t)stream, frames, masks, crops, A, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
+                       resolution, patch, p8, p8, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
+  } else {
+    const long long total = (long long)M * resolution * resolution;
+    hipLaunchKernelGGL(clip_crop_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, frames, masks, crops, A,
+                       out_f16, M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, mean3_host[0], mean3_host[1], mean3_host[2],
+                       std3_host[0], std3_host[1], std3_host[2]);
+  }
   return ovis::check_launch("clip_crop");
 }
 

@@ -20,8 +20,8 @@ def load(d, name):
 
 
 def short(k):
-    k = k.split("(")[0]
-    return k.replace("(anonymous namespace)::", "").replace("void ", "")[:90]
+    k = k.replace("(anonymous namespace)::", "").replace("void ", "")
+    return k.split("(")[0][:90]
 
 
 if __name__ == "__main__":
