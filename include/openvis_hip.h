@@ -52,6 +52,13 @@ int ovis_msda_forward_f64(const double* value, const int64_t* spatial_shapes,
                           int num_heads, int channels, int num_levels, int num_query,
                           int num_point, ovis_stream_t stream);
 
+/* Arithmetic used by the f32 GEMM / convolution entry points for large problems (>= 256 tiles of 128x128):
+ *   1 (default)  bf16x3: every f32 operand is split exactly into three bf16 values while staged into LDS and six bf16
+ *                MFMA products are accumulated in f32 -- same accuracy class as an f32 fmaf chain, ~2.5x the rate of
+ *   0            the native v_mfma_f32_32x32x2_f32 kernel (an exact f32 fmaf chain), which small problems always use.
+ * Replaces nothing in the reference (torch picks cuBLAS algorithms implicitly); process-wide, not thread-safe. */
+int ovis_set_f32_gemm_mode(int mode);
+
 /* ---- Dense layers and convolutions on the f32 matrix cores ---------------------------------
  * Replace the cuBLAS/cuDNN work behind the reference's nn.Linear / Conv2d modules on the path, e.g.
  *   ops/modules/ms_deform_attn.py:98-104,124 (value_proj, sampling_offsets, attention_weights, output_proj),

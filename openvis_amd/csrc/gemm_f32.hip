@@ -22,6 +22,7 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "gemm_loaders.h"
+#include "gemm_f32x3.h"
 
 namespace {
 
@@ -143,6 +144,10 @@ gemm_f32_kernel(LoaderA la, const float* __restrict__ B, long long ldb, float* _
   }
 }
 
+// 0: native f32 MFMA everywhere; 1 (default): large problems run on the bf16 matrix cores with the exact three-way
+// bf16 split of gemm_f32x3.h (same accuracy class, ~2.5x the throughput)
+int g_f32_gemm_mode = 1;
+
 template <typename LoaderA>
 int launch_gemm(LoaderA la, const float* B, long long ldb, float* C, long long ldc, int M, int N, int K,
                 const float* bias, const float* R, long long ldr, int act, hipStream_t stream, int batch = 1,
@@ -156,7 +161,9 @@ int launch_gemm(LoaderA la, const float* B, long long ldb, float* C, long long l
     hipLaunchKernelGGL((gemm_f32_kernel<BM_, BN_, LoaderA, VB_>), dim3(tm * tn, batch), dim3(256), 0, stream, la, B,  \
                        ldb, C, ldc, M, N, K, bias, R, ldr, act, tn, a_bs, b_bs, c_bs);                              \
   }
-  if (blocks128 >= 256) {
+  if (blocks128 >= 256 && vecb && g_f32_gemm_mode == 1) {
+    ovis::launch_gemm_f32x3(la, B, ldb, C, ldc, M, N, K, bias, R, ldr, act, stream, batch, a_bs, b_bs, c_bs);
+  } else if (blocks128 >= 256) {
     if (vecb) GEMM_LAUNCH(128, 128, true) else GEMM_LAUNCH(128, 128, false)
   } else {
     if (vecb) GEMM_LAUNCH(64, 64, true) else GEMM_LAUNCH(64, 64, false)
@@ -166,6 +173,12 @@ int launch_gemm(LoaderA la, const float* B, long long ldb, float* C, long long l
 }
 
 }  // namespace
+
+extern "C" int ovis_set_f32_gemm_mode(int mode) {
+  OVIS_REQUIRE(mode == 0 || mode == 1, "set_f32_gemm_mode: mode must be 0 (native f32 MFMA) or 1 (bf16x3 split)");
+  g_f32_gemm_mode = mode;
+  return 0;
+}
 
 extern "C" int ovis_gemm_nt_f32(const float* A, long long lda, const float* B, long long ldb, float* C,
                                 long long ldc, int M, int N, int K, const float* bias, const float* residual,

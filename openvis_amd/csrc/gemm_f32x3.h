@@ -1,0 +1,175 @@
+// f32 GEMM / implicit-GEMM convolution on the bf16 matrix cores with f32-grade accuracy ("bf16x3").
+//
+// gfx950's native f32 MFMA (v_mfma_f32_32x32x2_f32) peaks at 157 TFLOP/s; the bf16 MFMA at ~2.5 PFLOP/s.  Every f32
+// value is the EXACT sum of three bf16 values (8 + 8 + 8 significand bits = f32's 24, same exponent range):
+//     x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)      (both subtractions are exact)
+// so a*b = sum_{p,q} a_p b_q exactly.  The three terms with p + q >= 3 are below 2^-24 |a b| and are dropped; the
+// remaining six products (bf16 x bf16 is exact in f32) accumulate in the MFMA's f32 accumulator.  The result carries
+// the same rounding class as an f32 fmaf chain (measured: not worse than the native f32 MFMA kernel against an f64
+// reference) at 6 bf16 MFMAs per logical product, i.e. a ~417 TFLOP/s ceiling instead of 157.
+//
+// The split happens while the operands are staged into LDS (v_cvt_pk_bf16_f32 + exact residuals), so HBM traffic and
+// the interface (f32 in, f32 out) are unchanged.  Tiling: 128x128x32 per workgroup of 4 waves (64x64 per wave),
+// three bf16 planes per operand with 80-byte rows (conflict-free ds_read_b128), register-prefetched next K tile,
+// operand roles swapped for the vectorised epilogue (gemm_epilogue.h).
+#pragma once
+#include "common.h"
+#include "gemm_epilogue.h"
+#include "gemm_loaders.h"
+
+namespace ovis {
+
+using x3_f32x16 = __attribute__((ext_vector_type(16))) float;
+using x3_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+constexpr int X3_BK = 32;
+constexpr int X3_ROW = X3_BK + 8;   // bf16 elements per LDS row (80 bytes)
+
+struct X3Planes { uint4 p0, p1, p2; };
+
+__device__ __forceinline__ X3Planes x3_split8(bool ok0, float4 a, bool ok1, float4 b) {
+  const float x[8] = {ok0 ? a.x : 0.f, ok0 ? a.y : 0.f, ok0 ? a.z : 0.f, ok0 ? a.w : 0.f,
+                      ok1 ? b.x : 0.f, ok1 ? b.y : 0.f, ok1 ? b.z : 0.f, ok1 ? b.w : 0.f};
+  union { __bf16 h[8]; uint4 u; } o0, o1, o2;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h0 = (__bf16)x[e];
+    const float r1 = x[e] - (float)h0;
+    const __bf16 h1 = (__bf16)r1;
+    const float r2 = r1 - (float)h1;
+    o0.h[e] = h0; o1.h[e] = h1; o2.h[e] = (__bf16)r2;
+  }
+  return X3Planes{o0.u, o1.u, o2.u};
+}
+
+template <int BM, int BN, typename LoaderA>
+__global__ void __launch_bounds__(256)
+gemm_f32x3_kernel(LoaderA la, DenseA<true> lb, float* __restrict__ C, long long ldc, int M, int N, int K,
+                  const float* __restrict__ bias, const float* __restrict__ R, long long ldr, int act, int tiles_n,
+                  long long a_bs, long long b_bs, long long c_bs) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A_IT = BM / 64, B_IT = BN / 64;   // thread stages rows srow + 64 i, 8 consecutive k each
+  __shared__ __attribute__((aligned(16))) __bf16 As[3][BM * X3_ROW];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[3][BN * X3_ROW];
+
+  if (gridDim.y > 1) {
+    la.advance((long long)blockIdx.y * a_bs);
+    lb.advance((long long)blockIdx.y * b_bs);
+    C += (long long)blockIdx.y * c_bs;
+    if (R) R += (long long)blockIdx.y * c_bs;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bn = (int)(bid % tiles_n) * BN;
+  const int bm = (int)(bid / tiles_n) * BM;
+  const int srow = tid >> 2, scol = (tid & 3) * 8;
+
+  float4 pa[A_IT][2], pb[B_IT][2];       // raw prefetch of the tile after next
+  bool oka[A_IT][2], okb[B_IT][2];
+  X3Planes sa[A_IT], sb[B_IT];           // split planes of the next tile, waiting for the LDS buffer to be free
+  auto gload = [&](int k0) {
+    const int k = k0 + scol;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      pa[i][0] = la.load(bm + srow + i * 64, k, oka[i][0]);
+      pa[i][1] = la.load(bm + srow + i * 64, k + 4, oka[i][1]);
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      pb[i][0] = lb.load(bn + srow + i * 64, k, okb[i][0]);
+      pb[i][1] = lb.load(bn + srow + i * 64, k + 4, okb[i][1]);
+    }
+  };
+  auto split = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) sa[i] = x3_split8(oka[i][0], pa[i][0], oka[i][1], pa[i][1]);
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) sb[i] = x3_split8(okb[i][0], pb[i][0], okb[i][1], pb[i][1]);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int o = (srow + i * 64) * X3_ROW + scol;
+      *reinterpret_cast<uint4*>(&As[0][o]) = sa[i].p0;
+      *reinterpret_cast<uint4*>(&As[1][o]) = sa[i].p1;
+      *reinterpret_cast<uint4*>(&As[2][o]) = sa[i].p2;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int o = (srow + i * 64) * X3_ROW + scol;
+      *reinterpret_cast<uint4*>(&Bs[0][o]) = sb[i].p0;
+      *reinterpret_cast<uint4*>(&Bs[1][o]) = sb[i].p1;
+      *reinterpret_cast<uint4*>(&Bs[2][o]) = sb[i].p2;
+    }
+  };
+
+  x3_f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int r32 = lane & 31, h = lane >> 5;
+  const int nk = (K + X3_BK - 1) / X3_BK;
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};   // six products, smallest first
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  auto mma_step = [&](int s) {
+    x3_bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[p][i] = *reinterpret_cast<const x3_bf16x8*>(&As[p][(wr * (BM / 2) + i * 32 + r32) * X3_ROW + h * 16 + s * 8]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bf[p][j] = *reinterpret_cast<const x3_bf16x8*>(&Bs[p][(wc * (BN / 2) + j * 32 + r32) * X3_ROW + h * 16 + s * 8]);
+    }
+    // the (i,j) loop is innermost so consecutive MFMAs hit different accumulators
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[PB[t]][j], af[PA[t]][i], acc[i][j], 0, 0, 0);   // roles swapped
+  };
+
+  // pipeline: LDS holds tile kt, `sa/sb` hold the split tile kt+1 (produced under the MFMAs of tile kt), `pa/pb` are
+  // in flight for tile kt+2 (issued mid-iteration, consumed one full iteration later)
+  gload(0);
+  split();
+  if (nk > 1) gload(X3_BK);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    mma_step(0);
+    if (kt + 1 < nk) split();                       // VALU work, independent of the MFMAs around it
+    if (kt + 2 < nk) gload((kt + 2) * X3_BK);
+    mma_step(1);
+  }
+
+  const bool vec_ok = ((ldc & 3) == 0) && (!R || (ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                      (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const long long m = bm + wr * (BM / 2) + i * 32 + r32;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      epilogue_tile<false>(acc[i][j], m, m < M, bn + wc * (BN / 2) + j * 32, h, N, C, ldc, bias, R, ldr, act, vec_ok);
+  }
+}
+
+template <typename LoaderA>
+inline void launch_gemm_f32x3(LoaderA la, const float* B, long long ldb, float* C, long long ldc, int M, int N, int K,
+                              const float* bias, const float* R, long long ldr, int act, hipStream_t stream, int batch,
+                              long long a_bs, long long b_bs, long long c_bs) {
+  const int tm = cdiv(M, 128), tn = cdiv(N, 128);
+  hipLaunchKernelGGL((gemm_f32x3_kernel<128, 128, LoaderA>), dim3(tm * tn, batch), dim3(256), 0, stream, la,
+                     DenseA<true>{B, ldb, N, K}, C, ldc, M, N, K, bias, R, ldr, act, tn, a_bs, b_bs, c_bs);
+}
+
+}  // namespace ovis

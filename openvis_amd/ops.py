@@ -48,6 +48,11 @@ def _chk(*ts):
             raise _lib.OvisError("openvis_amd ops need contiguous HIP device tensors (no CPU fallback)")
 
 
+def set_f32_gemm_mode(mode):
+    """0: native f32 MFMA for every f32 GEMM/conv; 1 (default): large problems use the exact bf16x3 split (gemm_f32x3.h)."""
+    _lib.call("ovis_set_f32_gemm_mode", int(mode))
+
+
 def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None):
     """out[m,n] = act(sum_k a[m,k] w[n,k] + bias[n] + residual[m,n]); a [...,K] -> out [...,N].
     w16 (an fp16 copy of w) selects the autocast arithmetic: operands rounded to fp16, f32 accumulation."""

@@ -68,3 +68,56 @@ def test_gemm_rejects_cpu_tensors():
     from openvis_amd import ops, _lib
     with pytest.raises(_lib.OvisError):
         ops.gemm_nt(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+@pytest.fixture
+def gemm_modes():
+    from openvis_amd import ops
+    yield ops
+    ops.set_f32_gemm_mode(1)
+
+
+@pytest.mark.parametrize("M,N,K", [(96600, 256, 256), (40001, 288, 260), (33000, 256, 1024)])
+def test_large_gemm_bf16x3_split_is_f32_grade(gemm_modes, M, N, K):
+    # large problems run as six bf16 MFMA products of the exact 3-way bf16 split: must be as accurate as the f32 MFMA kernel
+    ops = gemm_modes
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, 1, generator=g))     # rows of very different scale
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ac, wc, bc = a.cuda(), w.cuda(), b.cuda()
+    ref = (ac.double() @ wc.double().T + bc.double()).relu()
+    row_scale = ac.double().abs() @ wc.double().abs().T + bc.double().abs()                  # condition-aware error measure
+    errs = []
+    for mode in (0, 1):
+        ops.set_f32_gemm_mode(mode)
+        out = ops.gemm_nt(ac, wc, bc, None, 1)
+        errs.append(((out.double() - ref).abs() / row_scale).max().item())
+    assert errs[0] < 2e-6 and errs[1] < 2e-6, errs
+    assert errs[1] <= 2.0 * errs[0] + 1e-8, errs
+
+
+def test_large_gemm_bf16x3_integer_exact(gemm_modes):
+    ops = gemm_modes
+    M, N, K = 70000, 130, 72
+    a = (torch.arange(M * K).reshape(M, K) % 251 - 125).float()
+    w = (torch.arange(N * K).reshape(N, K) % 97 - 48).float()
+    ops.set_f32_gemm_mode(1)
+    out = ops.gemm_nt(a.cuda(), w.cuda())
+    assert torch.equal(out.cpu(), (a.double() @ w.double().T).float())
+
+
+def test_large_conv_bf16x3_matches_native(gemm_modes):
+    ops = gemm_modes
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 120, 200, 64, generator=g).cuda()
+    w = (torch.randn(256, 3, 3, 64, generator=g) / 24).cuda()
+    b = torch.randn(256, generator=g).cuda()
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    outs = []
+    for mode in (0, 1):
+        ops.set_f32_gemm_mode(mode)
+        outs.append(ops.conv2d_nhwc(x, w, 1, 1, b, None, 0))
+    e0 = (outs[0].double() - ref).abs().max().item()
+    e1 = (outs[1].double() - ref).abs().max().item()
+    assert e1 <= 2 * e0 + 1e-7 and e1 < 2e-5, (e0, e1)
