@@ -207,7 +207,13 @@ def main():
     dom = max(agg.items(), key=lambda kv: kv[1][2])
     n_launch, flops, secs = dom[1]
     achieved = flops / secs / 1e12
-    peak = PEAK_F16_MFMA_TFLOPS if "f16" in dom[0].split("<")[0] else PEAK_F32_MFMA_TFLOPS
+    kbase = dom[0].split("<")[0]
+    if "f32x3" in kbase:      # f32 product = 6 bf16 MFMA products of the exact 3-way split: ceiling = bf16 peak / 6
+        peak, peak_note = round(PEAK_F16_MFMA_TFLOPS / 6.0, 1), "bf16 dense MFMA peak / 6 (six bf16 products per f32 product)"
+    elif "f16" in kbase:
+        peak, peak_note = PEAK_F16_MFMA_TFLOPS, "fp16 dense MFMA peak"
+    else:
+        peak, peak_note = PEAK_F32_MFMA_TFLOPS, "f32 MFMA peak"
     # HBM traffic of that kernel from the committed PMC passes of this same command (tools/pmc_traffic.py:
     # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs); null if no summary is committed
     traffic = None
@@ -221,7 +227,7 @@ def main():
     except Exception:
         traffic = None
     roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "peak_note": peak_note, "traffic": traffic,
                 "launches_per_step": n_launch, "avg_launch_ms": round(secs / n_launch * 1e3, 4),
                 "share_of_step": round(secs / (elapsed / args.steps), 3),
                 "gflop_per_launch": round(flops / n_launch / 1e9, 2),

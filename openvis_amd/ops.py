@@ -16,8 +16,13 @@ ACT_NONE, ACT_RELU, ACT_QUICKGELU = 0, 1, 2
 PROFILE = None
 
 
-def _gemm_variant(M, N, loader):
-    big = ((M + 127) // 128) * ((N + 127) // 128) >= 256       # mirrors launch_gemm() in csrc/gemm_f32.hip
+_F32_GEMM_MODE = 1
+
+
+def _gemm_variant(M, N, loader, K=4, batch=1):
+    big = ((M + 127) // 128) * ((N + 127) // 128) * batch >= 256       # mirrors launch_gemm() in csrc/gemm_f32.hip
+    if big and _F32_GEMM_MODE == 1 and K % 4 == 0:
+        return f"gemm_f32x3_kernel<128,128,{loader}>"
     return f"gemm_f32_kernel<{'128,128' if big else '64,64'},{loader}>"
 
 
@@ -50,7 +55,9 @@ def _chk(*ts):
 
 def set_f32_gemm_mode(mode):
     """0: native f32 MFMA for every f32 GEMM/conv; 1 (default): large problems use the exact bf16x3 split (gemm_f32x3.h)."""
+    global _F32_GEMM_MODE
     _lib.call("ovis_set_f32_gemm_mode", int(mode))
+    _F32_GEMM_MODE = int(mode)
 
 
 def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None):
@@ -70,7 +77,7 @@ def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None):
             _lib.call("ovis_gemm_nt_f32a_f16w", a2, _ll(K), w16, _ll(K), out, _ll(N), M, N, K, bias, r2, _ll(N), act,
                       _lib.stream_ptr())
         return out.view(*a.shape[:-1], N)
-    with _Prof(_gemm_variant(M, N, "DenseA"), 2.0 * M * N * K):
+    with _Prof(_gemm_variant(M, N, "DenseA", K), 2.0 * M * N * K):
         _lib.call("ovis_gemm_nt_f32", a2, _ll(K), w, _ll(w.stride(0)), out, _ll(N), M, N, K, bias, r2, _ll(N), act,
                   _lib.stream_ptr())
     return out.view(*a.shape[:-1], N)
@@ -195,7 +202,7 @@ def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE, w
             _lib.call("ovis_conv2d_nhwc_f32a_f16w", x, w16, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act,
                       _lib.stream_ptr())
         return y
-    with _Prof(_gemm_variant(N * OH * OW, Cout, "ConvA"), 2.0 * N * OH * OW * Cout * KH * KW * Cin):
+    with _Prof(_gemm_variant(N * OH * OW, Cout, "ConvA", KH * KW * Cin), 2.0 * N * OH * OW * Cout * KH * KW * Cin):
         _lib.call("ovis_conv2d_nhwc_f32", x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act,
                   _lib.stream_ptr())
     return y
