@@ -65,7 +65,8 @@ int ovis_set_f32_gemm_mode(int mode);
  *   pixel_decoder/msdeformattn.py:118-121 (FFN), 227-235 (input_proj), 260-267, 276-296 (FPN convs),
  *   transformer_decoder/video_mask2former_transformer_decoder.py:175-179, 204-216 (FFN, MLP heads),
  *   detectron2 ResNet-50 bottlenecks (Base.yaml:2-16), mask_adapted_clip/model.py:238-268 (ViT blocks).
- * Activation codes: 0 none, 1 ReLU, 2 QuickGELU x*sigmoid(1.702x) (model.py:232-234).
+ * Activation codes: 0 none, 1 ReLU, 2 QuickGELU x*sigmoid(1.702x) (model.py:232-234), 3 GELU 0.5x(1+erf(x/sqrt 2))
+ * (nn.GELU of the Swin MLP, backbone/swin.py:21-41).
  *
  * ovis_gemm_nt_f32:  C[m,n] = act( sum_k A[m,k]*B[n,k] + bias[n] + residual[m,n] )
  *   A [M,K] row stride lda, B [N,K] row stride ldb (a torch Linear weight as stored), C [M,N] row stride ldc;
@@ -233,6 +234,28 @@ int ovis_hungarian_link_f32(const float* embeds, int* indices, float* workspace,
  *   element row (b, n) of src starts at src + b*src_bs + n*src_rs; len floats per row (len % 4 == 0). */
 int ovis_batch_index_rows_f32(const float* src, long long src_bs, long long src_rs, const int* idx, float* out,
                               long long out_bs, long long out_rs, int B, int M, long long len, ovis_stream_t stream);
+
+/* ---- Swin backbone data movement (backbone/swin.py) --------------------------------------------------------------
+ * x is a token map f32 [B,H,W,C] (C % 4 == 0); ws = window size, shift = cyclic shift (0 or ws/2);
+ * Hp, Wp = H, W rounded up to multiples of ws; nW = (Hp/ws)*(Wp/ws).
+ *
+ * ovis_swin_window_partition_f32: swin.py:241-262 -- F.pad (zeros) + torch.roll(-shift) + window_partition:
+ *   win[(b*nW + wy*(Wp/ws) + wx), iy*ws + ix, :] = xpad[b, (wy*ws+iy+shift) % Hp, (wx*ws+ix+shift) % Wp, :]
+ * ovis_swin_window_merge_add_f32: swin.py:267-281 -- window_reverse + torch.roll(+shift) + crop + residual:
+ *   out[b,y,x,:] = shortcut[b,y,x,:] + win[window/slot of ((y-shift) mod Hp, (x-shift) mod Wp)]
+ * ovis_swin_shift_mask_u8: swin.py:381-404 -- mask[w, i, j] = 1 where the shifted-window attention mask is -100
+ *   (tokens i and j of window w come from different regions), else 0; mask u8 [nW, ws*ws, ld] (ld >= ws*ws).
+ * ovis_swin_patch_merge_gather_f32: swin.py:303-317 -- out[b, y, x, :] = cat(x[2y,2x], x[2y+1,2x], x[2y,2x+1],
+ *   x[2y+1,2x+1]) with zeros beyond an odd H/W; out f32 [B, ceil(H/2), ceil(W/2), 4C].
+ * ovis_swin_relpos_bias_f32: swin.py:147-155 -- bias[h, i, j] = table[index(i,j), h] with
+ *   index = (yi-yj+ws-1)*(2ws-1) + (xi-xj+ws-1); table f32 [(2ws-1)^2, heads]; bias f32 [heads, ws*ws, ld]. */
+int ovis_swin_window_partition_f32(const float* x, float* win, int B, int H, int W, int C, int ws, int shift,
+                                   ovis_stream_t stream);
+int ovis_swin_window_merge_add_f32(const float* win, const float* shortcut, float* out, int B, int H, int W, int C, int ws,
+                                   int shift, ovis_stream_t stream);
+int ovis_swin_shift_mask_u8(uint8_t* mask, int H, int W, int ws, int shift, int ld, ovis_stream_t stream);
+int ovis_swin_patch_merge_gather_f32(const float* x, float* out, int B, int H, int W, int C, ovis_stream_t stream);
+int ovis_swin_relpos_bias_f32(const float* table, float* bias, int heads, int ws, int ld, ovis_stream_t stream);
 
 #ifdef __cplusplus
 }

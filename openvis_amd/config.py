@@ -69,6 +69,10 @@ def get_cfg():
             "BACKBONE": {"NAME": "build_resnet_backbone", "FREEZE_AT": 0},
             "RESNETS": {"DEPTH": 50, "STRIDE_IN_1X1": False, "OUT_FEATURES": ["res2", "res3", "res4", "res5"],
                         "STEM_OUT_CHANNELS": 64, "NORM": "FrozenBN"},
+            "SWIN": {"PRETRAIN_IMG_SIZE": 224, "PATCH_SIZE": 4, "EMBED_DIM": 96, "DEPTHS": [2, 2, 6, 2],
+                     "NUM_HEADS": [3, 6, 12, 24], "WINDOW_SIZE": 7, "MLP_RATIO": 4.0, "QKV_BIAS": True, "QK_SCALE": None,
+                     "DROP_RATE": 0.0, "ATTN_DROP_RATE": 0.0, "DROP_PATH_RATE": 0.3, "APE": False, "PATCH_NORM": True,
+                     "OUT_FEATURES": ["res2", "res3", "res4", "res5"], "USE_CHECKPOINT": False},
             "SEM_SEG_HEAD": {"NAME": "MaskFormerHead", "IGNORE_VALUE": 255, "NUM_CLASSES": 1, "LOSS_WEIGHT": 1.0,
                              "CONVS_DIM": 256, "MASK_DIM": 256, "NORM": "GN",
                              "PIXEL_DECODER_NAME": "MSDeformAttnPixelDecoder",

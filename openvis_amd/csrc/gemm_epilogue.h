@@ -18,6 +18,10 @@ __device__ __forceinline__ float quick_gelu(float v) {
   return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v));
 }
 
+__device__ __forceinline__ float gelu_erf(float v) {   // nn.GELU() (exact erf form) of the Swin MLP
+  return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+}
+
 // acc: tile with lane -> row m (m_ok), registers -> columns n_tile0 + 8g + 4h + e.
 template <bool OUT_F16>
 __device__ __forceinline__ void epilogue_tile(const f32x16_t& acc, long long m, bool m_ok, int n_tile0, int h, int N,
@@ -42,6 +46,9 @@ __device__ __forceinline__ void epilogue_tile(const f32x16_t& acc, long long m, 
       } else if (act == 2) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+      } else if (act == 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
       }
       if (m_ok) {
         if constexpr (OUT_F16) {
@@ -61,6 +68,7 @@ __device__ __forceinline__ void epilogue_tile(const f32x16_t& acc, long long m, 
         float x = v[e] + (bias ? bias[nc] : 0.f) + (R ? R[(m_ok ? m : 0) * ldr + nc] : 0.f);
         if (act == 1) x = fmaxf(x, 0.f);
         else if (act == 2) x = quick_gelu(x);
+        else if (act == 3) x = gelu_erf(x);
         if (ok) {
           if constexpr (OUT_F16) reinterpret_cast<_Float16*>(C)[m * ldc + ne] = (_Float16)x;
           else reinterpret_cast<float*>(C)[m * ldc + ne] = x;

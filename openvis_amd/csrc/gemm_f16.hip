@@ -373,7 +373,7 @@ extern "C" int ovis_gemm_nt_f16(const void* A, long long lda, const void* B, lon
   OVIS_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && ldc >= N,
                "gemm_nt_f16: K, lda, ldb must be multiples of 8 halfs");
   OVIS_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "gemm_nt_f16: A/B must be 16-byte aligned");
-  OVIS_REQUIRE(act >= 0 && act <= 2, "gemm_nt_f16: unknown activation %d", act);
+  OVIS_REQUIRE(act >= 0 && act <= 3, "gemm_nt_f16: unknown activation %d", act);
   OVIS_REQUIRE(!residual || ldr >= N, "gemm_nt_f16: residual leading dimension too small");
   const _Float16* a = reinterpret_cast<const _Float16*>(A);
   const _Float16* b = reinterpret_cast<const _Float16*>(B);

@@ -152,7 +152,7 @@ extern "C" int ovis_gemm_nt_f32a_f16w(const float* A, long long lda, const void*
   OVIS_REQUIRE(K % 8 == 0 && lda % 4 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && ldc >= N,
                "gemm_nt_f32a_f16w: need K %% 8 == 0, lda %% 4 == 0, ldb %% 8 == 0");
   OVIS_REQUIRE((((uintptr_t)A | (uintptr_t)B16) & 15) == 0, "gemm_nt_f32a_f16w: A/B must be 16-byte aligned");
-  OVIS_REQUIRE(act >= 0 && act <= 2, "gemm_nt_f32a_f16w: unknown activation %d", act);
+  OVIS_REQUIRE(act >= 0 && act <= 3, "gemm_nt_f32a_f16w: unknown activation %d", act);
   OVIS_REQUIRE(!residual || ldr >= N, "gemm_nt_f32a_f16w: residual leading dimension too small");
   return launch(DenseA<true>{A, lda, M, K}, (const _Float16*)B16, ldb, C, ldc, M, N, K, bias, residual, ldr, act,
                 (hipStream_t)stream);
@@ -166,7 +166,7 @@ extern "C" int ovis_gemm_nt_f32a_f16w_batched(const float* A, long long lda, lon
   OVIS_REQUIRE(K % 8 == 0 && lda % 4 == 0 && ldb % 8 == 0 && a_bs % 4 == 0 && b_bs % 8 == 0 && lda >= K && ldb >= K &&
                    ldc >= N && (((uintptr_t)A | (uintptr_t)B16) & 15) == 0,
                "gemm_nt_f32a_f16w_batched: alignment (K %% 8, lda %% 4, ldb %% 8, strides, 16-byte pointers)");
-  OVIS_REQUIRE(act >= 0 && act <= 2, "gemm_nt_f32a_f16w_batched: unknown activation %d", act);
+  OVIS_REQUIRE(act >= 0 && act <= 3, "gemm_nt_f32a_f16w_batched: unknown activation %d", act);
   return launch(DenseA<true>{A, lda, M, K}, (const _Float16*)B16, ldb, C, ldc, M, N, K, bias, nullptr, 0, act,
                 (hipStream_t)stream, batch, a_bs, b_bs, c_bs);
 }
@@ -179,7 +179,7 @@ extern "C" int ovis_conv2d_nhwc_f32a_f16w(const float* x, const void* w16, float
                "conv2d_nhwc_f32a_f16w: bad geometry");
   OVIS_REQUIRE(Cin % 4 == 0 && (KH * KW * Cin) % 8 == 0, "conv2d_nhwc_f32a_f16w: need Cin %% 4 == 0 and KH*KW*Cin %% 8 == 0");
   OVIS_REQUIRE((((uintptr_t)x | (uintptr_t)w16) & 15) == 0, "conv2d_nhwc_f32a_f16w: x/w must be 16-byte aligned");
-  OVIS_REQUIRE(act >= 0 && act <= 2, "conv2d_nhwc_f32a_f16w: unknown activation %d", act);
+  OVIS_REQUIRE(act >= 0 && act <= 3, "conv2d_nhwc_f32a_f16w: unknown activation %d", act);
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   OVIS_REQUIRE(OH > 0 && OW > 0, "conv2d_nhwc_f32a_f16w: empty output");
   const long long M = (long long)N * OH * OW;

@@ -186,7 +186,7 @@ extern "C" int ovis_gemm_nt_f32(const float* A, long long lda, const float* B, l
   OVIS_REQUIRE(A && B && C, "gemm_nt_f32: null pointer");
   OVIS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt_f32: non-positive size (M=%d N=%d K=%d)", M, N, K);
   OVIS_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm_nt_f32: leading dimension too small");
-  OVIS_REQUIRE(act >= 0 && act <= 2, "gemm_nt_f32: unknown activation %d", act);
+  OVIS_REQUIRE(act >= 0 && act <= 3, "gemm_nt_f32: unknown activation %d", act);
   OVIS_REQUIRE(!residual || ldr >= N, "gemm_nt_f32: residual leading dimension too small");
   const bool veca = (K % 4 == 0) && ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
   if (veca) return launch_gemm(DenseA<true>{A, lda, M, K}, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream);
@@ -199,7 +199,7 @@ extern "C" int ovis_gemm_nt_f32_batched(const float* A, long long lda, long long
   OVIS_REQUIRE(A && B && C, "gemm_nt_f32_batched: null pointer");
   OVIS_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0, "gemm_nt_f32_batched: non-positive size");
   OVIS_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm_nt_f32_batched: leading dimension too small");
-  OVIS_REQUIRE(act >= 0 && act <= 2, "gemm_nt_f32_batched: unknown activation %d", act);
+  OVIS_REQUIRE(act >= 0 && act <= 3, "gemm_nt_f32_batched: unknown activation %d", act);
   OVIS_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && a_bs % 4 == 0 && b_bs % 4 == 0 &&
                    (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
                "gemm_nt_f32_batched: K, lda, ldb, strides must be multiples of 4 and pointers 16-byte aligned");
@@ -215,7 +215,7 @@ extern "C" int ovis_conv2d_nhwc_f32(const float* x, const float* w, float* y, in
                "conv2d_nhwc_f32: bad geometry");
   OVIS_REQUIRE(Cin % 4 == 0, "conv2d_nhwc_f32: Cin (%d) must be a multiple of 4 (pad channels)", Cin);
   OVIS_REQUIRE((((uintptr_t)x | (uintptr_t)w) & 15) == 0, "conv2d_nhwc_f32: x/w must be 16-byte aligned");
-  OVIS_REQUIRE(act >= 0 && act <= 2, "conv2d_nhwc_f32: unknown activation %d", act);
+  OVIS_REQUIRE(act >= 0 && act <= 3, "conv2d_nhwc_f32: unknown activation %d", act);
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   OVIS_REQUIRE(OH > 0 && OW > 0, "conv2d_nhwc_f32: empty output");
   const long long M = (long long)N * OH * OW;

@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 
-ACT_NONE, ACT_RELU, ACT_QUICKGELU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_QUICKGELU, ACT_GELU = 0, 1, 2, 3
 
 # bench.py sets this to a list to time every MFMA GEMM launch with HIP events on the launch stream:
 # entries are (kernel name, algorithmic flops, start event, end event).
@@ -266,7 +266,7 @@ def pe_sine(T, H, W, npf, three_d, add_c, device):
 
 
 def attention(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, mask=None, row_open=None, nsplit=1,
-              out_f16=False, mask_per_batch=False, bias=None, out=None, o_bs=None, o_ld=None):
+              out_f16=False, mask_per_batch=False, bias=None, out=None, o_bs=None, o_ld=None, bias_strides=None):
     """q/k/v: tensors (possibly column-sliced views of a fused projection) whose element (b,row,h,d) sits at
     data_ptr + (b*bs + row*ld + h*D + d)*4.  Returns out [B,Nq,H*D]."""
     for t in (q, k, v):
@@ -285,7 +285,8 @@ def attention(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, mask
     if bias is not None:                      # additive f32 bias [B,H,Nq,ld]
         _chk(bias)
         b_ld = bias.shape[-1]
-        b_args = (bias, _ll(H * Nq * b_ld), _ll(Nq * b_ld), b_ld)
+        bs_, hs_ = bias_strides if bias_strides is not None else (H * Nq * b_ld, Nq * b_ld)   # (batch, head) strides
+        b_args = (bias, _ll(bs_), _ll(hs_), b_ld)
     else:
         b_args = (None, _ll(0), _ll(0), 0)
     _lib.call("ovis_attention_f32", vp(q), _ll(q_bs), q_ld, vp(k), _ll(k_bs), k_ld, vp(v), _ll(v_bs), v_ld, out,
@@ -399,3 +400,45 @@ def final_masks(masks, sel_q, Hp, Wp, H, W, OH, OW):
     out = torch.empty((n, T, OH, OW), dtype=torch.uint8, device=masks.device)
     _lib.call("ovis_final_masks_u8", masks, sel_q, out, n, Q, T, h, w, Hp, Wp, H, W, OH, OW, _lib.stream_ptr())
     return out
+
+
+# ---- Swin backbone data movement (csrc/swin_ops.hip) -----------------------------------------------------------------
+def swin_window_partition(x, ws, shift):
+    """x [B,H,W,C] -> zero-padded, cyclically shifted windows [B*nW, ws*ws, C] (swin.py:241-262)."""
+    _chk(x)
+    B, H, W, C = x.shape
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    win = torch.empty((B * (Hp // ws) * (Wp // ws), ws * ws, C), dtype=torch.float32, device=x.device)
+    _lib.call("ovis_swin_window_partition_f32", x, win, B, H, W, C, ws, shift, _lib.stream_ptr())
+    return win
+
+
+def swin_window_merge_add(win, shortcut, ws, shift):
+    """shortcut [B,H,W,C] + window_reverse / un-shift / crop of win [B*nW, ws*ws, C] (swin.py:267-281)."""
+    _chk(win, shortcut)
+    B, H, W, C = shortcut.shape
+    out = torch.empty_like(shortcut)
+    _lib.call("ovis_swin_window_merge_add_f32", win, shortcut, out, B, H, W, C, ws, shift, _lib.stream_ptr())
+    return out
+
+
+def swin_shift_mask(H, W, ws, shift, ld, device):
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    mask = torch.empty(((Hp // ws) * (Wp // ws), ws * ws, ld), dtype=torch.uint8, device=device)
+    _lib.call("ovis_swin_shift_mask_u8", mask, H, W, ws, shift, ld, _lib.stream_ptr())
+    return mask
+
+
+def swin_patch_merge_gather(x):
+    _chk(x)
+    B, H, W, C = x.shape
+    out = torch.empty((B, (H + 1) // 2, (W + 1) // 2, 4 * C), dtype=torch.float32, device=x.device)
+    _lib.call("ovis_swin_patch_merge_gather_f32", x, out, B, H, W, C, _lib.stream_ptr())
+    return out
+
+
+def swin_relpos_bias(table, heads, ws, ld):
+    _chk(table)
+    bias = torch.empty((heads, ws * ws, ld), dtype=torch.float32, device=table.device)
+    _lib.call("ovis_swin_relpos_bias_f32", table, bias, heads, ws, ld, _lib.stream_ptr())
+    return bias

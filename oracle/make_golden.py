@@ -99,8 +99,9 @@ def _build_pixel_decoder():
 def _load_synth(module, seed):
     from tests._synth import synth_weights, spec_of
     spec = spec_of(module.state_dict())
-    module.load_state_dict(synth_weights(spec, seed), strict=True)
-    return spec
+    missing = module.load_state_dict(synth_weights(spec, seed), strict=False)
+    assert not missing.unexpected_keys and all(not module.state_dict()[k].dtype.is_floating_point for k in missing.missing_keys), missing
+    return spec            # integer buffers (e.g. Swin's relative_position_index) keep their constructed values
 
 
 PD_SEED, PD_IN_SEED, DEC_SEED, CLIP_SEED = 101, 102, 103, 104
@@ -279,7 +280,25 @@ def gen_resampler():
     print("wrote resampler.npz", out["pred_masks"].shape, ad.biases.shape)
 
 
-GENERATORS = {"msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "san": gen_side_adapter, "resampler": gen_resampler, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual,
+def gen_swin():
+    """Reference SwinTransformer.forward (backbone/swin.py:702-722): head_dim 32, window 5 (so every stage pads), both
+    shifted and unshifted blocks, odd-sized patch merging."""
+    from tests._synth import synth_inputs
+    sw = R.ref("openvis.modeling.backbone.swin")
+    cfg = dict(embed_dim=64, depths=[2, 2, 2, 2], num_heads=[2, 4, 8, 16], window_size=5)
+    m = sw.SwinTransformer(pretrain_img_size=224, patch_size=4, in_chans=3, drop_path_rate=0.0, **cfg)
+    m.eval()                                           # the reference's train() override returns None
+    spec = _load_synth(m, 151)
+    x = synth_inputs([(2, 3, 64, 104)], 152)[0]
+    with torch.no_grad():
+        out = m(x)
+    np.savez_compressed(os.path.join(GOLD, "swin.npz"), spec=_spec_arrays(spec), seeds=np.array([151, 152]),
+                        cfg=np.array([cfg["embed_dim"], cfg["window_size"]] + cfg["depths"] + cfg["num_heads"]),
+                        **{k: v.numpy() for k, v in out.items()})
+    print("wrote swin.npz", {k: tuple(v.shape) for k, v in out.items()})
+
+
+GENERATORS = {"swin": gen_swin, "msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "san": gen_side_adapter, "resampler": gen_resampler, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual,
               "pe": gen_position_encodings}
 
 if __name__ == "__main__":

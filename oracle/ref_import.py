@@ -134,6 +134,7 @@ def install():
          build_backbone=None, build_sem_seg_head=None)
     _mod("detectron2.modeling.backbone", Backbone=nn.Module)
     sys.modules["detectron2.modeling"].Backbone = nn.Module
+    sys.modules["detectron2.modeling"].ShapeSpec = _ShapeSpec
     _mod("detectron2.utils")
     _mod("detectron2.utils.registry", Registry=_Registry)
     _mod("detectron2.utils.comm", get_local_rank=lambda: 0, synchronize=lambda: None,

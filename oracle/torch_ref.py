@@ -65,6 +65,78 @@ def _conv_bn(x, W, prefix, stride=1, padding=0):
 RESNET50_STAGES = (("res2", 3, 1), ("res3", 4, 2), ("res4", 6, 2), ("res5", 3, 2))
 
 
+# ---- A2 (alternative backbone): Swin Transformer, backbone/swin.py -------------------------------------------------
+def _swin_rel_index(ws):
+    """relative_position_index of WindowAttention (swin.py:111-122)."""
+    c = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)      # [2, N]
+    rel = (c[:, :, None] - c[:, None, :]).permute(1, 2, 0) + (ws - 1)
+    return rel[..., 0] * (2 * ws - 1) + rel[..., 1]
+
+
+def _swin_shift_mask(Hp, Wp, ws, shift):
+    """0 / -100 attention mask of the shifted windows (swin.py:381-404)."""
+    img = torch.zeros(Hp, Wp)
+    cnt = 0
+    for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img[hs, wsl] = cnt
+            cnt += 1
+    mw = img.view(Hp // ws, ws, Wp // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+    d = mw[:, None, :] - mw[:, :, None]
+    return torch.where(d != 0, torch.full_like(d, -100.0), torch.zeros_like(d))
+
+
+def swin(x, W, embed_dim, depths, num_heads, ws, prefix="backbone.", patch_norm=True):
+    """x fp32 [B,3,H,W] -> {res2..res5: [B,C_i,H_i,W_i]} (swin.py:702-722, 224-284, 303-317, 480-497)."""
+    x = F.conv2d(x, W[prefix + "patch_embed.proj.weight"], W[prefix + "patch_embed.proj.bias"], stride=4)
+    B, C, H, Wd = x.shape
+    x = x.flatten(2).transpose(1, 2)                                                             # [B, H*W, C]
+    if patch_norm:
+        x = F.layer_norm(x, (C,), W[prefix + "patch_embed.norm.weight"], W[prefix + "patch_embed.norm.bias"])
+    outs = {}
+    for i, depth in enumerate(depths):
+        C = embed_dim * 2 ** i
+        heads = num_heads[i]
+        Hp, Wp = -(-H // ws) * ws, -(-Wd // ws) * ws
+        shift_mask = _swin_shift_mask(Hp, Wp, ws, ws // 2)
+        ridx = _swin_rel_index(ws).view(-1)
+        for j in range(depth):
+            p = f"{prefix}layers.{i}.blocks.{j}."
+            shift = 0 if j % 2 == 0 else ws // 2
+            h = F.layer_norm(x, (C,), W[p + "norm1.weight"], W[p + "norm1.bias"]).view(B, H, Wd, C)
+            h = F.pad(h, (0, 0, 0, Wp - Wd, 0, Hp - H))
+            if shift:
+                h = torch.roll(h, (-shift, -shift), (1, 2))
+            win = h.view(B, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+            qkv = F.linear(win, W[p + "attn.qkv.weight"], W.get(p + "attn.qkv.bias"))
+            qkv = qkv.view(win.shape[0], ws * ws, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+            attn = (qkv[0] * (C // heads) ** -0.5) @ qkv[1].transpose(-2, -1)
+            bias = W[p + "attn.relative_position_bias_table"][ridx].view(ws * ws, ws * ws, heads).permute(2, 0, 1)
+            attn = attn + bias[None]
+            if shift:
+                nW = shift_mask.shape[0]
+                attn = (attn.view(B, nW, heads, ws * ws, ws * ws) + shift_mask[None, :, None]).view(-1, heads, ws * ws, ws * ws)
+            a = (attn.softmax(-1) @ qkv[2]).transpose(1, 2).reshape(-1, ws * ws, C)
+            a = F.linear(a, W[p + "attn.proj.weight"], W[p + "attn.proj.bias"])
+            a = a.view(B, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+            if shift:
+                a = torch.roll(a, (shift, shift), (1, 2))
+            x = x + a[:, :H, :Wd].reshape(B, H * Wd, C)
+            h = F.layer_norm(x, (C,), W[p + "norm2.weight"], W[p + "norm2.bias"])
+            h = F.linear(F.gelu(F.linear(h, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"])), W[p + "mlp.fc2.weight"], W[p + "mlp.fc2.bias"])
+            x = x + h
+        o = F.layer_norm(x, (C,), W[f"{prefix}norm{i}.weight"], W[f"{prefix}norm{i}.bias"])
+        outs[f"res{i + 2}"] = o.view(B, H, Wd, C).permute(0, 3, 1, 2).contiguous()
+        if i < len(depths) - 1:
+            h = F.pad(x.view(B, H, Wd, C), (0, 0, 0, Wd % 2, 0, H % 2))
+            h = torch.cat([h[:, 0::2, 0::2], h[:, 1::2, 0::2], h[:, 0::2, 1::2], h[:, 1::2, 1::2]], -1)
+            H, Wd = (H + 1) // 2, (Wd + 1) // 2
+            h = F.layer_norm(h.view(B, H * Wd, 4 * C), (4 * C,), W[f"{prefix}layers.{i}.downsample.norm.weight"],
+                             W[f"{prefix}layers.{i}.downsample.norm.bias"])
+            x = F.linear(h, W[f"{prefix}layers.{i}.downsample.reduction.weight"])
+    return outs
+
+
 def resnet50(x, W, prefix="backbone."):
     x = F.relu(_conv_bn(x, W, prefix + "stem.conv1", stride=2, padding=3))
     x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
