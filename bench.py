@@ -45,31 +45,49 @@ def synth_text(K, dim, seed=1):
     return torch.nn.functional.normalize(base + 0.05 * torch.randn(K, dim, generator=g), dim=-1)
 
 
-MODELS = {   # --model: (META_ARCHITECTURE, decoder, weight spec)
-    "openvis": ("OpenVIS", "VideoMultiScaleMaskedTransformerDecoder", "openvis_r50_spec"),
-    "openvis_online": ("OpenVISOnline", "FrameMultiScaleMaskedTransformerDecoder", "openvis_r50_spec"),
-    "san_online": ("SANOnline", "SideAdapterFrameMultiScaleMaskedTransformerDecoder", "san_r50_spec"),
-    "brivis": ("BriVIS", "SideAdapterFrameMultiScaleMaskedTransformerDecoder", "brivis_r50_spec"),
+MODELS = {   # --model: META_ARCHITECTURE, decoder, weight spec, backbone, CLIP tower, queries
+    "openvis": dict(arch="OpenVIS", decoder="VideoMultiScaleMaskedTransformerDecoder", spec="openvis_spec"),
+    "openvis_online": dict(arch="OpenVISOnline", decoder="FrameMultiScaleMaskedTransformerDecoder", spec="openvis_spec"),
+    "san_online": dict(arch="SANOnline", decoder="SideAdapterFrameMultiScaleMaskedTransformerDecoder", spec="san_spec"),
+    "brivis": dict(arch="BriVIS", decoder="SideAdapterFrameMultiScaleMaskedTransformerDecoder", spec="brivis_spec"),
+    # BASELINE.json configs[4]: Swin-L (swin/openvis_swinL_*.yaml:5-9) + CLIP ViT-L/14@336 side adapter
+    # (swin/brivis_SwinB_*.yaml:17-22: MERGE_IDS [6,12,18], BROKEN_ID 21, 16 heads, embed 768)
+    "brivis_swinl": dict(arch="BriVIS", decoder="SideAdapterFrameMultiScaleMaskedTransformerDecoder", spec="brivis_spec",
+                         backbone="swin_l", clip="ViT-L/14@336px"),
+    "openvis_swinl": dict(arch="OpenVIS", decoder="VideoMultiScaleMaskedTransformerDecoder", spec="openvis_spec",
+                          backbone="swin_l", clip="ViT-L/14@336px", queries=200),
 }
 
 
 def build_model(device, seed=42, clip_precision="fp16", precision="mixed", model_name="openvis"):
     from openvis_amd import config, weights
     from openvis_amd.catalog import MetadataCatalog
-    arch, decoder, spec_fn = MODELS[model_name]
+    from openvis_amd.modeling.clip_adapter.adapter import _CLIP_ARCH
+    m = MODELS[model_name]
+    backbone, clip, queries = m.get("backbone", "r50"), m.get("clip", "ViT-B/16"), m.get("queries", 100)
     cfg = config.get_cfg()
     cfg.MODEL.DEVICE = str(device)
-    cfg.MODEL.META_ARCHITECTURE = arch
-    cfg.MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME = decoder
+    cfg.MODEL.META_ARCHITECTURE = m["arch"]
+    cfg.MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME = m["decoder"]
+    cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES = queries
     cfg.MODEL.CLIP_ADAPTER.PRECISION = clip_precision
+    cfg.MODEL.CLIP_ADAPTER.CLIP_MODEL_NAME = clip
+    if clip == "ViT-L/14@336px":
+        cfg.MODEL.CLIP_ADAPTER.MERGE_IDS, cfg.MODEL.CLIP_ADAPTER.BROKEN_ID = [6, 12, 18], 21
+        cfg.MODEL.CLIP_ADAPTER.CLIP_NUM_HEADS, cfg.MODEL.CLIP_ADAPTER.CLIP_EMBED_DIMS = 16, 768
+    if backbone != "r50":
+        a = weights.SWIN_ARCH[backbone]
+        cfg.MODEL.BACKBONE.NAME = "D2SwinTransformer"
+        cfg.MODEL.SWIN.EMBED_DIM, cfg.MODEL.SWIN.DEPTHS = a["embed_dim"], list(a["depths"])
+        cfg.MODEL.SWIN.NUM_HEADS, cfg.MODEL.SWIN.WINDOW_SIZE = list(a["num_heads"]), a["window"]
     cfg.MODEL.PRECISION = precision
     model = config.build_model(cfg)
     model.device = torch.device(device)
-    sd = weights.random_init(getattr(weights, spec_fn)(), seed=seed)
+    sd = weights.random_init(getattr(weights, m["spec"])(backbone, _CLIP_ARCH[clip], queries), seed=seed)
     model.load_state_dict(sd)
     names = [f"class_{i}" for i in range(NUM_CLASSES)]
     MetadataCatalog.get("synthetic_burst_val").set(thing_classes=names)
-    text = synth_text(NUM_CLASSES, 512)
+    text = synth_text(NUM_CLASSES, _CLIP_ARCH[clip]["embed_dim"])
     model.clip_adapter.set_text_features(names, text)
     return model, sd, text
 
@@ -148,6 +166,8 @@ def main():
                     help="default openvis = the BASELINE.json headline (configs[1]); san_online = configs[2]; brivis = "
                          "configs[3] (one clip of --frames frames, frame-sharded over the ranks, strong scaling)")
     ap.add_argument("--frames", type=int, default=0, help="frames per clip (default 5; brivis: 36)")
+    ap.add_argument("--resolution", type=int, default=0, choices=[0, 720, 1080],
+                    help="frame height (16:9); default 720, *_swinl models: 1080 (BASELINE.json configs[4])")
     ap.add_argument("--precision", default="mixed", choices=["mixed", "fp32"],
                     help="dense-path policy: mixed = the reference's autocast policy, fp32 = exact f32 everywhere")
     args = ap.parse_args()
@@ -159,18 +179,20 @@ def main():
 
     from openvis_amd import ops
     model, sd, text = build_model(device, clip_precision=args.clip_precision, precision=args.precision, model_name=args.model)
-    frame_sharded = args.model == "brivis" and world > 1
-    T = args.frames or (36 if args.model == "brivis" else T_CLIP)
+    frame_sharded = args.model.startswith("brivis") and world > 1
+    T = args.frames or (36 if args.model.startswith("brivis") else T_CLIP)
+    res = args.resolution or (1080 if args.model.endswith("_swinl") else 720)
+    FH, FW = res, res * 16 // 9                          # frame size of this run
     fwd_kw = {}
     if frame_sharded:
         # ONE clip, contiguous frame blocks per rank, all-gather of query embeddings before the linker
         fr = D.inference_shard(T, rank, world)
         fwd_kw = {"frame_range": (fr.start, fr.stop)}
-        clips = [synth_frames(T, H720, W720, 1000 + i, device) for i in range(2)]
+        clips = [synth_frames(T, FH, FW, 1000 + i, device) for i in range(2)]
     else:
         # clip-level sharding (InferenceSampler layout): 2*world clips, each rank owns a contiguous shard
         my_clips = D.inference_shard(2 * world, rank, world)
-        clips = [synth_frames(T, H720, W720, 1000 + i, device) for i in my_clips]
+        clips = [synth_frames(T, FH, FW, 1000 + i, device) for i in my_clips]
     inputs = [[{"image": [f for f in c], "dataset_name": "synthetic_burst_val"}] for c in clips]
     _model = model
     model = (lambda inp, **kw: _model(inp, **fwd_kw, **kw)) if fwd_kw else _model
@@ -234,21 +256,23 @@ def main():
                 "all_gemm_kernels": {k: {"launches": v[0], "ms": round(v[2] * 1e3, 3), "TFLOPs": round(v[1] / v[2] / 1e12, 1)}
                                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}}
 
+    bb_name = {"r50": "R50", "swin_l": "Swin-L"}[MODELS[args.model].get("backbone", "r50")]
     if rank == 0:
         frames_total = T * args.steps * (1 if frame_sharded else world)
         n_valid = int(st["valid"].sum()) if "valid" in st else 0
         line = {
-            "metric": ("frames/sec (whole node) OpenVIS R50 720p inference" if args.model == "openvis" else
-                       f"frames/sec (whole node) {args.model} R50 720p inference"), "value": round(frames_total / elapsed, 3),
+            "metric": ("frames/sec (whole node) OpenVIS R50 720p inference" if args.model == "openvis" and res == 720 else
+                       f"frames/sec (whole node) {args.model} {bb_name} {res}p inference"), "value": round(frames_total / elapsed, 3),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if frame_sharded else "weak",
             "vs_baseline": None, "dtype": "f16" if (_model.clip_adapter.precision == "fp16" or args.precision == "mixed") else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.model}_R50 720p (720x1280 -> 736x1280), 100 queries, 482 classes, {T}-frame clips, "
+            "config": {"workload": f"{args.model} {bb_name} {res}p ({FH}x{FW} -> {(FH + 31) // 32 * 32}x{(FW + 31) // 32 * 32}), "
+                                   f"{MODELS[args.model].get('queries', 100)} queries, 482 classes, {T}-frame clips, "
                                    + ("ClipAdapter" if args.model.startswith("openvis") else "SideAdapter")
-                                   + " ViT-B/16, random-init weights", "frames_per_step": T,
+                                   + f" {MODELS[args.model].get('clip', 'ViT-B/16')}, random-init weights", "frames_per_step": T,
                        "precision": ("reference autocast policy: backbone + decoder GEMM operands fp16 / f32 accumulate, "
-                                     "pixel decoder + logits exact-f32 MFMA; " if args.precision == "mixed" else
+                                     "pixel decoder + logits f32 (exact 3-way bf16 split on the bf16 MFMA); " if args.precision == "mixed" else
                                      "backbone/pixel decoder/decoder/masks/logits: exact-f32 MFMA; ")
                                     + "CLIP ViT GEMM operands: "
                                     + ("fp16 with f32 accumulation (the reference's GPU CLIP dtype)"

@@ -187,7 +187,7 @@ int ovis_mask_bbox(const float* masks, int* boxes, int Q, int T, int h, int w, i
  *   A is f32, or fp16 when out_f16 != 0 (the reference feeds CLIP fp16 crops, adapter.py:108-111). */
 int ovis_clip_crop_patches(const uint8_t* frames, const float* masks, const int* crops, void* A, int out_f16, int M,
                            int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int resolution, int patch,
-                           const float* mean3_host, const float* std3_host, ovis_stream_t stream);
+                           long long lda, const float* mean3_host, const float* std3_host, ovis_stream_t stream);
 /* ViT token assembly + ln_pre (model.py:341-343): out [M,L1,C]; patch [M,L1-1,C]; cls [C]; pos [L1,C]. */
 int ovis_vit_embed_ln_f32(const float* patch, const float* cls, const float* pos, const float* gamma, const float* beta,
                           float* out, int M, int L1, int C, float eps, ovis_stream_t stream);
@@ -209,7 +209,7 @@ int ovis_final_masks_u8(const float* masks, const int* sel_q, uint8_t* out, int 
  *   from (H,W) to (Hp,Wp), CLIP mean/std normalisation, written as the patch-embedding im2col matrix
  *   A[(t*G*G + py*G + px), c*ps*ps + iy*ps + ix] (f32, or fp16 when out_f16 != 0). frames uint8 [T,3,H,W]. */
 int ovis_san_front_patches(const uint8_t* frames, void* A, int out_f16, int T, int H, int W, int Hp, int Wp,
-                           int resolution, int patch, const float* mean3_host, const float* std3_host,
+                           int resolution, int patch, long long lda, const float* mean3_host, const float* std3_host,
                            ovis_stream_t stream);
 /* F.adaptive_max_pool2d over N planes [H,W] -> [OH,OW] (side_adapter.py:244, downsample2d(method="max")). */
 int ovis_adaptive_maxpool2d_f32(const float* x, float* y, long long N, int H, int W, int OH, int OW, ovis_stream_t stream);

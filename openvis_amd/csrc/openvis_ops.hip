@@ -236,7 +236,7 @@ __device__ __forceinline__ bool ra_prep(float& v, int size, int& lo, int& hi) {
 __global__ void __launch_bounds__(256)
 clip_crop_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ masks, const int* __restrict__ crops,
                  void* __restrict__ Av, int out_f16, int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int R,
-                 int ps, float m0, float m1, float m2, float s0, float s1, float s2) {
+                 int ps, long long lda, float m0, float m1, float m2, float s0, float s1, float s2) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)M * R * R;
   if (i >= total) return;
@@ -312,10 +312,10 @@ clip_crop_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ m
   const long long row = (long long)m * G * G + (py / ps) * G + (px / ps);
   const int col = (py % ps) * ps + (px % ps);
   if (out_f16) {
-    _Float16* ap = reinterpret_cast<_Float16*>(Av) + row * (3 * ps * ps) + col;
+    _Float16* ap = reinterpret_cast<_Float16*>(Av) + row * lda + col;
     ap[0] = (_Float16)r0; ap[ps * ps] = (_Float16)r1; ap[2 * ps * ps] = (_Float16)r2;
   } else {
-    float* ap = reinterpret_cast<float*>(Av) + row * (3 * ps * ps) + col;
+    float* ap = reinterpret_cast<float*>(Av) + row * lda + col;
     ap[0] = r0; ap[ps * ps] = r1; ap[2 * ps * ps] = r2;
   }
 }
@@ -328,7 +328,7 @@ template <int TY, int TX>
 __global__ void __launch_bounds__(TY * TX)
 clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ masks, const int* __restrict__ crops,
                        void* __restrict__ Av, int out_f16, int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp,
-                       int R, int ps, int PRmax, int PWmax, float m0, float m1, float m2, float s0, float s1, float s2) {
+                       int R, int ps, long long lda, int PRmax, int PWmax, float m0, float m1, float m2, float s0, float s1, float s2) {
   extern __shared__ uint2 patch[];                      // [PR][PW]: .x = r | g<<8 | b<<16, .y = bits of the soft mask
   const int tiles_x = R / TX, tiles_y = R / TY;
   const int tid = threadIdx.x;
@@ -415,10 +415,10 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
   const long long row = (long long)m * G * G + (py / ps) * G + (px / ps);
   const int col = (py % ps) * ps + (px % ps);
   if (out_f16) {
-    _Float16* ap = reinterpret_cast<_Float16*>(Av) + row * (3 * ps * ps) + col;
+    _Float16* ap = reinterpret_cast<_Float16*>(Av) + row * lda + col;
     ap[0] = (_Float16)r0; ap[ps * ps] = (_Float16)r1; ap[2 * ps * ps] = (_Float16)r2;
   } else {
-    float* ap = reinterpret_cast<float*>(Av) + row * (3 * ps * ps) + col;
+    float* ap = reinterpret_cast<float*>(Av) + row * lda + col;
     ap[0] = r0; ap[ps * ps] = r1; ap[2 * ps * ps] = r2;
   }
 }
@@ -650,9 +650,11 @@ extern "C" int ovis_mask_bbox(const float* masks, int* boxes, int Q, int T, int 
 
 extern "C" int ovis_clip_crop_patches(const uint8_t* frames, const float* masks, const int* crops, void* A, int out_f16,
                                       int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int resolution,
-                                      int patch, const float* mean3_host, const float* std3_host, ovis_stream_t stream) {
+                                      int patch, long long lda, const float* mean3_host, const float* std3_host,
+                                      ovis_stream_t stream) {
   OVIS_REQUIRE(frames && masks && crops && A && mean3_host && std3_host, "clip_crop: null pointer");
   OVIS_REQUIRE(M > 0 && resolution > 0 && patch > 0 && resolution % patch == 0, "clip_crop: bad sizes");
+  OVIS_REQUIRE(lda >= 3ll * patch * patch, "clip_crop: lda smaller than a patch row (3*patch*patch)");
   // tile the output bins when the source rectangle of a tile fits in LDS (boxes never exceed the padded frame)
   const float bin_max = (float)(Hp > Wp ? Hp : Wp) / (float)resolution;
   auto args = [&](int ty) { return (int)ceilf((float)ty * bin_max) + 4; };
@@ -667,15 +669,15 @@ extern "C" int ovis_clip_crop_patches(const uint8_t* frames, const float* masks,
     }
     hipLaunchKernelGGL((clip_crop_tiled_kernel<16, 16>), dim3((unsigned)((long long)M * (resolution / 16) * (resolution / 16))), dim3(256),
                        (size_t)p16 * p16 * 8, (hipStream_t)stream, frames, masks, crops, A, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
-                       resolution, patch, p16, p16, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
+                       resolution, patch, lda, p16, p16, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
   } else if (resolution % 8 == 0 && (size_t)p8 * p8 * 8 <= 64 * 1024) {
     hipLaunchKernelGGL((clip_crop_tiled_kernel<8, 8>), dim3((unsigned)((long long)M * (resolution / 8) * (resolution / 8))), dim3(64),
                        (size_t)p8 * p8 * 8, (hipStream_t)stream, frames, masks, crops, A, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
-                       resolution, patch, p8, p8, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
+                       resolution, patch, lda, p8, p8, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
   } else {
     const long long total = (long long)M * resolution * resolution;
     hipLaunchKernelGGL(clip_crop_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, frames, masks, crops, A,
-                       out_f16, M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, mean3_host[0], mean3_host[1], mean3_host[2],
+                       out_f16, M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, lda, mean3_host[0], mean3_host[1], mean3_host[2],
                        std3_host[0], std3_host[1], std3_host[2]);
   }
   return ovis::check_launch("clip_crop");

@@ -15,7 +15,7 @@ __device__ __forceinline__ float cc2(float x, float A) { return ((A * x - 5.f * 
 // zero-padded from (H,W) to (Hp,Wp); then (v - mean)/std; output = im2col of the patchify conv (see clip_crop_kernel).
 __global__ void __launch_bounds__(256)
 san_front_kernel(const uint8_t* __restrict__ frames, void* __restrict__ Av, int out_f16, int T, int H, int W, int Hp, int Wp,
-                 int R, int ps, float m0, float m1, float m2, float s0, float s1, float s2) {
+                 int R, int ps, long long lda, float m0, float m1, float m2, float s0, float s1, float s2) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)T * R * R;
   if (i >= total) return;
@@ -50,10 +50,10 @@ san_front_kernel(const uint8_t* __restrict__ frames, void* __restrict__ Av, int 
   const long long rowi = (long long)t * G * G + (oy / ps) * G + (ox / ps);
   const int col = (oy % ps) * ps + (ox % ps);
   if (out_f16) {
-    _Float16* ap = reinterpret_cast<_Float16*>(Av) + rowi * (3 * ps * ps) + col;
+    _Float16* ap = reinterpret_cast<_Float16*>(Av) + rowi * lda + col;
     ap[0] = (_Float16)r0; ap[ps * ps] = (_Float16)r1; ap[2 * ps * ps] = (_Float16)r2;
   } else {
-    float* ap = reinterpret_cast<float*>(Av) + rowi * (3 * ps * ps) + col;
+    float* ap = reinterpret_cast<float*>(Av) + rowi * lda + col;
     ap[0] = r0; ap[ps * ps] = r1; ap[2 * ps * ps] = r2;
   }
 }
@@ -127,14 +127,15 @@ resize_add_kernel(float* __restrict__ dst, const float* __restrict__ src, int N,
 }  // namespace
 
 extern "C" int ovis_san_front_patches(const uint8_t* frames, void* A, int out_f16, int T, int H, int W, int Hp, int Wp,
-                                      int resolution, int patch, const float* mean3_host, const float* std3_host,
+                                      int resolution, int patch, long long lda, const float* mean3_host, const float* std3_host,
                                       ovis_stream_t stream) {
   OVIS_REQUIRE(frames && A && mean3_host && std3_host, "san_front_patches: null pointer");
   OVIS_REQUIRE(T > 0 && H > 0 && W > 0 && Hp >= H && Wp >= W && resolution > 0 && patch > 0 && resolution % patch == 0,
                "san_front_patches: bad geometry");
+  OVIS_REQUIRE(lda >= 3ll * patch * patch, "san_front_patches: lda smaller than a patch row (3*patch*patch)");
   const long long total = (long long)T * resolution * resolution;
   hipLaunchKernelGGL(san_front_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, frames, A, out_f16, T, H,
-                     W, Hp, Wp, resolution, patch, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1],
+                     W, Hp, Wp, resolution, patch, lda, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1],
                      std3_host[2]);
   return ovis::check_launch("san_front_patches");
 }

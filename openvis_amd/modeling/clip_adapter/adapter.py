@@ -37,7 +37,8 @@ class ClipVisual:
         g = lambda k: sd[prefix + k].float().contiguous().to(device)
         w = self.w
         cw = g("conv1.weight")
-        w["conv1"] = cw.view(cw.shape[0], -1).contiguous()
+        cw = cw.view(cw.shape[0], -1)
+        w["conv1"] = torch.nn.functional.pad(cw, (0, ops.patch_row_len(self.patch) - cw.shape[1])).contiguous()   # zero pad columns
         w["cls"], w["pos"] = g("class_embedding"), g("positional_embedding")
         for n in ("ln_pre", "ln_post"):
             w[n + ".w"], w[n + ".b"] = g(n + ".weight"), g(n + ".bias")

@@ -124,13 +124,25 @@ def gemm_nt_batched(a, b, out, batch, M, N, K, lda, a_bs, ldb, b_bs, ldc, c_bs, 
     return out
 
 
+def patch_row_len(patch):
+    """row length of the ViT patch-embedding im2col matrix: 3*patch*patch padded to a multiple of 8 (16-byte fp16 rows;
+    ViT-L/14: 588 -> 592, the pad columns are zero and meet zero weight columns)."""
+    return (3 * patch * patch + 7) // 8 * 8
+
+
+def _patch_matrix(rows, patch, out_f16, device):
+    k, ld = 3 * patch * patch, patch_row_len(patch)
+    dt = torch.float16 if out_f16 else torch.float32
+    return torch.empty((rows, ld), dtype=dt, device=device) if ld == k else torch.zeros((rows, ld), dtype=dt, device=device)
+
+
 def san_front_patches(frames, Hp, Wp, resolution, patch, mean, std, out_f16=False):
     _chk(frames)
     T, _, H, W = frames.shape
     G = resolution // patch
-    A = torch.empty((T * G * G, 3 * patch * patch), dtype=torch.float16 if out_f16 else torch.float32, device=frames.device)
-    _lib.call("ovis_san_front_patches", frames, A, int(out_f16), T, H, W, Hp, Wp, resolution, patch, _f3(mean), _f3(std),
-              _lib.stream_ptr())
+    A = _patch_matrix(T * G * G, patch, out_f16, frames.device)
+    _lib.call("ovis_san_front_patches", frames, A, int(out_f16), T, H, W, Hp, Wp, resolution, patch, _ll(A.shape[1]), _f3(mean),
+              _f3(std), _lib.stream_ptr())
     return A
 
 
@@ -351,10 +363,9 @@ def clip_crop_patches(frames, masks, crops, Hp, Wp, resolution, patch, mean, std
     Q, _, h, w = masks.shape
     M = crops.shape[0]
     G = resolution // patch
-    A = torch.empty((M * G * G, 3 * patch * patch), dtype=torch.float16 if out_f16 else torch.float32,
-                    device=frames.device)
+    A = _patch_matrix(M * G * G, patch, out_f16, frames.device)
     _lib.call("ovis_clip_crop_patches", frames, masks, crops, A, int(out_f16), M, Q, T, H, W, h, w, Hp, Wp, resolution,
-              patch, _f3(mean), _f3(std), _lib.stream_ptr())
+              patch, _ll(A.shape[1]), _f3(mean), _f3(std), _lib.stream_ptr())
     return A
 
 

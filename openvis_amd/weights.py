@@ -30,9 +30,35 @@ def resnet50_spec(prefix="backbone."):
     return spec
 
 
-def pixel_decoder_spec(prefix="sem_seg_head.pixel_decoder.", C=256, layers=6, ffn=1024, M=8, L=3, P=4):
+def swin_spec(prefix="backbone.", embed_dim=192, depths=(2, 2, 18, 2), num_heads=(6, 12, 24, 48), window=12):
+    """backbone/swin.py state dict (float tensors; the integer relative_position_index buffers are derived)."""
+    s = [(prefix + "patch_embed.proj.weight", (embed_dim, 3, 4, 4)), (prefix + "patch_embed.proj.bias", (embed_dim,)),
+         (prefix + "patch_embed.norm.weight", (embed_dim,)), (prefix + "patch_embed.norm.bias", (embed_dim,))]
+    for i, d in enumerate(depths):
+        C = embed_dim * 2 ** i
+        for j in range(d):
+            p = f"{prefix}layers.{i}.blocks.{j}."
+            s += [(p + "norm1.weight", (C,)), (p + "norm1.bias", (C,)),
+                  (p + "attn.relative_position_bias_table", ((2 * window - 1) ** 2, num_heads[i])),
+                  (p + "attn.qkv.weight", (3 * C, C)), (p + "attn.qkv.bias", (3 * C,)), (p + "attn.proj.weight", (C, C)),
+                  (p + "attn.proj.bias", (C,)), (p + "norm2.weight", (C,)), (p + "norm2.bias", (C,)),
+                  (p + "mlp.fc1.weight", (4 * C, C)), (p + "mlp.fc1.bias", (4 * C,)), (p + "mlp.fc2.weight", (C, 4 * C)),
+                  (p + "mlp.fc2.bias", (C,))]
+        if i < len(depths) - 1:
+            s += [(f"{prefix}layers.{i}.downsample.reduction.weight", (2 * C, 4 * C)),
+                  (f"{prefix}layers.{i}.downsample.norm.weight", (4 * C,)), (f"{prefix}layers.{i}.downsample.norm.bias", (4 * C,))]
+        s += [(f"{prefix}norm{i}.weight", (C,)), (f"{prefix}norm{i}.bias", (C,))]
+    return s
+
+
+SWIN_ARCH = {"swin_l": dict(embed_dim=192, depths=(2, 2, 18, 2), num_heads=(6, 12, 24, 48), window=12),     # swin/openvis_swinL_*.yaml:5-9
+             "swin_b": dict(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32), window=12)}      # swin/brivis_SwinB_*.yaml:5-9
+
+
+def pixel_decoder_spec(prefix="sem_seg_head.pixel_decoder.", C=256, layers=6, ffn=1024, M=8, L=3, P=4,
+                       in_channels=(256, 512, 1024, 2048)):
     s = []
-    for i, cin in enumerate((2048, 1024, 512)):
+    for i, cin in enumerate(in_channels[:0:-1]):
         s += [(f"{prefix}input_proj.{i}.0.weight", (C, cin, 1, 1)), (f"{prefix}input_proj.{i}.0.bias", (C,)),
               (f"{prefix}input_proj.{i}.1.weight", (C,)), (f"{prefix}input_proj.{i}.1.bias", (C,))]
     s.append((prefix + "transformer.level_embed", (L, C)))
@@ -47,7 +73,7 @@ def pixel_decoder_spec(prefix="sem_seg_head.pixel_decoder.", C=256, layers=6, ff
               (p + "linear2.weight", (C, ffn)), (p + "linear2.bias", (C,)),
               (p + "norm2.weight", (C,)), (p + "norm2.bias", (C,))]
     s += [(prefix + "mask_features.weight", (C, C, 1, 1)), (prefix + "mask_features.bias", (C,)),
-          (prefix + "adapter_1.weight", (C, 256, 1, 1)), (prefix + "adapter_1.norm.weight", (C,)), (prefix + "adapter_1.norm.bias", (C,)),
+          (prefix + "adapter_1.weight", (C, in_channels[0], 1, 1)), (prefix + "adapter_1.norm.weight", (C,)), (prefix + "adapter_1.norm.bias", (C,)),
           (prefix + "layer_1.weight", (C, C, 3, 3)), (prefix + "layer_1.norm.weight", (C,)), (prefix + "layer_1.norm.bias", (C,))]
     return s
 
@@ -139,6 +165,31 @@ def brivis_r50_spec(clip_arch=None, num_queries=100):
 def openvis_r50_spec(clip_arch=None, num_queries=100):
     arch = dict(clip_arch or _CLIP_ARCH["ViT-B/16"])
     return resnet50_spec() + pixel_decoder_spec() + video_decoder_spec(Q=num_queries) + clip_visual_spec(**arch)
+
+
+def _backbone(backbone):
+    """-> (backbone spec, res2..res5 channels) for "r50" or a SWIN_ARCH name."""
+    if backbone == "r50":
+        return resnet50_spec(), (256, 512, 1024, 2048)
+    a = SWIN_ARCH[backbone]
+    return swin_spec(**a), tuple(a["embed_dim"] * 2 ** i for i in range(4))
+
+
+def san_spec(backbone="r50", clip_arch=None, num_queries=100):
+    arch = dict(clip_arch or _CLIP_ARCH["ViT-B/16"])
+    bb, ch = _backbone(backbone)
+    return (bb + pixel_decoder_spec(in_channels=ch) + side_decoder_spec(clip_heads=arch["width"] // 64, Q=num_queries) +
+            side_adapter_spec(**arch))
+
+
+def brivis_spec(backbone="r50", clip_arch=None, num_queries=100):
+    return san_spec(backbone, clip_arch, num_queries) + resampler_spec()
+
+
+def openvis_spec(backbone="r50", clip_arch=None, num_queries=100):
+    arch = dict(clip_arch or _CLIP_ARCH["ViT-B/16"])
+    bb, ch = _backbone(backbone)
+    return bb + pixel_decoder_spec(in_channels=ch) + video_decoder_spec(Q=num_queries) + clip_visual_spec(**arch)
 
 
 def random_init(spec, seed=42):
