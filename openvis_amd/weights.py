@@ -171,7 +171,7 @@ def _backbone(backbone):
     """-> (backbone spec, res2..res5 channels) for "r50" or a SWIN_ARCH name."""
     if backbone == "r50":
         return resnet50_spec(), (256, 512, 1024, 2048)
-    a = SWIN_ARCH[backbone]
+    a = backbone if isinstance(backbone, dict) else SWIN_ARCH[backbone]
     return swin_spec(**a), tuple(a["embed_dim"] * 2 ** i for i in range(4))
 
 

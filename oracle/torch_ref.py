@@ -589,11 +589,11 @@ def inference_video(num_queries, num_classes, pred_cls, pred_masks, img_size, ou
             "pred_labels": labels_per_image.tolist(), "pred_masks": [m for m in masks], "rows": topk_indices.tolist()}
 
 
-def openvis_forward(frames, W, text_features, out_hw=None, stages=None, clip_heads=12, clip_resolution=224):
+def openvis_forward(frames, W, text_features, out_hw=None, stages=None, clip_heads=12, clip_resolution=224, backbone_fn=None):
     """OpenVIS.forward, eval (openvis/openvis.py:47-108). frames: uint8 [T,3,H,W]."""
     T = frames.shape[0]
     images, (H, Wd) = preprocess([f for f in frames])
-    feats = resnet50(images, W)
+    feats = (backbone_fn or resnet50)(images, W)
     mask_features, _, ms = pixel_decoder(feats, W)
     cls, pred_masks = video_decoder(ms, mask_features, W)
     mask_pred = pred_masks[0]                                                # [Q,T,h,w]
@@ -849,7 +849,7 @@ def side_frame_decoder(ms_feats, mask_features, W, prefix="sem_seg_head.predicto
 
 
 def san_online_image_outputs(frames, W, text_features, broken_idx=9, merge_ids=(3, 6, 9), resolution=224, clip_heads=12,
-                             num_queries=100):
+                             num_queries=100, backbone_fn=None):
     """SANOnline.forward up to the per-frame logits (san.py:211-231). frames uint8 [T,3,H,W]; text_features [K,E]."""
     images, (H, Wd) = preprocess([f for f in frames])
     Hp, Wp = images.shape[-2:]
@@ -857,7 +857,7 @@ def san_online_image_outputs(frames, W, text_features, broken_idx=9, merge_ids=(
     ori[:, :, :H, :Wd] = frames.float()                                   # ImageList.from_tensors(ori_images): zero pad
     mg, bk = san_front_encode_image(ori, W, broken_idx=broken_idx, merge_ids=merge_ids, resolution=resolution)
     tf = san_text_with_bg(text_features, W)
-    feats = resnet50(images, W)
+    feats = (backbone_fn or resnet50)(images, W)
     mask_features, _, ms = pixel_decoder(feats, W, extra_features=mg)
     out = side_frame_decoder(ms, mask_features, W, clip_heads=clip_heads)
     sos = san_post_encode_image(bk, out["class_attn_biases"][0], W, broken_idx=broken_idx, num_sos=num_queries)

@@ -106,3 +106,49 @@ def test_swin_window12_720p_stage_shapes_vs_oracle():
         got = out[k].permute(0, 3, 1, 2).cpu()
         assert got.shape == ref[k].shape
         assert (got - ref[k]).abs().max() < 5e-5, (k, (got - ref[k]).abs().max())
+
+
+def test_san_online_with_swin_backbone_end_to_end():
+    """SANOnline on a small Swin backbone (window 7, head_dim 32) + small side-adapter CLIP vs the oracle, exact-f32 policy."""
+    from openvis_amd import config, weights
+    from openvis_amd.catalog import MetadataCatalog
+    from openvis_amd.modeling.clip_adapter.side_adapter import SideAdapter
+    from tests.test_openvis_gpu import _frames, K
+    from tests.test_san_gpu import SAN_E2E_ARCH
+
+    Q = 100
+    swin = dict(embed_dim=32, depths=(2, 1, 2, 1), num_heads=(1, 2, 4, 8), window=7)
+    sd = weights.random_init(weights.san_spec(swin, SAN_E2E_ARCH, Q), seed=23)
+    cfg = config.get_cfg()
+    cfg.MODEL.META_ARCHITECTURE = "SANOnline"
+    cfg.MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME = "SideAdapterFrameMultiScaleMaskedTransformerDecoder"
+    cfg.MODEL.CLIP_ADAPTER.CLIP_NUM_HEADS = 4
+    cfg.MODEL.BACKBONE.NAME = "D2SwinTransformer"
+    cfg.MODEL.SWIN.EMBED_DIM, cfg.MODEL.SWIN.DEPTHS = swin["embed_dim"], list(swin["depths"])
+    cfg.MODEL.SWIN.NUM_HEADS, cfg.MODEL.SWIN.WINDOW_SIZE = list(swin["num_heads"]), swin["window"]
+    cfg.MODEL.PRECISION = "fp32"
+    model = config.build_model(cfg)
+    model.clip_adapter = SideAdapter("tiny", broken_idx=3, merge_ids=[1, 2, 3], num_queries=Q, arch=SAN_E2E_ARCH, precision="fp32")
+    model.load_state_dict(sd)
+    names = [f"class_{i}" for i in range(K)]
+    MetadataCatalog.get("synthetic_val").set(thing_classes=names)
+    gen = torch.Generator().manual_seed(1)
+    base = torch.randn(1, 64, generator=gen)
+    text = torch.nn.functional.normalize(base + 0.05 * torch.randn(K, 64, generator=gen), dim=-1)
+    model.clip_adapter.set_text_features(names, text)
+    frames = _frames(3)
+    st, ref_st = {}, {}
+    model([{"image": [f for f in frames], "dataset_name": "synthetic_val"}], stages=st)
+    bb = lambda images, W: TR.swin(images, W, swin["embed_dim"], swin["depths"], swin["num_heads"], swin["window"])
+    with torch.no_grad():
+        TR.san_online_forward(frames, sd, text, stages=ref_st, broken_idx=3, merge_ids=(1, 2, 3), resolution=64, clip_heads=4,
+                              num_queries=Q, backbone_fn=bb)
+    ig, ir = st["indices"].cpu().numpy().reshape(ref_st["indices"].shape), ref_st["indices"].numpy()
+    same = (ig == ir).all(axis=0)
+    assert same.mean() > 0.9, same.mean()
+    sel = torch.from_numpy(np.nonzero(same)[0])
+    g, r = st["pred_masks"].cpu()[:, sel], ref_st["pred_masks"][:, sel]
+    agree = ((g > 0) == (r > 0)).float().mean().item()
+    assert agree > 0.999, agree
+    lg, lr = st["pred_logits"].cpu()[:, :, sel], ref_st["pred_logits"][:, :, sel]
+    assert (lg - lr).abs().max().item() < 2e-2, (lg - lr).abs().max().item()
