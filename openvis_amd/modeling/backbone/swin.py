@@ -2,7 +2,7 @@
 
 The token map stays `[B,H,W,C]` (channel-last = the layout the pixel decoder wants, so the reference's final
 `permute(0,3,1,2)` disappears).  Per block (swin.py:224-284):
-  LayerNorm -> [pad + roll + window_partition: ONE kernel] -> qkv GEMM -> flash window attention (relative-position
+  LayerNorm (fp16 result under the autocast policy) -> [pad + roll + window_partition: ONE kernel] -> qkv GEMM -> flash window attention (relative-position
   bias as an additive f32 table, shifted-window mask as a uint8 table, both built once per stage/geometry)
   -> proj GEMM -> [window_reverse + roll + crop + residual: ONE kernel] -> LayerNorm -> fc1 + exact GELU (epilogue)
   -> fc2 + residual (epilogue).
@@ -74,9 +74,13 @@ class SwinTransformer:
         self._tables = {}
         return self
 
-    def _lin(self, x, name, act=ops.ACT_NONE, residual=None, bias=True):
-        return ops.gemm_nt(x, self.w[name + ".weight"], self.w.get(name + ".bias") if bias else None, residual, act,
-                           w16=self.w16.get(name + ".weight"))
+    def _lin(self, x, name, act=ops.ACT_NONE, residual=None, bias=True, out_f16=False):
+        """fp32 policy: exact-f32 GEMM.  fp16 policy (= the reference under autocast): fp16 activations x fp16 weights on the
+        persistent fp16 MFMA kernel, f32 accumulation, f32 bias / residual, f32 or fp16 result."""
+        b = self.w.get(name + ".bias") if bias else None
+        if x.dtype == torch.float16:
+            return ops.gemm_nt_f16(x, self.w16[name + ".weight"], b, residual, act, out_f16=out_f16)
+        return ops.gemm_nt(x, self.w[name + ".weight"], b, residual, act)
 
     def _stage_tables(self, i, j, B, H, W, device):
         """(relative position bias [heads,N,ld] of block (i,j), shift mask [B*nW,N,ld] or None) -- cached per geometry."""
@@ -99,17 +103,18 @@ class SwinTransformer:
         shift = 0 if j % 2 == 0 else ws // 2
         p = f"layers.{i}.blocks.{j}."
         bias, mask, ld = self._stage_tables(i, j, B, H, W, x.device)
-        h = ops.layernorm(x, self.w[p + "norm1.weight"], self.w[p + "norm1.bias"])
+        f16 = self.precision == "fp16"
+        h = ops.layernorm(x, self.w[p + "norm1.weight"], self.w[p + "norm1.bias"], out_f16=f16)
         win = ops.swin_window_partition(h, ws, shift)                                            # [B*nW, N, C]
         nwin, N = win.shape[0], ws * ws
-        qkv = self._lin(win.view(-1, C), p + "attn.qkv", bias=self.qkv_bias).view(nwin, N, 3 * C)
+        qkv = self._lin(win.view(-1, C), p + "attn.qkv", bias=self.qkv_bias).view(nwin, N, 3 * C)   # f32 out
         a = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], nwin, heads, N, N, 32, N * 3 * C, 3 * C, N * 3 * C,
                           3 * C, N * 3 * C, 3 * C, mask=mask if shift > 0 else None, mask_per_batch=True, bias=bias,
-                          bias_strides=(0, N * ld))
+                          bias_strides=(0, N * ld), out_f16=f16)
         a = self._lin(a.view(-1, C), p + "attn.proj").view(nwin, N, C)
         x = ops.swin_window_merge_add(a, x, ws, shift)                                            # shortcut + attention
-        h = ops.layernorm(x, self.w[p + "norm2.weight"], self.w[p + "norm2.bias"])
-        h = self._lin(h.view(-1, C), p + "mlp.fc1", act=ops.ACT_GELU)
+        h = ops.layernorm(x, self.w[p + "norm2.weight"], self.w[p + "norm2.bias"], out_f16=f16)
+        h = self._lin(h.view(-1, C), p + "mlp.fc1", act=ops.ACT_GELU, out_f16=f16)
         return self._lin(h, p + "mlp.fc2", residual=x.view(-1, C)).view(B, H, W, C)
 
     def forward(self, x):
@@ -127,7 +132,8 @@ class SwinTransformer:
             if i < len(self.depths) - 1:
                 B, H, W, C = x.shape
                 g = ops.swin_patch_merge_gather(x)                                               # [B,H/2,W/2,4C]
-                g = ops.layernorm(g, w[f"layers.{i}.downsample.norm.weight"], w[f"layers.{i}.downsample.norm.bias"])
+                g = ops.layernorm(g, w[f"layers.{i}.downsample.norm.weight"], w[f"layers.{i}.downsample.norm.bias"],
+                                  out_f16=self.precision == "fp16")
                 x = self._lin(g.view(-1, 4 * C), f"layers.{i}.downsample.reduction", bias=False).view(B, g.shape[1], g.shape[2], 2 * C)
         return feats
 

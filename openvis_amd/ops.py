@@ -419,8 +419,13 @@ def swin_window_partition(x, ws, shift):
     _chk(x)
     B, H, W, C = x.shape
     Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
-    win = torch.empty((B * (Hp // ws) * (Wp // ws), ws * ws, C), dtype=torch.float32, device=x.device)
-    _lib.call("ovis_swin_window_partition_f32", x, win, B, H, W, C, ws, shift, _lib.stream_ptr())
+    win = torch.empty((B * (Hp // ws) * (Wp // ws), ws * ws, C), dtype=x.dtype, device=x.device)
+    # pure 16-byte data movement: an fp16 map is moved as C/2 "floats" per token
+    cf = C if x.dtype == torch.float32 else C // 2
+    if x.dtype == torch.float16 and C % 8:
+        raise _lib.OvisError("swin_window_partition: fp16 maps need C % 8 == 0")
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.call("ovis_swin_window_partition_f32", vp(x), vp(win), B, H, W, cf, ws, shift, _lib.stream_ptr())
     return win
 
 
