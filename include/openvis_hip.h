@@ -249,6 +249,12 @@ int ovis_batch_index_rows_f32(const float* src, long long src_bs, long long src_
  *   x[2y+1,2x+1]) with zeros beyond an odd H/W; out f32 [B, ceil(H/2), ceil(W/2), 4C].
  * ovis_swin_relpos_bias_f32: swin.py:147-155 -- bias[h, i, j] = table[index(i,j), h] with
  *   index = (yi-yj+ws-1)*(2ws-1) + (xi-xj+ws-1); table f32 [(2ws-1)^2, heads]; bias f32 [heads, ws*ws, ld]. */
+/* ovis_swin_window_attention_f16: swin.py:130-169 (WindowAttention.forward) on fp16 operands with f32 softmax.
+ *   qkv fp16 [nwin, N, 3C] (q | k | v, head h in columns h*32..h*32+31 of each third), N = ws*ws <= 160, head_dim 32;
+ *   bias f32 [heads, N, ld] (ovis_swin_relpos_bias_f32), mask u8 [nW, N, ld] of the window (b mod nW) or NULL
+ *   (ovis_swin_shift_mask_u8), out fp16 [nwin, N, C].  scale = head_dim ** -0.5. */
+int ovis_swin_window_attention_f16(const void* qkv, void* out, const float* bias, const uint8_t* mask, long long nwin, int N,
+                                   int C, int heads, int nW, int ld, float scale, ovis_stream_t stream);
 int ovis_swin_window_partition_f32(const float* x, float* win, int B, int H, int W, int C, int ws, int shift,
                                    ovis_stream_t stream);
 int ovis_swin_window_merge_add_f32(const float* win, const float* shortcut, float* out, int B, int H, int W, int C, int ws,

@@ -93,7 +93,8 @@ class SwinTransformer:
         km = ("mask", i, B, H, W)
         if km not in self._tables:
             m = ops.swin_shift_mask(H, W, ws, ws // 2, ld, device)                             # [nW,N,ld]
-            self._tables[km] = m.repeat(B, 1, 1).contiguous()                                    # batch index = b*nW + w
+            # the f32 flash kernel indexes the mask by batch (b*nW + w); the window kernel by (b*nW + w) mod nW
+            self._tables[km] = m if self.precision == "fp16" else m.repeat(B, 1, 1).contiguous()
         return self._tables[kb], self._tables[km], ld
 
     # ---- forward --------------------------------------------------------------------------------------------------
@@ -107,10 +108,14 @@ class SwinTransformer:
         h = ops.layernorm(x, self.w[p + "norm1.weight"], self.w[p + "norm1.bias"], out_f16=f16)
         win = ops.swin_window_partition(h, ws, shift)                                            # [B*nW, N, C]
         nwin, N = win.shape[0], ws * ws
-        qkv = self._lin(win.view(-1, C), p + "attn.qkv", bias=self.qkv_bias).view(nwin, N, 3 * C)   # f32 out
-        a = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], nwin, heads, N, N, 32, N * 3 * C, 3 * C, N * 3 * C,
-                          3 * C, N * 3 * C, 3 * C, mask=mask if shift > 0 else None, mask_per_batch=True, bias=bias,
-                          bias_strides=(0, N * ld), out_f16=f16)
+        if f16:
+            qkv = self._lin(win.view(-1, C), p + "attn.qkv", bias=self.qkv_bias, out_f16=True).view(nwin, N, 3 * C)
+            a = ops.swin_window_attention_f16(qkv, bias, mask if shift > 0 else None, heads)
+        else:
+            qkv = self._lin(win.view(-1, C), p + "attn.qkv", bias=self.qkv_bias).view(nwin, N, 3 * C)
+            a = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], nwin, heads, N, N, 32, N * 3 * C, 3 * C,
+                              N * 3 * C, 3 * C, N * 3 * C, 3 * C, mask=mask if shift > 0 else None, mask_per_batch=True,
+                              bias=bias, bias_strides=(0, N * ld))
         a = self._lin(a.view(-1, C), p + "attn.proj").view(nwin, N, C)
         x = ops.swin_window_merge_add(a, x, ws, shift)                                            # shortcut + attention
         h = ops.layernorm(x, self.w[p + "norm2.weight"], self.w[p + "norm2.bias"], out_f16=f16)

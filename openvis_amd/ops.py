@@ -458,3 +458,14 @@ def swin_relpos_bias(table, heads, ws, ld):
     bias = torch.empty((heads, ws * ws, ld), dtype=torch.float32, device=table.device)
     _lib.call("ovis_swin_relpos_bias_f32", table, bias, heads, ws, ld, _lib.stream_ptr())
     return bias
+
+
+def swin_window_attention_f16(qkv, bias, mask, heads):
+    """qkv fp16 [nwin,N,3C] -> fp16 [nwin,N,C]; bias f32 [heads,N,ld]; mask u8 [nW,N,ld] (window = b mod nW) or None."""
+    _chk(qkv, bias, mask)
+    nwin, N, C3 = qkv.shape
+    C = C3 // 3
+    out = torch.empty((nwin, N, C), dtype=torch.float16, device=qkv.device)
+    _lib.call("ovis_swin_window_attention_f16", qkv, out, bias, mask, _ll(nwin), N, C, heads, mask.shape[0] if mask is not None else 0,
+              bias.shape[-1], float(32) ** -0.5, _lib.stream_ptr())
+    return out

@@ -152,3 +152,25 @@ def test_san_online_with_swin_backbone_end_to_end():
     assert agree > 0.999, agree
     lg, lr = st["pred_logits"].cpu()[:, :, sel], ref_st["pred_logits"][:, :, sel]
     assert (lg - lr).abs().max().item() < 2e-2, (lg - lr).abs().max().item()
+
+
+@pytest.mark.parametrize("ws,heads,nW,B,masked", [(12, 6, 6, 2, True), (12, 3, 4, 1, False), (7, 2, 9, 2, True), (5, 4, 3, 1, True), (4, 1, 2, 3, False)])
+def test_swin_window_attention_f16_kernel(ws, heads, nW, B, masked):
+    from openvis_amd import ops
+    N, C = ws * ws, heads * 32
+    ld = (N + 3) // 4 * 4
+    g = torch.Generator().manual_seed(ws * 100 + heads)
+    qkv = torch.randn(B * nW, N, 3 * C, generator=g).half()
+    bias = torch.zeros(heads, N, ld)
+    bias[:, :, :N] = torch.randn(heads, N, N, generator=g)
+    mask = torch.zeros(nW, N, ld, dtype=torch.uint8)
+    if masked:
+        ids = torch.randint(0, 3, (nW, N), generator=g)
+        mask[:, :, :N] = (ids[:, :, None] != ids[:, None, :]).to(torch.uint8)
+    q, k, v = [t.view(B * nW, N, heads, 32).permute(0, 2, 1, 3).double() for t in qkv.split(C, dim=-1)]
+    att = q @ k.transpose(-1, -2) * 32 ** -0.5 + bias[None, :, :, :N].double()
+    if masked:
+        att = att + (mask[:, :, :N].double() * -100.0).repeat(B, 1, 1)[:, None]
+    ref = (att.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B * nW, N, C)
+    out = ops.swin_window_attention_f16(qkv.cuda(), bias.cuda(), mask.cuda() if masked else None, heads).cpu().double()
+    assert (out - ref).abs().max().item() < 6e-3, (out - ref).abs().max().item()
