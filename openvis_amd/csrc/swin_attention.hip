@@ -1,9 +1,9 @@
 // Swin window attention (backbone/swin.py:130-169) for gfx950, fp16 operands / f32 softmax -- the reference's autocast
 // arithmetic.  One workgroup = one (window, head); one wavefront = one tile of 32 queries; the whole window fits on chip:
 //   * K [N,32] and V [N,32] of the head are staged once in LDS (N <= 160 tokens, 20 KB);
-//   * S^T = K Q^T (v_mfma_f32_32x32x16_f16): a lane owns ONE query and all its N scores live in registers
-//     (register r of lane-half h of key tile kt  <->  key 32 kt + (r&3) + 8 (r>>2) + 4 h), so the softmax over the
-//     window is a plain in-register reduction plus one cross-half shuffle -- no online rescaling;
+//   * S^T = K Q^T (v_mfma_f32_32x32x16_f16): a lane owns ONE query; register r of lane-half h of key tile kt  <->
+//     key 32 kt + (r&3) + 8 (r>>2) + 4 h, so the softmax statistics are in-register reductions plus one cross-half
+//     shuffle; tiles of 32 keys are folded in with the online (running max / sum) recurrence to keep ~80 VGPRs;
 //   * relative-position bias (f32 table [heads,N,ld]) and the shifted-window mask (u8 table [nW,N,ld], window = blockIdx
 //     mod nW) are added as 16-byte / 4-byte row loads that match the register layout;
 //   * O^T += V^T P^T with V consumed through ds_read_b64_tr_b16 (hardware transpose read), P straight from registers.
@@ -58,26 +58,27 @@ swin_window_attn_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__
   for (int st = 0; st < 2; ++st) qf[st] = *reinterpret_cast<const f16x8*>(base + (long long)qc * 3 * C + 16 * st + 8 * h);
   __syncthreads();
 
-  // ---- S^T = K Q^T -------------------------------------------------------------------------------
-  f32x16 s[KT];
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      const f16x8 kk = *reinterpret_cast<const f16x8*>(&Ks[(kt * 32 + r32) * KROW + 16 * st + 8 * h]);
-      s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kk, qf[st], s[kt], 0, 0, 0);
-    }
-  }
-
-  // ---- scale + relative-position bias + shift mask, softmax over the window -----------------------
+  // ---- per key tile: S^T = K Q^T, + bias / mask, online softmax, O^T += V^T P^T -------------------
   const float* brow = bias + ((long long)head * N + qc) * ld;
   const uint8_t* mrow = mask ? mask + ((win % nW) * N + qc) * (long long)ld : nullptr;
   const float sl2 = scale * 1.4426950408889634f, l2e = 1.4426950408889634f;
-  float mx = -INFINITY;
+  const int g16 = lane >> 4, li = lane & 15;
+  const int tr_off = (li >> 2) * VROW + 16 * (g16 & 1) + 4 * (li & 3);
+  f32x16 o;
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt)
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m_run = -INFINITY, sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const f16x8 kk = *reinterpret_cast<const f16x8*>(&Ks[(kt * 32 + r32) * KROW + 16 * st + 8 * h]);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kk, qf[st], s, 0, 0, 0);
+    }
+    float mt = -INFINITY;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int key0 = kt * 32 + 8 * g + 4 * h;
@@ -88,36 +89,32 @@ swin_window_attn_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const bool dead = key0 + e >= N || ((mk >> (8 * e)) & 0xffu);
-        const float x = dead ? -INFINITY : s[kt][4 * g + e] * sl2 + bb[e] * l2e;
-        s[kt][4 * g + e] = x;
-        mx = fmaxf(mx, x);
+        const float x = dead ? -INFINITY : s[4 * g + e] * sl2 + bb[e] * l2e;
+        s[4 * g + e] = x;
+        mt = fmaxf(mt, x);
       }
     }
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                          // the other lane-half holds the other keys
-  float sum = 0.f;
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt)
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));                        // the other lane-half holds the other keys
+    const float m_new = fmaxf(m_run, mt);
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;         // a whole tile can be masked for this row
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+    float ps = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = __builtin_amdgcn_exp2f(s[kt][r] - mx);      // every row has at least its own key alive
-      s[kt][r] = p;
-      sum += p;
+      const float p = __builtin_amdgcn_exp2f(s[r] - m_safe);
+      s[r] = p;
+      ps += p;
     }
-  sum += __shfl_xor(sum, 32, 64);
-
-  // ---- O^T = V^T P^T -----------------------------------------------------------------------------
-  const int g16 = lane >> 4, li = lane & 15;
-  const int tr_off = (li >> 2) * VROW + 16 * (g16 & 1) + 4 * (li & 3);
-  f32x16 o;
+    ps += __shfl_xor(ps, 32, 64);
+    sum = sum * alpha + ps;
+    m_run = m_new;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt)
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {
       f16x8 pb;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pb[j] = (_Float16)s[kt][8 * sp + j];
+      for (int j = 0; j < 8; ++j) pb[j] = (_Float16)s[8 * sp + j];
       const int key0a = kt * 32 + 16 * sp + 4 * h, key0b = key0a + 8;
       const f16x4 va = tr_read(&Vs[key0a * VROW + tr_off]);
       const f16x4 vb = tr_read(&Vs[key0b * VROW + tr_off]);
@@ -126,6 +123,7 @@ swin_window_attn_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__
       av[4] = vb[0]; av[5] = vb[1]; av[6] = vb[2]; av[7] = vb[3];
       o = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, pb, o, 0, 0, 0);
     }
+  }
 
   if (!q_ok) return;
   const float inv = 1.f / sum;
