@@ -220,9 +220,9 @@ def main():
     model(inputs[0], stages=st)
     torch.cuda.synchronize()
     prof, ops.PROFILE = ops.PROFILE, None
-    agg = {}
+    agg, hbm = {}, {}
     for name, flops, e0, e1 in prof:
-        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a = (hbm if name.startswith("hbm:") else agg).setdefault(name.replace("hbm:", ""), [0, 0.0, 0.0])
         a[0] += 1
         a[1] += flops
         a[2] += e0.elapsed_time(e1) * 1e-3
@@ -238,7 +238,7 @@ def main():
         peak, peak_note = PEAK_F32_MFMA_TFLOPS, "f32 MFMA peak"
     # HBM traffic of that kernel from the committed PMC passes of this same command (tools/pmc_traffic.py:
     # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs); null if no summary is committed
-    traffic = None
+    traffic, pmc = None, {}
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_bench.json")))["kernels"]
         key = dom[0].replace("<true>", "ILb1E").replace("<false>", "ILb0E").split("<")[0]
@@ -257,6 +257,22 @@ def main():
                                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}}
 
     bb_name = {"r50": "R50", "swin_l": "Swin-L"}[MODELS[args.model].get("backbone", "r50")]
+    # K1 (deformable sampling): HBM roofline of the gather kernel, same live HIP-event measurement
+    roofline_k1 = None
+    if hbm:
+        kname, (kn, kbytes, ksecs) = max(hbm.items(), key=lambda kv: kv[1][2])
+        gbs = kbytes / ksecs / 1e9
+        ktraffic = None
+        try:
+            for k, v in pmc.items():
+                if kname.split("<")[0] in k:
+                    ktraffic = v["hbm_bytes_per_launch"]
+                    break
+        except Exception:
+            ktraffic = None
+        roofline_k1 = {"kernel": kname, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                       "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": ktraffic, "launches_per_step": kn,
+                       "avg_launch_ms": round(ksecs / kn * 1e3, 4), "algorithmic_mb_per_launch": round(kbytes / kn / 1e6, 2)}
     if rank == 0:
         frames_total = T * args.steps * (1 if frame_sharded else world)
         n_valid = int(st["valid"].sum()) if "valid" in st else 0
@@ -279,7 +295,7 @@ def main():
                                        if _model.clip_adapter.precision == "fp16" else "f32"),
                        "valid_crops_per_clip": n_valid,
                        "parallelism": (f"frame-sharded x{world} + RCCL all-gather" if frame_sharded else f"clip-replicas x{world}")},
-            "roofline": roofline,
+            "roofline": roofline, "roofline_k1": roofline_k1,
         }
         if not args.no_cpu_baseline and world == 1 and args.model == "openvis":
             line["cpu_baseline"] = cpu_baseline(sd, text)

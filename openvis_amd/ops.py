@@ -27,8 +27,8 @@ def _gemm_variant(M, N, loader, K=4, batch=1):
 
 
 class _Prof:
-    def __init__(self, name, flops):
-        self.name, self.flops = name, flops
+    def __init__(self, name, flops, unit="flop"):
+        self.name, self.flops = (name if unit == "flop" else "hbm:" + name), flops   # "hbm:" entries carry BYTES
 
     def __enter__(self):
         if PROFILE is not None:
@@ -324,8 +324,10 @@ def msda_encoder_fused(value, oa, shapes, lsi, M=8, L=3, P=4):
     _chk(value, oa, shapes, lsi)
     B, S, C = value.shape
     out = torch.empty_like(value)
-    _lib.call("ovis_msda_encoder_fused_f32", value, oa, oa.shape[-1], shapes, lsi, out, B, S, M, C // M, L, P,
-              _lib.stream_ptr())
+    # algorithmic bytes (DESIGN.md section 3 / SURVEY.md 8d): f32 value + offsets/logits + output rows, once each
+    with _Prof(f"msda_encoder_fused_kernel<{L},{P}>", 4.0 * B * S * (2 * C + oa.shape[-1]), unit="byte"):
+        _lib.call("ovis_msda_encoder_fused_f32", value, oa, oa.shape[-1], shapes, lsi, out, B, S, M, C // M, L, P,
+                  _lib.stream_ptr())
     return out
 
 

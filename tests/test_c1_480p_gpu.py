@@ -1,0 +1,58 @@
+"""GPU: BASELINE.json configs[0] -- openvis_R50, ONE 480p frame (480x854), 100 queries, 40 classes, the full
+architecture (ResNet-50, 6-layer pixel decoder, 9-layer decoder, CLIP ViT-B/16 @224) with seeded random weights --
+HIP path (exact-f32 policy) against the CPU oracle run in the same process (case C1)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c1_single_480p_frame_matches_oracle():
+    import bench
+    from openvis_amd import config, weights
+    from openvis_amd.catalog import MetadataCatalog
+    from oracle import torch_ref as TR
+
+    K = 40
+    sd = weights.random_init(weights.openvis_spec("r50", None, 100), seed=42)
+    cfg = config.get_cfg()
+    cfg.MODEL.PRECISION = "fp32"
+    cfg.MODEL.CLIP_ADAPTER.PRECISION = "fp32"
+    model = config.build_model(cfg)
+    model.load_state_dict(sd)
+    names = [f"class_{i}" for i in range(K)]
+    MetadataCatalog.get("synthetic_c1").set(thing_classes=names)
+    text = bench.synth_text(K, 512)
+    model.clip_adapter.set_text_features(names, text)
+    frames = bench.synth_frames(1, 480, 854, 0, "cpu")
+    st, ref_st = {}, {}
+    out = model([{"image": [f for f in frames], "dataset_name": "synthetic_c1"}], stages=st)
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = TR.openvis_forward(frames, sd, text, stages=ref_st)
+
+    g, r = st["pred_masks"].cpu(), ref_st["pred_masks"]
+    agree = ((g > 0) == (r > 0)).float().mean().item()
+    inter, union = ((g > 0) & (r > 0)).sum().item(), ((g > 0) | (r > 0)).sum().item()
+    assert agree > 0.9995 and inter / max(union, 1) > 0.999, (agree, inter / max(union, 1))      # north star: mask IoU >= 0.999
+    vg, vr = st["valid"], ref_st["valid"].numpy()
+    assert (vg == vr).mean() > 0.99
+    lg, lr = st["crop_logits"].cpu().numpy(), ref_st["crop_logits"].numpy()
+    ig = {tuple(x): i for i, x in enumerate(np.argwhere(vg))}
+    ir = {tuple(x): i for i, x in enumerate(np.argwhere(vr))}
+    common = [k for k in ig if k in ir]
+    d = np.array([np.abs(lg[ig[k]] - lr[ir[k]]).max() for k in common])
+    assert len(common) > 0 and np.median(d) < 2e-2 and (d < 1e-1).mean() > 0.97, (np.median(d), d.max())   # 1e-3 on the cosine
+    # final output: 10 masks at 480x854, IoU per matched (query, label)
+    assert len(out["pred_masks"]) == 10 and tuple(out["pred_masks"][0].shape) == (1, 480, 854)
+    sg = {(q, l): i for i, (q, l) in enumerate(zip(out["pred_queries"], out["pred_labels"]))}
+    sr = {(q, l): i for i, (q, l) in enumerate(zip(ref["rows"], ref["pred_labels"]))}
+    both = set(sg) & set(sr)
+    assert len(both) >= 8, (sorted(sg), sorted(sr))
+    for k in both:
+        a, b = out["pred_masks"][sg[k]].cpu().numpy().astype(bool), np.asarray(ref["pred_masks"][sr[k]]).astype(bool)
+        u = (a | b).sum()
+        assert u == 0 or (a & b).sum() / u > 0.999
+        assert abs(out["pred_scores"][sg[k]] - ref["pred_scores"][sr[k]]) < 1e-3
