@@ -263,6 +263,9 @@ int ovis_swin_shift_mask_u8(uint8_t* mask, int H, int W, int ws, int shift, int 
 int ovis_swin_patch_merge_gather_f32(const float* x, float* out, int B, int H, int W, int C, ovis_stream_t stream);
 int ovis_swin_relpos_bias_f32(const float* table, float* bias, int heads, int ws, int ld, ovis_stream_t stream);
 
+/* Prompt-ensemble mean (adapter.py:131-134: torch.stack(text_embeds_bucket).mean(dim=0)): y[i] = mean_t x[t*len + i]. */
+int ovis_mean_dim0_f32(const float* x, float* y, int n, long long len, ovis_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -239,6 +239,16 @@ pe_sine_kernel(float* __restrict__ out, int T, int H, int W, int npf, int three_
   out[i] = v;
 }
 
+// y[i] = mean_t x[t*len + i]   (prompt-ensemble mean over templates, adapter.py:133; sequential sum in t)
+__global__ void __launch_bounds__(256)
+mean_dim0_kernel(const float* __restrict__ x, float* __restrict__ y, int n, long long len) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  float s = 0.f;
+  for (int t = 0; t < n; ++t) s += x[(long long)t * len + i];
+  y[i] = s / (float)n;
+}
+
 }  // namespace
 
 extern "C" int ovis_preprocess_u8_nhwc4(const uint8_t* frames, float* out, int T, int H, int W, int Hp, int Wp,
@@ -326,4 +336,10 @@ extern "C" int ovis_pe_sine_f32(float* out, int T, int H, int W, int num_pos_fea
   hipLaunchKernelGGL(pe_sine_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, out, T, H, W,
                      num_pos_feats, three_d, add_c);
   return ovis::check_launch("pe_sine");
+}
+
+extern "C" int ovis_mean_dim0_f32(const float* x, float* y, int n, long long len, ovis_stream_t stream) {
+  OVIS_REQUIRE(x && y && n > 0 && len > 0, "mean_dim0: bad arguments");
+  hipLaunchKernelGGL(mean_dim0_kernel, dim3(ovis::cdiv(len, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, len);
+  return ovis::check_launch("mean_dim0");
 }

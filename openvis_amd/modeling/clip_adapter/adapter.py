@@ -121,8 +121,11 @@ class ClipAdapter:
         self.text_cache = {}
 
     def load_state_dict(self, sd, prefix="clip_adapter.", device="cuda"):
+        from .text import ClipText
         self.device = device
         self.visual.load_state_dict(sd, prefix + "clip_model.visual.", device)
+        self.text_tower = ClipText.from_state_dict(sd, prefix + "clip_model.", device)     # None: vision-only checkpoint
+        self.tokenizer = None
         return self
 
     # ---- text side -------------------------------------------------------------------------
@@ -131,12 +134,25 @@ class ClipAdapter:
         feats = feats.float().to(self.device)
         self.text_cache.update(dict(zip(noun_list, feats)))
 
+    def set_tokenizer(self, tokenizer):
+        """tokenizer: openvis_amd.simple_tokenizer.SimpleTokenizer (needs CLIP's public BPE merge table)."""
+        self.tokenizer = tokenizer
+
     def encode_text(self, noun_list):
+        """adapter.py:121-138: prompt-ensemble embeddings of the words not cached yet (text tower on the GPU), then the
+        cached unit rows [K, embed_dim]."""
         missing = [w for w in noun_list if w not in self.text_cache]
         if missing:
-            raise NotImplementedError(
-                f"no cached text embedding for {missing[:3]}...: the CLIP text tower is a later §8(f) row; "
-                "call ClipAdapter.set_text_features(class_names, embeddings) first")
+            if getattr(self, "text_tower", None) is None:
+                raise NotImplementedError(
+                    f"no cached text embedding for {missing[:3]}... and the checkpoint has no CLIP text tower: "
+                    "call ClipAdapter.set_text_features(class_names, embeddings) first")
+            from .text import PREDEFINED_TEMPLATES, encode_nouns
+            if self.tokenizer is None:
+                from ...simple_tokenizer import SimpleTokenizer
+                self.tokenizer = SimpleTokenizer()
+            templates = PREDEFINED_TEMPLATES[self.templates] if isinstance(self.templates, str) else self.templates
+            self.text_cache.update(dict(zip(missing, encode_nouns(self.text_tower, self.tokenizer, templates, missing))))
         return torch.stack([self.text_cache[w] for w in noun_list]).contiguous()
 
     # ---- image side ------------------------------------------------------------------------

@@ -31,7 +31,10 @@ class SideAdapter:
     def load_state_dict(self, sd, prefix="clip_adapter.", device="cuda"):
         self.device = device
         g = lambda k: sd[prefix + k].float().contiguous().to(device)
+        from .text import ClipText
         self.visual.load_state_dict(sd, prefix + "clip_model.visual.", device)
+        self.text_tower = ClipText.from_state_dict(sd, prefix + "clip_model.", device)     # None: vision-only checkpoint
+        self.tokenizer = None
         for i in range(len(self.merge_ids)):
             wt = g(f"attn_projs.{i}.weight")
             self.w[f"attn_projs.{i}.w"] = wt.view(wt.shape[0], wt.shape[1]).contiguous()
@@ -51,10 +54,17 @@ class SideAdapter:
 
     def encode_text(self, x, w_bg=True):
         x = [self._clean(w) for w in x]
-        missing = [w for w in x if w not in self.text_cache]
+        missing = [w for w in dict.fromkeys(x) if w not in self.text_cache]
         if missing:
-            raise NotImplementedError(f"no cached text embedding for {missing[:3]}...: call set_text_features first "
-                                      "(the CLIP text tower is a later §8(f) row)")
+            if getattr(self, "text_tower", None) is None:
+                raise NotImplementedError(f"no cached text embedding for {missing[:3]}... and the checkpoint has no CLIP "
+                                          "text tower: call set_text_features first")
+            from .text import PREDEFINED_TEMPLATES, encode_nouns
+            if self.tokenizer is None:
+                from ...simple_tokenizer import SimpleTokenizer
+                self.tokenizer = SimpleTokenizer()
+            templates = PREDEFINED_TEMPLATES[self.templates] if isinstance(self.templates, str) else self.templates
+            self.text_cache.update(dict(zip(missing, encode_nouns(self.text_tower, self.tokenizer, templates, missing))))
         cat = torch.stack([self.text_cache[w] for w in x])
         if w_bg:
             bg = ops.l2norm_rows(self.w["bg_embed"].view(1, -1).contiguous(), 1.0)

@@ -471,3 +471,11 @@ def swin_window_attention_f16(qkv, bias, mask, heads):
     _lib.call("ovis_swin_window_attention_f16", qkv, out, bias, mask, _ll(nwin), N, C, heads, mask.shape[0] if mask is not None else 0,
               bias.shape[-1], float(32) ** -0.5, _lib.stream_ptr())
     return out
+
+
+def mean_over_dim0(x):
+    """x [n, ...] -> mean over the first dim (prompt ensemble)."""
+    _chk(x)
+    y = torch.empty(x.shape[1:], dtype=torch.float32, device=x.device)
+    _lib.call("ovis_mean_dim0_f32", x, y, x.shape[0], _ll(y.numel()), _lib.stream_ptr())
+    return y

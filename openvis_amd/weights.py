@@ -192,6 +192,21 @@ def openvis_spec(backbone="r50", clip_arch=None, num_queries=100):
     return bb + pixel_decoder_spec(in_channels=ch) + video_decoder_spec(Q=num_queries) + clip_visual_spec(**arch)
 
 
+def clip_text_spec(prefix="clip_adapter.clip_model.", width=512, layers=12, embed_dim=512, vocab=49408, context=77):
+    """Text side of the CLIP state dict (mask_adapted_clip/model.py:408-423); ViT-B/16: width 512, 8 heads, embed 512;
+    ViT-L/14: width 768, 12 heads, embed 768."""
+    s = [(prefix + "token_embedding.weight", (vocab, width)), (prefix + "positional_embedding", (context, width)),
+         (prefix + "ln_final.weight", (width,)), (prefix + "ln_final.bias", (width,)), (prefix + "text_projection", (width, embed_dim))]
+    for i in range(layers):
+        p = f"{prefix}transformer.resblocks.{i}."
+        s += [(p + "attn.in_proj_weight", (3 * width, width)), (p + "attn.in_proj_bias", (3 * width,)),
+              (p + "attn.out_proj.weight", (width, width)), (p + "attn.out_proj.bias", (width,)),
+              (p + "ln_1.weight", (width,)), (p + "ln_1.bias", (width,)), (p + "ln_2.weight", (width,)), (p + "ln_2.bias", (width,)),
+              (p + "mlp.c_fc.weight", (4 * width, width)), (p + "mlp.c_fc.bias", (4 * width,)),
+              (p + "mlp.c_proj.weight", (width, 4 * width)), (p + "mlp.c_proj.bias", (width,))]
+    return s
+
+
 def random_init(spec, seed=42):
     """Seeded random weights with sane scales (fan-in scaled matrices, unit norms, small biases)."""
     g = torch.Generator().manual_seed(int(seed))

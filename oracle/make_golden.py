@@ -298,7 +298,54 @@ def gen_swin():
     print("wrote swin.npz", {k: tuple(v.shape) for k, v in out.items()})
 
 
-GENERATORS = {"swin": gen_swin, "msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "san": gen_side_adapter, "resampler": gen_resampler, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual,
+TEXT_NOUNS = ["person", "traffic light", "hot dog", "teddy bear", "skateboard", "giant_panda", "earless_seal", "ape"]
+
+
+def gen_clip_text():
+    """Reference tokenizer (mask_adapted_clip/simple_tokenizer.py + clip.py:239-283 tokenize) on the 14 "vild" templates x a
+    few class names, and the reference CLIP.encode_text + ClipAdapter.encode_text prompt ensemble (adapter.py:121-138) on a
+    tiny text tower (width 64, 1 head of 64, 2 layers, embed 32; the 49 408-entry vocabulary is the real one)."""
+    import types
+    R.install()
+    sys.modules.setdefault("ftfy", types.SimpleNamespace(fix_text=lambda t: t))        # ftfy is absent; ASCII input: identity
+    tk = R.ref("mask_adapted_clip.simple_tokenizer").SimpleTokenizer()
+    sot, eot = tk.encoder["<|startoftext|>"], tk.encoder["<|endoftext|>"]
+    templates = R.ref("openvis.modeling.clip_adapter.text_prompt").PREDEFINED_TEMPLATES["vild"]
+
+    def tokenize(text):                                                                # clip.py:266-283
+        ids = [sot] + tk.encode(text) + [eot]
+        out = np.zeros(77, np.int64)
+        out[:len(ids)] = ids
+        return out
+    tokens = np.stack([np.stack([tokenize(t.format(n)) for n in TEXT_NOUNS]) for t in templates])      # [14, K, 77]
+    odd = ["Hello, World!!  it's  a café's dog", "3 cats & 12dogs (x-ray)", "  trailing   spaces ", "naïve façade", "a_b-c/d"]
+    odd_tok = np.stack([tokenize(t) for t in odd])
+    mm = R.ref("mask_adapted_clip.model")
+    clip = mm.CLIP(embed_dim=32, image_resolution=32, vision_layers=1, vision_width=64, vision_patch_size=16, context_length=77,
+                   vocab_size=49408, transformer_width=64, transformer_heads=1, transformer_layers=2, mask_prompt_depth=0).eval()
+    spec = [(k, s) for k, s in __import__("tests._synth", fromlist=["spec_of"]).spec_of(clip.state_dict())
+            if not k.startswith("visual.")]
+    from tests._synth import synth_weights
+    sd = synth_weights(spec, 161)
+    clip.load_state_dict(sd, strict=False)
+    with torch.no_grad():
+        bucket = []
+        for t in range(tokens.shape[0]):
+            e = clip.encode_text(torch.from_numpy(tokens[t]))
+            if t == 0:
+                raw0 = e.clone()
+            bucket.append(e / e.norm(dim=-1, keepdim=True))
+        ens = torch.stack(bucket).mean(dim=0)
+        ens = ens / ens.norm(dim=-1, keepdim=True)
+    np.savez_compressed(os.path.join(GOLD, "clip_text.npz"), spec=_spec_arrays(spec), seeds=np.array([161]),
+                        tokens=tokens.astype(np.int32), odd_tokens=odd_tok.astype(np.int32),
+                        odd_texts=np.frombuffer("\n".join(odd).encode("utf-8"), dtype=np.uint8),
+                        nouns=np.frombuffer("\n".join(TEXT_NOUNS).encode(), dtype=np.uint8),
+                        encode_text_template0=raw0.numpy(), ensemble=ens.numpy())
+    print("wrote clip_text.npz", tokens.shape, ens.shape)
+
+
+GENERATORS = {"text": gen_clip_text, "swin": gen_swin, "msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "san": gen_side_adapter, "resampler": gen_resampler, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual,
               "pe": gen_position_encodings}
 
 if __name__ == "__main__":

@@ -524,6 +524,39 @@ def clip_visual(x, W, prefix="clip_adapter.clip_model.visual.", heads=12):
     return x @ W[p + "proj"]
 
 
+def clip_encode_text(tokens, W, prefix="clip_adapter.clip_model.", heads=8):
+    """CLIP.encode_text (mask_adapted_clip/model.py:478-491): token + positional embedding, causal transformer,
+    ln_final, feature of the eot token (= arg-max token id) times text_projection.  tokens int64 [B,77]."""
+    p = prefix
+    x = W[p + "token_embedding.weight"][tokens] + W[p + "positional_embedding"]
+    L = x.shape[1]
+    causal = torch.full((L, L), float("-inf")).triu_(1)                      # model.py:463-469
+    x = x.permute(1, 0, 2)
+    n_layers = 1 + max(int(k[len(p + "transformer.resblocks."):].split(".")[0]) for k in W
+                       if k.startswith(p + "transformer.resblocks."))
+    for i in range(n_layers):
+        bp = f"{p}transformer.resblocks.{i}."
+        h = _ln(x, W, bp + "ln_1")
+        x = x + _mha(W, bp + "attn.", h, h, h, causal, heads)
+        h = _ln(x, W, bp + "ln_2")
+        h = F.linear(h, W[bp + "mlp.c_fc.weight"], W[bp + "mlp.c_fc.bias"])
+        h = h * torch.sigmoid(1.702 * h)
+        x = x + F.linear(h, W[bp + "mlp.c_proj.weight"], W[bp + "mlp.c_proj.bias"])
+    x = _ln(x.permute(1, 0, 2), W, p + "ln_final")
+    return x[torch.arange(x.shape[0]), tokens.argmax(dim=-1)] @ W[p + "text_projection"]
+
+
+def clip_text_ensemble(tokens_per_template, W, prefix="clip_adapter.clip_model.", heads=8):
+    """ClipAdapter.encode_text (adapter.py:121-138): per template L2-normalised embeddings, mean over templates,
+    L2-normalise.  tokens_per_template int64 [n_templates, K, 77] -> [K, E]."""
+    bucket = []
+    for tok in tokens_per_template:
+        e = clip_encode_text(tok, W, prefix, heads)
+        bucket.append(e / e.norm(dim=-1, keepdim=True))
+    e = torch.stack(bucket).mean(dim=0)
+    return e / e.norm(dim=-1, keepdim=True)
+
+
 def clip_encode_image(regions, W, prefix="clip_adapter.clip_model.visual.", resolution=224, heads=12):
     """adapter.py:140-144."""
     image = F.interpolate(regions / 255., (resolution, resolution), mode="bicubic")
