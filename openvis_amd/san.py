@@ -1,4 +1,4 @@
-"""SANOnline meta-architecture — mirror of openvis/san.py:146-283 (eval path; registered as "SANOnline").
+"""SAN / SANOnline meta-architectures — mirror of openvis/san.py:23-283 (eval path; registered as "SAN", "SANOnline").
 
 CLIP front blocks feed the pixel decoder, the side-adapter frame decoder predicts masks + per-head attention biases,
 the CLIP back blocks classify every query with [SOS] tokens, the MinVIS tracker links queries over time."""
@@ -9,7 +9,73 @@ from . import ops
 from .catalog import MetadataCatalog
 from .modeling.clip_adapter.side_adapter import SideAdapter
 from .modeling.minvis import MinVIS
+from .modeling.video_maskformer import VideoMaskFormer
 from .registry import META_ARCH_REGISTRY
+
+
+def _build_side_adapter(cfg):
+    return SideAdapter(cfg.MODEL.CLIP_ADAPTER.CLIP_MODEL_NAME, broken_idx=cfg.MODEL.CLIP_ADAPTER.BROKEN_ID,
+                       merge_ids=cfg.MODEL.CLIP_ADAPTER.MERGE_IDS, num_queries=cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES,
+                       precision=cfg.MODEL.CLIP_ADAPTER.get("PRECISION", "fp16"))
+
+
+def _classify(pred_logits):
+    """mean over frames, softmax, drop the background column (san.py:116,257; video_maskformer.py:218-219) -> probs [Q,K]."""
+    lg = pred_logits[0]                                                                   # [T,Q,K+1]
+    T, Q, K1 = lg.shape
+    slot = torch.arange(T * Q, dtype=torch.int32, device=lg.device).view(T, Q)           # every (t,q) is valid
+    probs, _ = ops.openvis_aggregate(lg.reshape(T * Q, K1).contiguous(), slot)
+    return probs[:, :-1].contiguous()
+
+
+@META_ARCH_REGISTRY.register()
+class SAN(VideoMaskFormer):
+    """openvis/san.py:23-144 (eval path; registered as "SAN"): the offline (clip-level) side-adapter model.  CLIP front
+    blocks feed the pixel decoder, SideAdapterVideoMultiScaleMaskedTransformerDecoder predicts one set of query masks for
+    the clip plus per-frame per-head attention biases, the CLIP back blocks classify every (frame, query) with [SOS]
+    tokens and the logits are averaged over the frames."""
+
+    def __init__(self, *, clip_adapter, **kwargs):
+        super().__init__(**kwargs)
+        self.clip_adapter = clip_adapter
+
+    @classmethod
+    def from_config(cls, cfg):
+        args = VideoMaskFormer.from_config(cfg)
+        args["clip_adapter"] = _build_side_adapter(cfg)
+        return args
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        self.clip_adapter.load_state_dict(sd, "clip_adapter.", self.device)
+        return self
+
+    def get_class_name_list(self, dataset_name):
+        return [c.strip() for c in MetadataCatalog.get(dataset_name).thing_classes]
+
+    def forward(self, batched_inputs, stages=None):
+        dataset_name = list(set(x["dataset_name"] for x in batched_inputs))[0]
+        class_names = self.get_class_name_list(dataset_name)
+        self.sem_seg_head.num_classes = len(class_names)
+        frames = self._frames_to_device(batched_inputs)
+        images, image_size, padded = self.preprocess(frames)
+        mg_feats, clip_tokens = self.clip_adapter.front_encode_image(frames, padded)          # san.py:103
+        text_feats = self.clip_adapter.encode_text(class_names)
+        features = self.backbone(images)
+        outputs = self.sem_seg_head(features, extra_feats=mg_feats)
+        clip_feats = self.clip_adapter.post_encode_image(clip_tokens, outputs["class_attn_biases"][0])   # san.py:115
+        pred_logits = self.clip_adapter.cal_sim_logits(text_feats, clip_feats).unsqueeze(0)               # [1,T,Q,K+1]
+        probs = _classify(pred_logits)
+        masks_lowres = outputs["pred_masks"][0]
+        if stages is not None:
+            stages.update(dict(images=images, pred_masks=outputs["pred_masks"], pred_logits=pred_logits, probs=probs,
+                               class_attn_biases=outputs["class_attn_biases"]))
+        inp = batched_inputs[0]
+        row_ids = np.arange(self.num_queries, dtype=np.int32)
+        return self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
+                                    inp.get("height", image_size[0]), inp.get("width", image_size[1]))
+
+    __call__ = forward
 
 
 @META_ARCH_REGISTRY.register()
@@ -21,10 +87,7 @@ class SANOnline(MinVIS):
     @classmethod
     def from_config(cls, cfg):
         args = MinVIS.from_config(cfg)
-        args["clip_adapter"] = SideAdapter(cfg.MODEL.CLIP_ADAPTER.CLIP_MODEL_NAME, broken_idx=cfg.MODEL.CLIP_ADAPTER.BROKEN_ID,
-                                           merge_ids=cfg.MODEL.CLIP_ADAPTER.MERGE_IDS,
-                                           num_queries=cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES,
-                                           precision=cfg.MODEL.CLIP_ADAPTER.get("PRECISION", "fp16"))
+        args["clip_adapter"] = _build_side_adapter(cfg)
         return args
 
     def load_state_dict(self, sd):
@@ -49,11 +112,7 @@ class SANOnline(MinVIS):
 
     def classify(self, pred_logits):
         """mean over frames, softmax, drop the background column (san.py:257,264-265) -> probs [Q,K]."""
-        lg = pred_logits[0]                                                                   # [T,Q,K+1]
-        T, Q, K1 = lg.shape
-        slot = torch.arange(T * Q, dtype=torch.int32, device=lg.device).view(T, Q)           # every (t,q) is valid
-        probs, _ = ops.openvis_aggregate(lg.reshape(T * Q, K1).contiguous(), slot)
-        return probs[:, :-1].contiguous()
+        return _classify(pred_logits)
 
     def forward(self, batched_inputs, stages=None):
         dataset_name = list(set(x["dataset_name"] for x in batched_inputs))[0]

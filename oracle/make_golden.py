@@ -253,6 +253,35 @@ def gen_side_adapter():
     print("wrote side_adapter.npz", sos.shape, logits.shape, out["class_attn_biases"].shape)
 
 
+def gen_side_video_decoder():
+    """Reference SideAdapterVideoMultiScaleMaskedTransformerDecoder.forward (side-video decoder:51-142), eval: one query
+    set for the whole clip, per-frame per-head attention biases."""
+    from tests._synth import synth_inputs, synth_weights
+    from oracle import torch_ref as TR
+    svd = R.ref("openvis.modeling.transformer_decoder.side_adapter_video_mask2former_transformer_decoder")
+    Q, T = 12, 3
+    dec = svd.SideAdapterVideoMultiScaleMaskedTransformerDecoder(
+        clip_heads=4, mask_classification=True, in_channels=256, num_classes=1, hidden_dim=256, num_queries=Q, nheads=8,
+        dim_feedforward=2048, dec_layers=9, pre_norm=False, mask_dim=256, enforce_input_project=False, num_frames=T).eval()
+    spec = _load_synth(dec, 171)
+    Wd = synth_weights(spec, 171, "sem_seg_head.predictor.")
+    for s_ms in range(172, 272, 10):                                   # stable seed (see gen_frame_decoder_and_tracker)
+        ms = synth_inputs([(T, 256, 3, 4), (T, 256, 6, 8), (T, 256, 12, 16)], s_ms)
+        mf = synth_inputs([(T, 256, 24, 32)], s_ms + 1)[0]
+        with torch.no_grad():
+            out = dec(ms, mf)
+            mine = TR.side_video_decoder(ms, mf, Wd, clip_heads=4)
+        if (out["pred_masks"] - mine["pred_masks"]).abs().max() < 1e-3:
+            break
+    else:
+        raise RuntimeError("no stable seed found")
+    print("side-video decoder fixture uses input seed", s_ms, "oracle diff",
+          (out["pred_masks"] - mine["pred_masks"]).abs().max().item(), (out["class_attn_biases"] - mine["class_attn_biases"]).abs().max().item())
+    np.savez_compressed(os.path.join(GOLD, "side_video_decoder.npz"), spec=_spec_arrays(spec), seeds=np.array([171, s_ms, s_ms + 1]),
+                        dims=np.array([Q, T]), class_attn_biases=out["class_attn_biases"].numpy(), pred_masks=out["pred_masks"].numpy())
+    print("wrote side_video_decoder.npz", out["class_attn_biases"].shape, out["pred_masks"].shape)
+
+
 def gen_resampler():
     """Reference TemporalInstanceResampler.forward (resampler.py:244-316) with a stub adapter (the CLIP pass of its
     prediction heads is covered by the side_adapter fixture)."""
@@ -345,7 +374,7 @@ def gen_clip_text():
     print("wrote clip_text.npz", tokens.shape, ens.shape)
 
 
-GENERATORS = {"text": gen_clip_text, "swin": gen_swin, "msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "san": gen_side_adapter, "resampler": gen_resampler, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual,
+GENERATORS = {"sidevideo": gen_side_video_decoder, "text": gen_clip_text, "swin": gen_swin, "msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "san": gen_side_adapter, "resampler": gen_resampler, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual,
               "pe": gen_position_encodings}
 
 if __name__ == "__main__":

@@ -881,6 +881,84 @@ def side_frame_decoder(ms_feats, mask_features, W, prefix="sem_seg_head.predicto
             "pred_embeds": pred_embeds.permute(1, 0, 2).unsqueeze(0), "attn_feats": af, "mask_feats": mask_features}
 
 
+def side_video_decoder(ms_feats, mask_features, W, prefix="sem_seg_head.predictor.", n_layers=9, nheads=8, clip_heads=12):
+    """SideAdapterVideoMultiScaleMaskedTransformerDecoder.forward, eval: bs = 1, t = T
+    (side_adapter_video_mask2former_transformer_decoder.py:51-142)."""
+    p = prefix
+    bt, c, h_m, w_m = mask_features.shape
+    bs, t = 1, bt
+    af = F.interpolate(mask_features, scale_factor=0.25, mode="bilinear", align_corners=False)
+    ha, wa = af.shape[-2:]
+    for j in range(3):
+        af = F.conv2d(af, W[f"{p}attn_mlp.layers.{j}.weight"], W[f"{p}attn_mlp.layers.{j}.bias"])
+        if j < 2:
+            af = F.relu(af)
+    af = af.reshape(bs, t, clip_heads, c, ha, wa)
+    mf = mask_features.view(bs, t, c, h_m, w_m)
+    src, pos, size_list = [], [], []
+    for i in range(3):
+        h, w = ms_feats[i].shape[-2:]
+        size_list.append((h, w))
+        pe = pe_sine_3d(bs, t, h, w).flatten(3)
+        s = ms_feats[i].flatten(2) + W[p + "level_embed.weight"][i][None, :, None]
+        pos.append(pe.view(bs, t, c, h * w).permute(1, 3, 0, 2).flatten(0, 1))
+        src.append(s.view(bs, t, c, h * w).permute(1, 3, 0, 2).flatten(0, 1))
+    query_embed = W[p + "query_embed.weight"].unsqueeze(1).repeat(1, bs, 1)
+    output = W[p + "query_feat.weight"].unsqueeze(1).repeat(1, bs, 1)
+
+    def heads(out, target):
+        dec = _ln(out, W, p + "decoder_norm").transpose(0, 1)
+        attn_embed = _mlp3(dec, W, p + "attn_embed.")
+        mask_embed = _mlp3(dec, W, p + "mask_embed.")
+        biases = torch.einsum("bqc,btnchw->btnqhw", attn_embed, af)
+        masks = torch.einsum("bqc,btchw->bqthw", mask_embed, mf)
+        b, q, tt = masks.shape[:3]
+        am = F.interpolate(masks.flatten(0, 1), size=target, mode="bilinear", align_corners=False).view(b, q, tt, *target)
+        am = (am.sigmoid().flatten(2).unsqueeze(1).repeat(1, nheads, 1, 1).flatten(0, 1) < 0.5).bool()
+        return biases, masks, am
+
+    biases, msk, attn_mask = heads(output, size_list[0])
+    for i in range(n_layers):
+        li = i % 3
+        attn_mask[torch.where(attn_mask.sum(-1) == attn_mask.shape[-1])] = False
+        cp = f"{p}transformer_cross_attention_layers.{i}."
+        tgt2 = _mha(W, cp + "multihead_attn.", output + query_embed, src[li] + pos[li], src[li], attn_mask, nheads)
+        output = _ln(output + tgt2, W, cp + "norm")
+        sp = f"{p}transformer_self_attention_layers.{i}."
+        qk = output + query_embed
+        output = _ln(output + _mha(W, sp + "self_attn.", qk, qk, output, None, nheads), W, sp + "norm")
+        fp = f"{p}transformer_ffn_layers.{i}."
+        tgt2 = F.linear(F.relu(F.linear(output, W[fp + "linear1.weight"], W[fp + "linear1.bias"])),
+                        W[fp + "linear2.weight"], W[fp + "linear2.bias"])
+        output = _ln(output + tgt2, W, fp + "norm")
+        biases, msk, attn_mask = heads(output, size_list[(i + 1) % 3])
+    return {"class_attn_biases": biases, "pred_masks": msk}
+
+
+def san_forward(frames, W, text_features, out_hw=None, stages=None, broken_idx=9, merge_ids=(3, 6, 9), resolution=224,
+                clip_heads=12, num_queries=100, backbone_fn=None):
+    """SAN.forward, eval (san.py:85-144)."""
+    images, (H, Wd) = preprocess([f for f in frames])
+    Hp, Wp = images.shape[-2:]
+    ori = torch.zeros(frames.shape[0], 3, Hp, Wp)
+    ori[:, :, :H, :Wd] = frames.float()
+    mg, bk = san_front_encode_image(ori, W, broken_idx=broken_idx, merge_ids=merge_ids, resolution=resolution)
+    tf = san_text_with_bg(text_features, W)
+    feats = (backbone_fn or resnet50)(images, W)
+    mask_features, _, ms = pixel_decoder(feats, W, extra_features=mg)
+    out = side_video_decoder(ms, mask_features, W, clip_heads=clip_heads)
+    sos = san_post_encode_image(bk, out["class_attn_biases"][0], W, broken_idx=broken_idx, num_sos=num_queries)
+    logits = san_cal_sim_logits(tf, sos, W)                                               # [T,Q,K+1]
+    probs = F.softmax(logits.mean(dim=0), dim=-1)[:, :-1]                                 # san.py:116; postprocess :218-219
+    mask_pred = F.interpolate(out["pred_masks"][0], size=(Hp, Wp), mode="bilinear", align_corners=False)
+    oh, ow = out_hw if out_hw is not None else (H, Wd)
+    res = inference_video(mask_pred.shape[0], text_features.shape[0], probs, mask_pred, (H, Wd), oh, ow)
+    if stages is not None:
+        stages.update(dict(pred_masks=out["pred_masks"], pred_logits=logits.unsqueeze(0), probs=probs,
+                           class_attn_biases=out["class_attn_biases"]))
+    return res
+
+
 def san_online_image_outputs(frames, W, text_features, broken_idx=9, merge_ids=(3, 6, 9), resolution=224, clip_heads=12,
                              num_queries=100, backbone_fn=None):
     """SANOnline.forward up to the per-frame logits (san.py:211-231). frames uint8 [T,3,H,W]; text_features [K,E]."""

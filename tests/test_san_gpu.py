@@ -154,3 +154,67 @@ def test_san_brivis_end_to_end(arch_name, policy):
         sg = {(q, l): s for q, l, s in zip(out["pred_queries"], out["pred_labels"], out["pred_scores"])}
         sr = {(rr, l): s for rr, l, s in zip(ref["rows"], ref["pred_labels"], ref["pred_scores"])}
         assert len(set(sg) & set(sr)) >= 8
+
+
+def test_side_video_decoder_matches_reference():
+    from openvis_amd.modeling.transformer_decoder import SideAdapterVideoMultiScaleMaskedTransformerDecoder as Dec
+    from tests.test_oracle_path import load_side_video_case
+    g, Wd, ms, mf = load_side_video_case()
+    Q, T = [int(x) for x in g["dims"]]
+    dec = Dec(4, True, in_channels=256, num_classes=1, hidden_dim=256, num_queries=Q, nheads=8, dim_feedforward=2048,
+              dec_layers=9, pre_norm=False, mask_dim=256, enforce_input_project=False, num_frames=T, precision="fp32")
+    dec.load_state_dict(Wd, "sem_seg_head.predictor.", "cuda")
+    out = dec([nhwc(m) for m in ms], nhwc(mf))
+    pm = out["pred_masks"].cpu().numpy()
+    assert np.abs(pm - g["pred_masks"]).max() < 3e-3
+    assert ((pm > 0) == (g["pred_masks"] > 0)).mean() > 0.9999
+    cab = out["class_attn_biases"].cpu().numpy()
+    assert np.abs(cab - g["class_attn_biases"]).max() < 3e-3 * max(1.0, np.abs(g["class_attn_biases"]).max())
+
+
+@pytest.mark.parametrize("policy", ["fp32", "mixed"])
+def test_san_offline_end_to_end(policy):
+    """META_ARCHITECTURE "SAN" (san.py:23-144): clip-level decoder + side adapter vs the oracle."""
+    from openvis_amd import config, weights
+    from openvis_amd.catalog import MetadataCatalog
+    from openvis_amd.modeling.clip_adapter.side_adapter import SideAdapter
+    from oracle import torch_ref as TR
+    from tests.test_openvis_gpu import _frames, K
+
+    Q = 100
+    sd = weights.random_init(weights.san_spec("r50", SAN_E2E_ARCH, Q), seed=25)
+    cfg = config.get_cfg()
+    cfg.MODEL.META_ARCHITECTURE = "SAN"
+    cfg.MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME = "SideAdapterVideoMultiScaleMaskedTransformerDecoder"
+    cfg.MODEL.CLIP_ADAPTER.CLIP_NUM_HEADS = 4
+    cfg.MODEL.PRECISION = policy
+    model = config.build_model(cfg)
+    model.clip_adapter = SideAdapter("tiny", broken_idx=3, merge_ids=[1, 2, 3], num_queries=Q, arch=SAN_E2E_ARCH,
+                                     precision="fp32" if policy == "fp32" else "fp16")
+    model.load_state_dict(sd)
+    names = [f"class_{i}" for i in range(K)]
+    MetadataCatalog.get("synthetic_val").set(thing_classes=names)
+    gen = torch.Generator().manual_seed(1)
+    base = torch.randn(1, 64, generator=gen)
+    text = torch.nn.functional.normalize(base + 0.05 * torch.randn(K, 64, generator=gen), dim=-1)
+    model.clip_adapter.set_text_features(names, text)
+    frames = _frames(5)
+    st, ref_st = {}, {}
+    out = model([{"image": [f for f in frames], "dataset_name": "synthetic_val"}], stages=st)
+    with torch.no_grad():
+        ref = TR.san_forward(frames, sd, text, stages=ref_st, broken_idx=3, merge_ids=(1, 2, 3), resolution=64, clip_heads=4,
+                             num_queries=Q)
+    g, r = st["pred_masks"].cpu(), ref_st["pred_masks"]
+    agree = ((g > 0) == (r > 0)).float().mean().item()
+    inter, union = ((g > 0) & (r > 0)).sum().item(), ((g > 0) | (r > 0)).sum().item()
+    if policy == "fp32":
+        assert agree > 0.9995 and inter / max(union, 1) > 0.999, (agree, inter / max(union, 1))
+    else:
+        assert agree > 0.995 and inter / max(union, 1) > 0.98, (agree, inter / max(union, 1))
+    d = (st["pred_logits"].cpu() - ref_st["pred_logits"]).abs().max().item()
+    assert d < (5e-3 if policy == "fp32" else 0.5), d
+    assert (st["probs"].cpu() - ref_st["probs"]).abs().max().item() < (1e-3 if policy == "fp32" else 5e-2)
+    if policy == "fp32":
+        sg = {(q, l) for q, l in zip(out["pred_queries"], out["pred_labels"])}
+        sr = {(q, l) for q, l in zip(ref["rows"], ref["pred_labels"])}
+        assert len(sg & sr) >= 8
