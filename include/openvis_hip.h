@@ -200,9 +200,10 @@ int ovis_openvis_aggregate_f32(const float* crop_logits, const int* slot, float*
  *   of the selected rows (video_maskformer.py:267-272). */
 int ovis_topk_entropy_f32(const float* probs, const int* row_ids, int nrows, int K, int topk, int* out_idx,
                           float* out_score, float* out_entropy, ovis_stream_t stream);
-/* final masks of the selected queries (openvis.py:87-96 + video_maskformer.py:273-278): out uint8 [n_sel,T,OH,OW]. */
+/* final masks of the selected queries (openvis.py:87-96 + video_maskformer.py:273-278): out uint8 [n_sel,T,OH,OW], or
+ * [n_sel,T,OW,OH] when column_major != 0 (the order in which COCO RLE scans a mask, see ovis_rle_encode_u8). */
 int ovis_final_masks_u8(const float* masks, const int* sel_q, uint8_t* out, int n_sel, int Q, int T, int h, int w, int Hp,
-                        int Wp, int H, int W, int OH, int OW, ovis_stream_t stream);
+                        int Wp, int H, int W, int OH, int OW, int column_major, ovis_stream_t stream);
 
 /* ---- A13: SideAdapter (SAN / BriVIS) helpers -------------------------------------------------------
  * Front image path (side_adapter.py:150-153): F.interpolate(frames/255, (R,R), "bicubic") of the raw frames zero-padded
@@ -265,6 +266,13 @@ int ovis_swin_relpos_bias_f32(const float* table, float* bias, int heads, int ws
 
 /* Prompt-ensemble mean (adapter.py:131-134: torch.stack(text_embeds_bucket).mean(dim=0)): y[i] = mean_t x[t*len + i]. */
 int ovis_mean_dim0_f32(const float* x, float* y, int n, long long len, ovis_stream_t stream);
+
+/* COCO run-length encoding on the GPU -- replaces the per-mask host loop of openvis/data/evals/ytvis_eval.py:258-301
+ * (mask.cpu() -> np.array(order="F") -> pycocotools rleEncode).
+ *   masks u8 [n_masks, len]: each mask flattened in COLUMN-major order (ovis_final_masks_u8 with column_major = 1);
+ *   counts int32 [n_masks, cap]: uncompressed COCO counts (0-run first, may be 0); n_runs int32 [n_masks].
+ *   n_runs[i] > cap means the buffer was too small for mask i (its first cap-1 counts are valid). */
+int ovis_rle_encode_u8(const uint8_t* masks, int n_masks, long long len, int* counts, int* n_runs, int cap, ovis_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,8 @@ def get_cfg():
                             "ENC_LAYERS": 0, "DEC_LAYERS": 10, "PRE_NORM": False, "ENFORCE_INPUT_PROJ": False,
                             "SIZE_DIVISIBILITY": 32,
                             "TEST": {"OBJECT_MASK_THRESHOLD": 0.8, "OVERLAP_THRESHOLD": 0.8, "WINDOW_INFERENCE": False,
+                                     # not a reference key: return COCO RLE (encoded on the GPU) instead of dense masks
+                                     "OUTPUT_RLE": False,
                                      "WINDOW_SIZE": 10}},
             "CLIP_ADAPTER": {"NAME": "ClipAdapter", "PROMPT_NAME": "vild", "CLIP_MODEL_NAME": "ViT-B/16",
                              "CLIP_NUM_HEADS": 12, "CLIP_EMBED_DIMS": 512, "MERGE_IDS": [3, 6, 9], "BROKEN_ID": 9,
@@ -105,4 +107,6 @@ def build_model(cfg):
     from . import openvis, san, brivis  # noqa: F401  (registers the meta-architectures)
     from .registry import META_ARCH_REGISTRY
     cls = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)
-    return cls(**cls.from_config(cfg))
+    model = cls(**cls.from_config(cfg))
+    model.output_rle = bool(cfg.MODEL.MASK_FORMER.TEST.get("OUTPUT_RLE", False))
+    return model

@@ -577,14 +577,15 @@ topk_entropy_kernel(const float* __restrict__ probs, const int* __restrict__ row
 // (OH,OW), threshold > 0 (openvis.py:87-96; video_maskformer.py:273-278). out uint8 [n_sel,T,OH,OW].
 __global__ void __launch_bounds__(256)
 final_masks_kernel(const float* __restrict__ masks, const int* __restrict__ sel_q, uint8_t* __restrict__ out, int n_sel,
-                   int Q, int T, int h, int w, int Hp, int Wp, int H, int W, int OH, int OW) {
+                   int Q, int T, int h, int w, int Hp, int Wp, int H, int W, int OH, int OW, int column_major) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)n_sel * T * OH * OW;
   if (i >= total) return;
-  const int ox = (int)(i % OW);
-  long long r = i / OW;
-  const int oy = (int)(r % OH);
-  r /= OH;
+  // row-major [.., OH, OW] (the reference's tensor) or column-major [.., OW, OH] (the order COCO RLE scans a mask in)
+  int ox, oy;
+  long long r;
+  if (column_major) { oy = (int)(i % OH); r = i / OH; ox = (int)(r % OW); r /= OW; }
+  else { ox = (int)(i % OW); r = i / OW; oy = (int)(r % OH); r /= OH; }
   const int t = (int)(r % T);
   const int j = (int)(r / T);
   const float* mp = masks + ((long long)sel_q[j] * T + t) * h * w;
@@ -723,11 +724,11 @@ extern "C" int ovis_topk_entropy_f32(const float* probs, const int* row_ids, int
 }
 
 extern "C" int ovis_final_masks_u8(const float* masks, const int* sel_q, uint8_t* out, int n_sel, int Q, int T, int h, int w,
-                                   int Hp, int Wp, int H, int W, int OH, int OW, ovis_stream_t stream) {
+                                   int Hp, int Wp, int H, int W, int OH, int OW, int column_major, ovis_stream_t stream) {
   OVIS_REQUIRE(masks && sel_q && out, "final_masks: null pointer");
   OVIS_REQUIRE(n_sel > 0 && T > 0 && H <= Hp && W <= Wp && OH > 0 && OW > 0, "final_masks: bad sizes");
   const long long total = (long long)n_sel * T * OH * OW;
   hipLaunchKernelGGL(final_masks_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, masks, sel_q, out, n_sel,
-                     Q, T, h, w, Hp, Wp, H, W, OH, OW);
+                     Q, T, h, w, Hp, Wp, H, W, OH, OW, column_major);
   return ovis::check_launch("final_masks");
 }

@@ -58,8 +58,9 @@ class VideoMaskFormer:
         Hp, Wp = ((H + d - 1) // d * d, (W + d - 1) // d * d) if d > 1 else (H, W)
         return ops.preprocess_u8(frames_u8, Hp, Wp, self.pixel_mean, self.pixel_std), (H, W), (Hp, Wp)
 
-    @classmethod
-    def inference_video(cls, num_queries, num_classes, probs, row_ids, pred_masks_lowres, padded_hw, img_size,
+    output_rle = False        # MODEL.MASK_FORMER.TEST.OUTPUT_RLE (not a reference key): RLE hand-off instead of dense masks
+
+    def inference_video(self, num_queries, num_classes, probs, row_ids, pred_masks_lowres, padded_hw, img_size,
                         output_height, output_width, topk=10):
         """video_maskformer.py:262-298.  probs [Q,K] (rows of valid queries filled), row_ids = valid query ids."""
         if row_ids is None or len(row_ids) == 0:
@@ -74,6 +75,18 @@ class VideoMaskFormer:
         rows = [i // K for i in idx_h]
         sel_q = torch.as_tensor([int(row_ids[r]) for r in rows], dtype=torch.int32, device=dev)
         Q, T, h, w = pred_masks_lowres.shape
+        if self.output_rle:
+            # hand the evaluator COCO RLE instead of dense masks -- the masks are produced column-major
+            # and run-length encoded on the GPU, only the run lengths cross PCIe (ytvis_eval.py:258-301 does this per
+            # mask on the host after a dense D2H copy)
+            from .. import rle
+            cm = ops.final_masks(pred_masks_lowres, sel_q, padded_hw[0], padded_hw[1], img_size[0], img_size[1],
+                                 output_height, output_width, column_major=True)
+            counts, n_runs = ops.rle_encode(cm.view(-1, output_height * output_width))
+            return {"image_size": (output_height, output_width), "pred_entropys": ent.cpu().tolist(),
+                    "pred_scores": score.cpu().tolist(), "pred_labels": labels,
+                    "pred_masks_rle": rle.encode_video_masks(counts, n_runs, len(rows), T, output_height, output_width),
+                    "pred_queries": sel_q.cpu().tolist()}
         masks = ops.final_masks(pred_masks_lowres, sel_q, padded_hw[0], padded_hw[1], img_size[0], img_size[1],
                                 output_height, output_width)
         # D2H of the 10 output masks (video_maskformer.py:283): pinned staging buffer from torch's caching host

@@ -406,13 +406,26 @@ def topk_entropy(probs, row_ids, topk):
     return idx, score, ent
 
 
-def final_masks(masks, sel_q, Hp, Wp, H, W, OH, OW):
+def final_masks(masks, sel_q, Hp, Wp, H, W, OH, OW, column_major=False):
+    """-> uint8 [n,T,OH,OW] (or [n,T,OW,OH] column-major, the scan order of COCO RLE)."""
     _chk(masks, sel_q)
     Q, T, h, w = masks.shape
     n = sel_q.numel()
-    out = torch.empty((n, T, OH, OW), dtype=torch.uint8, device=masks.device)
-    _lib.call("ovis_final_masks_u8", masks, sel_q, out, n, Q, T, h, w, Hp, Wp, H, W, OH, OW, _lib.stream_ptr())
+    out = torch.empty((n, T, OW, OH) if column_major else (n, T, OH, OW), dtype=torch.uint8, device=masks.device)
+    _lib.call("ovis_final_masks_u8", masks, sel_q, out, n, Q, T, h, w, Hp, Wp, H, W, OH, OW, int(column_major), _lib.stream_ptr())
     return out
+
+
+def rle_encode(masks_cm, cap=None):
+    """masks_cm uint8 [n, len] (each mask flattened column-major) -> (counts int32 [n, cap], n_runs int32 [n]) on the device:
+    uncompressed COCO RLE counts (see include/openvis_hip.h)."""
+    _chk(masks_cm)
+    n, length = masks_cm.shape
+    cap = int(cap or length + 1)
+    counts = torch.empty((n, cap), dtype=torch.int32, device=masks_cm.device)
+    n_runs = torch.empty((n,), dtype=torch.int32, device=masks_cm.device)
+    _lib.call("ovis_rle_encode_u8", masks_cm, n, _ll(length), counts, n_runs, cap, _lib.stream_ptr())
+    return counts, n_runs
 
 
 # ---- Swin backbone data movement (csrc/swin_ops.hip) -----------------------------------------------------------------
