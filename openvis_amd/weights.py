@@ -207,6 +207,25 @@ def clip_text_spec(prefix="clip_adapter.clip_model.", width=512, layers=12, embe
     return s
 
 
+def spec_for_cfg(cfg):
+    """Weight spec of the architecture a config names (meta-architecture, backbone, CLIP tower, queries)."""
+    clip = _CLIP_ARCH[cfg.MODEL.CLIP_ADAPTER.CLIP_MODEL_NAME]
+    q = cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES
+    if cfg.MODEL.BACKBONE.NAME == "D2SwinTransformer":
+        sw = cfg.MODEL.SWIN
+        bb = dict(embed_dim=sw.EMBED_DIM, depths=tuple(sw.DEPTHS), num_heads=tuple(sw.NUM_HEADS), window=sw.WINDOW_SIZE)
+    else:
+        bb = "r50"
+    arch = cfg.MODEL.META_ARCHITECTURE
+    if arch in ("OpenVIS", "OpenVISOnline"):
+        return openvis_spec(bb, clip, q)
+    if arch in ("SAN", "SANOnline"):
+        return san_spec(bb, clip, q)
+    if arch == "BriVIS":
+        return brivis_spec(bb, clip, q)
+    raise KeyError(f"no weight spec for META_ARCHITECTURE {arch}")
+
+
 def random_init(spec, seed=42):
     """Seeded random weights with sane scales (fan-in scaled matrices, unit norms, small biases)."""
     g = torch.Generator().manual_seed(int(seed))
