@@ -25,10 +25,25 @@ def batch_video_match_via_embeds(pred_embeds):
 class MinVIS(VideoMaskFormer):
     def __init__(self, *, window_inference=False, window_size=10, **kwargs):
         super().__init__(**kwargs)
-        if window_inference:
-            raise NotImplementedError("window inference (minvis.py:340-362) is a later §8(f) row; 288 GB HBM keeps "
-                                      "whole clips resident")
         self.window_inference, self.window_size = window_inference, window_size
+
+    # time dimension of every per-frame output tensor (others, e.g. text features, are window independent)
+    _TIME_DIM = {"pred_masks": 2, "pred_embeds": 1, "pred_logits": 1, "class_attn_biases": 1, "attn_feats": 0, "mask_feats": 0,
+                 "clip_tokens": 0, "images": 0}
+
+    def run_window_inference(self, fn, T):
+        """minvis.py:340-362: run the per-frame part `fn(begin, end) -> dict` on windows of WINDOW_SIZE frames and
+        concatenate the per-frame outputs along time.  Every tensor up to the tracker is per-frame, so the result equals
+        the un-windowed one; the windows only bound the activation memory of long videos (the reference additionally parks
+        the masks on the CPU, minvis.py:358 -- with 288 GB of HBM they stay on the device)."""
+        if not self.window_inference or T <= self.window_size:
+            return fn(0, T)
+        parts = [fn(b, min(b + self.window_size, T)) for b in range(0, T, self.window_size)]
+        out = dict(parts[0])
+        for k, d in self._TIME_DIM.items():
+            if k in out and torch.is_tensor(out[k]):
+                out[k] = torch.cat([p[k] for p in parts], dim=d)
+        return out
 
     @classmethod
     def from_config(cls, cfg):

@@ -81,16 +81,19 @@ class OpenVISOnline(OpenVIS):
     """openvis/openvis.py:150-281: per-frame decoder + MinVIS tracker, then the same masked-crop CLIP classification.
     (The reference chunks CLIP crops by 10 frames instead of 5 only to bound memory, openvis.py:247.)"""
 
-    def __init__(self, **kwargs):
+    def __init__(self, *, window=(False, 10), **kwargs):
         super().__init__(**kwargs)
         from .modeling.minvis import MinVIS
         self._post = MinVIS.post_processing
+        self._windowed = MinVIS.run_window_inference
+        self._TIME_DIM = MinVIS._TIME_DIM
+        self.window_inference, self.window_size = window
 
     @classmethod
     def from_config(cls, cfg):
-        if cfg.MODEL.MASK_FORMER.TEST.WINDOW_INFERENCE:
-            raise NotImplementedError("window inference is a later §8(f) row")
-        return OpenVIS.from_config(cfg)
+        args = OpenVIS.from_config(cfg)
+        args["window"] = (cfg.MODEL.MASK_FORMER.TEST.WINDOW_INFERENCE, cfg.MODEL.MASK_FORMER.TEST.WINDOW_SIZE)
+        return args
 
     def forward(self, batched_inputs, stages=None):
         dataset_name = batched_inputs[0]["dataset_name"]
@@ -98,8 +101,14 @@ class OpenVISOnline(OpenVIS):
         self.sem_seg_head.num_classes = len(class_names)
         frames = self._frames_to_device(batched_inputs)
         images, image_size, padded = self.preprocess(frames)
-        features = self.backbone(images)
-        outputs = self._post(self, self.sem_seg_head(features))            # tracker re-ordering (minvis.py:320-338)
+        features = None
+
+        def per_window(b0, b1):                                            # openvis.py:283-305 (run_window_inference)
+            nonlocal features
+            features = self.backbone(images[b0:b1])
+            return self.sem_seg_head(features)
+
+        outputs = self._post(self, self._windowed(self, per_window, images.shape[0]))   # tracker (minvis.py:320-338)
         masks_lowres = outputs["pred_masks"][0]
         probs, row_ids, extras = self.open_vocabulary_inference(outputs["pred_logits"][0], masks_lowres, frames,
                                                                 class_names, padded)

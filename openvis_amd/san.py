@@ -99,16 +99,26 @@ class SANOnline(MinVIS):
         return [c.strip() for c in MetadataCatalog.get(dataset_name).thing_classes]
 
     def image_outputs(self, frames, class_names):
-        """frames uint8 [T,3,H,W] -> per-frame head outputs incl. pred_logits [1,T,Q,K+1] (san.py:211-231)."""
-        images, image_size, padded = self.preprocess(frames)
-        mg_feats, clip_tokens = self.clip_adapter.front_encode_image(frames, padded)          # san.py:221
+        """frames uint8 [T,3,H,W] -> per-frame head outputs incl. pred_logits [1,T,Q,K+1] (san.py:211-231); long videos
+        go through windows of MODEL.MASK_FORMER.TEST.WINDOW_SIZE frames (san.py:285-307)."""
+        T, _, H, W = frames.shape
+        d = self.size_divisibility
+        padded = ((H + d - 1) // d * d, (W + d - 1) // d * d) if d > 1 else (H, W)
         text_feats = self.clip_adapter.encode_text(class_names)                               # san.py:222
-        features = self.backbone(images)
-        outputs = self.sem_seg_head(features, extra_feats=mg_feats)
-        clip_feats = self.clip_adapter.post_encode_image(clip_tokens, outputs["class_attn_biases"][0])   # san.py:230
-        outputs["pred_logits"] = self.clip_adapter.cal_sim_logits(text_feats, clip_feats).unsqueeze(0)   # [1,T,Q,K+1]
-        outputs["clip_tokens"], outputs["text_feats"] = clip_tokens, text_feats
-        return outputs, images, image_size, padded
+
+        def per_window(b0, b1):
+            fr = frames[b0:b1]
+            images, _, _ = self.preprocess(fr)
+            mg_feats, clip_tokens = self.clip_adapter.front_encode_image(fr, padded)          # san.py:221
+            outputs = self.sem_seg_head(self.backbone(images), extra_feats=mg_feats)
+            clip_feats = self.clip_adapter.post_encode_image(clip_tokens, outputs["class_attn_biases"][0])   # san.py:230
+            outputs["pred_logits"] = self.clip_adapter.cal_sim_logits(text_feats, clip_feats).unsqueeze(0)   # [1,t,Q,K+1]
+            outputs["clip_tokens"], outputs["images"] = clip_tokens, images
+            return outputs
+
+        outputs = self.run_window_inference(per_window, T)
+        outputs["text_feats"] = text_feats
+        return outputs, outputs.pop("images"), (H, W), padded
 
     def classify(self, pred_logits):
         """mean over frames, softmax, drop the background column (san.py:257,264-265) -> probs [Q,K]."""

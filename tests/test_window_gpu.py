@@ -1,0 +1,56 @@
+"""GPU: window inference (minvis.py:340-362 / san.py:285-307 / openvis.py:283-305) of the online models equals the
+un-windowed run: per-frame stages are independent, windows only bound activation memory."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("arch,decoder", [("OpenVISOnline", "FrameMultiScaleMaskedTransformerDecoder"),
+                                          ("SANOnline", "SideAdapterFrameMultiScaleMaskedTransformerDecoder"),
+                                          ("BriVIS", "SideAdapterFrameMultiScaleMaskedTransformerDecoder")])
+def test_window_inference_equals_full_clip(arch, decoder):
+    import bench
+    from openvis_amd import config, weights
+    from openvis_amd.catalog import MetadataCatalog
+    from openvis_amd.modeling.clip_adapter.adapter import ClipAdapter
+    from openvis_amd.modeling.clip_adapter.side_adapter import SideAdapter
+    from tests.test_openvis_gpu import CLIP_ARCH, K, _frames
+    from tests.test_san_gpu import SAN_E2E_ARCH
+
+    names = [f"class_{i}" for i in range(K)]
+    MetadataCatalog.get("synthetic_val").set(thing_classes=names)
+    frames = torch.cat([_frames(s) for s in (0, 1, 2)])[:5]                 # 5 frames, windows of 2 -> 2 + 2 + 1
+    outs, stages = [], []
+    for window in (False, True):
+        cfg = config.get_cfg()
+        cfg.MODEL.META_ARCHITECTURE = arch
+        cfg.MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME = decoder
+        cfg.MODEL.MASK_FORMER.TEST.WINDOW_INFERENCE = window
+        cfg.MODEL.MASK_FORMER.TEST.WINDOW_SIZE = 2
+        cfg.MODEL.CLIP_ADAPTER.CLIP_NUM_HEADS = 4
+        cfg.MODEL.PRECISION = "fp32"
+        model = config.build_model(cfg)
+        if arch == "OpenVISOnline":
+            sd = weights.random_init(weights.openvis_spec("r50", CLIP_ARCH, 100), seed=9)
+            model.clip_adapter = ClipAdapter("tiny", arch=CLIP_ARCH, precision="fp32")
+            dim = CLIP_ARCH["embed_dim"]
+        else:
+            sd = weights.random_init(weights.brivis_spec("r50", SAN_E2E_ARCH, 100), seed=9)
+            model.clip_adapter = SideAdapter("tiny", broken_idx=3, merge_ids=[1, 2, 3], num_queries=100, arch=SAN_E2E_ARCH, precision="fp32")
+            dim = SAN_E2E_ARCH["embed_dim"]
+        model.load_state_dict(sd)
+        model.clip_adapter.set_text_features(names, bench.synth_text(K, dim))
+        st = {}
+        outs.append(model([{"image": [f for f in frames], "dataset_name": "synthetic_val"}], stages=st))
+        stages.append(st)
+    a, b = stages
+    assert torch.equal(a["indices"].cpu(), b["indices"].cpu())
+    pm_a, pm_b = a["pred_masks"].cpu(), b["pred_masks"].cpu()
+    assert pm_a.shape == pm_b.shape and (pm_a - pm_b).abs().max().item() < 1e-3
+    assert ((pm_a > 0) == (pm_b > 0)).float().mean().item() > 0.9999
+    assert (a["probs"].cpu() - b["probs"].cpu()).abs().max().item() < 1e-4
+    assert outs[0]["pred_labels"] == outs[1]["pred_labels"]
+    for m0, m1 in zip(outs[0]["pred_masks"], outs[1]["pred_masks"]):
+        assert (m0 != m1).float().mean().item() < 1e-4
