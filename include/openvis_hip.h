@@ -274,6 +274,15 @@ int ovis_mean_dim0_f32(const float* x, float* y, int n, long long len, ovis_stre
  *   n_runs[i] > cap means the buffer was too small for mask i (its first cap-1 counts are valid). */
 int ovis_rle_encode_u8(const uint8_t* masks, int n_masks, long long len, int* counts, int* n_runs, int cap, ovis_stream_t stream);
 
+/* Test-time input resize (augmentation.py:368-373 -> detectron2 ResizeShortestEdge -> PIL Image.resize(BILINEAR)),
+ * bit-exact with Pillow's 22-bit fixed-point separable resampling.  src u8 [H,W,3] (decoded frame, device), tmp u8
+ * [H,OW,3] scratch, dst u8 [3,OH,OW] (planar, what ovis_preprocess_u8_nhwc4 reads).  {x,y}bounds int32 [out,2] =
+ * (first input index, tap count), {x,y}k int32 [out,ksize] fixed-point coefficients (openvis_amd/data.py builds them
+ * as Pillow's precompute_coeffs + normalize_coeffs_8bpc). */
+int ovis_pil_resize_u8_hwc_to_chw(const uint8_t* src, int H, int W, uint8_t* tmp, uint8_t* dst, int OH, int OW,
+                                  const int* xbounds, const int* xk, int xksize, const int* ybounds, const int* yk, int yksize,
+                                  ovis_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

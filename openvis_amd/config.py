@@ -96,7 +96,7 @@ def get_cfg():
                              # reference's GPU CLIP, or "fp32")
                              "PRECISION": "fp16"},
         },
-        "INPUT": {"SAMPLING_FRAME_NUM": 2, "MIN_SIZE_TEST": 360, "FORMAT": "RGB"},
+        "INPUT": {"SAMPLING_FRAME_NUM": 2, "MIN_SIZE_TEST": 360, "MAX_SIZE_TEST": 1333, "FORMAT": "RGB"},
         "DATASETS": {"TEST": ["burst_val"]},
         "SEED": 42,
     })

@@ -30,3 +30,22 @@ def test_train_net_eval_only_writes_ytvis_results(tmp_path):
 def test_train_net_refuses_training():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train_net.py"), "--synthetic", "1"], capture_output=True, text=True)
     assert r.returncode != 0 and "eval-only" in (r.stderr + r.stdout)
+
+
+def test_train_net_on_a_directory_of_frames(tmp_path):
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    for v in ("vid_a", "vid_b"):
+        os.makedirs(tmp_path / "videos" / v)
+        for t in range(2):
+            Image.fromarray(rng.integers(0, 256, (200, 300, 3), dtype=np.uint8)).save(tmp_path / "videos" / v / f"{t:05d}.png")
+    (tmp_path / "classes.txt").write_text("cat\ndog\nzebra\n")
+    out = tmp_path / "res.json"
+    cmd = [sys.executable, os.path.join(ROOT, "train_net.py"), "--eval-only", "--input", str(tmp_path / "videos"), "--classes",
+           str(tmp_path / "classes.txt"), "--output", str(out), "INPUT.MIN_SIZE_TEST", "120"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.load(open(out))
+    assert {x["video_id"] for x in res} == {"vid_a", "vid_b"} and all(1 <= x["category_id"] <= 3 for x in res)
+    assert res[0]["segmentations"][0]["size"] == [200, 300]               # masks are returned at the original frame size

@@ -6,8 +6,8 @@ KEY VALUE opts) for the MI355X-native hot path.
         --num-gpus 8 --input /data/videos --classes classes.txt --output results.json MODEL.WEIGHTS model_final.pth
 
 Only what surrounds `model.forward` at eval time lives here (datasets, mappers and evaluators are out of
-scope): videos are directories of frame images under --input (or --synthetic N clips), frames are resized like the
-test-time mapper (shortest edge = INPUT.MIN_SIZE_TEST), videos are sharded over the ranks in the InferenceSampler layout
+scope): videos are directories of frame images under --input (or --synthetic N clips), frames are resized on the GPU exactly like
+the test-time mapper (shortest edge = INPUT.MIN_SIZE_TEST, PIL bilinear), videos are sharded over the ranks in the InferenceSampler layout
 (data/build.py:238-247), results are gathered on rank 0 and written as the YTVIS result list the reference's evaluator
 dumps (ytvis_eval.py:258-301) with GPU-encoded COCO RLE segmentations.  Training is not part of this tier."""
 import argparse
@@ -22,18 +22,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def load_video_dir(path, min_size):
+def load_video_dir(path, min_size, max_size, device):
+    """decode on the host (PIL), ResizeShortestEdge + BILINEAR on the GPU, bit-exact with the reference's mapper
+    (ytvis_dataset_mapper.py:298-313 -> openvis_amd/data.py)."""
     from PIL import Image
+    from openvis_amd import data
     names = sorted(n for n in os.listdir(path) if n.lower().endswith((".jpg", ".jpeg", ".png")))
-    frames = []
-    for n in names:
-        im = Image.open(os.path.join(path, n)).convert("RGB")
-        w, h = im.size
-        if min_size > 0:
-            s = min_size / min(h, w)                      # ResizeShortestEdge (ytvis_dataset_mapper.py:298-313)
-            im = im.resize((int(w * s + 0.5), int(h * s + 0.5)), Image.BILINEAR)
-        frames.append(torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1).contiguous())
-    return frames, (h, w)
+    decoded = [np.asarray(Image.open(os.path.join(path, n)).convert("RGB")) for n in names]
+    return data.load_and_resize(decoded, min_size, max_size, device)
 
 
 def worker(rank, world, args):
@@ -85,7 +81,7 @@ def worker(rank, world, args):
             frames = [f for f in bench.synth_frames(args.frames, 360, 640, 1000 + vi, "cpu")]
             hw = (360, 640)
         else:
-            frames, hw = load_video_dir(path, cfg.INPUT.MIN_SIZE_TEST)
+            frames, hw = load_video_dir(path, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.get("MAX_SIZE_TEST", 1333), model.device)
         out = model([{"image": frames, "dataset_name": dataset, "height": hw[0], "width": hw[1], "video_id": vid, "length": len(frames)}])
         for s, l, segs in zip(out["pred_scores"], out["pred_labels"], out.get("pred_masks_rle", [])):
             results.append({"video_id": vid, "score": s, "category_id": l + 1, "segmentations": segs})   # ytvis_eval.py:296
