@@ -324,12 +324,16 @@ clip_crop_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ m
 // small rectangle of the frame; it is staged ONCE in LDS as (packed RGB bytes, soft-mask value = sigmoid of the x4
 // up-sampled logit), so every up-sampled logit / sigmoid is evaluated once per source pixel instead of once per tap
 // (~3x fewer) and the 4 x grid^2 taps of a bin become LDS reads.  Arithmetic per bin is the same as clip_crop_kernel.
+constexpr int CROP_GMAX = 8;       // samples per bin and axis the tiled kernel supports (roi side <= 8 x resolution)
+struct AxisTap { short fl, fh, ml, mh; float fw, mw; short f_ok, m_ok; };
+
 template <int TY, int TX>
 __global__ void __launch_bounds__(TY * TX)
 clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ masks, const int* __restrict__ crops,
                        void* __restrict__ Av, int out_f16, int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp,
                        int R, int ps, long long lda, int PRmax, int PWmax, float m0, float m1, float m2, float s0, float s1, float s2) {
   extern __shared__ uint2 patch[];                      // [PR][PW]: .x = r | g<<8 | b<<16, .y = bits of the soft mask
+  __shared__ AxisTap xtab[TX * CROP_GMAX], ytab[TY * CROP_GMAX];
   const int tiles_x = R / TX, tiles_y = R / TY;
   const int tid = threadIdx.x;
   const int tx_i = blockIdx.x % tiles_x, ty_i = (blockIdx.x / tiles_x) % tiles_y;
@@ -359,51 +363,111 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
   const int yhi = min((int)floorf(fmaxf(y_last, 0.f)) + 1, Hp - 1);
   const int xhi = min((int)floorf(fmaxf(x_last, 0.f)) + 1, Wp - 1);
   const int PR = min(max(yhi - ylo + 1, 1), PRmax), PW = min(max(xhi - xlo + 1, 1), PWmax);
+  // odd row stride (in 8-byte elements): the 4 bin rows a wavefront covers read 4 different patch rows at similar
+  // columns; with an even stride those rows alias to the same LDS banks (4-way conflicts on every tap read)
+  const int PWs = PW | 1;
 
-  for (int idx = tid; idx < PR * PW; idx += TY * TX) {
-    const int r = idx / PW, c = idx - r * PW;
-    const int y = ylo + r, x = xlo + c;
-    const float soft = fast_sigmoid(bilerp(mp, w, make_tap(y, usy, h), make_tap(x, usx, w)));
-    unsigned rgb = 0u;
-    if (y < H && x < W) {
-      const long long o = (long long)y * W + x;
-      rgb = (unsigned)fp[o] | ((unsigned)fp[plane + o] << 8) | ((unsigned)fp[2 * plane + o] << 16);
+  // staging: wavefront -> patch rows, lane -> patch columns (no integer division; the column taps of a lane are hoisted
+  // out of the row loop, the row taps are wavefront-uniform)
+  {
+    constexpr int NW = TY * TX / 64;
+    const int lane = tid & 63, wv = tid >> 6;
+    Tap txs[2];
+    bool cin[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int c = lane + 64 * m;
+      txs[m] = make_tap(min(xlo + c, Wp - 1), usx, w);
+      cin[m] = c < PW;
     }
-    patch[idx] = make_uint2(rgb, __float_as_uint(soft));
+    // software pipeline: the 14 gathers of the next row are in flight while the current row is blended and stored
+    struct RowLoads { float a[2], b[2], c[2], d[2]; unsigned r[2], g[2], bl[2]; Tap ty; };
+    auto issue = [&](int r, RowLoads& L) {
+      const int y = min(ylo + r, Hp - 1);
+      L.ty = make_tap(y, usy, h);
+      const float* r0 = mp + (long long)L.ty.i0 * w;
+      const float* r1 = mp + (long long)L.ty.i1 * w;
+      const bool yin = y < H;
+      const uint8_t* frow = fp + (long long)(yin ? y : 0) * W;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        L.a[m] = r0[txs[m].i0]; L.b[m] = r0[txs[m].i1]; L.c[m] = r1[txs[m].i0]; L.d[m] = r1[txs[m].i1];
+        const int x = xlo + lane + 64 * m;
+        const bool in = yin && x < W;
+        const int xc = in ? x : 0;
+        const unsigned v0 = frow[xc], v1 = frow[plane + xc], v2 = frow[2 * plane + xc];
+        L.r[m] = in ? v0 : 0u; L.g[m] = in ? v1 : 0u; L.bl[m] = in ? v2 : 0u;
+      }
+    };
+    RowLoads cur, nxt;
+    if (wv < PR) issue(wv, cur);
+    for (int r = wv; r < PR; r += NW) {
+      if (r + NW < PR) issue(r + NW, nxt);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if (cin[m]) {
+          const float u = cur.ty.l0 * (txs[m].l0 * cur.a[m] + txs[m].l1 * cur.b[m]) +
+                          cur.ty.l1 * (txs[m].l0 * cur.c[m] + txs[m].l1 * cur.d[m]);                      // == bilerp()
+          patch[r * PWs + lane + 64 * m] = make_uint2(cur.r[m] | (cur.g[m] << 8) | (cur.bl[m] << 16), __float_as_uint(fast_sigmoid(u)));
+        }
+      }
+      cur = nxt;
+    }
+  }
+  __syncthreads();
+
+  // per-axis sample tables of the tile: everything that depends on (bin, sample) along ONE axis is computed once and
+  // shared by the 16 bins of the other axis (lo/hi taps relative to the patch origin, lerp weight, validity)
+  for (int en = tid; en < TX * CROP_GMAX; en += TY * TX) {
+    const int ix = en % CROP_GMAX, lx_ = en / CROP_GMAX;
+    AxisTap e;
+    e.f_ok = e.m_ok = 0; e.fl = e.fh = e.ml = e.mh = 0; e.fw = e.mw = 0.f;
+    if (ix < grid) {
+      const float xx = bx0 + (float)(tx_i * TX + lx_) * bin + ((float)ix + .5f) * step;
+      float x = xx; int lo, hi;
+      if (ra_prep(x, W, lo, hi)) { e.f_ok = 1; e.fl = (short)(lo - xlo); e.fh = (short)(hi - xlo); e.fw = x - (float)lo; }
+      x = xx;
+      if (ra_prep(x, Wp, lo, hi)) { e.m_ok = 1; e.ml = (short)(lo - xlo); e.mh = (short)(hi - xlo); e.mw = x - (float)lo; }
+    }
+    xtab[en] = e;
+  }
+  for (int en = tid; en < TY * CROP_GMAX; en += TY * TX) {
+    const int iy = en % CROP_GMAX, ly_ = en / CROP_GMAX;
+    AxisTap e;
+    e.f_ok = e.m_ok = 0; e.fl = e.fh = e.ml = e.mh = 0; e.fw = e.mw = 0.f;
+    if (iy < grid) {
+      const float yy = by0 + (float)(ty_i * TY + ly_) * bin + ((float)iy + .5f) * step;
+      float y = yy; int lo, hi;
+      if (ra_prep(y, H, lo, hi)) { e.f_ok = 1; e.fl = (short)((lo - ylo) * PWs); e.fh = (short)((hi - ylo) * PWs); e.fw = y - (float)lo; }
+      y = yy;
+      if (ra_prep(y, Hp, lo, hi)) { e.m_ok = 1; e.ml = (short)((lo - ylo) * PWs); e.mh = (short)((hi - ylo) * PWs); e.mw = y - (float)lo; }
+    }
+    ytab[en] = e;
   }
   __syncthreads();
 
   float f0 = 0.f, f1 = 0.f, f2 = 0.f, mk = 0.f;
+  const AxisTap* xt = xtab + (tid % TX) * CROP_GMAX;
+  const AxisTap* yt = ytab + (tid / TX) * CROP_GMAX;
   for (int iy = 0; iy < grid; ++iy) {
-    const float yy = by0 + (float)py * bin + ((float)iy + .5f) * step;
-    float yf = yy; int fyl, fyh;
-    const bool fy_ok = ra_prep(yf, H, fyl, fyh);
-    const float fly = yf - (float)fyl, fhy = 1.f - fly;
-    float ym = yy; int myl, myh;
-    const bool my_ok = ra_prep(ym, Hp, myl, myh);
-    const float mly = ym - (float)myl, mhy = 1.f - mly;
-    const uint2* fr0 = patch + (fyl - ylo) * PW - xlo; const uint2* fr1 = patch + (fyh - ylo) * PW - xlo;
-    const uint2* mr0 = patch + (myl - ylo) * PW - xlo; const uint2* mr1 = patch + (myh - ylo) * PW - xlo;
+    const AxisTap ey = yt[iy];
+    const float fly = ey.fw, fhy = 1.f - fly, mly = ey.mw, mhy = 1.f - mly;
+    const uint2* fr0 = patch + ey.fl; const uint2* fr1 = patch + ey.fh;
+    const uint2* mr0 = patch + ey.ml; const uint2* mr1 = patch + ey.mh;
     for (int ix = 0; ix < grid; ++ix) {
-      const float xx = bx0 + (float)px * bin + ((float)ix + .5f) * step;
-      {
-        float x = xx; int xl, xh;
-        if (fy_ok && ra_prep(x, W, xl, xh)) {
-          const float lx = x - (float)xl, hx = 1.f - lx;
-          const float w1 = fhy * hx, w2 = fhy * lx, w3 = fly * hx, w4 = fly * lx;
-          const unsigned a = fr0[xl].x, b = fr0[xh].x, c = fr1[xl].x, d = fr1[xh].x;
-          f0 += w1 * (float)(a & 255u) + w2 * (float)(b & 255u) + w3 * (float)(c & 255u) + w4 * (float)(d & 255u);
-          f1 += w1 * (float)((a >> 8) & 255u) + w2 * (float)((b >> 8) & 255u) + w3 * (float)((c >> 8) & 255u) + w4 * (float)((d >> 8) & 255u);
-          f2 += w1 * (float)(a >> 16) + w2 * (float)(b >> 16) + w3 * (float)(c >> 16) + w4 * (float)(d >> 16);
-        }
+      const AxisTap ex = xt[ix];
+      if (ey.f_ok && ex.f_ok) {
+        const float lx = ex.fw, hx = 1.f - lx;
+        const float w1 = fhy * hx, w2 = fhy * lx, w3 = fly * hx, w4 = fly * lx;
+        const unsigned a = fr0[ex.fl].x, b = fr0[ex.fh].x, c = fr1[ex.fl].x, d = fr1[ex.fh].x;
+        f0 += w1 * (float)(a & 255u) + w2 * (float)(b & 255u) + w3 * (float)(c & 255u) + w4 * (float)(d & 255u);
+        f1 += w1 * (float)((a >> 8) & 255u) + w2 * (float)((b >> 8) & 255u) + w3 * (float)((c >> 8) & 255u) + w4 * (float)((d >> 8) & 255u);
+        f2 += w1 * (float)(a >> 16) + w2 * (float)(b >> 16) + w3 * (float)(c >> 16) + w4 * (float)(d >> 16);
       }
-      {
-        float x = xx; int xl, xh;
-        if (my_ok && ra_prep(x, Wp, xl, xh)) {
-          const float lx = x - (float)xl, hx = 1.f - lx;
-          mk += (mhy * hx) * __uint_as_float(mr0[xl].y) + (mhy * lx) * __uint_as_float(mr0[xh].y) +
-                (mly * hx) * __uint_as_float(mr1[xl].y) + (mly * lx) * __uint_as_float(mr1[xh].y);
-        }
+      if (ey.m_ok && ex.m_ok) {
+        const float lx = ex.mw, hx = 1.f - lx;
+        mk += (mhy * hx) * __uint_as_float(mr0[ex.ml].y) + (mhy * lx) * __uint_as_float(mr0[ex.mh].y) +
+              (mly * hx) * __uint_as_float(mr1[ex.ml].y) + (mly * lx) * __uint_as_float(mr1[ex.mh].y);
       }
     }
   }
@@ -660,7 +724,8 @@ extern "C" int ovis_clip_crop_patches(const uint8_t* frames, const float* masks,
   const float bin_max = (float)(Hp > Wp ? Hp : Wp) / (float)resolution;
   auto args = [&](int ty) { return (int)ceilf((float)ty * bin_max) + 4; };
   const int p16 = args(16), p8 = args(8);
-  if (resolution % 16 == 0 && (size_t)p16 * p16 * 8 <= 76 * 1024) {
+  const bool grid_ok = bin_max <= (float)CROP_GMAX;
+  if (grid_ok && resolution % 16 == 0 && (size_t)p16 * (p16 + 1) * 8 <= 76 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
       OVIS_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&clip_crop_tiled_kernel<16, 16>),
@@ -669,11 +734,11 @@ extern "C" int ovis_clip_crop_patches(const uint8_t* frames, const float* masks,
       attr_set = true;
     }
     hipLaunchKernelGGL((clip_crop_tiled_kernel<16, 16>), dim3((unsigned)((long long)M * (resolution / 16) * (resolution / 16))), dim3(256),
-                       (size_t)p16 * p16 * 8, (hipStream_t)stream, frames, masks, crops, A, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
+                       (size_t)p16 * (p16 + 1) * 8, (hipStream_t)stream, frames, masks, crops, A, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
                        resolution, patch, lda, p16, p16, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
-  } else if (resolution % 8 == 0 && (size_t)p8 * p8 * 8 <= 64 * 1024) {
+  } else if (grid_ok && resolution % 8 == 0 && (size_t)p8 * (p8 + 1) * 8 <= 64 * 1024) {
     hipLaunchKernelGGL((clip_crop_tiled_kernel<8, 8>), dim3((unsigned)((long long)M * (resolution / 8) * (resolution / 8))), dim3(64),
-                       (size_t)p8 * p8 * 8, (hipStream_t)stream, frames, masks, crops, A, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
+                       (size_t)p8 * (p8 + 1) * 8, (hipStream_t)stream, frames, masks, crops, A, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
                        resolution, patch, lda, p8, p8, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
   } else {
     const long long total = (long long)M * resolution * resolution;
