@@ -27,6 +27,47 @@ template <bool OUT_F16>
 __device__ __forceinline__ void epilogue_tile(const f32x16_t& acc, long long m, bool m_ok, int n_tile0, int h, int N,
                                               void* __restrict__ C, long long ldc, const float* __restrict__ bias,
                                               const float* __restrict__ R, long long ldr, int act, bool vec_ok) {
+  if constexpr (OUT_F16) {
+    // fp16 fast path (no residual, whole 32-column tile inside N, 16-byte aligned rows): the two lanes that share an
+    // output row (h = 0 / 1) each hold 4 of the 8 columns of a group; v_permlane32_swap exchanges the halves of two
+    // groups so that a lane owns 8 consecutive columns and the tile goes out as 16-byte stores (half as many as below)
+    if (vec_ok && !R && n_tile0 + 31 < N && (ldc & 7) == 0) {
+      unsigned pk[4][2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        if (bias) {
+          const float4 b = *reinterpret_cast<const float4*>(bias + n_tile0 + 8 * g + 4 * h);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (act == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+        } else if (act == 3) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        f16x4_t o;
+        o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+        const uint2 u = __builtin_bit_cast(uint2, o);
+        pk[g][0] = u.x; pk[g][1] = u.y;
+      }
+#pragma unroll
+      for (int gp = 0; gp < 4; gp += 2) {
+        // A' = {h=0: A (group gp, cols 0-3), h=1: B from h=0 (group gp+1, cols 0-3)}; B' = {h=0: A from h=1 (gp, cols 4-7), h=1: B}
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[gp][0], pk[gp + 1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[gp][1], pk[gp + 1][1], false, false);
+        if (m_ok) {
+          const int n = n_tile0 + 8 * (gp + h);
+          *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(C) + m * ldc + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int n = n_tile0 + 8 * g + 4 * h;
