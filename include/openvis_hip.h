@@ -173,6 +173,14 @@ int ovis_attention_f16(const void* q, long long q_bs, int q_ld, const void* k, l
 int ovis_msda_encoder_fused_f32(const float* value, const float* offs_attn, int ld_oa, const int64_t* spatial_shapes,
                                 const int64_t* level_start_index, float* out, int batch, int spatial_size,
                                 int num_heads, int channels, int num_levels, int num_point, ovis_stream_t stream);
+/* Same operation with the level shapes also given on the host (shapes_host int32 [3,2] = (H_l, W_l), coarse to fine): the
+ * queries of the finest level run as 8x8 query tiles per head whose +/- `radius` pixel value windows are staged in LDS
+ * (coalesced 128-byte row reads; taps beyond the radius fall back to a global load, so results are identical for any
+ * offsets); the queries of the two coarser levels use the direct-gather kernel.  head_dim (channels) must be 32. */
+int ovis_msda_encoder_fused_tiled_f32(const float* value, const float* offs_attn, int ld_oa, const int64_t* spatial_shapes,
+                                      const int64_t* level_start_index, const int* shapes_host, float* out, int batch,
+                                      int spatial_size, int num_heads, int channels, int num_levels, int num_point, int radius,
+                                      ovis_stream_t stream);
 /* mask[q,k] = sigmoid(logits[q,k]) < 0.5 ; row_open[q] = #unblocked (video decoder:465-469, 419). */
 int ovis_attn_mask_from_logits(const float* logits, long long ld, uint8_t* mask, long long mask_ld, int* row_open,
                                int Q, int Nk, ovis_stream_t stream);

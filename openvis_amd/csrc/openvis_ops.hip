@@ -44,17 +44,19 @@ template <int L, int P>
 __global__ void __launch_bounds__(256)
 msda_encoder_fused_kernel(const float* __restrict__ value, const float* __restrict__ oa, int ld_oa,
                           const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
-                          float* __restrict__ out, long long n_items, int S, int M, int D) {
+                          float* __restrict__ out, long long n_items, int S, int M, int D, int s_begin, int s_cnt) {
   const unsigned blk = ovis::xcd_remap(blockIdx.x, gridDim.x);
   const long long item = (long long)blk * blockDim.x + threadIdx.x;
   if (item >= n_items) return;
   const int dv = D >> 2;
   const int cv = (int)(item % dv);
-  const long long sidx = item / dv;              // (b*S + s)*M + m
-  const int m = (int)(sidx % M);
-  const long long bs = sidx / M;                 // b*S + s
-  const int s = (int)(bs % S);
-  const long long b = bs / S;
+  const long long qm = item / dv;                // (b*s_cnt + s_local)*M + m : queries s_begin .. s_begin + s_cnt - 1
+  const int m = (int)(qm % M);
+  const long long bq = qm / M;
+  const int s = s_begin + (int)(bq % s_cnt);
+  const long long b = bq / s_cnt;
+  const long long bs = b * S + s;                // b*S + s
+  const long long sidx = bs * M + m;             // (b*S + s)*M + m
   const int qid_stride = M * D;
 
   int Hs[L], Ws[L], starts[L];
@@ -115,6 +117,116 @@ msda_encoder_fused_kernel(const float* __restrict__ value, const float* __restri
     }
   }
   *reinterpret_cast<float4*>(out + sidx * D + cv * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// -------------------------------------------------------------------------------------------------
+// LDS-staged variant for the queries of the FINEST level (76 % of the tokens at 720p).
+// One workgroup = one head x one tile of 8x8 neighbouring queries.  Neighbouring queries sample neighbouring pixels, so
+// for each of the 3 levels the value rows of the window  [tile's reference points -/+ R pixels]  of this head are copied
+// ONCE into LDS with coalesced 128-byte row reads (~1.3 KB per query-head instead of the 6 KB the direct gather pulls
+// through L2), and the 48 bilinear taps of a query are LDS reads.  A tap that falls outside its window (offset larger
+// than R pixels) is fetched from global memory, so the result is identical to msda_encoder_fused_kernel for any input.
+// Rows are padded to 144 bytes so that the 128-byte rows of different queries do not alias in the 64 LDS banks.
+// -------------------------------------------------------------------------------------------------
+struct MsdaWin { int H[3], W[3], start[3], wh[3], ww[3], base[3]; };   // window sizes / LDS float offsets per level
+constexpr int MSDA_TQ = 8;           // tile of MSDA_TQ x MSDA_TQ queries
+constexpr int MSDA_PX = 36;          // floats per staged pixel row (32 + 4 pad)
+
+template <int P>
+__global__ void __launch_bounds__(MSDA_TQ * MSDA_TQ * 8)
+msda_encoder_tiled_kernel(const float* __restrict__ value, const float* __restrict__ oa, int ld_oa, float* __restrict__ out,
+                          int S, int M, MsdaWin g, int R, int tiles_x) {
+  constexpr int L = 3, D = 32;
+  extern __shared__ float win[];
+  const int tid = threadIdx.x, cv = tid & 7, ql = tid >> 3;                    // 8 lanes x 4 channels per query
+  const int m = blockIdx.y;
+  const long long b = blockIdx.z;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int Hq = g.H[L - 1], Wq = g.W[L - 1];
+  const int qid_stride = M * D;
+  const float* vb = value + b * (long long)S * qid_stride + m * D + cv * 4;
+
+  // ---- stage the three windows: all loads of a level are issued before the first LDS store (the copy is latency
+  // bound: one workgroup per CU, every row is a separate 128-byte segment) -------------------------------
+  constexpr int MAXIT = 6;                               // ceil(window pixels / 64) per level (host checks)
+  int loy[L], lox[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    loy[l] = (int)floorf(((float)(ty * MSDA_TQ) + 0.5f) / (float)Hq * (float)g.H[l] - 0.5f) - R;
+    lox[l] = (int)floorf(((float)(tx * MSDA_TQ) + 0.5f) / (float)Wq * (float)g.W[l] - 0.5f) - R;
+    const int npx = g.wh[l] * g.ww[l];
+    float4 buf[MAXIT];
+    bool ok[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int p = ql + it * MSDA_TQ * MSDA_TQ;
+      const int wy = p / g.ww[l], wx = p - wy * g.ww[l];
+      const int y = loy[l] + wy, x = lox[l] + wx;
+      ok[it] = p < npx && y >= 0 && y < g.H[l] && x >= 0 && x < g.W[l];
+      const long long tok = ok[it] ? (long long)g.start[l] + (long long)y * g.W[l] + x : 0;
+      buf[it] = *reinterpret_cast<const float4*>(vb + tok * qid_stride);
+    }
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int p = ql + it * MSDA_TQ * MSDA_TQ;
+      if (ok[it]) *reinterpret_cast<float4*>(&win[g.base[l] + p * MSDA_PX + cv * 4]) = buf[it];
+    }
+  }
+  __syncthreads();
+
+  const int qy = ty * MSDA_TQ + ql / MSDA_TQ, qx = tx * MSDA_TQ + ql % MSDA_TQ;
+  if (qy >= Hq || qx >= Wq) return;
+  const int s = g.start[L - 1] + qy * Wq + qx;
+  const long long bs = b * S + s;
+  const float refx = ((float)qx + 0.5f) / (float)Wq, refy = ((float)qy + 0.5f) / (float)Hq;
+  const float* op = oa + bs * ld_oa + m * (L * P * 2);
+  const float* ap = oa + bs * ld_oa + M * L * P * 2 + m * (L * P);
+  float lg[L * P];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < L * P; ++i) { lg[i] = ap[i]; mx = fmaxf(mx, lg[i]); }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < L * P; ++i) { lg[i] = expf(lg[i] - mx); sum += lg[i]; }
+
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int H = g.H[l], W = g.W[l];
+    const float* vp = vb + (long long)g.start[l] * qid_stride;
+    const float* wl = win + g.base[l] + cv * 4;
+    const int wh = g.wh[l], ww = g.ww[l], oy = loy[l], ox = lox[l];
+    auto tap = [&](int y, int x) -> float4 {
+      const int wy = y - oy, wx = x - ox;
+      if ((unsigned)wy < (unsigned)wh && (unsigned)wx < (unsigned)ww)
+        return *reinterpret_cast<const float4*>(wl + (wy * ww + wx) * MSDA_PX);
+      return *reinterpret_cast<const float4*>(vp + ((long long)y * W + x) * qid_stride);      // outside the window
+    };
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float loc_w = refx + op[(l * P + p) * 2] / (float)W;
+      const float loc_h = refy + op[(l * P + p) * 2 + 1] / (float)H;
+      const float weight = lg[l * P + p] / sum;
+      const float h_im = loc_h * (float)H - 0.5f;
+      const float w_im = loc_w * (float)W - 0.5f;
+      if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
+        float4 v1 = make_float4(0, 0, 0, 0), v2 = v1, v3 = v1, v4 = v1;
+        if (h_low >= 0 && w_low >= 0) v1 = tap(h_low, w_low);
+        if (h_low >= 0 && w_high <= W - 1) v2 = tap(h_low, w_high);
+        if (h_high <= H - 1 && w_low >= 0) v3 = tap(h_high, w_low);
+        if (h_high <= H - 1 && w_high <= W - 1) v4 = tap(h_high, w_high);
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        acc[0] += (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) * weight;
+        acc[1] += (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) * weight;
+        acc[2] += (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) * weight;
+        acc[3] += (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w) * weight;
+      }
+    }
+  }
+  *reinterpret_cast<float4*>(out + (bs * M + m) * D + cv * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
 // =================================================================================================
@@ -677,8 +789,60 @@ extern "C" int ovis_msda_encoder_fused_f32(const float* value, const float* offs
   OVIS_REQUIRE(ld_oa >= num_heads * num_levels * num_point * 3, "msda_encoder_fused: ld_oa too small");
   const long long n_items = (long long)batch * spatial_size * num_heads * (channels / 4);
   hipLaunchKernelGGL((msda_encoder_fused_kernel<3, 4>), dim3(ovis::cdiv(n_items, 256)), dim3(256), 0, (hipStream_t)stream,
-                     value, offs_attn, ld_oa, spatial_shapes, level_start_index, out, n_items, spatial_size, num_heads, channels);
+                     value, offs_attn, ld_oa, spatial_shapes, level_start_index, out, n_items, spatial_size, num_heads, channels,
+                     0, spatial_size);
   return ovis::check_launch("msda_encoder_fused");
+}
+
+extern "C" int ovis_msda_encoder_fused_tiled_f32(const float* value, const float* offs_attn, int ld_oa,
+                                                 const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                                 const int* shapes_host, float* out, int batch, int spatial_size,
+                                                 int num_heads, int channels, int num_levels, int num_point, int radius,
+                                                 ovis_stream_t stream) {
+  OVIS_REQUIRE(value && offs_attn && spatial_shapes && level_start_index && shapes_host && out, "msda_encoder_fused_tiled: null pointer");
+  OVIS_REQUIRE(batch > 0 && spatial_size > 0 && num_levels == 3 && num_point == 4 && num_heads > 0 && channels == 32,
+               "msda_encoder_fused_tiled: built for L=3, P=4, head_dim (channels) 32");
+  OVIS_REQUIRE(ld_oa >= num_heads * num_levels * num_point * 3 && radius >= 0 && radius <= 8, "msda_encoder_fused_tiled: bad ld_oa / radius");
+  MsdaWin g;
+  int start = 0, fl = 0;
+  for (int l = 0; l < 3; ++l) {
+    g.H[l] = shapes_host[2 * l]; g.W[l] = shapes_host[2 * l + 1]; g.start[l] = start;
+    OVIS_REQUIRE(g.H[l] > 0 && g.W[l] > 0, "msda_encoder_fused_tiled: bad level shape");
+    start += g.H[l] * g.W[l];
+  }
+  OVIS_REQUIRE(start == spatial_size, "msda_encoder_fused_tiled: shapes do not add up to spatial_size");
+  OVIS_REQUIRE(g.H[2] >= g.H[1] && g.H[1] >= g.H[0] && g.W[2] >= g.W[1] && g.W[1] >= g.W[0],
+               "msda_encoder_fused_tiled: levels must be ordered coarse to fine");
+  for (int l = 0; l < 3; ++l) {       // window = span of the tile's reference points on level l + the radius + bilinear tap + margin
+    g.wh[l] = (int)ceilf((float)(MSDA_TQ - 1) * (float)g.H[l] / (float)g.H[2]) + 2 * radius + 3;
+    g.ww[l] = (int)ceilf((float)(MSDA_TQ - 1) * (float)g.W[l] / (float)g.W[2]) + 2 * radius + 3;
+    g.base[l] = fl;
+    fl += g.wh[l] * g.ww[l] * MSDA_PX;
+  }
+  const size_t shmem = (size_t)fl * sizeof(float);
+  OVIS_REQUIRE(g.wh[2] * g.ww[2] <= 6 * MSDA_TQ * MSDA_TQ, "msda_encoder_fused_tiled: window too large for the staging loop (radius %d)", radius);
+  OVIS_REQUIRE(shmem <= 150 * 1024, "msda_encoder_fused_tiled: windows do not fit in LDS (radius %d)", radius);
+  hipStream_t s = (hipStream_t)stream;
+  static size_t attr_bytes = 0;
+  if (shmem > attr_bytes) {
+    OVIS_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_encoder_tiled_kernel<4>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) == hipSuccess,
+                 "msda_encoder_fused_tiled: cannot raise the dynamic LDS limit");
+    attr_bytes = shmem;
+  }
+  const int tiles_x = ovis::cdiv(g.W[2], MSDA_TQ), tiles_y = ovis::cdiv(g.H[2], MSDA_TQ);
+  hipLaunchKernelGGL((msda_encoder_tiled_kernel<4>), dim3(tiles_x * tiles_y, num_heads, batch), dim3(MSDA_TQ * MSDA_TQ * 8), shmem, s,
+                     value, offs_attn, ld_oa, out, spatial_size, num_heads, g, radius, tiles_x);
+  int rc = ovis::check_launch("msda_encoder_fused_tiled (finest level)");
+  if (rc) return rc;
+  const int s_cnt = g.start[2];                                   // queries of the two coarser levels: direct gather
+  if (s_cnt > 0) {
+    const long long n_items = (long long)batch * s_cnt * num_heads * (channels / 4);
+    hipLaunchKernelGGL((msda_encoder_fused_kernel<3, 4>), dim3(ovis::cdiv(n_items, 256)), dim3(256), 0, s, value, offs_attn, ld_oa,
+                       spatial_shapes, level_start_index, out, n_items, spatial_size, num_heads, channels, 0, s_cnt);
+    rc = ovis::check_launch("msda_encoder_fused_tiled (coarse levels)");
+  }
+  return rc;
 }
 
 extern "C" int ovis_attn_mask_from_logits(const float* logits, long long ld, uint8_t* mask, long long mask_ld,

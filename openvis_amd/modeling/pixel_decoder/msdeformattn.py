@@ -33,10 +33,11 @@ class MSDeformAttnTransformerEncoderLayer:
                   "norm2.weight", "norm2.bias"):
             self.w[k] = sd[prefix + k].float().contiguous().to(device)
 
-    def forward(self, src, pos, spatial_shapes, level_start_index):
+    def forward(self, src, pos, spatial_shapes, level_start_index, shapes_host=None):
         w = self.w
         q = ops.add_bcast(src, pos)                                                 # with_pos_embed (:138)
-        y = self.self_attn.forward_encoder_fused(q, src, spatial_shapes, level_start_index, residual=src)
+        y = self.self_attn.forward_encoder_fused(q, src, spatial_shapes, level_start_index, residual=src,
+                                                 shapes_host=shapes_host)
         src = ops.layernorm(y, w["norm1.weight"], w["norm1.bias"])                   # :139-141
         h = ops.gemm_nt(src, w["linear1.weight"], w["linear1.bias"], None, ops.ACT_RELU)
         y = ops.gemm_nt(h, w["linear2.weight"], w["linear2.bias"], src)              # :118-121
@@ -125,7 +126,7 @@ class MSDeformAttnPixelDecoder:
         pos, shapes, lsi = self._pos(shapes_list)
         src = torch.cat(srcs, 1).contiguous()                                          # [T,S,C] (copy only)
         for layer in self.layers:
-            src = layer.forward(src, pos, shapes, lsi)
+            src = layer.forward(src, pos, shapes, lsi, shapes_host=shapes_list)
         T = src.shape[0]
         outs, start = [], 0
         for (H, W) in shapes_list:

@@ -52,13 +52,13 @@ class MSDeformAttn:
                                          loc.contiguous(), aw.contiguous(), self.im2col_step)
         return ops.gemm_nt(out, self.w["output_proj.weight"], self.w["output_proj.bias"])
 
-    def forward_encoder_fused(self, query, src, spatial_shapes, level_start_index, residual):
+    def forward_encoder_fused(self, query, src, spatial_shapes, level_start_index, residual, shapes_host=None):
         """Encoder fast path: value_proj + fused [offsets|weights] GEMM + fused softmax/location/sampling kernel +
         output_proj with the residual add fused.  Reference points are the encoder's (msdeformattn.py:155-168)."""
         value = ops.gemm_nt(src, self.w["value_proj.weight"], self.w["value_proj.bias"])
         oa = ops.gemm_nt(query, self.w["oa.weight"], self.w["oa.bias"])
         samp = ops.msda_encoder_fused(value, oa, spatial_shapes, level_start_index, self.n_heads, self.n_levels,
-                                      self.n_points)
+                                      self.n_points, shapes_host=shapes_host)
         return ops.gemm_nt(samp, self.w["output_proj.weight"], self.w["output_proj.bias"], residual)
 
     __call__ = forward

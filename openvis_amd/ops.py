@@ -319,13 +319,28 @@ def attention_f16(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld):
     return out
 
 
-def msda_encoder_fused(value, oa, shapes, lsi, M=8, L=3, P=4):
-    """value [B,S,C], oa [B,S,M*L*P*3] -> [B,S,C]."""
+# LDS-staged tiled K1 (csrc/openvis_ops.hip: msda_encoder_tiled_kernel): radius in pixels of the value window staged per
+# 8x8 query tile, or -1 = off.  OFF by default: measured on MI355X (tools/bench_msda_fused.py, 5 frames at 720p) the
+# direct-gather kernel takes 370 us, the tiled one 480 us (radius 2-3) / 720 us (radius 4): the windows' halo makes the
+# staged volume ~5x the tile's own pixels, more than what L1/L2 already save the direct gather.
+MSDA_TILE_RADIUS = -1
+
+
+def msda_encoder_fused(value, oa, shapes, lsi, M=8, L=3, P=4, shapes_host=None):
+    """value [B,S,C], oa [B,S,M*L*P*3] -> [B,S,C].  shapes_host: the level shapes as python ints [(H,W)] * L (coarse to
+    fine) -> the LDS-staged tiled kernel handles the finest level's queries."""
     _chk(value, oa, shapes, lsi)
     B, S, C = value.shape
     out = torch.empty_like(value)
     # algorithmic bytes (DESIGN.md section 3 / SURVEY.md 8d): f32 value + offsets/logits + output rows, once each
-    with _Prof(f"msda_encoder_fused_kernel<{L},{P}>", 4.0 * B * S * (2 * C + oa.shape[-1]), unit="byte"):
+    nbytes = 4.0 * B * S * (2 * C + oa.shape[-1])
+    if shapes_host is not None and L == 3 and P == 4 and C // M == 32 and MSDA_TILE_RADIUS >= 0:
+        sh = (ctypes.c_int * 6)(*[int(v) for hw in shapes_host for v in hw])
+        with _Prof(f"msda_encoder_tiled_kernel<{P}>+fused<{L},{P}>", nbytes, unit="byte"):
+            _lib.call("ovis_msda_encoder_fused_tiled_f32", value, oa, oa.shape[-1], shapes, lsi, sh, out, B, S, M, C // M, L, P,
+                      MSDA_TILE_RADIUS, _lib.stream_ptr())
+        return out
+    with _Prof(f"msda_encoder_fused_kernel<{L},{P}>", nbytes, unit="byte"):
         _lib.call("ovis_msda_encoder_fused_f32", value, oa, oa.shape[-1], shapes, lsi, out, B, S, M, C // M, L, P,
                   _lib.stream_ptr())
     return out

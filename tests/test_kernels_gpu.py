@@ -247,3 +247,29 @@ def test_aggregate_topk():
     ent_ref = {int(i): float((-ref[i // K] * ref[i // K].log()).sum()) for i in ri}
     for i, e in zip(idx.cpu().tolist(), ent.cpu().tolist()):
         assert abs(e - ent_ref[i]) < 1e-5
+
+
+@pytest.mark.parametrize("sizes,scale", [([(4, 7), (8, 14), (15, 27)], 3.0), ([(23, 40), (46, 80), (92, 160)], 2.0),
+                                         ([(23, 40), (46, 80), (92, 160)], 12.0), ([(5, 5), (9, 10), (17, 19)], 1.0)])
+def test_msda_encoder_tiled_lds_kernel_is_identical_to_direct_gather(sizes, scale):
+    """The LDS-staged tiled K1 (finest level) + direct gather (coarse levels) must give exactly the direct-gather result for
+    any offsets -- small ones hit the staged windows, large ones (scale 12 px) take the global fallback."""
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(len(sizes) + int(scale))
+    shapes = torch.tensor(sizes)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    B = 2
+    value = torch.randn(B, S, 256, generator=g).cuda()
+    oa = torch.randn(B, S, 288, generator=g)
+    oa[..., :192] *= scale
+    oa = oa.cuda()
+    plain = ops.msda_encoder_fused(value, oa, shapes.cuda(), lsi.cuda())
+    old = ops.MSDA_TILE_RADIUS
+    try:
+        for radius in (2, 4):
+            ops.MSDA_TILE_RADIUS = radius                        # the tiled variant is off by default (slower, see ops.py)
+            tiled = ops.msda_encoder_fused(value, oa, shapes.cuda(), lsi.cuda(), shapes_host=sizes)
+            assert torch.equal(plain, tiled), radius
+    finally:
+        ops.MSDA_TILE_RADIUS = old
