@@ -165,6 +165,137 @@ flash_attn_f16_kernel(AttnH a) {
     }
 }
 
+// Whole-sequence variant for short sequences (Nk <= 224, e.g. the 197 tokens of ViT-B/16 @224): one workgroup = one
+// (batch, head), one wavefront = one tile of 32 queries; K and V of the head are staged ONCE in LDS (the tiled kernel
+// above re-stages them for every group of 4 query tiles and synchronises twice per key tile), then every wavefront
+// walks the key tiles on its own with the online-softmax recurrence -- no barrier inside the loop.
+template <int KT>
+__global__ void __launch_bounds__(64 * KT)
+flash_attn_f16_seq_kernel(AttnH a) {
+  constexpr int D = 64;
+  constexpr int KROW = D + 8;    // halfs -> 144 B rows (ds_read_b128, conflict-free)
+  constexpr int VROW = D + 32;   // halfs -> 192 B rows (transposed reads tile the 64 banks)
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+  _Float16* Ks = smem;
+  _Float16* Vs = smem + 32 * KT * KROW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int head = blockIdx.x, b = blockIdx.y;
+  const _Float16* qp = a.q + b * a.q_bs + (long long)head * D;
+  const _Float16* kp = a.k + b * a.k_bs + (long long)head * D;
+  const _Float16* vp = a.v + b * a.v_bs + (long long)head * D;
+
+  for (int c = tid; c < 32 * KT * 8; c += 64 * KT) {            // rows >= Nk zero
+    const int row = c >> 3, ch = c & 7;
+    const bool ok = row < a.Nk;
+    const int rc = ok ? row : 0;
+    const uint4 kk = *reinterpret_cast<const uint4*>(kp + (long long)rc * a.k_ld + ch * 8);
+    const uint4 vv = *reinterpret_cast<const uint4*>(vp + (long long)rc * a.v_ld + ch * 8);
+    *reinterpret_cast<uint4*>(&Ks[row * KROW + ch * 8]) = make_uint4(ok ? kk.x : 0u, ok ? kk.y : 0u, ok ? kk.z : 0u, ok ? kk.w : 0u);
+    *reinterpret_cast<uint4*>(&Vs[row * VROW + ch * 8]) = make_uint4(ok ? vv.x : 0u, ok ? vv.y : 0u, ok ? vv.z : 0u, ok ? vv.w : 0u);
+  }
+  const int qi = wave * 32 + r32;
+  const bool q_ok = qi < a.Nq;
+  const int qc = q_ok ? qi : a.Nq - 1;
+  f16x8 qf[D / 16];
+#pragma unroll
+  for (int st = 0; st < D / 16; ++st) qf[st] = *reinterpret_cast<const f16x8*>(qp + (long long)qc * a.q_ld + 16 * st + 8 * h);
+  __syncthreads();
+  if (wave * 32 >= a.Nq) return;
+
+  const int g16 = lane >> 4, li = lane & 15;
+  const int tr_off = (li >> 2) * VROW + 16 * (g16 & 1) + 4 * (li & 3);
+  const float sl2 = a.scale * 1.4426950408889634f;
+  f32x16 o[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int nkt = (a.Nk + 31) / 32;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt >= nkt) break;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < D / 16; ++st) {
+      const f16x8 kk = *reinterpret_cast<const f16x8*>(&Ks[(kt * 32 + r32) * KROW + 16 * st + 8 * h]);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kk, qf[st], s, 0, 0, 0);
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float x = key < a.Nk ? s[r] * sl2 : -INFINITY;
+      s[r] = x;
+      mt = fmaxf(mt, x);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);                        // finite: every key tile holds at least one valid key
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __builtin_amdgcn_exp2f(s[r] - m_new);
+      s[r] = p;
+      ps += p;
+    }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      f16x8 pb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pb[j] = (_Float16)s[8 * sp + j];
+      const int key0a = kt * 32 + 16 * sp + 4 * h, key0b = key0a + 8;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f16x4 va = tr_read(&Vs[key0a * VROW + t * 32 + tr_off]);
+        const f16x4 vb = tr_read(&Vs[key0b * VROW + t * 32 + tr_off]);
+        f16x8 av;
+        av[0] = va[0]; av[1] = va[1]; av[2] = va[2]; av[3] = va[3];
+        av[4] = vb[0]; av[5] = vb[1]; av[6] = vb[2]; av[7] = vb[3];
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, pb, o[t], 0, 0, 0);
+      }
+    }
+  }
+  if (!q_ok) return;
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+  _Float16* op = a.out + b * a.o_bs + (long long)qi * a.o_ld + head * D;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d = t * 32 + 8 * g4 + 4 * h;
+      f16x4 r;
+      r[0] = (_Float16)(o[t][4 * g4] * inv); r[1] = (_Float16)(o[t][4 * g4 + 1] * inv);
+      r[2] = (_Float16)(o[t][4 * g4 + 2] * inv); r[3] = (_Float16)(o[t][4 * g4 + 3] * inv);
+      *reinterpret_cast<f16x4*>(op + d) = r;
+    }
+}
+
+template <int KT>
+int launch_seq(const AttnH& a, hipStream_t stream) {
+  const size_t shmem = (size_t)32 * KT * ((64 + 8) + (64 + 32)) * sizeof(_Float16);
+  static bool attr_set = false;
+  if (shmem > 64 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_f16_seq_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)shmem) != hipSuccess)
+      return ovis::fail(OVIS_EINVAL, "attention_f16: cannot raise the dynamic LDS limit");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((flash_attn_f16_seq_kernel<KT>), dim3(a.H, a.B), dim3(64 * KT), shmem, stream, a);
+  return ovis::check_launch("attention_f16 (whole sequence)");
+}
+
 }  // namespace
 
 extern "C" int ovis_attention_f16(const void* q, long long q_bs, int q_ld, const void* k, long long k_bs, int k_ld,
@@ -182,6 +313,19 @@ extern "C" int ovis_attention_f16(const void* q, long long q_bs, int q_ld, const
   a.q = (const _Float16*)q; a.q_bs = q_bs; a.q_ld = q_ld; a.k = (const _Float16*)k; a.k_bs = k_bs; a.k_ld = k_ld;
   a.v = (const _Float16*)v; a.v_bs = v_bs; a.v_ld = v_ld; a.out = (_Float16*)out; a.o_bs = o_bs; a.o_ld = o_ld;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+  // short sequences: whole K/V of a head in LDS, one wavefront per query tile
+  const int kt = ovis::cdiv(Nk, 32);
+  if (kt <= 7 && ovis::cdiv(Nq, 32) <= kt) {
+    switch (kt) {
+      case 1: return launch_seq<1>(a, (hipStream_t)stream);
+      case 2: return launch_seq<2>(a, (hipStream_t)stream);
+      case 3: return launch_seq<3>(a, (hipStream_t)stream);
+      case 4: return launch_seq<4>(a, (hipStream_t)stream);
+      case 5: return launch_seq<5>(a, (hipStream_t)stream);
+      case 6: return launch_seq<6>(a, (hipStream_t)stream);
+      default: return launch_seq<7>(a, (hipStream_t)stream);
+    }
+  }
   hipLaunchKernelGGL(flash_attn_f16_kernel, dim3(ovis::cdiv(Nq, 128), B * H), dim3(256), 0, (hipStream_t)stream, a);
   return ovis::check_launch("attention_f16");
 }
