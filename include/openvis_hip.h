@@ -59,6 +59,17 @@ int ovis_msda_forward_f64(const double* value, const int64_t* spatial_shapes,
  * Replaces nothing in the reference (torch picks cuBLAS algorithms implicitly); process-wide, not thread-safe. */
 int ovis_set_f32_gemm_mode(int mode);
 
+/* Constant f32 weights can be split ONCE into the three bf16 planes of the bf16x3 arithmetic (planes bf16 [3][n], x ==
+ * p0 + p1 + p2 exactly); the *_w3 entry points then skip the per-tile split of the B operand (same results bit for bit).
+ * They also take the f32 weights, which small problems / mode 0 keep using. */
+int ovis_split_f32_to_bf16x3(const float* x, void* planes, long long n, ovis_stream_t stream);
+int ovis_gemm_nt_f32_w3(const float* A, long long lda, const float* B, long long ldb, const void* W3, long long plane, float* C,
+                        long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr, int act,
+                        ovis_stream_t stream);
+int ovis_conv2d_nhwc_f32_w3(const float* x, const float* w, const void* w3, long long plane, float* y, int N, int H, int W, int Cin,
+                            int Cout, int KH, int KW, int stride, int pad, const float* bias, const float* residual, int act,
+                            ovis_stream_t stream);
+
 /* ---- Dense layers and convolutions on the f32 matrix cores ---------------------------------
  * Replace the cuBLAS/cuDNN work behind the reference's nn.Linear / Conv2d modules on the path, e.g.
  *   ops/modules/ms_deform_attn.py:98-104,124 (value_proj, sampling_offsets, attention_weights, output_proj),

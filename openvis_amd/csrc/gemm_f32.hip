@@ -225,3 +225,44 @@ extern "C" int ovis_conv2d_nhwc_f32(const float* x, const float* w, float* y, in
   return launch_gemm(la, w, (long long)K, y, (long long)Cout, (int)M, Cout, K, bias, residual, (long long)Cout, act,
                      (hipStream_t)stream);
 }
+
+// ---- constant f32 weights pre-split into three bf16 planes (gemm_f32x3.h) -------------------------------------------
+extern "C" int ovis_split_f32_to_bf16x3(const float* x, void* planes, long long n, ovis_stream_t stream) {
+  OVIS_REQUIRE(x && planes && n > 0, "split_f32_to_bf16x3: bad arguments");
+  hipLaunchKernelGGL(ovis::x3_split_kernel, dim3(ovis::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)planes, n);
+  return ovis::check_launch("split_f32_to_bf16x3");
+}
+
+extern "C" int ovis_gemm_nt_f32_w3(const float* A, long long lda, const float* B, long long ldb, const void* W3, long long plane,
+                                   float* C, long long ldc, int M, int N, int K, const float* bias, const float* residual,
+                                   long long ldr, int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(A && B && W3 && C, "gemm_nt_f32_w3: null pointer");
+  const bool veca = (K % 8 == 0) && ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0) && ldb % 8 == 0 && (((uintptr_t)W3 & 15) == 0) &&
+                    plane % 8 == 0;
+  const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128);
+  if (!(veca && blocks128 >= 256 && g_f32_gemm_mode == 1))           // small / unaligned / exact-chain mode: the f32 copy
+    return ovis_gemm_nt_f32(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, stream);
+  OVIS_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldb >= K && ldc >= N && act >= 0 && act <= 3 && (!residual || ldr >= N),
+               "gemm_nt_f32_w3: bad sizes");
+  ovis::launch_gemm_f32x3_w3(DenseA<true>{A, lda, M, K}, W3, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream);
+  return ovis::check_launch("gemm_f32x3 (pre-split weights)");
+}
+
+extern "C" int ovis_conv2d_nhwc_f32_w3(const float* x, const float* w, const void* w3, long long plane, float* y, int N, int H, int W,
+                                       int Cin, int Cout, int KH, int KW, int stride, int pad, const float* bias,
+                                       const float* residual, int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(x && w && w3 && y, "conv2d_nhwc_f32_w3: null pointer");
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  const long long M = (long long)N * OH * OW;
+  const int K = KH * KW * Cin;
+  const long long blocks128 = ovis::cdiv(M, 128) * (long long)ovis::cdiv(Cout, 128);
+  const bool ok = Cin % 4 == 0 && K % 8 == 0 && (((uintptr_t)x | (uintptr_t)w3) & 15) == 0 && plane % 8 == 0 && OH > 0 && OW > 0 &&
+                  M < (1ll << 31);
+  if (!(ok && blocks128 >= 256 && g_f32_gemm_mode == 1))
+    return ovis_conv2d_nhwc_f32(x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act, stream);
+  OVIS_REQUIRE(act >= 0 && act <= 3, "conv2d_nhwc_f32_w3: unknown activation %d", act);
+  ConvA la{x, ConvGeom{H, W, Cin, OH, OW, KH, KW, stride, pad}, (int)M, K};
+  ovis::launch_gemm_f32x3_w3(la, w3, (long long)K, plane, y, (long long)Cout, (int)M, Cout, K, bias, residual, (long long)Cout, act,
+                             (hipStream_t)stream);
+  return ovis::check_launch("conv_f32x3 (pre-split weights)");
+}

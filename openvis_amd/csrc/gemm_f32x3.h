@@ -13,6 +13,7 @@
 // three bf16 planes per operand with 80-byte rows (conflict-free ds_read_b128), register-prefetched next K tile,
 // operand roles swapped for the vectorised epilogue (gemm_epilogue.h).
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "gemm_loaders.h"
@@ -42,9 +43,17 @@ __device__ __forceinline__ X3Planes x3_split8(bool ok0, float4 a, bool ok1, floa
   return X3Planes{o0.u, o1.u, o2.u};
 }
 
-template <int BM, int BN, typename LoaderA>
+// B operand given as three pre-split bf16 planes [3][N][ldb] (constant weights: split once at load, x3_split_kernel)
+struct PlanesB {
+  const __bf16* P;
+  long long ldb, plane;      // row stride and plane stride in elements
+  int N, K;
+  __device__ __forceinline__ void advance(long long elems) { P += elems; }
+};
+
+template <int BM, int BN, typename LoaderA, typename LoaderB = DenseA<true>>
 __global__ void __launch_bounds__(256)
-gemm_f32x3_kernel(LoaderA la, DenseA<true> lb, float* __restrict__ C, long long ldc, int M, int N, int K,
+gemm_f32x3_kernel(LoaderA la, LoaderB lb, float* __restrict__ C, long long ldc, int M, int N, int K,
                   const float* __restrict__ bias, const float* __restrict__ R, long long ldr, int act, int tiles_n,
                   long long a_bs, long long b_bs, long long c_bs) {
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -65,9 +74,11 @@ gemm_f32x3_kernel(LoaderA la, DenseA<true> lb, float* __restrict__ C, long long 
   const int bm = (int)(bid / tiles_n) * BM;
   const int srow = tid >> 2, scol = (tid & 3) * 8;
 
+  constexpr bool BSPLIT = !std::is_same<LoaderB, PlanesB>::value;   // false: B arrives already split
   float4 pa[A_IT][2], pb[B_IT][2];       // raw prefetch of the tile after next
   bool oka[A_IT][2], okb[B_IT][2];
   X3Planes sa[A_IT], sb[B_IT];           // split planes of the next tile, waiting for the LDS buffer to be free
+  X3Planes qb[B_IT];                     // pre-split B: planes in flight
   auto gload = [&](int k0) {
     const int k = k0 + scol;
 #pragma unroll
@@ -77,15 +88,32 @@ gemm_f32x3_kernel(LoaderA la, DenseA<true> lb, float* __restrict__ C, long long 
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      pb[i][0] = lb.load(bn + srow + i * 64, k, okb[i][0]);
-      pb[i][1] = lb.load(bn + srow + i * 64, k + 4, okb[i][1]);
+      if constexpr (BSPLIT) {
+        pb[i][0] = lb.load(bn + srow + i * 64, k, okb[i][0]);
+        pb[i][1] = lb.load(bn + srow + i * 64, k + 4, okb[i][1]);
+      } else {
+        const int n = bn + srow + i * 64;
+        okb[i][0] = n < lb.N && k < lb.K;                      // K % 8 == 0: a chunk of 8 is all-in or all-out
+        const __bf16* p = lb.P + (okb[i][0] ? (long long)n * lb.ldb + k : 0);
+        qb[i].p0 = *reinterpret_cast<const uint4*>(p);
+        qb[i].p1 = *reinterpret_cast<const uint4*>(p + lb.plane);
+        qb[i].p2 = *reinterpret_cast<const uint4*>(p + 2 * lb.plane);
+      }
     }
   };
   auto split = [&]() {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) sa[i] = x3_split8(oka[i][0], pa[i][0], oka[i][1], pa[i][1]);
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) sb[i] = x3_split8(okb[i][0], pb[i][0], okb[i][1], pb[i][1]);
+    for (int i = 0; i < B_IT; ++i) {
+      if constexpr (BSPLIT) sb[i] = x3_split8(okb[i][0], pb[i][0], okb[i][1], pb[i][1]);
+      else {
+        const bool ok = okb[i][0];
+        sb[i].p0 = make_uint4(ok ? qb[i].p0.x : 0u, ok ? qb[i].p0.y : 0u, ok ? qb[i].p0.z : 0u, ok ? qb[i].p0.w : 0u);
+        sb[i].p1 = make_uint4(ok ? qb[i].p1.x : 0u, ok ? qb[i].p1.y : 0u, ok ? qb[i].p1.z : 0u, ok ? qb[i].p1.w : 0u);
+        sb[i].p2 = make_uint4(ok ? qb[i].p2.x : 0u, ok ? qb[i].p2.y : 0u, ok ? qb[i].p2.z : 0u, ok ? qb[i].p2.w : 0u);
+      }
+    }
   };
   auto lstore = [&]() {
 #pragma unroll
@@ -170,6 +198,28 @@ inline void launch_gemm_f32x3(LoaderA la, const float* B, long long ldb, float* 
   const int tm = cdiv(M, 128), tn = cdiv(N, 128);
   hipLaunchKernelGGL((gemm_f32x3_kernel<128, 128, LoaderA>), dim3(tm * tn, batch), dim3(256), 0, stream, la,
                      DenseA<true>{B, ldb, N, K}, C, ldc, M, N, K, bias, R, ldr, act, tn, a_bs, b_bs, c_bs);
+}
+
+// pre-split weights: same kernel, B planes read as 16-byte bf16 chunks (no VALU split for B)
+template <typename LoaderA>
+inline void launch_gemm_f32x3_w3(LoaderA la, const void* W3, long long ldb, long long plane, float* C, long long ldc, int M, int N,
+                                 int K, const float* bias, const float* R, long long ldr, int act, hipStream_t stream) {
+  const int tm = cdiv(M, 128), tn = cdiv(N, 128);
+  hipLaunchKernelGGL((gemm_f32x3_kernel<128, 128, LoaderA, PlanesB>), dim3(tm * tn, 1), dim3(256), 0, stream, la,
+                     PlanesB{(const __bf16*)W3, ldb, plane, N, K}, C, ldc, M, N, K, bias, R, ldr, act, tn, 0ll, 0ll, 0ll);
+}
+
+// x [n] f32 -> planes [3][n] bf16 with x == p0 + p1 + p2 exactly
+__global__ void __launch_bounds__(256)
+x3_split_kernel(const float* __restrict__ x, __bf16* __restrict__ planes, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  const __bf16 h0 = (__bf16)v;
+  const float r1 = v - (float)h0;
+  const __bf16 h1 = (__bf16)r1;
+  const float r2 = r1 - (float)h1;
+  planes[i] = h0; planes[n + i] = h1; planes[2 * n + i] = (__bf16)r2;
 }
 
 }  // namespace ovis

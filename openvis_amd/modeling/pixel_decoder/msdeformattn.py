@@ -39,8 +39,8 @@ class MSDeformAttnTransformerEncoderLayer:
         y = self.self_attn.forward_encoder_fused(q, src, spatial_shapes, level_start_index, residual=src,
                                                  shapes_host=shapes_host)
         src = ops.layernorm(y, w["norm1.weight"], w["norm1.bias"])                   # :139-141
-        h = ops.gemm_nt(src, w["linear1.weight"], w["linear1.bias"], None, ops.ACT_RELU)
-        y = ops.gemm_nt(h, w["linear2.weight"], w["linear2.bias"], src)              # :118-121
+        h = ops.gemm_nt(src, w["linear1.weight"], w["linear1.bias"], None, ops.ACT_RELU, cw=True)
+        y = ops.gemm_nt(h, w["linear2.weight"], w["linear2.bias"], src, cw=True)              # :118-121
         return ops.layernorm(y, w["norm2.weight"], w["norm2.bias"])
 
 
@@ -113,7 +113,7 @@ class MSDeformAttnPixelDecoder:
         for idx, f in enumerate(self.transformer_in_features[::-1]):                   # res5, res4, res3
             x = features[f]
             T, H, W, C = x.shape
-            y = ops.gemm_nt(x.view(-1, C), w[f"input_proj.{idx}.w"], w[f"input_proj.{idx}.b"]).view(T, H, W, -1)
+            y = ops.gemm_nt(x.view(-1, C), w[f"input_proj.{idx}.w"], w[f"input_proj.{idx}.b"], cw=True).view(T, H, W, -1)
             y = ops.groupnorm_nhwc(y, w[f"input_proj.{idx}.gn_w"], w[f"input_proj.{idx}.gn_b"])
             if extra_features is not None:                                             # SAN injection (:338-344)
                 ex = extra_features[idx]
@@ -136,12 +136,12 @@ class MSDeformAttnPixelDecoder:
             k = self.num_fpn_levels - idx
             x = features[f]
             T, H, W, C = x.shape
-            cur = ops.gemm_nt(x.view(-1, C), w[f"adapter_{k}.w"]).view(T, H, W, -1)
+            cur = ops.gemm_nt(x.view(-1, C), w[f"adapter_{k}.w"], cw=True).view(T, H, W, -1)
             y = ops.groupnorm_nhwc(cur, w[f"adapter_{k}.gn_w"], w[f"adapter_{k}.gn_b"], up_add=outs[-1])   # :369-371
-            y = ops.conv2d_nhwc(y, w[f"layer_{k}.w"], 1, 1)
+            y = ops.conv2d_nhwc(y, w[f"layer_{k}.w"], 1, 1, cw=True)
             y = ops.groupnorm_nhwc(y, w[f"layer_{k}.gn_w"], w[f"layer_{k}.gn_b"], relu=True)
             outs.append(y)
         top = outs[-1]
         T, H, W, C = top.shape
-        mask_features = ops.gemm_nt(top.view(-1, C), w["mask_features.w"], w["mask_features.b"]).view(T, H, W, -1)
+        mask_features = ops.gemm_nt(top.view(-1, C), w["mask_features.w"], w["mask_features.b"], cw=True).view(T, H, W, -1)
         return mask_features, outs[0], outs[: self.maskformer_num_feature_levels]

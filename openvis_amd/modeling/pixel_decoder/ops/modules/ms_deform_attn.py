@@ -33,11 +33,11 @@ class MSDeformAttn:
         N, Len_in, _ = input_flatten.shape
         assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == Len_in
         M, L, P = self.n_heads, self.n_levels, self.n_points
-        value = ops.gemm_nt(input_flatten, self.w["value_proj.weight"], self.w["value_proj.bias"])
+        value = ops.gemm_nt(input_flatten, self.w["value_proj.weight"], self.w["value_proj.bias"], cw=True)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, M, self.d_model // M)
-        oa = ops.gemm_nt(query, self.w["oa.weight"], self.w["oa.bias"])
+        oa = ops.gemm_nt(query, self.w["oa.weight"], self.w["oa.bias"], cw=True)
         off = oa[..., : M * L * P * 2].reshape(N, Len_q, M, L, P, 2)
         aw = torch.softmax(oa[..., M * L * P * 2:].reshape(N, Len_q, M, L * P), -1).view(N, Len_q, M, L, P)
         if reference_points.shape[-1] == 2:
@@ -50,15 +50,15 @@ class MSDeformAttn:
                 reference_points.shape[-1]))
         out = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
                                          loc.contiguous(), aw.contiguous(), self.im2col_step)
-        return ops.gemm_nt(out, self.w["output_proj.weight"], self.w["output_proj.bias"])
+        return ops.gemm_nt(out, self.w["output_proj.weight"], self.w["output_proj.bias"], cw=True)
 
     def forward_encoder_fused(self, query, src, spatial_shapes, level_start_index, residual, shapes_host=None):
         """Encoder fast path: value_proj + fused [offsets|weights] GEMM + fused softmax/location/sampling kernel +
         output_proj with the residual add fused.  Reference points are the encoder's (msdeformattn.py:155-168)."""
-        value = ops.gemm_nt(src, self.w["value_proj.weight"], self.w["value_proj.bias"])
-        oa = ops.gemm_nt(query, self.w["oa.weight"], self.w["oa.bias"])
+        value = ops.gemm_nt(src, self.w["value_proj.weight"], self.w["value_proj.bias"], cw=True)
+        oa = ops.gemm_nt(query, self.w["oa.weight"], self.w["oa.bias"], cw=True)
         samp = ops.msda_encoder_fused(value, oa, spatial_shapes, level_start_index, self.n_heads, self.n_levels,
                                       self.n_points, shapes_host=shapes_host)
-        return ops.gemm_nt(samp, self.w["output_proj.weight"], self.w["output_proj.bias"], residual)
+        return ops.gemm_nt(samp, self.w["output_proj.weight"], self.w["output_proj.bias"], residual, cw=True)
 
     __call__ = forward

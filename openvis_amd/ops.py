@@ -60,9 +60,28 @@ def set_f32_gemm_mode(mode):
     _F32_GEMM_MODE = int(mode)
 
 
-def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None):
+import weakref
+
+_W3_CACHE = {}      # id(constant f32 weight tensor) -> (weakref to it, its three bf16 planes); split once per tensor
+
+
+def w3_of(w):
+    """The exact 3-way bf16 split of a CONSTANT weight tensor, cached per tensor object (csrc/gemm_f32x3.h)."""
+    key = id(w)
+    hit = _W3_CACHE.get(key)
+    if hit is not None and hit[0]() is w:
+        return hit[1]
+    _chk(w)
+    p = torch.empty((3,) + tuple(w.shape), dtype=torch.bfloat16, device=w.device)
+    _lib.call("ovis_split_f32_to_bf16x3", w, p, _ll(w.numel()), _lib.stream_ptr())
+    _W3_CACHE[key] = (weakref.ref(w, lambda _r, k=key: _W3_CACHE.pop(k, None)), p)
+    return p
+
+
+def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None, cw=False):
     """out[m,n] = act(sum_k a[m,k] w[n,k] + bias[n] + residual[m,n]); a [...,K] -> out [...,N].
-    w16 (an fp16 copy of w) selects the autocast arithmetic: operands rounded to fp16, f32 accumulation."""
+    w16 (an fp16 copy of w) selects the autocast arithmetic: operands rounded to fp16, f32 accumulation.
+    cw=True: w is a constant weight (not an activation) -> its bf16x3 planes are split once and cached (same results)."""
     K = a.shape[-1]
     N = w.shape[0]
     a2 = a.reshape(-1, K)
@@ -78,8 +97,12 @@ def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None):
                       _lib.stream_ptr())
         return out.view(*a.shape[:-1], N)
     with _Prof(_gemm_variant(M, N, "DenseA", K), 2.0 * M * N * K):
-        _lib.call("ovis_gemm_nt_f32", a2, _ll(K), w, _ll(w.stride(0)), out, _ll(N), M, N, K, bias, r2, _ll(N), act,
-                  _lib.stream_ptr())
+        if cw and w.is_contiguous() and K % 8 == 0 and _F32_GEMM_MODE == 1 and ((M + 127) // 128) * ((N + 127) // 128) >= 256:
+            _lib.call("ovis_gemm_nt_f32_w3", a2, _ll(K), w, _ll(K), w3_of(w), _ll(w.numel()), out, _ll(N), M, N, K, bias, r2,
+                      _ll(N), act, _lib.stream_ptr())
+        else:
+            _lib.call("ovis_gemm_nt_f32", a2, _ll(K), w, _ll(w.stride(0)), out, _ll(N), M, N, K, bias, r2, _ll(N), act,
+                      _lib.stream_ptr())
     return out.view(*a.shape[:-1], N)
 
 
@@ -200,8 +223,9 @@ def cast_f16(x):
     return y
 
 
-def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE, w16=None):
-    """x [N,H,W,Cin], w [Cout,KH,KW,Cin] -> [N,OH,OW,Cout]. w16: fp16 copy of w -> autocast arithmetic."""
+def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE, w16=None, cw=False):
+    """x [N,H,W,Cin], w [Cout,KH,KW,Cin] -> [N,OH,OW,Cout]. w16: fp16 copy of w -> autocast arithmetic.
+    cw=True: constant weights -> cached bf16x3 planes for the f32 path (see gemm_nt)."""
     _chk(x, w, bias, residual, w16)
     N, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
@@ -215,8 +239,12 @@ def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE, w
                       _lib.stream_ptr())
         return y
     with _Prof(_gemm_variant(N * OH * OW, Cout, "ConvA", KH * KW * Cin), 2.0 * N * OH * OW * Cout * KH * KW * Cin):
-        _lib.call("ovis_conv2d_nhwc_f32", x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act,
-                  _lib.stream_ptr())
+        if cw and (KH * KW * Cin) % 8 == 0 and _F32_GEMM_MODE == 1:
+            _lib.call("ovis_conv2d_nhwc_f32_w3", x, w, w3_of(w), _ll(w.numel()), y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias,
+                      residual, act, _lib.stream_ptr())
+        else:
+            _lib.call("ovis_conv2d_nhwc_f32", x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act,
+                      _lib.stream_ptr())
     return y
 
 

@@ -121,3 +121,21 @@ def test_large_conv_bf16x3_matches_native(gemm_modes):
     e0 = (outs[0].double() - ref).abs().max().item()
     e1 = (outs[1].double() - ref).abs().max().item()
     assert e1 <= 2 * e0 + 1e-7 and e1 < 2e-5, (e0, e1)
+
+
+def test_presplit_weight_planes_give_identical_results(gemm_modes):
+    """cw=True (constant weights split once into bf16 planes) must equal the on-the-fly split bit for bit."""
+    ops = gemm_modes
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(40000, 256, generator=g).cuda()
+    w = (torch.randn(288, 256, generator=g) / 16).cuda()
+    b = torch.randn(288, generator=g).cuda()
+    r = torch.randn(40000, 288, generator=g).cuda()
+    assert torch.equal(ops.gemm_nt(a, w, b, r, 1), ops.gemm_nt(a, w, b, r, 1, cw=True))
+    p = ops.w3_of(w).float()
+    assert torch.equal(p[0] + p[1] + p[2], w) and ops.w3_of(w) is ops.w3_of(w)
+    x = torch.randn(3, 120, 200, 64, generator=g).cuda()
+    cwt = (torch.randn(256, 3, 3, 64, generator=g) / 24).cuda()
+    assert torch.equal(ops.conv2d_nhwc(x, cwt, 1, 1, b[:256].contiguous(), None, 1), ops.conv2d_nhwc(x, cwt, 1, 1, b[:256].contiguous(), None, 1, cw=True))
+    small = torch.randn(100, 256, generator=g).cuda()                     # small problems keep using the f32 weights
+    assert torch.equal(ops.gemm_nt(small, w, b), ops.gemm_nt(small, w, b, cw=True))
