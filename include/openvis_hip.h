@@ -244,9 +244,10 @@ int ovis_bilinear_resize_add_nhwc_f32(float* dst, const float* src, int N, int H
  *   openvis/modeling/minvis.py:28-72 (cost 1 - cosine, scipy.optimize.linear_sum_assignment on target x current,
  *   targets of frame t = frame t-1's embeddings in their assigned order; frame 0 is matched against itself).
  *   embeds f32 [T,Q,C] (Q % 4 == 0, C % 4 == 0); indices int32 [T,Q]; workspace of
- *   ovis_hungarian_link_workspace_bytes(T,Q,C) bytes.  Three launches for the whole chain: row normalisation, one batched
- *   GEMM for every frame-to-frame cosine matrix, one single-wavefront Jonker-Volgenant chain (the reference does one
- *   GPU->CPU sync + scipy call per frame). */
+ *   ovis_hungarian_link_workspace_bytes(T,Q,C) bytes.  Row normalisation, one batched GEMM for every frame-to-frame
+ *   cosine matrix, T INDEPENDENT single-wavefront Jonker-Volgenant solves (a row permutation of the cost matrix only
+ *   permutes its optimal assignment, so frame t is solved on the un-permuted rows) and one composition of the T
+ *   permutations (the reference does one GPU->CPU sync + scipy call per frame, sequentially). */
 long long ovis_hungarian_link_workspace_bytes(int T, int Q, int C);
 int ovis_hungarian_link_f32(const float* embeds, int* indices, float* workspace, int T, int Q, int C,
                             ovis_stream_t stream);

@@ -4,8 +4,9 @@
 //   cost[i][j] = 1 - <tgt_i/|tgt_i|, cur_j/|cur_j|>,  tgt = embeds[t-1][indices[t-1]] (tgt = embeds[0] for t = 0),
 //   indices[t] = column assignment of scipy.optimize.linear_sum_assignment(cost) (rows = targets, cols = current).
 // The reference syncs to the host and calls scipy once per frame; here all frame-to-frame cosine matrices come from ONE
-// batched MFMA GEMM and the whole sequential assignment chain over T runs in ONE single-wavefront launch, so there is
-// no GPU->CPU round trip per frame.  The assignment is the Jonker-Volgenant shortest-augmenting-path algorithm in the
+// batched MFMA GEMM; because a row permutation of a cost matrix only permutes its optimal assignment, the T assignment
+// problems are solved INDEPENDENTLY (one single-wavefront workgroup per frame, in parallel) on the un-permuted rows and
+// the sequential part shrinks to composing T permutations.  No GPU->CPU round trip per frame.  The assignment is the Jonker-Volgenant shortest-augmenting-path algorithm in the
 // form scipy uses (rectangular_lsap.cpp: dual variables u, v; ties prefer an unassigned column), in f64 like scipy.
 // Also here: the row gather that applies the permutation to per-frame tensors (utils/index.py:4-18 batch_index).
 #include "common.h"
@@ -42,7 +43,7 @@ __device__ __forceinline__ bool lnk_better(double v, int j, int fr, double bv, i
 // latency-bound inner loop never waits on L2.
 template <int NC, bool G_LDS>
 __global__ void __launch_bounds__(64)
-hungarian_chain_kernel(const float* __restrict__ G, int ldg, int* __restrict__ indices, int T, int Q) {
+hungarian_chain_kernel(const float* __restrict__ G, int ldg, int* __restrict__ indices, int T, int Q, int parallel) {
   extern __shared__ double shd[];
   double* u = shd;                                    // [Q] row duals
   int* path = reinterpret_cast<int*>(u + Q);          // [Q] column -> predecessor row
@@ -52,7 +53,9 @@ hungarian_chain_kernel(const float* __restrict__ G, int ldg, int* __restrict__ i
   float* Gs = reinterpret_cast<float*>(prev + Q);     // [Q*ldg] (G_LDS only)
   const int lane = threadIdx.x;
 
-  for (int t = 0; t < T; ++t) {
+  // parallel != 0: workgroup b solves frame b on the UN-permuted rows (see compose_assignments_kernel); else the chain
+  const int t_begin = parallel ? blockIdx.x : 0, t_end = parallel ? blockIdx.x + 1 : T;
+  for (int t = t_begin; t < t_end; ++t) {
     const float* Gt = G + (long long)t * Q * ldg;
     if (G_LDS) {
       const float4* g4 = reinterpret_cast<const float4*>(Gt);
@@ -64,7 +67,7 @@ hungarian_chain_kernel(const float* __restrict__ G, int ldg, int* __restrict__ i
     for (int c = 0; c < NC; ++c) v[c] = 0.0;
     for (int q = lane; q < Q; q += 64) {
       u[q] = 0.0; col4row[q] = -1; row4col[q] = -1;
-      prev[q] = (t == 0) ? q : indices[(t - 1) * Q + q];
+      prev[q] = (t == 0 || parallel) ? q : indices[(t - 1) * Q + q];
     }
     __syncthreads();
     for (int cur_row = 0; cur_row < Q; ++cur_row) {
@@ -132,6 +135,27 @@ hungarian_chain_kernel(const float* __restrict__ G, int ldg, int* __restrict__ i
   }
 }
 
+// A row permutation of the cost matrix only permutes the optimal assignment: cost_t = P_{t-1} C_t with
+// C_t[r][j] = 1 - <e_{t-1,r}, e_{t,j}>, so  assignment_t[i] = sol_t[indices[t-1][i]]  where sol_t solves C_t on the original row
+// order.  The T assignment problems are therefore independent (one workgroup each) and only this trivial composition is
+// sequential in t.  (Identical to the sequential scipy chain whenever every optimum is unique, i.e. for any real data.)
+__global__ void __launch_bounds__(256)
+compose_assignments_kernel(int* __restrict__ indices, int T, int Q) {
+  extern __shared__ int cur[];
+  for (int q = threadIdx.x; q < Q; q += blockDim.x) cur[q] = indices[q];          // t = 0: sol_0 as is
+  __syncthreads();
+  for (int t = 1; t < T; ++t) {
+    int* row = indices + (long long)t * Q;
+    int v[4];
+    int n = 0;
+    for (int q = threadIdx.x; q < Q; q += blockDim.x) v[n++] = row[cur[q]];        // sol_t[indices[t-1][q]]  (Q <= 1024)
+    __syncthreads();
+    n = 0;
+    for (int q = threadIdx.x; q < Q; q += blockDim.x) { row[q] = v[n]; cur[q] = v[n]; ++n; }
+    __syncthreads();
+  }
+}
+
 // out[(b, m), :] = src[(b, idx[b, m]), :]   rows of `len` floats; element (b,n) of src at src + b*src_bs + n*src_rs
 __global__ void __launch_bounds__(256)
 batch_index_rows_kernel(const float* __restrict__ src, long long src_bs, long long src_rs, const int* __restrict__ idx,
@@ -177,12 +201,15 @@ extern "C" int ovis_hungarian_link_f32(const float* embeds, int* indices, float*
   }
   const size_t base = sizeof(double) * Q + sizeof(int) * 4 * Q;
   if (Q <= 112)        // 112*112*4 = 50 KB of LDS for the staged cosine matrix
-    hipLaunchKernelGGL((hungarian_chain_kernel<2, true>), dim3(1), dim3(64), base + sizeof(float) * Q * ldg, s, G, ldg, indices, T, Q);
+    hipLaunchKernelGGL((hungarian_chain_kernel<2, true>), dim3(T), dim3(64), base + sizeof(float) * Q * ldg, s, G, ldg, indices, T, Q, 1);
   else if (Q <= 256)
-    hipLaunchKernelGGL((hungarian_chain_kernel<4, false>), dim3(1), dim3(64), base, s, G, ldg, indices, T, Q);
+    hipLaunchKernelGGL((hungarian_chain_kernel<4, false>), dim3(T), dim3(64), base, s, G, ldg, indices, T, Q, 1);
   else
-    hipLaunchKernelGGL((hungarian_chain_kernel<16, false>), dim3(1), dim3(64), base, s, G, ldg, indices, T, Q);
-  return ovis::check_launch("hungarian_link chain");
+    hipLaunchKernelGGL((hungarian_chain_kernel<16, false>), dim3(T), dim3(64), base, s, G, ldg, indices, T, Q, 1);
+  rc = ovis::check_launch("hungarian_link solve");
+  if (rc) return rc;
+  hipLaunchKernelGGL(compose_assignments_kernel, dim3(1), dim3(256), sizeof(int) * Q, s, indices, T, Q);
+  return ovis::check_launch("hungarian_link compose");
 }
 
 extern "C" int ovis_batch_index_rows_f32(const float* src, long long src_bs, long long src_rs, const int* idx, float* out,
