@@ -273,3 +273,33 @@ def test_msda_encoder_tiled_lds_kernel_is_identical_to_direct_gather(sizes, scal
             assert torch.equal(plain, tiled), radius
     finally:
         ops.MSDA_TILE_RADIUS = old
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("fp16", 3e-2)])
+def test_clip_patch14_tower_and_crops_vs_oracle(precision, tol):
+    """ViT-L/14-style geometry: patch 14 -> 588-column patch rows, padded to 592 (ops.patch_row_len) for 16-byte fp16 rows;
+    crops (ClipAdapter) and the tower against the oracle at a small resolution (56 = 4 x 14)."""
+    from openvis_amd import ops, weights
+    from openvis_amd.modeling.clip_adapter.adapter import ClipAdapter
+    from oracle import torch_ref as TR
+    arch = dict(width=256, layers=2, heads=4, patch=14, resolution=56, embed_dim=64)
+    sd = weights.random_init(weights.clip_visual_spec(**arch), seed=31)
+    ad = ClipAdapter("tiny14", arch=arch, precision=precision).load_state_dict(sd, "clip_adapter.", "cuda")
+    assert ops.patch_row_len(14) == 592
+    g = torch.Generator().manual_seed(2)
+    T, Q, H, W = 2, 5, 70, 90
+    Hp, Wp = 96, 96
+    frames = (torch.rand(T, 3, H, W, generator=g) * 255).to(torch.uint8)
+    masks = torch.randn(Q, T, Hp // 4, Wp // 4, generator=g) * 3
+    names = [f"c{i}" for i in range(6)]
+    text = torch.nn.functional.normalize(torch.randn(6, 64, generator=g), dim=-1)
+    ad.set_text_features(names, text)
+    logits, valid, crops = ad(frames.cuda(), names, masks.cuda(), (Hp, Wp))
+    up = torch.nn.functional.interpolate(masks, size=(Hp, Wp), mode="bilinear", align_corners=False)
+    part = up.sigmoid().transpose(0, 1).contiguous()                            # [T,Q,Hp,Wp]
+    with torch.no_grad():
+        regions, v2, _ = TR.clip_crops(frames, part, resolution=56)
+        feat = TR.clip_encode_image(regions, sd, resolution=56, heads=4)
+        ref = 100.0 * feat @ text.T
+    assert (valid == v2.numpy()).all()
+    assert (logits.cpu() - ref).abs().max().item() < tol * 100, (logits.cpu() - ref).abs().max().item()
