@@ -218,3 +218,32 @@ def test_san_offline_end_to_end(policy):
         sg = {(q, l) for q, l in zip(out["pred_queries"], out["pred_labels"])}
         sr = {(q, l) for q, l in zip(ref["rows"], ref["pred_labels"])}
         assert len(sg & sr) >= 8
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 3e-4), ("fp16", 3e-2)])
+def test_side_adapter_patch14_front_and_back_vs_oracle(precision, tol):
+    """SideAdapter with a ViT-L/14-style patch size (588-column patch rows padded to 592): front features, the attention
+    bias path and the SOS embeddings against the oracle."""
+    from openvis_amd import weights
+    from openvis_amd.modeling.clip_adapter.side_adapter import SideAdapter
+    from oracle import torch_ref as TR
+    arch = dict(width=256, layers=4, heads=4, patch=14, resolution=56, embed_dim=64)
+    Q, T = 10, 2
+    sd = weights.random_init(weights.side_adapter_spec(**arch), seed=33)
+    ad = SideAdapter("tiny14", broken_idx=3, merge_ids=[1, 2, 3], num_queries=Q, arch=arch, precision=precision)
+    ad.load_state_dict(sd, "clip_adapter.", "cuda")
+    g = torch.Generator().manual_seed(4)
+    frames = (torch.rand(T, 3, 50, 70, generator=g) * 255).to(torch.uint8)
+    Hp, Wp = 64, 96
+    ori = torch.zeros(T, 3, Hp, Wp)
+    ori[:, :, :50, :70] = frames.float()
+    mg, tok = ad.front_encode_image(frames.cuda(), (Hp, Wp))
+    with torch.no_grad():
+        mg_r, bk_r = TR.san_front_encode_image(ori, sd, broken_idx=3, merge_ids=(1, 2, 3), resolution=56)
+    for a, b in zip(mg, mg_r):
+        assert (a.permute(0, 3, 1, 2).cpu() - b).abs().max().item() < tol * max(1.0, b.abs().max().item())
+    biases = torch.randn(T, 4, Q, 5, 7, generator=g)
+    sos = ad.post_encode_image(tok, biases.cuda())
+    with torch.no_grad():
+        sos_r = TR.san_post_encode_image(bk_r, biases, sd, broken_idx=3, num_sos=Q)
+    assert (sos.cpu() - sos_r).abs().max().item() < tol
