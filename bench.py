@@ -256,6 +256,30 @@ def main():
                 "all_gemm_kernels": {k: {"launches": v[0], "ms": round(v[2] * 1e3, 3), "TFLOPs": round(v[1] / v[2] / 1e12, 1)}
                                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}}
 
+    # stage breakdown (untimed extra pass, OpenVIS only): wall time of each stage with a device sync after it
+    stage_ms = None
+    if args.model == "openvis" and world == 1:
+        def _t(fn):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize()
+            return r, (time.perf_counter() - t) * 1e3
+        m = _model
+        inp = inputs[0]
+        names = m.get_class_name_list(inp[0]["dataset_name"])
+        frames, t_in = _t(lambda: m._frames_to_device(inp))
+        (images, image_size, padded), t_a1 = _t(lambda: m.preprocess(frames))
+        feats, t_a2 = _t(lambda: m.backbone(images))
+        (mf_out), t_a36 = _t(lambda: m.sem_seg_head.pixel_decoder.forward_features(feats))
+        outs, t_a78 = _t(lambda: m.sem_seg_head.predictor(mf_out[2], mf_out[0]))
+        (probs, row_ids, _e), t_clip = _t(lambda: m.open_vocabulary_inference(outs["pred_logits"][0], outs["pred_masks"][0], frames, names, padded))
+        _, t_out = _t(lambda: m.inference_video(m.num_queries, len(names), probs, row_ids, outs["pred_masks"][0], padded, image_size,
+                                                 image_size[0], image_size[1]))
+        stage_ms = {"A1_preprocess": round(t_a1, 2), "A2_backbone": round(t_a2, 2), "A3-A6_pixel_decoder": round(t_a36, 2),
+                    "A7-A8_decoder": round(t_a78, 2), "A9-A12_boxes_crops_clip_logits": round(t_clip, 2),
+                    "A16_topk_masks_d2h": round(t_out, 2)}
+
     bb_name = {"r50": "R50", "swin_l": "Swin-L"}[MODELS[args.model].get("backbone", "r50")]
     # K1 (deformable sampling): HBM roofline of the gather kernel, same live HIP-event measurement
     roofline_k1 = None
@@ -295,7 +319,7 @@ def main():
                                        if _model.clip_adapter.precision == "fp16" else "f32"),
                        "valid_crops_per_clip": n_valid,
                        "parallelism": (f"frame-sharded x{world} + RCCL all-gather" if frame_sharded else f"clip-replicas x{world}")},
-            "roofline": roofline, "roofline_k1": roofline_k1,
+            "roofline": roofline, "roofline_k1": roofline_k1, "stage_ms": stage_ms,
         }
         if not args.no_cpu_baseline and world == 1 and args.model == "openvis":
             line["cpu_baseline"] = cpu_baseline(sd, text)
