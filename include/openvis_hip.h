@@ -218,7 +218,8 @@ int ovis_openvis_aggregate_f32(const float* crop_logits, const int* slot, float*
 /* top-k over the flattened probabilities of rows row_ids (flat index = i*K + k over the compacted rows) + entropy
  *   of the selected rows (video_maskformer.py:267-272). */
 int ovis_topk_entropy_f32(const float* probs, const int* row_ids, int nrows, int K, int topk, int* out_idx,
-                          float* out_score, float* out_entropy, ovis_stream_t stream);
+                          float* out_score, float* out_entropy, int* out_query /* row_ids[idx / K], may be NULL */,
+                          ovis_stream_t stream);
 /* final masks of the selected queries (openvis.py:87-96 + video_maskformer.py:273-278): out uint8 [n_sel,T,OH,OW], or
  * [n_sel,T,OW,OH] when column_major != 0 (the order in which COCO RLE scans a mask, see ovis_rle_encode_u8). */
 int ovis_final_masks_u8(const float* masks, const int* sel_q, uint8_t* out, int n_sel, int Q, int T, int h, int w, int Hp,

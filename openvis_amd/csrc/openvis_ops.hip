@@ -707,7 +707,8 @@ openvis_aggregate_kernel(const float* __restrict__ crop_logits, const int* __res
 // (video_maskformer.py:267-272).  row_ids [nrows] = rows of `probs` that take part.  Single workgroup.
 __global__ void __launch_bounds__(1024)
 topk_entropy_kernel(const float* __restrict__ probs, const int* __restrict__ row_ids, int nrows, int K, int topk,
-                    int* __restrict__ out_idx, float* __restrict__ out_score, float* __restrict__ out_entropy) {
+                    int* __restrict__ out_idx, float* __restrict__ out_score, float* __restrict__ out_entropy,
+                    int* __restrict__ out_query) {
   __shared__ float bv[1024];
   __shared__ long long bi[1024];
   __shared__ long long chosen[64];
@@ -733,7 +734,10 @@ topk_entropy_kernel(const float* __restrict__ probs, const int* __restrict__ row
       }
       __syncthreads();
     }
-    if (threadIdx.x == 0) { chosen[j] = bi[0]; out_idx[j] = (int)bi[0]; out_score[j] = bv[0]; }
+    if (threadIdx.x == 0) {
+      chosen[j] = bi[0]; out_idx[j] = (int)bi[0]; out_score[j] = bv[0];
+      if (out_query) out_query[j] = row_ids[bi[0] / K];          // query id of the selected row: lets the mask kernel start
+    }                                                             // without a host round trip
     __syncthreads();
   }
   // entropy of each selected row: -sum p log p
@@ -944,11 +948,11 @@ extern "C" int ovis_openvis_aggregate_f32(const float* crop_logits, const int* s
 }
 
 extern "C" int ovis_topk_entropy_f32(const float* probs, const int* row_ids, int nrows, int K, int topk, int* out_idx,
-                                     float* out_score, float* out_entropy, ovis_stream_t stream) {
+                                     float* out_score, float* out_entropy, int* out_query, ovis_stream_t stream) {
   OVIS_REQUIRE(probs && row_ids && out_idx && out_score && out_entropy, "topk_entropy: null pointer");
   OVIS_REQUIRE(nrows > 0 && K > 0 && topk > 0 && topk <= 64 && (long long)nrows * K >= topk, "topk_entropy: need 0 < topk <= min(64, nrows*K)");
   hipLaunchKernelGGL(topk_entropy_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, probs, row_ids, nrows, K, topk, out_idx,
-                     out_score, out_entropy);
+                     out_score, out_entropy, out_query);
   return ovis::check_launch("topk_entropy");
 }
 

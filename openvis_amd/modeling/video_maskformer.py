@@ -69,11 +69,9 @@ class VideoMaskFormer:
         dev = probs.device
         K = probs.shape[1]
         rid = torch.as_tensor(row_ids, dtype=torch.int32, device=dev)
-        idx, score, ent = ops.topk_entropy(probs, rid, topk)                  # raises if rows*K < topk (as torch.topk)
-        idx_h = idx.cpu().tolist()
-        labels = [i % K for i in idx_h]
-        rows = [i // K for i in idx_h]
-        sel_q = torch.as_tensor([int(row_ids[r]) for r in rows], dtype=torch.int32, device=dev)
+        # the kernel also emits the query id of every selected row, so the mask kernels are launched without waiting for
+        # the host to read the indices back (the reference syncs on .tolist() here, video_maskformer.py:267-272)
+        idx, score, ent, sel_q = ops.topk_entropy(probs, rid, topk)          # raises if rows*K < topk (as torch.topk)
         Q, T, h, w = pred_masks_lowres.shape
         if self.output_rle:
             # hand the evaluator COCO RLE instead of dense masks -- the masks are produced column-major
@@ -83,9 +81,10 @@ class VideoMaskFormer:
             cm = ops.final_masks(pred_masks_lowres, sel_q, padded_hw[0], padded_hw[1], img_size[0], img_size[1],
                                  output_height, output_width, column_major=True)
             counts, n_runs = ops.rle_encode(cm.view(-1, output_height * output_width))
+            labels = [i % K for i in idx.cpu().tolist()]
             return {"image_size": (output_height, output_width), "pred_entropys": ent.cpu().tolist(),
                     "pred_scores": score.cpu().tolist(), "pred_labels": labels,
-                    "pred_masks_rle": rle.encode_video_masks(counts, n_runs, len(rows), T, output_height, output_width),
+                    "pred_masks_rle": rle.encode_video_masks(counts, n_runs, topk, T, output_height, output_width),
                     "pred_queries": sel_q.cpu().tolist()}
         masks = ops.final_masks(pred_masks_lowres, sel_q, padded_hw[0], padded_hw[1], img_size[0], img_size[1],
                                 output_height, output_width)
@@ -95,6 +94,7 @@ class VideoMaskFormer:
         host.copy_(masks, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         masks_cpu = host.view(torch.bool)
+        labels = [i % K for i in idx.cpu().tolist()]                          # video_maskformer.py:269-270
         return {"image_size": (output_height, output_width), "pred_entropys": ent.cpu().tolist(),
                 "pred_scores": score.cpu().tolist(), "pred_labels": labels, "pred_masks": [m for m in masks_cpu],
                 "pred_queries": sel_q.cpu().tolist()}

@@ -445,8 +445,9 @@ def topk_entropy(probs, row_ids, topk):
     idx = torch.empty((topk,), dtype=torch.int32, device=probs.device)
     score = torch.empty((topk,), dtype=torch.float32, device=probs.device)
     ent = torch.empty((topk,), dtype=torch.float32, device=probs.device)
-    _lib.call("ovis_topk_entropy_f32", probs, row_ids, row_ids.numel(), K, topk, idx, score, ent, _lib.stream_ptr())
-    return idx, score, ent
+    sel_q = torch.empty((topk,), dtype=torch.int32, device=probs.device)
+    _lib.call("ovis_topk_entropy_f32", probs, row_ids, row_ids.numel(), K, topk, idx, score, ent, sel_q, _lib.stream_ptr())
+    return idx, score, ent, sel_q
 
 
 def final_masks(masks, sel_q, Hp, Wp, H, W, OH, OW, column_major=False):

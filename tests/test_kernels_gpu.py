@@ -241,7 +241,8 @@ def test_aggregate_topk():
     ref = torch.stack([logits[ids[:, 1] == q].mean(0) for q in vq]).softmax(-1)
     assert torch.equal(qv.cpu().bool(), valid.any(0))
     assert (probs.cpu()[vq] - ref).abs().max() < 1e-6
-    idx, score, ent = ops.topk_entropy(probs, vq.int().cuda(), 10)
+    idx, score, ent, sel_q = ops.topk_entropy(probs, vq.int().cuda(), 10)
+    assert torch.equal(sel_q.cpu().long(), vq[(idx.cpu().long() // probs.shape[1])].long())
     rs, ri = ref.flatten().topk(10)
     assert set(idx.cpu().tolist()) == set(ri.tolist())
     ent_ref = {int(i): float((-ref[i // K] * ref[i // K].log()).sum()) for i in ri}
