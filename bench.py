@@ -259,12 +259,16 @@ def main():
     # stage breakdown (untimed extra pass, OpenVIS only): wall time of each stage with a device sync after it
     stage_ms = None
     if args.model == "openvis" and world == 1:
-        def _t(fn):
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            r = fn()
-            torch.cuda.synchronize()
-            return r, (time.perf_counter() - t) * 1e3
+        def _t(fn, reps=3):                                   # best of 3: the pass is outside the timed region
+            best, r = None, None
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                r = fn()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t) * 1e3
+                best = dt if best is None else min(best, dt)
+            return r, best
         m = _model
         inp = inputs[0]
         names = m.get_class_name_list(inp[0]["dataset_name"])
