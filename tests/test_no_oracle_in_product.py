@@ -11,6 +11,7 @@ def _sources():
             if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
                 yield os.path.join(d, f)
     yield os.path.join(ROOT, "MultiScaleDeformableAttention.py")
+    yield os.path.join(ROOT, "train_net.py")
 
 
 def test_product_does_not_touch_oracle_or_reference():
@@ -20,3 +21,12 @@ def test_product_does_not_touch_oracle_or_reference():
         if re.search(r"^\s*(from|import)\s+oracle\b", s, re.M) or "liboracle" in s or "/root/reference" in s:
             bad.append(p)
     assert not bad, bad
+
+
+def test_bench_uses_the_oracle_only_in_the_cpu_baseline_leg():
+    s = open(os.path.join(ROOT, "bench.py")).read()
+    hits = [m.start() for m in re.finditer(r"^\s*(from|import)\s+oracle\b", s, re.M)]
+    assert len(hits) == 1
+    start = s.index("def cpu_baseline(")
+    end = s.index("\ndef ", start + 1)
+    assert start < hits[0] < end                      # the timed path never touches the oracle
