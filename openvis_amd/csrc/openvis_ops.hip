@@ -75,45 +75,54 @@ msda_encoder_fused_kernel(const float* __restrict__ value, const float* __restri
   }
   const float* op = oa + bs * ld_oa + m * (L * P * 2);
   const float* ap = oa + bs * ld_oa + M * L * P * 2 + m * (L * P);
-  float lg[L * P];
+  // softmax statistics first; the weights are re-derived where they are used so that nothing has to be kept in an
+  // indexed array (which the compiler parks in scratch as soon as it does not fully unroll the sampling loops)
   float mx = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < L * P; ++i) { lg[i] = ap[i]; mx = fmaxf(mx, lg[i]); }
+  for (int i = 0; i < L * P; ++i) mx = fmaxf(mx, ap[i]);
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < L * P; ++i) { lg[i] = expf(lg[i] - mx); sum += lg[i]; }
+  for (int i = 0; i < L * P; ++i) sum += __builtin_amdgcn_exp2f((ap[i] - mx) * 1.4426950408889634f);   // v_exp_f32 (1 ulp)
+  const float rsum = 1.f / sum;
 
   const float* vbase = value + b * (long long)S * qid_stride + m * D + cv * 4;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int l = 0; l < L; ++l) {
     const int H = Hs[l], W = Ws[l];
+    const float rW = 1.f / (float)W, rH = 1.f / (float)H;
     const float* vp = vbase + (long long)starts[l] * qid_stride;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      const float loc_w = refx + op[(l * P + p) * 2] / (float)W;
-      const float loc_h = refy + op[(l * P + p) * 2 + 1] / (float)H;
-      const float weight = lg[l * P + p] / sum;
+      const float loc_w = refx + op[(l * P + p) * 2] * rW;            // off / W as off * (1 / W): one division per level
+      const float loc_h = refy + op[(l * P + p) * 2 + 1] * rH;
+      const float weight = __builtin_amdgcn_exp2f((ap[l * P + p] - mx) * 1.4426950408889634f) * rsum;
       const float h_im = loc_h * (float)H - 0.5f;
       const float w_im = loc_w * (float)W - 0.5f;
-      if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
-        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      {
+        // BRANCH-FREE taps: clamped addresses + selects.  Predicated loads compile to exec-masked branches with their own
+        // s_waitcnt, which serialises the four gathers of a point; unconditional loads let all taps of a level be in flight.
+        const bool in = h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const int h_low = in ? (int)hf : 0, w_low = in ? (int)wf : 0;
         const int h_high = h_low + 1, w_high = w_low + 1;
-        const float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
-        const long long h_stride = (long long)W * qid_stride;
-        const float* r0 = vp + h_low * h_stride;
-        const float* r1 = r0 + h_stride;
-        float4 v1 = make_float4(0, 0, 0, 0), v2 = v1, v3 = v1, v4 = v1;
-        if (h_low >= 0 && w_low >= 0) v1 = *reinterpret_cast<const float4*>(r0 + (long long)w_low * qid_stride);
-        if (h_low >= 0 && w_high <= W - 1) v2 = *reinterpret_cast<const float4*>(r0 + (long long)w_high * qid_stride);
-        if (h_high <= H - 1 && w_low >= 0) v3 = *reinterpret_cast<const float4*>(r1 + (long long)w_low * qid_stride);
-        if (h_high <= H - 1 && w_high <= W - 1) v4 = *reinterpret_cast<const float4*>(r1 + (long long)w_high * qid_stride);
-        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        const float lh = h_im - hf, lw = w_im - wf, hh = 1 - lh, hw = 1 - lw;
+        const bool t1 = in && h_low >= 0 && w_low >= 0, t2 = in && h_low >= 0 && w_high <= W - 1;
+        const bool t3 = in && h_high <= H - 1 && w_low >= 0, t4 = in && h_high <= H - 1 && w_high <= W - 1;
+        const int yl = max(h_low, 0), yh = min(h_high, H - 1), xl = max(w_low, 0), xh = min(w_high, W - 1);
+        const float4 v1 = *reinterpret_cast<const float4*>(vp + (yl * W + xl) * qid_stride);
+        const float4 v2 = *reinterpret_cast<const float4*>(vp + (yl * W + xh) * qid_stride);
+        const float4 v3 = *reinterpret_cast<const float4*>(vp + (yh * W + xl) * qid_stride);
+        const float4 v4 = *reinterpret_cast<const float4*>(vp + (yh * W + xh) * qid_stride);
+        // a tap outside the map contributes 0: its WEIGHT is zeroed (one select per tap; the value read at the clamped
+        // address is finite data).  (A 128-bit value select is lowered through scratch memory by hipcc -- measured 7x slower.)
+        const float w1 = t1 ? hh * hw : 0.f, w2 = t2 ? hh * lw : 0.f, w3 = t3 ? lh * hw : 0.f, w4 = t4 ? lh * lw : 0.f;
         acc[0] += (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) * weight;
         acc[1] += (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) * weight;
         acc[2] += (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) * weight;
         acc[3] += (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w) * weight;
       }
+      if (p == P - 1) __builtin_amdgcn_sched_barrier(0);   // one level's 16 taps in flight at a time (registers / occupancy; measured best)
     }
   }
   *reinterpret_cast<float4*>(out + sidx * D + cv * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -187,12 +196,14 @@ msda_encoder_tiled_kernel(const float* __restrict__ value, const float* __restri
   for (int i = 0; i < L * P; ++i) { lg[i] = ap[i]; mx = fmaxf(mx, lg[i]); }
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < L * P; ++i) { lg[i] = expf(lg[i] - mx); sum += lg[i]; }
+  for (int i = 0; i < L * P; ++i) { lg[i] = __builtin_amdgcn_exp2f((lg[i] - mx) * 1.4426950408889634f); sum += lg[i]; }   // v_exp_f32 (1 ulp)
+  const float rsum = 1.f / sum;
 
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int l = 0; l < L; ++l) {
     const int H = g.H[l], W = g.W[l];
+    const float rW = 1.f / (float)W, rH = 1.f / (float)H;
     const float* vp = vb + (long long)g.start[l] * qid_stride;
     const float* wl = win + g.base[l] + cv * 4;
     const int wh = g.wh[l], ww = g.ww[l], oy = loy[l], ox = lox[l];
@@ -204,9 +215,9 @@ msda_encoder_tiled_kernel(const float* __restrict__ value, const float* __restri
     };
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      const float loc_w = refx + op[(l * P + p) * 2] / (float)W;
-      const float loc_h = refy + op[(l * P + p) * 2 + 1] / (float)H;
-      const float weight = lg[l * P + p] / sum;
+      const float loc_w = refx + op[(l * P + p) * 2] * rW;            // off / W as off * (1 / W): one division per level
+      const float loc_h = refy + op[(l * P + p) * 2 + 1] * rH;
+      const float weight = lg[l * P + p] * rsum;
       const float h_im = loc_h * (float)H - 0.5f;
       const float w_im = loc_w * (float)W - 0.5f;
       if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
