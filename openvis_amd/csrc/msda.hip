@@ -32,14 +32,17 @@ template <typename T> __device__ __forceinline__ T tfloor(T x);
 template <> __device__ __forceinline__ float tfloor<float>(float x) { return floorf(x); }
 template <> __device__ __forceinline__ double tfloor<double>(double x) { return floor(x); }
 
+// BRANCH-FREE tap: the caller passes an address that is always valid (clamped); `pred` only selects value or zero.
+// (A predicated load compiles to an exec-masked branch with its own s_waitcnt, which serialises the four gathers of a
+// point; per-component selects keep all four in flight.  Results are unchanged bit for bit.)
 template <typename T, int VEC>
 __device__ __forceinline__ void load_vec(T (&v)[VEC], const T* p, bool pred) {
   if constexpr (VEC == 4) {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pred) t = *reinterpret_cast<const float4*>(p);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = pred ? t.x : 0.f; v[1] = pred ? t.y : 0.f; v[2] = pred ? t.z : 0.f; v[3] = pred ? t.w : 0.f;
   } else {
-    v[0] = pred ? p[0] : T(0);
+    const T t = p[0];
+    v[0] = pred ? t : T(0);
   }
 }
 
@@ -55,13 +58,15 @@ __device__ __forceinline__ void sample_point(T (&acc)[VEC], const T* vp, int H, 
     const T lh = h_im - h_low, lw = w_im - w_low;
     const T hh = 1 - lh, hw = 1 - lw;
     const long long h_stride = (long long)W * qid_stride;
-    const T* r0 = vp + h_low * h_stride;
-    const T* r1 = r0 + h_stride;
+    const int yl = h_low < 0 ? 0 : h_low, yh = h_high > H - 1 ? H - 1 : h_high;       // clamped (always valid) tap coordinates
+    const int xl = w_low < 0 ? 0 : w_low, xh = w_high > W - 1 ? W - 1 : w_high;
+    const T* r0 = vp + yl * h_stride;
+    const T* r1 = vp + yh * h_stride;
     T v1[VEC], v2[VEC], v3[VEC], v4[VEC];
-    load_vec<T, VEC>(v1, r0 + (long long)w_low * qid_stride, h_low >= 0 && w_low >= 0);
-    load_vec<T, VEC>(v2, r0 + (long long)w_high * qid_stride, h_low >= 0 && w_high <= W - 1);
-    load_vec<T, VEC>(v3, r1 + (long long)w_low * qid_stride, h_high <= H - 1 && w_low >= 0);
-    load_vec<T, VEC>(v4, r1 + (long long)w_high * qid_stride, h_high <= H - 1 && w_high <= W - 1);
+    load_vec<T, VEC>(v1, r0 + (long long)xl * qid_stride, h_low >= 0 && w_low >= 0);
+    load_vec<T, VEC>(v2, r0 + (long long)xh * qid_stride, h_low >= 0 && w_high <= W - 1);
+    load_vec<T, VEC>(v3, r1 + (long long)xl * qid_stride, h_high <= H - 1 && w_low >= 0);
+    load_vec<T, VEC>(v4, r1 + (long long)xh * qid_stride, h_high <= H - 1 && w_high <= W - 1);
     const T w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
