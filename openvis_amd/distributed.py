@@ -68,14 +68,21 @@ def all_gather_frames(local, total_frames):
     tmax = max(sizes)
     pad = local.new_zeros((tmax,) + tuple(local.shape[1:]))
     pad[: local.shape[0]] = local
+    dev = local.device
+    if dist.get_backend() == "gloo" and local.is_cuda:          # test rigs without RCCL: stage through the host
+        pad = pad.cpu()
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad.contiguous())
-    return torch.cat([o[:n] for o, n in zip(out, sizes)], dim=0)
+    return torch.cat([o[:n] for o, n in zip(out, sizes)], dim=0).to(dev)
 
 
 def all_reduce_sum(t):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
+        if dist.get_backend() == "gloo" and t.is_cuda:          # test rigs without RCCL: stage through the host
+            h = t.cpu().contiguous()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            return h.to(t.device)
         t = t.contiguous()
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t

@@ -1,0 +1,47 @@
+"""Worker of tests/test_sharded_gpu.py: one rank of a frame-sharded BriVIS run (gloo rendezvous, all ranks on cuda:0 --
+the GPU box has one device; the exchange logic is what is under test, RCCL itself is the driver's multi-GPU bench)."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_path = sys.argv[1]
+    import bench
+    from openvis_amd import config, weights, distributed as D
+    from openvis_amd.catalog import MetadataCatalog
+    from openvis_amd.modeling.clip_adapter.side_adapter import SideAdapter
+    rank, world, _ = D.init_from_env("gloo")
+    torch.cuda.set_device(0)
+    arch = dict(width=256, layers=4, heads=4, patch=16, resolution=64, embed_dim=64)
+    K, T = 7, 7
+    names = [f"class_{i}" for i in range(K)]
+    MetadataCatalog.get("synthetic_shard").set(thing_classes=names)
+    cfg = config.get_cfg()
+    cfg.MODEL.META_ARCHITECTURE = "BriVIS"
+    cfg.MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME = "SideAdapterFrameMultiScaleMaskedTransformerDecoder"
+    cfg.MODEL.CLIP_ADAPTER.CLIP_NUM_HEADS = 4
+    cfg.MODEL.PRECISION = "fp32"
+    model = config.build_model(cfg)
+    model.clip_adapter = SideAdapter("tiny", broken_idx=3, merge_ids=[1, 2, 3], num_queries=100, arch=arch, precision="fp32")
+    model.load_state_dict(weights.random_init(weights.brivis_spec("r50", arch, 100), seed=5))
+    model.clip_adapter.set_text_features(names, bench.synth_text(K, 64))
+    frames = bench.synth_frames(T, 90, 120, 3, "cpu")
+    inp = [{"image": [f for f in frames], "dataset_name": "synthetic_shard"}]
+    fr = D.inference_shard(T, rank, world)
+    st = {}
+    out = model(inp, stages=st, frame_range=(fr.start, fr.stop) if world > 1 else None)
+    res = {"rank": rank, "world": world, "range": [fr.start, fr.stop], "labels": out["pred_labels"], "scores": out["pred_scores"],
+           "queries": out["pred_queries"], "indices": st["indices"].cpu().tolist(), "probs": st["probs"].cpu().tolist(),
+           "mask_sums": [int(m.sum()) for m in out["pred_masks"]], "mask_shape": list(out["pred_masks"][0].shape)}
+    json.dump(res, open(f"{out_path}.{rank}", "w"))
+    D.barrier()
+
+
+if __name__ == "__main__":
+    main()

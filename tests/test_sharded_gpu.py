@@ -1,0 +1,39 @@
+"""GPU: frame-sharded BriVIS (BASELINE configs[3]) with TWO ranks equals the single-rank run: same linker
+indices, class probabilities and top-10; each rank returns the masks of its own frames.  (gloo rendezvous, both ranks on
+cuda:0: the box has one GPU; RCCL itself is exercised by the driver's multi-GPU bench.)"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(world, out, port):
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_brivis_sharded_worker.py"), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-3000:]
+    return [json.load(open(f"{out}.{r}")) for r in range(world)]
+
+
+def test_two_rank_frame_sharded_brivis_equals_single_rank(tmp_path):
+    single = _run(1, str(tmp_path / "single"), 29641)[0]
+    two = _run(2, str(tmp_path / "two"), 29642)
+    assert two[0]["range"] == [0, 4] and two[1]["range"] == [4, 7]                  # InferenceSampler layout of 7 frames
+    for r in two:
+        assert r["indices"] == single["indices"]                                      # replicated linker: identical tracks
+        assert np.abs(np.array(r["probs"]) - np.array(single["probs"])).max() < 1e-5  # all-reduced logit sums
+        assert r["labels"] == single["labels"] and r["queries"] == single["queries"]
+        assert np.abs(np.array(r["scores"]) - np.array(single["scores"])).max() < 1e-5
+    assert two[0]["mask_shape"][0] == 4 and two[1]["mask_shape"][0] == 3 and single["mask_shape"][0] == 7
+    # the union of the ranks' masks is the single-rank result (pixel counts per instance add up)
+    assert [a + b for a, b in zip(two[0]["mask_sums"], two[1]["mask_sums"])] == single["mask_sums"]
