@@ -173,9 +173,12 @@ def main():
     args = ap.parse_args()
 
     from openvis_amd import distributed as D
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    rank, world, local_rank = D.init_from_env("nccl")              # "nccl" is RCCL on ROCm
-    device = torch.device("cuda", local_rank)
+    # OVIS_BENCH_TEST_RIG=1 (tests only): all ranks on cuda:0 with a gloo rendezvous, to exercise the N > 1 control flow on a
+    # one-GPU box; the driver's multi-GPU runs use one GPU per rank over RCCL
+    rig = os.environ.get("OVIS_BENCH_TEST_RIG") == "1"
+    torch.cuda.set_device(0 if rig else int(os.environ.get("LOCAL_RANK", "0")))
+    rank, world, local_rank = D.init_from_env("gloo" if rig else "nccl")   # "nccl" is RCCL on ROCm
+    device = torch.device("cuda", 0 if rig else local_rank)
 
     from openvis_amd import ops
     model, sd, text = build_model(device, clip_precision=args.clip_precision, precision=args.precision, model_name=args.model)
@@ -211,7 +214,7 @@ def main():
         out = model(inputs[i % len(inputs)])
     sync_all()
     elapsed = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed, device)
+    elapsed = D.max_over_ranks(elapsed, "cpu" if rig else device)
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream -----------
     # one extra (untimed) step with per-launch events around every f32-MFMA GEMM launch

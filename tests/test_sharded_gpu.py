@@ -37,3 +37,24 @@ def test_two_rank_frame_sharded_brivis_equals_single_rank(tmp_path):
     assert two[0]["mask_shape"][0] == 4 and two[1]["mask_shape"][0] == 3 and single["mask_shape"][0] == 7
     # the union of the ranks' masks is the single-rank result (pixel counts per instance add up)
     assert [a + b for a, b in zip(two[0]["mask_sums"], two[1]["mask_sums"])] == single["mask_sums"]
+
+
+@pytest.mark.parametrize("model,scaling", [("openvis", "weak"), ("brivis", "strong")])
+def test_bench_multi_rank_control_flow(model, scaling, tmp_path):
+    """bench.py with WORLD_SIZE=2 (test rig: both ranks on cuda:0, gloo): rank 0 prints ONE JSON line with n_gpus = 2."""
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="29651",
+                   OVIS_BENCH_TEST_RIG="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                       "--model", model, "--frames", "6" if model == "brivis" else "0"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=900)
+        assert p.returncode == 0, e[-3000:]
+        outs.append([l for l in o.splitlines() if l.startswith("{")])
+    assert len(outs[0]) == 1 and len(outs[1]) == 0
+    d = json.loads(outs[0][0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == scaling and d["value"] > 0
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and "roofline" in d
