@@ -72,11 +72,10 @@ class BriVIS(SANOnline):
         if not sharded:
             return self.classify(logits.unsqueeze(0))
         t, Q, K1 = logits.shape
-        # sum over local frames (mean x t) -> all-reduce -> / T_total -> softmax: re-use the aggregate kernel on the sums
-        slot = torch.arange(t * Q, dtype=torch.int32, device=logits.device).view(t, Q)
-        _ = slot
-        local_sum = logits.sum(dim=0)                                                     # [Q,K+1] (tiny reduction)
-        total = D.all_reduce_sum(local_sum) / float(T_total)
+        # mean over the local frames (kernel) weighted by the shard's share of the clip -> all-reduce = mean over ALL frames
+        # -> softmax through the aggregate kernel.  The weighting is one elementwise scale of a [Q,K+1] tensor.
+        local = ops.mean_over_dim0(logits.contiguous()) * (float(t) / float(T_total))
+        total = D.all_reduce_sum(local)
         one = torch.arange(Q, dtype=torch.int32, device=logits.device).view(1, Q)
         probs, _ = ops.openvis_aggregate(total.contiguous(), one)
         return probs[:, :-1].contiguous()
