@@ -28,7 +28,10 @@ class MSDeformAttn:
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
-        """General (drop-in) path: explicit reference points, un-fused op call (ms_deform_attn.py:82-125)."""
+        """General (drop-in) path: explicit reference points, un-fused op call (ms_deform_attn.py:82-125).  The projections
+        and the sampling run on the HIP kernels; the 12-way softmax and `loc = ref + off / (W, H)` are plain torch
+        elementwise ops on the device here (this generic entry is not on the model's path: the encoder uses
+        forward_encoder_fused, where both are fused into the sampling kernel)."""
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == Len_in
