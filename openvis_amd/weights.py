@@ -253,3 +253,18 @@ def random_init(spec, seed=42):
             t = torch.randn(shape, generator=g) / math.sqrt(fan_in)
         sd[key] = t
     return sd
+
+
+def load_checkpoint(path):
+    """State dict of a reference checkpoint: a torch `.pth` / `.pt` file ({"model": state_dict} as DetectionCheckpointer
+    writes it, or a bare state dict) or a detectron2 model-zoo `.pkl` (pickle of {"model": {key: numpy array}, ...})."""
+    if path.endswith(".pkl"):
+        import pickle
+        import numpy as np
+        with open(path, "rb") as f:
+            data = pickle.load(f, encoding="latin1")
+        model = data.get("model", data)
+        return {k: torch.from_numpy(np.ascontiguousarray(v)) if not torch.is_tensor(v) else v
+                for k, v in model.items() if not k.startswith("__")}
+    ck = torch.load(path, map_location="cpu")
+    return ck.get("model", ck) if isinstance(ck, dict) else ck

@@ -51,3 +51,16 @@ def test_reference_yaml_files_load_unchanged():
         assert TRANSFORMER_DECODER_REGISTRY.get(cfg.MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME) is not None, f
         spec = weights.spec_for_cfg(cfg)                      # architecture described by the yaml is one we can build
         assert len(spec) > 500
+
+
+def test_load_checkpoint_pth_and_pkl(tmp_path):
+    import pickle
+    import numpy as np
+    import torch
+    sd = {"backbone.stem.conv1.weight": torch.randn(4, 3, 7, 7), "x.bias": torch.randn(5)}
+    torch.save({"model": sd, "iteration": 3}, tmp_path / "m.pth")
+    with open(tmp_path / "m.pkl", "wb") as f:
+        pickle.dump({"model": {k: v.numpy() for k, v in sd.items()}, "__author__": "x", "matching_heuristics": True}, f)
+    for name in ("m.pth", "m.pkl"):
+        got = weights.load_checkpoint(str(tmp_path / name))
+        assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)

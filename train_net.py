@@ -49,8 +49,7 @@ def worker(rank, world, args):
     model = config.build_model(cfg)
     model.device = torch.device("cuda", rank)
     if cfg.MODEL.WEIGHTS and os.path.isfile(cfg.MODEL.WEIGHTS):
-        ck = torch.load(cfg.MODEL.WEIGHTS, map_location="cpu")
-        sd = ck.get("model", ck)
+        sd = weights.load_checkpoint(cfg.MODEL.WEIGHTS)
     else:
         if rank == 0:
             print(f"[train_net] MODEL.WEIGHTS '{cfg.MODEL.WEIGHTS}' not found: seeded random-init weights of the configured architecture")
