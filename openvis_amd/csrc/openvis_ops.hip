@@ -446,9 +446,10 @@ clip_crop_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ m
 // Tiled variant: one workgroup = one TY x TX tile of output bins of one crop.  The source pixels a tile can touch form a
 // small rectangle of the frame; it is staged ONCE in LDS as (packed RGB bytes, soft-mask value = sigmoid of the x4
 // up-sampled logit), so every up-sampled logit / sigmoid is evaluated once per source pixel instead of once per tap
-// (~3x fewer) and the 4 x grid^2 taps of a bin become LDS reads.  Arithmetic per bin is the same as clip_crop_kernel.
+// (~3x fewer) and the taps of a bin become LDS reads, folded per axis (separable sum: same value up to f32 summation order).
 constexpr int CROP_GMAX = 8;       // samples per bin and axis the tiled kernel supports (roi side <= 8 x resolution)
-struct AxisTap { short fl, fh, ml, mh; float fw, mw; short f_ok, m_ok; };
+constexpr int CROP_WMAX = CROP_GMAX + 2;   // source pixels one bin can touch along an axis
+struct AxisW { short fbase, mbase, fn, mn; float fw[CROP_WMAX], mw[CROP_WMAX]; };
 
 template <int TY, int TX>
 __global__ void __launch_bounds__(TY * TX)
@@ -456,7 +457,7 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
                        void* __restrict__ Av, int out_f16, int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp,
                        int R, int ps, long long lda, int PRmax, int PWmax, float m0, float m1, float m2, float s0, float s1, float s2) {
   extern __shared__ uint2 patch[];                      // [PR][PW]: .x = r | g<<8 | b<<16, .y = bits of the soft mask
-  __shared__ AxisTap xtab[TX * CROP_GMAX], ytab[TY * CROP_GMAX];
+  __shared__ AxisW xtab[TX], ytab[TY];
   const int tiles_x = R / TX, tiles_y = R / TY;
   const int tid = threadIdx.x;
   const int tx_i = blockIdx.x % tiles_x, ty_i = (blockIdx.x / tiles_x) % tiles_y;
@@ -539,59 +540,67 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
   }
   __syncthreads();
 
-  // per-axis sample tables of the tile: everything that depends on (bin, sample) along ONE axis is computed once and
-  // shared by the 16 bins of the other axis (lo/hi taps relative to the patch origin, lerp weight, validity)
-  for (int en = tid; en < TX * CROP_GMAX; en += TY * TX) {
-    const int ix = en % CROP_GMAX, lx_ = en / CROP_GMAX;
-    AxisTap e;
-    e.f_ok = e.m_ok = 0; e.fl = e.fh = e.ml = e.mh = 0; e.fw = e.mw = 0.f;
-    if (ix < grid) {
-      const float xx = bx0 + (float)(tx_i * TX + lx_) * bin + ((float)ix + .5f) * step;
-      float x = xx; int lo, hi;
-      if (ra_prep(x, W, lo, hi)) { e.f_ok = 1; e.fl = (short)(lo - xlo); e.fh = (short)(hi - xlo); e.fw = x - (float)lo; }
-      x = xx;
-      if (ra_prep(x, Wp, lo, hi)) { e.m_ok = 1; e.ml = (short)(lo - xlo); e.mh = (short)(hi - xlo); e.mw = x - (float)lo; }
+  // The average over a bin's grid x grid bilinear samples is SEPARABLE: sum_s sum_taps w_y w_x P[y][x] =
+  // sum_r Wy[r] sum_c Wx[c] P[r][c] with Wy / Wx = the per-axis tap weights accumulated over the samples of the bin.
+  // Per axis and bin these weights (span <= grid + 1 source pixels) are built once by one thread and shared by the 16 bins of
+  // the other axis; a bin then reads (grid+1)^2 source pixels instead of 4 grid^2 taps (49 vs 144 at full-frame boxes).
+  // Frame (H x W) and mask (Hp x Wp) clamp differently at the borders, so each has its own weights.
+  // one thread per (axis bin, weight slot): it walks the bin's <= 8 samples and keeps what lands in its slot (no LDS
+  // read-modify-write chains); slot 0 also records the base pixel and the span
+  for (int en = tid; en < (TX + TY) * CROP_WMAX; en += TY * TX) {
+    const int k = en % CROP_WMAX, bq = en / CROP_WMAX;
+    const bool is_y = bq >= TX;
+    const int b_ = is_y ? bq - TX : bq;
+    AxisW& e = is_y ? ytab[b_] : xtab[b_];
+    const float c0 = is_y ? by0 + (float)(ty_i * TY + b_) * bin : bx0 + (float)(tx_i * TX + b_) * bin;
+    const int fsize = is_y ? H : W, msize = is_y ? Hp : Wp, org = is_y ? ylo : xlo;
+    int fbase = 0, mbase = 0, fn = 0, mn = 0;
+    float fwk = 0.f, mwk = 0.f;
+    for (int i = 0; i < grid; ++i) {
+      const float cc = c0 + ((float)i + .5f) * step;
+      float x = cc; int lo, hi;
+      if (ra_prep(x, fsize, lo, hi)) {
+        if (fn == 0) fbase = lo - org;
+        const float l = x - (float)lo;
+        fwk += (lo - org - fbase == k ? 1.f - l : 0.f) + (hi - org - fbase == k ? l : 0.f);
+        fn = hi - org - fbase + 1;
+      }
+      x = cc;
+      if (ra_prep(x, msize, lo, hi)) {
+        if (mn == 0) mbase = lo - org;
+        const float l = x - (float)lo;
+        mwk += (lo - org - mbase == k ? 1.f - l : 0.f) + (hi - org - mbase == k ? l : 0.f);
+        mn = hi - org - mbase + 1;
+      }
     }
-    xtab[en] = e;
-  }
-  for (int en = tid; en < TY * CROP_GMAX; en += TY * TX) {
-    const int iy = en % CROP_GMAX, ly_ = en / CROP_GMAX;
-    AxisTap e;
-    e.f_ok = e.m_ok = 0; e.fl = e.fh = e.ml = e.mh = 0; e.fw = e.mw = 0.f;
-    if (iy < grid) {
-      const float yy = by0 + (float)(ty_i * TY + ly_) * bin + ((float)iy + .5f) * step;
-      float y = yy; int lo, hi;
-      if (ra_prep(y, H, lo, hi)) { e.f_ok = 1; e.fl = (short)((lo - ylo) * PWs); e.fh = (short)((hi - ylo) * PWs); e.fw = y - (float)lo; }
-      y = yy;
-      if (ra_prep(y, Hp, lo, hi)) { e.m_ok = 1; e.ml = (short)((lo - ylo) * PWs); e.mh = (short)((hi - ylo) * PWs); e.mw = y - (float)lo; }
-    }
-    ytab[en] = e;
+    e.fw[k] = fwk; e.mw[k] = mwk;
+    if (k == 0) { e.fbase = (short)fbase; e.mbase = (short)mbase; e.fn = (short)fn; e.mn = (short)mn; }
   }
   __syncthreads();
 
   float f0 = 0.f, f1 = 0.f, f2 = 0.f, mk = 0.f;
-  const AxisTap* xt = xtab + (tid % TX) * CROP_GMAX;
-  const AxisTap* yt = ytab + (tid / TX) * CROP_GMAX;
-  for (int iy = 0; iy < grid; ++iy) {
-    const AxisTap ey = yt[iy];
-    const float fly = ey.fw, fhy = 1.f - fly, mly = ey.mw, mhy = 1.f - mly;
-    const uint2* fr0 = patch + ey.fl; const uint2* fr1 = patch + ey.fh;
-    const uint2* mr0 = patch + ey.ml; const uint2* mr1 = patch + ey.mh;
-    for (int ix = 0; ix < grid; ++ix) {
-      const AxisTap ex = xt[ix];
-      if (ey.f_ok && ex.f_ok) {
-        const float lx = ex.fw, hx = 1.f - lx;
-        const float w1 = fhy * hx, w2 = fhy * lx, w3 = fly * hx, w4 = fly * lx;
-        const unsigned a = fr0[ex.fl].x, b = fr0[ex.fh].x, c = fr1[ex.fl].x, d = fr1[ex.fh].x;
-        f0 += w1 * (float)(a & 255u) + w2 * (float)(b & 255u) + w3 * (float)(c & 255u) + w4 * (float)(d & 255u);
-        f1 += w1 * (float)((a >> 8) & 255u) + w2 * (float)((b >> 8) & 255u) + w3 * (float)((c >> 8) & 255u) + w4 * (float)((d >> 8) & 255u);
-        f2 += w1 * (float)(a >> 16) + w2 * (float)(b >> 16) + w3 * (float)(c >> 16) + w4 * (float)(d >> 16);
+  {
+    const AxisW& ex = xtab[tid % TX];
+    const AxisW& ey = ytab[tid / TX];
+    const int fnx = ex.fn, fny = ey.fn, mnx = ex.mn, mny = ey.mn;
+    const uint2* fbase = patch + ey.fbase * PWs + ex.fbase;
+    for (int r = 0; r < fny; ++r) {
+      const uint2* row = fbase + r * PWs;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      for (int c = 0; c < fnx; ++c) {
+        const unsigned px_ = row[c].x;
+        const float wx = ex.fw[c];
+        a0 += wx * (float)(px_ & 255u); a1 += wx * (float)((px_ >> 8) & 255u); a2 += wx * (float)(px_ >> 16);
       }
-      if (ey.m_ok && ex.m_ok) {
-        const float lx = ex.mw, hx = 1.f - lx;
-        mk += (mhy * hx) * __uint_as_float(mr0[ex.ml].y) + (mhy * lx) * __uint_as_float(mr0[ex.mh].y) +
-              (mly * hx) * __uint_as_float(mr1[ex.ml].y) + (mly * lx) * __uint_as_float(mr1[ex.mh].y);
-      }
+      const float wy = ey.fw[r];
+      f0 += wy * a0; f1 += wy * a1; f2 += wy * a2;
+    }
+    const uint2* mbase = patch + ey.mbase * PWs + ex.mbase;
+    for (int r = 0; r < mny; ++r) {
+      const uint2* row = mbase + r * PWs;
+      float a = 0.f;
+      for (int c = 0; c < mnx; ++c) a += ex.mw[c] * __uint_as_float(row[c].y);
+      mk += ey.mw[r] * a;
     }
   }
   f0 /= count; f1 /= count; f2 /= count; mk /= count;
