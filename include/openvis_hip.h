@@ -207,6 +207,19 @@ int ovis_mask_bbox(const float* masks, int* boxes, int Q, int T, int h, int w, i
 int ovis_clip_crop_patches(const uint8_t* frames, const float* masks, const int* crops, void* A, int out_f16, int M,
                            int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int resolution, int patch,
                            long long lda, const float* mean3_host, const float* std3_host, ovis_stream_t stream);
+/* As ovis_clip_crop_patches, for AdaptedClipAdapter (mask_adapted_adapter.py:79-123, 143-147): additionally writes
+ *   patch_open[m*G*G + py*G + px] = ceil(AvgPool2d(patch)(mask_region)) (model.py:332-333) as 0/1 bytes -- 1 iff any bin of
+ *   the patch has a positive mask_region value.  patch_open (device, M*G*G bytes) is cleared by the call. */
+int ovis_clip_crop_patches_masked(const uint8_t* frames, const float* masks, const int* crops, void* A,
+                                  unsigned char* patch_open, int out_f16, int M, int Q, int T, int H, int W, int h, int w,
+                                  int Hp, int Wp, int resolution, int patch, long long lda, const float* mean3_host,
+                                  const float* std3_host, ovis_stream_t stream);
+/* Mask prompt of the mask-adapted CLIP ViT (third_parties/mask_adapted_clip/mask_adapted_clip/model.py:334-338 before
+ *   the class token, :349-352 after block d < mask_prompt_depth): in place,
+ *   x[m, first_token + l, :] = patch_open[m*L + l] ? x[m, first_token + l, :] : mask_embedding[emb_rows == 1 ? 0 : l, :];
+ *   x f32 [M, tokens_per_item, C]; mask_embedding f32 [emb_rows, C] (one depth slice). */
+int ovis_mask_prompt_select_f32(float* x, const unsigned char* patch_open, const float* mask_embedding, int M, int L, int C,
+                                int tokens_per_item, int first_token, int emb_rows, ovis_stream_t stream);
 /* ViT token assembly + ln_pre (model.py:341-343): out [M,L1,C]; patch [M,L1-1,C]; cls [C]; pos [L1,C]. */
 int ovis_vit_embed_ln_f32(const float* patch, const float* cls, const float* pos, const float* gamma, const float* beta,
                           float* out, int M, int L1, int C, float eps, ovis_stream_t stream);

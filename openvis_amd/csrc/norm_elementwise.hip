@@ -240,6 +240,22 @@ pe_sine_kernel(float* __restrict__ out, int T, int H, int W, int npf, int three_
 }
 
 // y[i] = mean_t x[t*len + i]   (prompt-ensemble mean over templates, adapter.py:133; sequential sum in t)
+// Mask prompt (mask_adapted_clip/model.py:334-338, 349-352): patch tokens whose pooled mask is 0 are REPLACED by the
+// learned mask embedding of that depth: x[m, first + l, :] = open[m*L + l] ? x : emb[(emb_rows == 1 ? 0 : l), :].
+// One thread per float4; closed tokens are rare (patches outside the frame), so most threads only read one byte.
+__global__ void __launch_bounds__(256)
+mask_prompt_select_kernel(float4* __restrict__ x, const unsigned char* __restrict__ open, const float4* __restrict__ emb,
+                          long long n4, int L, int C4, int tokens_per_item, int first, int emb_rows) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)(i % C4);
+  const long long tok = i / C4;                                  // m * L + l
+  if (open[tok]) return;
+  const int l = (int)(tok % L);
+  const long long m = tok / L;
+  x[(m * tokens_per_item + first + l) * C4 + c] = emb[(long long)(emb_rows == 1 ? 0 : l) * C4 + c];
+}
+
 __global__ void __launch_bounds__(256)
 mean_dim0_kernel(const float* __restrict__ x, float* __restrict__ y, int n, long long len) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -336,6 +352,22 @@ extern "C" int ovis_pe_sine_f32(float* out, int T, int H, int W, int num_pos_fea
   hipLaunchKernelGGL(pe_sine_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, out, T, H, W,
                      num_pos_feats, three_d, add_c);
   return ovis::check_launch("pe_sine");
+}
+
+extern "C" int ovis_mask_prompt_select_f32(float* x, const unsigned char* patch_open, const float* mask_embedding, int M,
+                                           int L, int C, int tokens_per_item, int first_token, int emb_rows,
+                                           ovis_stream_t stream) {
+  OVIS_REQUIRE(x && patch_open && mask_embedding, "mask_prompt_select: null pointer");
+  OVIS_REQUIRE(M > 0 && L > 0 && C > 0 && C % 4 == 0, "mask_prompt_select: C must be a positive multiple of 4");
+  OVIS_REQUIRE(first_token >= 0 && first_token + L <= tokens_per_item, "mask_prompt_select: tokens do not fit the item");
+  OVIS_REQUIRE(emb_rows == 1 || emb_rows == L, "mask_prompt_select: mask_embedding must have 1 or L rows");
+  OVIS_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(mask_embedding)) & 15) == 0,
+               "mask_prompt_select: x / mask_embedding must be 16-byte aligned");
+  const long long n4 = (long long)M * L * (C / 4);
+  hipLaunchKernelGGL(mask_prompt_select_kernel, dim3(ovis::cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<float4*>(x), patch_open, reinterpret_cast<const float4*>(mask_embedding), n4, L, C / 4,
+                     tokens_per_item, first_token, emb_rows);
+  return ovis::check_launch("mask_prompt_select");
 }
 
 extern "C" int ovis_mean_dim0_f32(const float* x, float* y, int n, long long len, ovis_stream_t stream) {

@@ -358,8 +358,9 @@ __device__ __forceinline__ bool ra_prep(float& v, int size, int& lo, int& hi) {
 
 __global__ void __launch_bounds__(256)
 clip_crop_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ masks, const int* __restrict__ crops,
-                 void* __restrict__ Av, int out_f16, int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int R,
-                 int ps, long long lda, float m0, float m1, float m2, float s0, float s1, float s2) {
+                 void* __restrict__ Av, unsigned char* __restrict__ patch_open, int out_f16, int M, int Q, int T, int H, int W,
+                 int h, int w, int Hp, int Wp, int R, int ps, long long lda, float m0, float m1, float m2, float s0, float s1,
+                 float s2) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)M * R * R;
   if (i >= total) return;
@@ -434,6 +435,8 @@ clip_crop_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ m
   const int G = R / ps;
   const long long row = (long long)m * G * G + (py / ps) * G + (px / ps);
   const int col = (py % ps) * ps + (px % ps);
+  // mask prompt (model.py:332-333): ceil(avg-pooled mask region) == 1 iff any bin of the patch is > 0 (values are >= 0)
+  if (patch_open && mk > 0.f) patch_open[row] = 1;
   if (out_f16) {
     _Float16* ap = reinterpret_cast<_Float16*>(Av) + row * lda + col;
     ap[0] = (_Float16)r0; ap[ps * ps] = (_Float16)r1; ap[2 * ps * ps] = (_Float16)r2;
@@ -454,8 +457,9 @@ struct AxisW { short fbase, mbase, fn, mn; float fw[CROP_WMAX], mw[CROP_WMAX]; }
 template <int TY, int TX>
 __global__ void __launch_bounds__(TY * TX)
 clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ masks, const int* __restrict__ crops,
-                       void* __restrict__ Av, int out_f16, int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp,
-                       int R, int ps, long long lda, int PRmax, int PWmax, float m0, float m1, float m2, float s0, float s1, float s2) {
+                       void* __restrict__ Av, unsigned char* __restrict__ patch_open, int out_f16, int M, int Q, int T, int H,
+                       int W, int h, int w, int Hp, int Wp, int R, int ps, long long lda, int PRmax, int PWmax, float m0,
+                       float m1, float m2, float s0, float s1, float s2) {
   extern __shared__ uint2 patch[];                      // [PR][PW]: .x = r | g<<8 | b<<16, .y = bits of the soft mask
   __shared__ AxisW xtab[TX], ytab[TY];
   const int tiles_x = R / TX, tiles_y = R / TY;
@@ -610,6 +614,8 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
   const int G = R / ps;
   const long long row = (long long)m * G * G + (py / ps) * G + (px / ps);
   const int col = (py % ps) * ps + (px % ps);
+  // mask prompt (model.py:332-333): ceil(avg-pooled mask region) == 1 iff any bin of the patch is > 0 (values are >= 0)
+  if (patch_open && mk > 0.f) patch_open[row] = 1;
   if (out_f16) {
     _Float16* ap = reinterpret_cast<_Float16*>(Av) + row * lda + col;
     ap[0] = (_Float16)r0; ap[ps * ps] = (_Float16)r1; ap[2 * ps * ps] = (_Float16)r2;
@@ -901,10 +907,9 @@ extern "C" int ovis_mask_bbox(const float* masks, int* boxes, int Q, int T, int 
   return ovis::check_launch("mask_bbox");
 }
 
-extern "C" int ovis_clip_crop_patches(const uint8_t* frames, const float* masks, const int* crops, void* A, int out_f16,
-                                      int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int resolution,
-                                      int patch, long long lda, const float* mean3_host, const float* std3_host,
-                                      ovis_stream_t stream) {
+static int clip_crop_impl(const uint8_t* frames, const float* masks, const int* crops, void* A, unsigned char* patch_open,
+                          int out_f16, int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int resolution,
+                          int patch, long long lda, const float* mean3_host, const float* std3_host, ovis_stream_t stream) {
   OVIS_REQUIRE(frames && masks && crops && A && mean3_host && std3_host, "clip_crop: null pointer");
   OVIS_REQUIRE(M > 0 && resolution > 0 && patch > 0 && resolution % patch == 0, "clip_crop: bad sizes");
   OVIS_REQUIRE(lda >= 3ll * patch * patch, "clip_crop: lda smaller than a patch row (3*patch*patch)");
@@ -922,19 +927,40 @@ extern "C" int ovis_clip_crop_patches(const uint8_t* frames, const float* masks,
       attr_set = true;
     }
     hipLaunchKernelGGL((clip_crop_tiled_kernel<16, 16>), dim3((unsigned)((long long)M * (resolution / 16) * (resolution / 16))), dim3(256),
-                       (size_t)p16 * (p16 + 1) * 8, (hipStream_t)stream, frames, masks, crops, A, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
+                       (size_t)p16 * (p16 + 1) * 8, (hipStream_t)stream, frames, masks, crops, A, patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
                        resolution, patch, lda, p16, p16, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
   } else if (grid_ok && resolution % 8 == 0 && (size_t)p8 * (p8 + 1) * 8 <= 64 * 1024) {
     hipLaunchKernelGGL((clip_crop_tiled_kernel<8, 8>), dim3((unsigned)((long long)M * (resolution / 8) * (resolution / 8))), dim3(64),
-                       (size_t)p8 * (p8 + 1) * 8, (hipStream_t)stream, frames, masks, crops, A, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
+                       (size_t)p8 * (p8 + 1) * 8, (hipStream_t)stream, frames, masks, crops, A, patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
                        resolution, patch, lda, p8, p8, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
   } else {
     const long long total = (long long)M * resolution * resolution;
     hipLaunchKernelGGL(clip_crop_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, frames, masks, crops, A,
-                       out_f16, M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, lda, mean3_host[0], mean3_host[1], mean3_host[2],
+                       patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, lda, mean3_host[0], mean3_host[1], mean3_host[2],
                        std3_host[0], std3_host[1], std3_host[2]);
   }
   return ovis::check_launch("clip_crop");
+}
+
+extern "C" int ovis_clip_crop_patches(const uint8_t* frames, const float* masks, const int* crops, void* A, int out_f16,
+                                      int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int resolution,
+                                      int patch, long long lda, const float* mean3_host, const float* std3_host,
+                                      ovis_stream_t stream) {
+  return clip_crop_impl(frames, masks, crops, A, nullptr, out_f16, M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, lda,
+                        mean3_host, std3_host, stream);
+}
+
+extern "C" int ovis_clip_crop_patches_masked(const uint8_t* frames, const float* masks, const int* crops, void* A,
+                                             unsigned char* patch_open, int out_f16, int M, int Q, int T, int H, int W, int h,
+                                             int w, int Hp, int Wp, int resolution, int patch, long long lda,
+                                             const float* mean3_host, const float* std3_host, ovis_stream_t stream) {
+  OVIS_REQUIRE(patch_open, "clip_crop_masked: null patch_open");
+  const long long G = resolution > 0 && patch > 0 ? resolution / patch : 0;
+  if (M > 0 && G > 0)
+    OVIS_REQUIRE(hipMemsetAsync(patch_open, 0, (size_t)M * G * G, (hipStream_t)stream) == hipSuccess,
+                 "clip_crop_masked: memset failed");
+  return clip_crop_impl(frames, masks, crops, A, patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, lda,
+                        mean3_host, std3_host, stream);
 }
 
 extern "C" int ovis_vit_embed_ln_f32(const float* patch, const float* cls, const float* pos, const float* gamma,

@@ -1,11 +1,16 @@
-from .adapter import ClipAdapter  # noqa: F401
+from .adapter import AdaptedClipAdapter, BgAdaptedClipAdapter, BgClipAdapter, ClipAdapter  # noqa: F401
 
-ADAPTER_REGISTER = {"ClipAdapter": ClipAdapter}
+ADAPTER_REGISTER = {x.__name__: x for x in [ClipAdapter, BgClipAdapter, AdaptedClipAdapter, BgAdaptedClipAdapter]}
 
 
 def build_clip_adapter(cfg):
-    """openvis/modeling/clip_adapter/__init__.py:9-15 (ClipAdapter; the other adapters are later §8 rows)."""
-    if cfg.NAME in ("ClipAdapter",):
-        return ADAPTER_REGISTER[cfg.NAME](cfg.CLIP_MODEL_NAME, text_templates=cfg.PROMPT_NAME,
-                                          precision=cfg.get("PRECISION", "fp16"))
-    raise NotImplementedError(f"clip adapter {cfg.NAME} is not built yet (SURVEY.md §8a A13 / later rows)")
+    """openvis/modeling/clip_adapter/__init__.py:9-15.  (SideAdapter is built by the SAN / BriVIS meta-architectures
+    themselves: openvis_amd/modeling/clip_adapter/side_adapter.py.)"""
+    precision = cfg.get("PRECISION", "fp16")
+    if cfg.NAME in ("ClipAdapter", "BgClipAdapter"):
+        return ADAPTER_REGISTER[cfg.NAME](cfg.CLIP_MODEL_NAME, text_templates=cfg.PROMPT_NAME, precision=precision)
+    if cfg.NAME in ("AdaptedClipAdapter", "BgAdaptedClipAdapter"):
+        return ADAPTER_REGISTER[cfg.NAME](cfg.CLIP_MODEL_NAME, mask_prompt_depth=cfg.MASK_PROMPT_DEPTH,
+                                          mask_prompt_fwd=cfg.MASK_PROMPT_FWD, text_templates=cfg.PROMPT_NAME,
+                                          precision=precision)
+    raise NotImplementedError(f"clip adapter {cfg.NAME} is not in ADAPTER_REGISTER {sorted(ADAPTER_REGISTER)}")

@@ -23,10 +23,12 @@ _CLIP_ARCH = {"ViT-B/16": dict(width=768, layers=12, heads=12, patch=16, resolut
 
 
 class ClipVisual:
-    """CLIP VisionTransformer.forward (mask_adapted_clip/model.py:327-362 with m=None)."""
+    """CLIP VisionTransformer.forward (mask_adapted_clip/model.py:327-362): m=None, or the mask-prompt path when
+    `patch_open` (the pooled, ceil'ed mask of model.py:332-333 as 0/1 bytes) is given."""
 
-    def __init__(self, width, layers, heads, patch, resolution, embed_dim, precision="fp16"):
+    def __init__(self, width, layers, heads, patch, resolution, embed_dim, precision="fp16", mask_prompt_depth=0):
         self.width, self.layers, self.heads, self.patch = width, layers, heads, patch
+        self.mask_prompt_depth = mask_prompt_depth
         self.input_resolution, self.output_dim = resolution, embed_dim
         if precision not in ("fp16", "fp32"):
             raise ValueError("precision must be 'fp16' (GEMM operands fp16 like the reference's GPU CLIP) or 'fp32'")
@@ -43,6 +45,8 @@ class ClipVisual:
         for n in ("ln_pre", "ln_post"):
             w[n + ".w"], w[n + ".b"] = g(n + ".weight"), g(n + ".bias")
         w["proj_t"] = g("proj").t().contiguous()                   # x @ proj == gemm_nt(x, proj^T)
+        if self.mask_prompt_depth > 0:
+            w["mask_embedding"] = g("mask_embedding")              # [depth, G*G or 1, width] (model.py:325)
         for i in range(self.layers):
             p = f"transformer.resblocks.{i}."
             for k in ("attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight", "attn.out_proj.bias",
@@ -55,11 +59,13 @@ class ClipVisual:
                 w[k + ".h"] = ops.cast_f16(w[k])
         return self
 
-    def embed(self, A, M):
+    def embed(self, A, M, patch_open=None):
         """patch im2col matrix [M*G*G, 3*ps*ps] (f32 or fp16) -> ln_pre(tokens) f32 [M, G*G+1, C] (model.py:328-343)."""
         w = self.w
         G = self.input_resolution // self.patch
         x = ops.gemm_nt_f16(A, w["conv1.h"]) if self.precision == "fp16" else ops.gemm_nt(A, w["conv1"])   # conv1, no bias
+        if patch_open is not None:                                  # model.py:334-338
+            ops.mask_prompt_select(x, patch_open, w["mask_embedding"][0], 0)
         return ops.vit_embed_ln(x, w["cls"], w["pos"], w["ln_pre.w"], w["ln_pre.b"], M, G * G + 1)
 
     def run_blocks(self, x, i0, i1, attn_bias=None):
@@ -104,18 +110,32 @@ class ClipVisual:
         w = self.w
         return ops.gemm_nt(ops.layernorm(tok, w["ln_post.w"], w["ln_post.b"]), w["proj_t"])
 
-    def forward_patches(self, A, M):
-        """A: patch im2col matrix [M*G*G, 3*ps*ps] -> image features [M, embed_dim] (before L2 normalisation)."""
-        x = self.run_blocks(self.embed(A, M), 0, self.layers)
+    def forward_patches(self, A, M, patch_open=None):
+        """A: patch im2col matrix [M*G*G, 3*ps*ps] -> image features [M, embed_dim] (before L2 normalisation).
+        patch_open uint8 [M, G*G]: the mask-prompt path (model.py:344-352) — after block d < mask_prompt_depth the
+        closed patch tokens are reset to mask_embedding[d]."""
+        if patch_open is None:
+            x = self.run_blocks(self.embed(A, M), 0, self.layers)
+        else:
+            if self.mask_prompt_depth < 1:
+                raise ValueError("mask prompt requested on a tower built with mask_prompt_depth=0 (no mask_embedding)")
+            x = self.embed(A, M, patch_open)
+            for i in range(self.layers):
+                x = self.run_blocks(x, i, i + 1)
+                if i + 1 < self.mask_prompt_depth:
+                    ops.mask_prompt_select(x, patch_open, self.w["mask_embedding"][i + 1], 1)
         return self.head(x[:, 0, :].contiguous())
 
 
 class ClipAdapter:
+    mask_prompt_depth = 0            # AdaptedClipAdapter: > 0 (the tower owns a mask_embedding)
+    mask_prompt_fwd = False
+
     def __init__(self, clip_model_name="ViT-B/16", text_templates="vild", arch=None, precision="fp16"):
         self.clip_model_name = clip_model_name
         self.arch = dict(arch or _CLIP_ARCH[clip_model_name])
         self.precision = precision
-        self.visual = ClipVisual(**self.arch, precision=precision)
+        self.visual = ClipVisual(**self.arch, precision=precision, mask_prompt_depth=self.mask_prompt_depth)
         self.input_resolution = self.arch["resolution"]
         self.templates = text_templates
         self.text_cache = {}
@@ -173,11 +193,54 @@ class ClipAdapter:
         if crops.shape[0] == 0:
             return None, valid, crops
         crops_d = torch.from_numpy(crops).to(self.device)
-        A = ops.clip_crop_patches(frames, masks_lowres, crops_d, Hp, Wp, self.input_resolution, self.arch["patch"],
-                                  PIXEL_MEAN, PIXEL_STD, out_f16=(self.precision == "fp16"))
-        feat = self.visual.forward_patches(A, crops.shape[0])
+        if self.mask_prompt_fwd:                                              # mask_adapted_adapter.py:68-69
+            A, patch_open = ops.clip_crop_patches_masked(frames, masks_lowres, crops_d, Hp, Wp, self.input_resolution,
+                                                         self.arch["patch"], PIXEL_MEAN, PIXEL_STD,
+                                                         out_f16=(self.precision == "fp16"))
+            feat = self.visual.forward_patches(A, crops.shape[0], patch_open)
+        else:
+            A = ops.clip_crop_patches(frames, masks_lowres, crops_d, Hp, Wp, self.input_resolution, self.arch["patch"],
+                                      PIXEL_MEAN, PIXEL_STD, out_f16=(self.precision == "fp16"))
+            feat = self.visual.forward_patches(A, crops.shape[0])
         text_features = self.encode_text(text)
         feat = ops.l2norm_rows(feat, 100.0)                                   # normalize, then temperature (:144,146)
         return ops.gemm_nt(feat, text_features), valid, crops
 
     __call__ = forward
+
+
+class _NonObjectMixin:
+    """Bg* adapters (adapter.py:150-161; mask_adapted_adapter.py:154-166): one learned, L2-normalised "non-object" row is
+    appended to the class embeddings, so sim_logits has K + 1 columns."""
+
+    def load_state_dict(self, sd, prefix="clip_adapter.", device="cuda"):
+        super().load_state_dict(sd, prefix, device)
+        e = sd[prefix + "non_object_embedding"].float().to(device).reshape(1, -1)
+        self.non_object_embedding = ops.l2norm_rows(e.contiguous())
+        return self
+
+    def encode_text(self, noun_list):
+        return torch.cat([super().encode_text(noun_list), self.non_object_embedding], dim=0).contiguous()
+
+
+class BgClipAdapter(_NonObjectMixin, ClipAdapter):
+    pass
+
+
+class AdaptedClipAdapter(ClipAdapter):
+    """mask_adapted_adapter.py:35-148: same crops as ClipAdapter (its _preprocess_image :79-123 is adapter.py:73-116 plus
+    the mask regions), CLIP tower built with `mask_prompt_depth` mask embeddings; with `mask_prompt_fwd` the tower gets the
+    mask regions (model.py:331-352), otherwise it runs as the plain ViT."""
+
+    def __init__(self, clip_model_name="ViT-B/16", mask_prompt_depth=3, mask_prompt_fwd=True, text_templates="vild", arch=None,
+                 precision="fp16"):
+        self.mask_prompt_depth = int(mask_prompt_depth)
+        self.mask_prompt_fwd = bool(mask_prompt_fwd)
+        if self.mask_prompt_fwd and self.mask_prompt_depth < 1:
+            # the reference indexes mask_embedding[0] of an empty parameter here (model.py:338) and raises
+            raise ValueError("MASK_PROMPT_FWD needs MASK_PROMPT_DEPTH >= 1")
+        super().__init__(clip_model_name, text_templates, arch, precision)
+
+
+class BgAdaptedClipAdapter(_NonObjectMixin, AdaptedClipAdapter):
+    pass

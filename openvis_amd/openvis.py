@@ -68,6 +68,12 @@ class OpenVIS(VideoMaskFormer):
         logits, valid, crops = self.clip_adapter(frames, class_names, masks_lowres, padded_hw)
         if logits is None:                                                    # openvis.py:127-128
             return None, None, {"valid": valid}
+        if logits.shape[1] != len(class_names):
+            # Bg* adapters add a "non-object" column; the reference's inference_video builds its label table from
+            # len(class_names) (openvis.py:108, video_maskformer.py:267-270) and mis-indexes it — only SimpleBaseline
+            # (out of this path's scope) consumes those K + 1 logits
+            raise ValueError(f"{type(self.clip_adapter).__name__} returns {logits.shape[1]} logits for {len(class_names)} "
+                             "classes; OpenVIS needs ClipAdapter or AdaptedClipAdapter")
         T, Q = valid.shape
         slot = -np.ones((T, Q), np.int32)
         slot[valid] = np.arange(crops.shape[0], dtype=np.int32)

@@ -414,6 +414,32 @@ def clip_crop_patches(frames, masks, crops, Hp, Wp, resolution, patch, mean, std
     return A
 
 
+def clip_crop_patches_masked(frames, masks, crops, Hp, Wp, resolution, patch, mean, std, out_f16=False):
+    """AdaptedClipAdapter crops: (patch matrix A, patch_open uint8 [M, G*G]) — see ovis_clip_crop_patches_masked."""
+    _chk(frames, masks, crops)
+    T, _, H, W = frames.shape
+    Q, _, h, w = masks.shape
+    M = crops.shape[0]
+    G = resolution // patch
+    A = _patch_matrix(M * G * G, patch, out_f16, frames.device)
+    patch_open = torch.empty((M, G * G), dtype=torch.uint8, device=frames.device)
+    _lib.call("ovis_clip_crop_patches_masked", frames, masks, crops, A, patch_open, int(out_f16), M, Q, T, H, W, h, w, Hp, Wp,
+              resolution, patch, _ll(A.shape[1]), _f3(mean), _f3(std), _lib.stream_ptr())
+    return A, patch_open
+
+
+def mask_prompt_select(x, patch_open, mask_embedding, first_token):
+    """In place: closed patch tokens of x f32 [M, tokens, C] take mask_embedding [1 or L, C] (model.py:334-338, 349-352)."""
+    _chk(x, patch_open, mask_embedding)
+    M, L = patch_open.shape
+    if x.dim() == 2:
+        x = x.view(M, L, -1)
+    assert x.is_contiguous() and x.dtype == torch.float32 and mask_embedding.is_contiguous()
+    _lib.call("ovis_mask_prompt_select_f32", x, patch_open, mask_embedding, M, L, x.shape[2], x.shape[1], first_token,
+              mask_embedding.shape[0], _lib.stream_ptr())
+    return x
+
+
 def vit_embed_ln(patch, cls, pos, gamma, beta, M, L1, eps=1e-5):
     _chk(patch, cls, pos, gamma, beta)
     C = cls.numel()

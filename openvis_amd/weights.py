@@ -98,7 +98,8 @@ def video_decoder_spec(prefix="sem_seg_head.predictor.", C=256, layers=9, ffn=20
 
 
 def clip_visual_spec(prefix="clip_adapter.clip_model.visual.", width=768, layers=12, heads=12, patch=16, resolution=224,
-                     embed_dim=512):
+                     embed_dim=512, mask_prompt_depth=0):
+    """mask_prompt_depth > 0: the mask-adapted tower's `mask_embedding` [depth, G*G, width] (mask_adapted_clip/model.py:325)."""
     G = resolution // patch
     s = [(prefix + "conv1.weight", (width, 3, patch, patch)), (prefix + "class_embedding", (width,)),
          (prefix + "positional_embedding", (G * G + 1, width)), (prefix + "ln_pre.weight", (width,)), (prefix + "ln_pre.bias", (width,)),
@@ -110,6 +111,8 @@ def clip_visual_spec(prefix="clip_adapter.clip_model.visual.", width=768, layers
               (p + "ln_1.weight", (width,)), (p + "ln_1.bias", (width,)), (p + "ln_2.weight", (width,)), (p + "ln_2.bias", (width,)),
               (p + "mlp.c_fc.weight", (4 * width, width)), (p + "mlp.c_fc.bias", (4 * width,)),
               (p + "mlp.c_proj.weight", (width, 4 * width)), (p + "mlp.c_proj.bias", (width,))]
+    if mask_prompt_depth > 0:
+        s.append((prefix + "mask_embedding", (mask_prompt_depth, G * G, width)))
     return s
 
 
@@ -186,10 +189,15 @@ def brivis_spec(backbone="r50", clip_arch=None, num_queries=100):
     return san_spec(backbone, clip_arch, num_queries) + resampler_spec()
 
 
-def openvis_spec(backbone="r50", clip_arch=None, num_queries=100):
+def openvis_spec(backbone="r50", clip_arch=None, num_queries=100, adapter="ClipAdapter", mask_prompt_depth=3):
+    """adapter: the CLIP_ADAPTER.NAME — Adapted* towers carry mask_embedding, Bg* adapters a non_object_embedding."""
     arch = dict(clip_arch or _CLIP_ARCH["ViT-B/16"])
     bb, ch = _backbone(backbone)
-    return bb + pixel_decoder_spec(in_channels=ch) + video_decoder_spec(Q=num_queries) + clip_visual_spec(**arch)
+    depth = mask_prompt_depth if "Adapted" in adapter else 0
+    s = bb + pixel_decoder_spec(in_channels=ch) + video_decoder_spec(Q=num_queries) + clip_visual_spec(**arch, mask_prompt_depth=depth)
+    if adapter.startswith("Bg"):
+        s.append(("clip_adapter.non_object_embedding", (1, arch["embed_dim"])))
+    return s
 
 
 def clip_text_spec(prefix="clip_adapter.clip_model.", width=512, layers=12, embed_dim=512, vocab=49408, context=77):
@@ -218,7 +226,8 @@ def spec_for_cfg(cfg):
         bb = "r50"
     arch = cfg.MODEL.META_ARCHITECTURE
     if arch in ("OpenVIS", "OpenVISOnline"):
-        return openvis_spec(bb, clip, q)
+        ca = cfg.MODEL.CLIP_ADAPTER
+        return openvis_spec(bb, clip, q, ca.NAME, ca.MASK_PROMPT_DEPTH)
     if arch in ("SAN", "SANOnline"):
         return san_spec(bb, clip, q)
     if arch == "BriVIS":
@@ -244,6 +253,8 @@ def random_init(spec, seed=42):
             t = torch.randn(shape, generator=g) * (0.5 / math.sqrt(shape[-1]))
         elif "query_feat" in key or "query_embed" in key:
             t = torch.randn(shape, generator=g)
+        elif key.endswith("mask_embedding"):
+            t = torch.randn(shape, generator=g) * 0.5             # token-sized, so that the mask prompt is visible in tests
         elif len(shape) == 1:
             t = 1.0 + 0.1 * torch.randn(shape, generator=g) if key.endswith("weight") else 0.05 * torch.randn(shape, generator=g)
         else:

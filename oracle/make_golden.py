@@ -153,6 +153,31 @@ def gen_clip_visual():
     print("wrote clip_visual_tiny.npz", y.shape)
 
 
+def gen_clip_visual_mask_prompt():
+    """Reference VisionTransformer.forward(x, m) with mask_prompt_depth=3 (mask_adapted_clip/model.py:327-362): the
+    mask-prompt path AdaptedClipAdapter.encode_image drives (mask_adapted_adapter.py:143-147)."""
+    from tests._synth import synth_inputs
+    mod = R.ref("mask_adapted_clip.model")
+    vit = mod.VisionTransformer(input_resolution=64, patch_size=16, mask_prompt_depth=3, width=256, layers=4,
+                                heads=4, output_dim=64).eval()
+    spec = _load_synth(vit, CLIP_SEED + 10)
+    x = synth_inputs([(4, 3, 64, 64)], CLIP_SEED + 11)[0]
+    # mask regions [M,1,64,64] >= 0 with whole patches at exactly 0 (what roi_align gives outside the image) and one
+    # patch that is 0 except for a single tiny positive value (ceil of the pooled mean must still open it)
+    m = synth_inputs([(4, 1, 64, 64)], CLIP_SEED + 12)[0].abs()
+    m[0, 0, :16, :] = 0
+    m[1, 0, :, 48:] = 0
+    m[2, 0, 16:48, 16:48] = 0
+    m[2, 0, 20, 20] = 1e-6
+    m[3] = 0
+    m[3, 0, 33, 1] = 0.25
+    with torch.no_grad():
+        y = vit(x, m)
+    np.savez_compressed(os.path.join(GOLD, "clip_visual_mask_prompt.npz"), spec=_spec_arrays(spec),
+                        seeds=np.array([CLIP_SEED + 10, CLIP_SEED + 11, CLIP_SEED + 12]), mask=m.numpy(), out=y.numpy())
+    print("wrote clip_visual_mask_prompt.npz", y.shape)
+
+
 def gen_position_encodings():
     pe2 = R.ref("openvis.modeling.pixel_decoder.position_encoding").PositionEmbeddingSine2D(128, normalize=True)
     pe3 = R.ref("openvis.modeling.transformer_decoder.position_encoding").PositionEmbeddingSine3D(128, normalize=True)
@@ -374,7 +399,7 @@ def gen_clip_text():
     print("wrote clip_text.npz", tokens.shape, ens.shape)
 
 
-GENERATORS = {"sidevideo": gen_side_video_decoder, "text": gen_clip_text, "swin": gen_swin, "msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "san": gen_side_adapter, "resampler": gen_resampler, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual,
+GENERATORS = {"sidevideo": gen_side_video_decoder, "text": gen_clip_text, "swin": gen_swin, "msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "san": gen_side_adapter, "resampler": gen_resampler, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual, "clipmask": gen_clip_visual_mask_prompt,
               "pe": gen_position_encodings}
 
 if __name__ == "__main__":

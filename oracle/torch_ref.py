@@ -467,14 +467,15 @@ def roi_align(inp, rois, output_size, spatial_scale=1.0, sampling_ratio=-1, alig
     return out
 
 
-def clip_crops(frames, masks, resolution=224):
-    """adapter.py:73-116. frames [T,3,H,W] (raw 0..255, un-padded), masks [T,N,Hp,Wp] (sigmoid probabilities).
-    Returns (regions [M,3,res,res] or None, valid [T,N] bool, boxes [M,4])."""
+def clip_crops(frames, masks, resolution=224, return_mask_regions=False):
+    """adapter.py:73-116 (== mask_adapted_adapter.py:79-123, which also returns mask_regions). frames [T,3,H,W] (raw
+    0..255, un-padded), masks [T,N,Hp,Wp] (sigmoid probabilities).
+    Returns (regions [M,3,res,res] or None, valid [T,N] bool, boxes [M,4]) (+ mask_regions [M,1,res,res])."""
     frames = frames.float()
     bin_masks = masks > 0.5
     valid = bin_masks.sum(dim=(-1, -2)) > 0
     if torch.sum(valid) == 0:
-        return None, valid, None
+        return (None, valid, None, None) if return_mask_regions else (None, valid, None)
     valid_bin_masks = bin_masks[valid]
     valid_masks = masks[valid]
     sboxes = bitmask_boxes(valid_bin_masks).clone()
@@ -489,6 +490,8 @@ def clip_crops(frames, masks, resolution=224):
     ind = torch.cat([torch.arange(len(sboxes))[:, None].float(), sboxes], dim=-1)
     mask_regions = roi_align(valid_masks[:, None], ind, (resolution, resolution))
     regions = mask_regions * regions + (1 - mask_regions) * 0.
+    if return_mask_regions:
+        return regions, valid, sboxes, mask_regions
     return regions, valid, sboxes
 
 
@@ -500,11 +503,21 @@ CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
-def clip_visual(x, W, prefix="clip_adapter.clip_model.visual.", heads=12):
+def clip_visual(x, W, prefix="clip_adapter.clip_model.visual.", heads=12, m=None, mask_prompt_depth=0):
+    """m: None (model.py:327-362 with m=None) or mask regions [M,1,res,res] — the mask-prompt path (model.py:331-354):
+    patch tokens whose pooled mask is 0 are replaced by mask_embedding[0] before the class token / positional embedding,
+    and again by mask_embedding[d] after block d for d < mask_prompt_depth."""
     p = prefix
     patch = W[p + "conv1.weight"].shape[-1]
     x = F.conv2d(x, W[p + "conv1.weight"], None, stride=patch)
     x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+    if m is not None:
+        m = F.avg_pool2d(m.float().reshape(m.shape[0], 1, m.shape[-2], m.shape[-1]), patch, stride=patch)
+        m = torch.ceil(m.reshape(m.shape[0], -1).unsqueeze(-1))                # [M, G*G, 1]
+        mask_embedding = W[p + "mask_embedding"]
+        if mask_embedding.shape[1] == 1:
+            mask_embedding = mask_embedding.repeat(1, x.shape[1], 1)
+        x = x * m + mask_embedding[0].unsqueeze(0) * (1 - m)
     cls = W[p + "class_embedding"].to(x.dtype) + torch.zeros(x.shape[0], 1, x.shape[-1], dtype=x.dtype)
     x = torch.cat([cls, x], dim=1) + W[p + "positional_embedding"]
     x = _ln(x, W, p + "ln_pre")
@@ -519,6 +532,10 @@ def clip_visual(x, W, prefix="clip_adapter.clip_model.visual.", heads=12):
         h = F.linear(h, W[bp + "mlp.c_fc.weight"], W[bp + "mlp.c_fc.bias"])
         h = h * torch.sigmoid(1.702 * h)
         x = x + F.linear(h, W[bp + "mlp.c_proj.weight"], W[bp + "mlp.c_proj.bias"])
+        if m is not None and i + 1 < mask_prompt_depth:                        # model.py:349-352
+            mp = m.permute(1, 0, 2)
+            masked_x = x[1:] * mp + mask_embedding[i + 1].unsqueeze(0).permute(1, 0, 2) * (1 - mp)
+            x = torch.cat([x[:1], masked_x], dim=0)
     x = x.permute(1, 0, 2)
     x = _ln(x[:, 0, :], W, p + "ln_post")
     return x @ W[p + "proj"]
@@ -557,13 +574,14 @@ def clip_text_ensemble(tokens_per_template, W, prefix="clip_adapter.clip_model."
     return e / e.norm(dim=-1, keepdim=True)
 
 
-def clip_encode_image(regions, W, prefix="clip_adapter.clip_model.visual.", resolution=224, heads=12):
-    """adapter.py:140-144."""
+def clip_encode_image(regions, W, prefix="clip_adapter.clip_model.visual.", resolution=224, heads=12, mask_regions=None,
+                      mask_prompt_depth=0):
+    """adapter.py:140-144; with mask_regions: AdaptedClipAdapter.encode_image (mask_adapted_adapter.py:143-147)."""
     image = F.interpolate(regions / 255., (resolution, resolution), mode="bicubic")
     mean = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)
     std = torch.tensor(CLIP_STD).view(1, 3, 1, 1)
     image = (image - mean) / std
-    feat = clip_visual(image, W, prefix, heads)
+    feat = clip_visual(image, W, prefix, heads, mask_regions, mask_prompt_depth)
     return feat / feat.norm(dim=-1, keepdim=True)
 
 
@@ -571,19 +589,25 @@ def clip_encode_image(regions, W, prefix="clip_adapter.clip_model.visual.", reso
 # A12 + OpenVIS.open_vocabulary_inference — openvis/openvis.py:110-147 ; A16 inference_video — video_maskformer.py:262-298
 # ----------------------------------------------------------------------------------------------
 def open_vocabulary_inference(masks, frames, text_features, W, part_len=5, temperature=100.0, clip_heads=12,
-                              clip_resolution=224):
+                              clip_resolution=224, mask_prompt_depth=None, mask_prompt_fwd=True):
     """masks [Q,T,Hp,Wp] logits (already upsampled); frames [T,3,H,W] uint8; text_features [K,512] unit rows.
+    mask_prompt_depth None: ClipAdapter (adapter.py:56-71); an int: AdaptedClipAdapter (mask_adapted_adapter.py:58-77),
+    whose tower sees the mask regions when mask_prompt_fwd.
     Returns (probs [Qv,K], masks[valid_query], extras)."""
     T = frames.shape[0]
     clip_cls, valid_flag, boxes = [], [], []
     for idx in range(0, T, part_len):
         part_frames = frames[idx:idx + part_len]
         part_masks = masks[:, idx:idx + part_len].sigmoid().transpose(0, 1).contiguous()
-        regions, valid, sb = clip_crops(part_frames, part_masks, clip_resolution)
+        regions, valid, sb, mregions = clip_crops(part_frames, part_masks, clip_resolution, return_mask_regions=True)
         if regions is None:
             logits = torch.empty(0, text_features.shape[0])
         else:
-            feat = clip_encode_image(regions, W, resolution=clip_resolution, heads=clip_heads)
+            if mask_prompt_depth is not None and mask_prompt_fwd:
+                feat = clip_encode_image(regions, W, resolution=clip_resolution, heads=clip_heads, mask_regions=mregions,
+                                         mask_prompt_depth=mask_prompt_depth)
+            else:
+                feat = clip_encode_image(regions, W, resolution=clip_resolution, heads=clip_heads)
             logits = temperature * feat @ text_features.T                     # adapter.py:146-147
             boxes.append(sb)
         clip_cls.append(logits)
@@ -622,8 +646,10 @@ def inference_video(num_queries, num_classes, pred_cls, pred_masks, img_size, ou
             "pred_labels": labels_per_image.tolist(), "pred_masks": [m for m in masks], "rows": topk_indices.tolist()}
 
 
-def openvis_forward(frames, W, text_features, out_hw=None, stages=None, clip_heads=12, clip_resolution=224, backbone_fn=None):
-    """OpenVIS.forward, eval (openvis/openvis.py:47-108). frames: uint8 [T,3,H,W]."""
+def openvis_forward(frames, W, text_features, out_hw=None, stages=None, clip_heads=12, clip_resolution=224, backbone_fn=None,
+                    mask_prompt_depth=None, mask_prompt_fwd=True):
+    """OpenVIS.forward, eval (openvis/openvis.py:47-108). frames: uint8 [T,3,H,W].  mask_prompt_depth: see
+    open_vocabulary_inference (None = ClipAdapter, int = AdaptedClipAdapter)."""
     T = frames.shape[0]
     images, (H, Wd) = preprocess([f for f in frames])
     feats = (backbone_fn or resnet50)(images, W)
@@ -633,7 +659,8 @@ def openvis_forward(frames, W, text_features, out_hw=None, stages=None, clip_hea
     ih, iw = images.shape[-2:]
     mask_pred = F.interpolate(mask_pred, size=(ih, iw), mode="bilinear", align_corners=False)   # openvis.py:87-96
     probs, vmasks, extras = open_vocabulary_inference(mask_pred, frames, text_features, W, clip_heads=clip_heads,
-                                                      clip_resolution=clip_resolution)
+                                                      clip_resolution=clip_resolution, mask_prompt_depth=mask_prompt_depth,
+                                                      mask_prompt_fwd=mask_prompt_fwd)
     oh, ow = out_hw if out_hw is not None else (H, Wd)
     K = text_features.shape[0]
     out = inference_video(pred_masks.shape[1], K, probs, vmasks, (H, Wd), oh, ow)

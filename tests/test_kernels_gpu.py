@@ -31,7 +31,8 @@ def test_gemm_f16(M, N, K, out_f16):
 
 
 @pytest.mark.parametrize("M,N,K", [(150, 70, 128), (2001, 1027, 128), (4099, 768, 192), (8200, 2060, 128),
-                                   (16384, 4096, 64)])                          # small-tile, LDS-DMA 128 and 256-ring paths
+                                   (16384, 4096, 64), (25500, 768, 128)])       # small-tile, LDS-DMA 128 and 256-ring paths;
+                                                                                # (8200,2060) and (25500,768) split off a tail round
 def test_gemm_f16_integer_exact(M, N, K):
     from openvis_amd import ops
     a = (torch.arange(M * K).reshape(M, K) % 13 - 6).half()
