@@ -64,3 +64,36 @@ def test_load_checkpoint_pth_and_pkl(tmp_path):
     for name in ("m.pth", "m.pkl"):
         got = weights.load_checkpoint(str(tmp_path / name))
         assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+
+
+def test_evaluator_handoff_formats():
+    """instances_to_coco_json_video / instances_to_burst_json_video (ytvis_eval.py:258-301, burst_eval.py:177-240) from
+    dense masks and from pre-encoded RLE give the same records; BURST keeps a track only on frames with > 20 pixels."""
+    import numpy as np
+    import torch
+    from openvis_amd import evals, rle
+    T, H, W = 3, 12, 17
+    rng = np.random.default_rng(0)
+    m0 = rng.random((T, H, W)) > 0.5
+    m1 = np.zeros((T, H, W), bool)
+    m1[0, 2:6, 3:9] = True            # 24 px: kept
+    m1[1, 0:4, 0:5] = True            # 20 px: dropped (needs > 20)
+    outputs = {"pred_scores": [0.9, 0.4], "pred_labels": [5, 2], "pred_entropys": [0.1, 0.7],
+               "pred_masks": [torch.from_numpy(m0), torch.from_numpy(m1)]}
+    inputs = [{"video_id": 7, "length": T, "width": W, "height": H, "seq_name": "s", "dataset": "d",
+               "annotated_image_paths": ["a", "b", "c"]}]
+    coco = evals.instances_to_coco_json_video(inputs, outputs)
+    assert [r["category_id"] for r in coco] == [5, 2] and coco[1]["entropy"] == 0.7 and coco[0]["video_id"] == 7
+    for r, m in zip(coco, (m0, m1)):
+        for seg, f in zip(r["segmentations"], m):
+            assert seg["size"] == [H, W]
+            assert (rle.counts_to_mask(rle.string_to_counts(seg["counts"]), H, W) == f).all()
+    pre = dict(outputs, pred_masks_rle=[r["segmentations"] for r in coco])
+    del pre["pred_masks"]
+    assert evals.instances_to_coco_json_video(inputs, pre) == coco
+    (burst,) = evals.instances_to_burst_json_video(inputs, pre)
+    assert burst["seq_name"] == "s" and burst["annotated_image_paths"] == ["a", "b", "c"] and len(burst["segmentations"]) == T
+    assert burst["track_category_ids"] == {0: 5, 1: 2}
+    assert [sorted(f) for f in burst["segmentations"]] == [[0, 1], [0], [0]]
+    a = burst["segmentations"][0][1]
+    assert a == {"rle": coco[1]["segmentations"][0]["counts"], "is_gt": False, "score": 0.4, "entropy": 0.7}

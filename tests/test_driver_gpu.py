@@ -15,7 +15,7 @@ def test_train_net_eval_only_writes_ytvis_results(tmp_path):
     out = tmp_path / "results.json"
     cmd = [sys.executable, os.path.join(ROOT, "train_net.py"), "--eval-only", "--synthetic", "2", "--frames", "3", "--output", str(out),
            "MODEL.META_ARCHITECTURE", "OpenVISOnline", "MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME",
-           "FrameMultiScaleMaskedTransformerDecoder"]
+           "FrameMultiScaleMaskedTransformerDecoder", "DATASETS.TEST", "['ytvis_2019_val']"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.load(open(out))
@@ -35,6 +35,7 @@ def test_train_net_refuses_training():
 def test_train_net_on_a_directory_of_frames(tmp_path):
     import numpy as np
     from PIL import Image
+    from openvis_amd import rle
     rng = np.random.default_rng(0)
     for v in ("vid_a", "vid_b"):
         os.makedirs(tmp_path / "videos" / v)
@@ -46,6 +47,15 @@ def test_train_net_on_a_directory_of_frames(tmp_path):
            str(tmp_path / "classes.txt"), "--output", str(out), "INPUT.MIN_SIZE_TEST", "120"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    res = json.load(open(out))
-    assert {x["video_id"] for x in res} == {"vid_a", "vid_b"} and all(1 <= x["category_id"] <= 3 for x in res)
-    assert res[0]["segmentations"][0]["size"] == [200, 300]               # masks are returned at the original frame size
+    # default test set of the shipped configs is burst_val (Base.yaml:19): BURST sequences (burst_eval.py:177-240, :160)
+    res = json.load(open(out))["sequences"]
+    assert {x["seq_name"] for x in res} == {"vid_a", "vid_b"}
+    for seq in res:
+        assert (seq["height"], seq["width"]) == (200, 300) and seq["annotated_image_paths"] == ["00000.png", "00001.png"]
+        assert len(seq["segmentations"]) == 2
+        assert all(1 <= c <= 3 for c in seq["track_category_ids"].values())
+        for frame in seq["segmentations"]:
+            for track_id, a in frame.items():
+                assert track_id in seq["track_category_ids"] and a["is_gt"] is False and 0.0 <= a["score"] <= 1.0
+                assert sum(rle.string_to_counts(a["rle"])[1::2]) > 20       # the > 20 pixel rule (burst_eval.py:203)
+                assert sum(rle.string_to_counts(a["rle"])) == 200 * 300     # masks are at the original frame size

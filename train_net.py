@@ -8,8 +8,9 @@ KEY VALUE opts) for the MI355X-native hot path.
 Only what surrounds `model.forward` at eval time lives here (datasets, mappers and evaluators are out of
 scope): videos are directories of frame images under --input (or --synthetic N clips), frames are resized on the GPU exactly like
 the test-time mapper (shortest edge = INPUT.MIN_SIZE_TEST, PIL bilinear), videos are sharded over the ranks in the InferenceSampler layout
-(data/build.py:238-247), results are gathered on rank 0 and written as the YTVIS result list the reference's evaluator
-dumps (ytvis_eval.py:258-301) with GPU-encoded COCO RLE segmentations.  Training is not part of this tier."""
+(data/build.py:238-247), results are gathered on rank 0 and written as the result list the reference's evaluator dumps —
+YTVIS tracks (ytvis_eval.py:258-301) or, for a `burst_*` test set, BURST sequences (burst_eval.py:177-240) — with
+GPU-encoded COCO RLE segmentations.  Training is not part of this tier."""
 import argparse
 import json
 import os
@@ -29,7 +30,7 @@ def load_video_dir(path, min_size, max_size, device):
     from openvis_amd import data
     names = sorted(n for n in os.listdir(path) if n.lower().endswith((".jpg", ".jpeg", ".png")))
     decoded = [np.asarray(Image.open(os.path.join(path, n)).convert("RGB")) for n in names]
-    return data.load_and_resize(decoded, min_size, max_size, device)
+    return data.load_and_resize(decoded, min_size, max_size, device) + (names,)
 
 
 def worker(rank, world, args):
@@ -37,7 +38,7 @@ def worker(rank, world, args):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", str(args.port))
     torch.cuda.set_device(rank)
-    from openvis_amd import config, weights, distributed as D
+    from openvis_amd import config, evals, weights, distributed as D
     from openvis_amd.catalog import MetadataCatalog
     D.init_from_env("nccl")
     cfg = config.get_cfg()
@@ -78,20 +79,34 @@ def worker(rank, world, args):
         vid, path = videos[vi]
         if path is None:
             frames = [f for f in bench.synth_frames(args.frames, 360, 640, 1000 + vi, "cpu")]
-            hw = (360, 640)
+            hw, fnames = (360, 640), [f"frame{i:04d}.jpg" for i in range(args.frames)]
         else:
-            frames, hw = load_video_dir(path, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.get("MAX_SIZE_TEST", 1333), model.device)
-        out = model([{"image": frames, "dataset_name": dataset, "height": hw[0], "width": hw[1], "video_id": vid, "length": len(frames)}])
-        for s, l, segs in zip(out["pred_scores"], out["pred_labels"], out.get("pred_masks_rle", [])):
-            results.append({"video_id": vid, "score": s, "category_id": l + 1, "segmentations": segs})   # ytvis_eval.py:296
+            frames, hw, fnames = load_video_dir(path, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.get("MAX_SIZE_TEST", 1333), model.device)
+        inputs = [{"image": frames, "dataset_name": dataset, "height": hw[0], "width": hw[1], "video_id": vid, "length": len(frames),
+                   "seq_name": vid, "dataset": os.path.basename(os.path.normpath(args.input)) if args.input else "synthetic",
+                   "annotated_image_paths": fnames}]
+        out = model(inputs)
+        if not out["pred_scores"]:
+            out["pred_masks_rle"] = []
+        # the evaluators then un-map contiguous ids to dataset ids (ytvis_eval.py:152-168, burst_eval.py:145-158); without
+        # dataset metadata the mapping is the 1-based identity
+        if dataset.startswith("burst"):
+            for seq in evals.instances_to_burst_json_video(inputs, out):
+                seq["track_category_ids"] = {k: l + 1 for k, l in seq["track_category_ids"].items()}
+                results.append(seq)
+        else:
+            for r in evals.instances_to_coco_json_video(inputs, out):
+                r["category_id"] += 1
+                results.append(r)
     if world > 1:
         import torch.distributed as dist
         gathered = [None] * world if rank == 0 else None
         dist.gather_object(results, gathered, dst=0)                  # comm.gather of the evaluator (ytvis_eval.py:122-128)
         results = [r for part in gathered for r in part] if rank == 0 else []
     if rank == 0:
-        json.dump(results, open(args.output, "w"))
-        print(f"[train_net] {len(videos)} videos, {len(results)} instance tracks -> {args.output}")
+        json.dump({"sequences": results} if dataset.startswith("burst") else results, open(args.output, "w"))   # burst_eval.py:160
+        kind = "BURST sequences" if dataset.startswith("burst") else "instance tracks"
+        print(f"[train_net] {len(videos)} videos, {len(results)} {kind} -> {args.output}")
 
 
 def main():
