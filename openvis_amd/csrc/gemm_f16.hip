@@ -298,12 +298,38 @@ gemm_f16_256_kernel(const _Float16* __restrict__ A, long long lda, const _Float1
   if (tile < n_tiles) { set_src(tile); dma(0, 0); }
   while (tile < n_tiles) {
     const int bn = (tile % tiles_n) * BN, bm = (tile / tiles_n) * BM;
+    // Accumulators start at bias + residual instead of 0 (tiles that lie inside N with 16-byte rows): all 32 residual
+    // loads of a lane are in flight together and complete under the wait for the first K stage, and the epilogue is left
+    // with conversions and stores only.  (Loaded per 32x32 tile inside the epilogue they cost one exposed memory round
+    // trip per tile: +103 us on the N = K = 768 out-projection, +22 us for the bias alone.)
+    const bool pre = vec_ok && bn + BN <= N && (bias || R);
+    if (pre) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 2; ++j) {
+        const int n0 = bn + wc * 64 + j * 32 + 4 * h;
+        float4 bv[4];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int g = 0; g < 4; ++g)
+          bv[g] = bias ? *reinterpret_cast<const float4*>(bias + n0 + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int i = 0; i < 4; ++i) {
+          const long long m = min((long long)bm + wr * 128 + i * 32 + r32, (long long)M - 1);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 rv = R ? *reinterpret_cast<const float4*>(R + m * ldr + n0 + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc[i][j][4 * g + 0] = bv[g].x + rv.x; acc[i][j][4 * g + 1] = bv[g].y + rv.y;
+            acc[i][j][4 * g + 2] = bv[g].z + rv.z; acc[i][j][4 * g + 3] = bv[g].w + rv.w;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this tile's first stage (issued during the previous epilogue)
     __builtin_amdgcn_s_barrier();
     ldfrag(lds + (g & 1) * STAGE, coff[0], a0, b0);
@@ -346,7 +372,8 @@ gemm_f16_256_kernel(const _Float16* __restrict__ A, long long lda, const _Float1
       const long long m = bm + wr * 128 + i * 32 + r32;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        ovis::epilogue_tile<OUT_F16>(acc[i][j], m, m < M, bn + wc * 64 + j * 32, h, N, Cv, ldc, bias, R, ldr, act, vec_ok);
+        ovis::epilogue_tile<OUT_F16>(acc[i][j], m, m < M, bn + wc * 64 + j * 32, h, N, Cv, ldc, pre ? nullptr : bias,
+                                     pre ? nullptr : R, ldr, act, vec_ok);
     }
     tile += nblk;
   }
