@@ -22,6 +22,26 @@ __device__ __forceinline__ float gelu_erf(float v) {   // nn.GELU() (exact erf f
   return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
 }
 
+// Accumulator start value bias + residual of one 32x32 tile (instead of 0) for kernels whose operands are fp16-rounded
+// anyway: every residual load of the lane is issued up front and the epilogue (called with bias = R = nullptr) is left
+// with conversions and stores.  Only for tiles on epilogue_tile's vector path: 16-byte aligned rows, tile inside N;
+// m must be clamped to a valid row by the caller.
+__device__ __forceinline__ void acc_init_tile(f32x16_t& acc, long long m, int n_tile0, int h, const float* __restrict__ bias,
+                                              const float* __restrict__ R, long long ldr) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int n = n_tile0 + 8 * g + 4 * h;
+    const float4 b = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 r = R ? *reinterpret_cast<const float4*>(R + m * ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    acc[4 * g + 0] = b.x + r.x; acc[4 * g + 1] = b.y + r.y; acc[4 * g + 2] = b.z + r.z; acc[4 * g + 3] = b.w + r.w;
+  }
+}
+
+__device__ __forceinline__ bool epilogue_vec_ok(const void* C, long long ldc, const float* bias, const float* R, long long ldr) {
+  return ((ldc & 3) == 0) && (!R || (ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+         (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
+}
+
 // acc: tile with lane -> row m (m_ok), registers -> columns n_tile0 + 8g + 4h + e.
 template <bool OUT_F16>
 __device__ __forceinline__ void epilogue_tile(const f32x16_t& acc, long long m, bool m_ok, int n_tile0, int h, int N,

@@ -67,15 +67,23 @@ gemm_f16_kernel(const _Float16* __restrict__ A, long long lda, const _Float16* _
           make_uint4(okb[i] ? pb[i].x : 0u, okb[i] ? pb[i].y : 0u, okb[i] ? pb[i].z : 0u, okb[i] ? pb[i].w : 0u);
   };
 
+  const int r32 = lane & 31, h = lane >> 5;
+  const bool vec_ok = ovis::epilogue_vec_ok(Cv, ldc, bias, R, ldr);
+  const bool pre = vec_ok && bn + BN <= N && (bias || R);       // accumulators start at bias + residual (gemm_epilogue.h)
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
+      if (pre) {
+        ovis::acc_init_tile(acc[i][j], min((long long)bm + wr * (BM / 2) + i * 32 + r32, (long long)M - 1),
+                            bn + wc * (BN / 2) + j * 32, h, bias, R, ldr);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      }
+    }
 
-  const int r32 = lane & 31, h = lane >> 5;
   const int nk = (K + BKH - 1) / BKH;
   gload(0);
   for (int kt = 0; kt < nk; ++kt) {
@@ -106,14 +114,13 @@ gemm_f16_kernel(const _Float16* __restrict__ A, long long lda, const _Float16* _
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);   // roles swapped
   }
 
-  const bool vec_ok = ((ldc & 3) == 0) && (!R || (ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cv) & 15) == 0) &&
-                      (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const long long m = bm + wr * (BM / 2) + i * 32 + r32;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      ovis::epilogue_tile<OUT_F16>(acc[i][j], m, m < M, bn + wc * (BN / 2) + j * 32, h, N, Cv, ldc, bias, R, ldr, act, vec_ok);
+      ovis::epilogue_tile<OUT_F16>(acc[i][j], m, m < M, bn + wc * (BN / 2) + j * 32, h, N, Cv, ldc, pre ? nullptr : bias,
+                                   pre ? nullptr : R, ldr, act, vec_ok);
   }
 }
 
@@ -164,15 +171,23 @@ gemm_f16_glds_kernel(const _Float16* __restrict__ A, long long lda, const _Float
     }
   };
 
+  const int r32 = lane & 31, h = lane >> 5;
+  const bool vec_ok = ovis::epilogue_vec_ok(Cv, ldc, bias, R, ldr);
+  const bool pre = vec_ok && bn + BN <= N && (bias || R);       // accumulators start at bias + residual (gemm_epilogue.h)
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
+      if (pre) {
+        ovis::acc_init_tile(acc[i][j], min((long long)bm + wr * 64 + i * 32 + r32, (long long)M - 1), bn + wc * 64 + j * 32, h,
+                            bias, R, ldr);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      }
+    }
 
-  const int r32 = lane & 31, h = lane >> 5;
   // fragment read offsets (halfs) inside a stage: row*64 + ((4h + s) ^ ((row>>1)&7))*8
   int aoff[TM], boff[TN], asw[TM], bsw[TN];
 #pragma unroll
@@ -205,14 +220,13 @@ gemm_f16_glds_kernel(const _Float16* __restrict__ A, long long lda, const _Float
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);   // roles swapped
   }
 
-  const bool vec_ok = ((ldc & 3) == 0) && (!R || (ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cv) & 15) == 0) &&
-                      (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const long long m = bm + wr * 64 + i * 32 + r32;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      ovis::epilogue_tile<OUT_F16>(acc[i][j], m, m < M, bn + wc * 64 + j * 32, h, N, Cv, ldc, bias, R, ldr, act, vec_ok);
+      ovis::epilogue_tile<OUT_F16>(acc[i][j], m, m < M, bn + wc * 64 + j * 32, h, N, Cv, ldc, pre ? nullptr : bias,
+                                   pre ? nullptr : R, ldr, act, vec_ok);
   }
 }
 
@@ -290,8 +304,7 @@ gemm_f16_256_kernel(const _Float16* __restrict__ A, long long lda, const _Float1
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // roles swapped
   };
 
-  const bool vec_ok = ((ldc & 3) == 0) && (!R || (ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cv) & 15) == 0) &&
-                      (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
+  const bool vec_ok = ovis::epilogue_vec_ok(Cv, ldc, bias, R, ldr);
   const int nk = K / BKS;
   f16x8 a0[4], b0[2], a1[4], b1[2];
   int g = 0;                                                   // running stage counter: LDS slot = g & 1

@@ -83,15 +83,23 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, fl
           make_uint4(okb[i] ? pb[i].x : 0u, okb[i] ? pb[i].y : 0u, okb[i] ? pb[i].z : 0u, okb[i] ? pb[i].w : 0u);
   };
 
+  const int r32 = lane & 31, h = lane >> 5;
+  const bool vec_ok = ovis::epilogue_vec_ok(C, ldc, bias, R, ldr);
+  const bool pre = vec_ok && bn + BN <= N && (bias || R);       // accumulators start at bias + residual (gemm_epilogue.h)
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
+      if (pre) {
+        ovis::acc_init_tile(acc[i][j], min((long long)bm + wr * (BM / 2) + i * 32 + r32, (long long)M - 1),
+                            bn + wc * (BN / 2) + j * 32, h, bias, R, ldr);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      }
+    }
 
-  const int r32 = lane & 31, h = lane >> 5;
   const int nk = (K + BKH - 1) / BKH;
   gload(0);
   for (int kt = 0; kt < nk; ++kt) {
@@ -114,14 +122,13 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, fl
     }
   }
 
-  const bool vec_ok = ((ldc & 3) == 0) && (!R || (ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
-                      (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const long long m = bm + wr * (BM / 2) + i * 32 + r32;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      ovis::epilogue_tile<false>(acc[i][j], m, m < M, bn + wc * (BN / 2) + j * 32, h, N, C, ldc, bias, R, ldr, act, vec_ok);
+      ovis::epilogue_tile<false>(acc[i][j], m, m < M, bn + wc * (BN / 2) + j * 32, h, N, C, ldc, pre ? nullptr : bias,
+                                 pre ? nullptr : R, ldr, act, vec_ok);
   }
 }
 
