@@ -186,21 +186,34 @@ flash_attn_f16_seq_kernel(AttnH a) {
   const _Float16* kp = a.k + b * a.k_bs + (long long)head * D;
   const _Float16* vp = a.v + b * a.v_bs + (long long)head * D;
 
-  for (int c = tid; c < 32 * KT * 8; c += 64 * KT) {            // rows >= Nk zero
-    const int row = c >> 3, ch = c & 7;
-    const bool ok = row < a.Nk;
-    const int rc = ok ? row : 0;
-    const uint4 kk = *reinterpret_cast<const uint4*>(kp + (long long)rc * a.k_ld + ch * 8);
-    const uint4 vv = *reinterpret_cast<const uint4*>(vp + (long long)rc * a.v_ld + ch * 8);
-    *reinterpret_cast<uint4*>(&Ks[row * KROW + ch * 8]) = make_uint4(ok ? kk.x : 0u, ok ? kk.y : 0u, ok ? kk.z : 0u, ok ? kk.w : 0u);
-    *reinterpret_cast<uint4*>(&Vs[row * VROW + ch * 8]) = make_uint4(ok ? vv.x : 0u, ok ? vv.y : 0u, ok ? vv.z : 0u, ok ? vv.w : 0u);
-  }
   const int qi = wave * 32 + r32;
   const bool q_ok = qi < a.Nq;
   const int qc = q_ok ? qi : a.Nq - 1;
   f16x8 qf[D / 16];
 #pragma unroll
   for (int st = 0; st < D / 16; ++st) qf[st] = *reinterpret_cast<const f16x8*>(qp + (long long)qc * a.q_ld + 16 * st + 8 * h);
+  // K / V staging: 32*KT rows x 8 chunks of 16 B over 64*KT threads = exactly 4 chunks each.  All 8 loads (and the 4 Q
+  // loads above) are issued before the first LDS store -- as a rolled loop this was 4 dependent memory round trips
+  // (load, wait, store) per workgroup.
+  uint4 kk[4], vv[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = tid + it * 64 * KT;
+    const int row = c >> 3, ch = c & 7;
+    const int rc = row < a.Nk ? row : 0;
+    kk[it] = *reinterpret_cast<const uint4*>(kp + (long long)rc * a.k_ld + ch * 8);
+    vv[it] = *reinterpret_cast<const uint4*>(vp + (long long)rc * a.v_ld + ch * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {                                // rows >= Nk zero
+    const int c = tid + it * 64 * KT;
+    const int row = c >> 3, ch = c & 7;
+    const bool ok = row < a.Nk;
+    *reinterpret_cast<uint4*>(&Ks[row * KROW + ch * 8]) =
+        make_uint4(ok ? kk[it].x : 0u, ok ? kk[it].y : 0u, ok ? kk[it].z : 0u, ok ? kk[it].w : 0u);
+    *reinterpret_cast<uint4*>(&Vs[row * VROW + ch * 8]) =
+        make_uint4(ok ? vv[it].x : 0u, ok ? vv[it].y : 0u, ok ? vv[it].z : 0u, ok ? vv[it].w : 0u);
+  }
   __syncthreads();
   if (wave * 32 >= a.Nq) return;
 
