@@ -730,52 +730,71 @@ openvis_aggregate_kernel(const float* __restrict__ crop_logits, const int* __res
 }
 
 // A16 (scores): top-k over the flattened [rows*K] probabilities of the valid rows + entropy of the selected rows
-// (video_maskformer.py:267-272).  row_ids [nrows] = rows of `probs` that take part.  Single workgroup.
+// (video_maskformer.py:267-272).  row_ids [nrows] = rows of `probs` that take part.  Single workgroup of 16 wavefronts:
+// per selection one pass over the (L2-resident) scores with the (row, column) of a thread's elements advanced
+// incrementally, a shuffle reduction inside each wavefront and one across the 16 partial results -- two barriers per
+// selection.  Ties go to the smaller flat index.  The entropies are then summed one wavefront per selected row.
+__device__ __forceinline__ bool topk_better(float v2, int i2, float v, int i) {
+  return i2 >= 0 && (v2 > v || (v2 == v && (i < 0 || i2 < i)));
+}
+
 __global__ void __launch_bounds__(1024)
 topk_entropy_kernel(const float* __restrict__ probs, const int* __restrict__ row_ids, int nrows, int K, int topk,
                     int* __restrict__ out_idx, float* __restrict__ out_score, float* __restrict__ out_entropy,
                     int* __restrict__ out_query) {
-  __shared__ float bv[1024];
-  __shared__ long long bi[1024];
-  __shared__ long long chosen[64];
-  const long long total = (long long)nrows * K;
+  __shared__ float wv[16];
+  __shared__ int wi[16];
+  __shared__ int chosen[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int total = nrows * K;
+  const int r0 = tid / K, k0 = tid - r0 * K;
+  const int dr = 1024 / K, dk = 1024 - dr * K;
   for (int j = 0; j < topk; ++j) {
     float best = -INFINITY;
-    long long besti = -1;
-    for (long long i = threadIdx.x; i < total; i += blockDim.x) {
+    int besti = -1;
+    int r = r0, k = k0;
+    for (int i = tid; i < total; i += 1024) {
       bool taken = false;
       for (int c = 0; c < j; ++c) taken |= (chosen[c] == i);
-      if (taken) continue;
-      const float v = probs[(long long)row_ids[i / K] * K + (i % K)];
-      if (v > best || (v == best && (besti < 0 || i < besti))) { best = v; besti = i; }
-    }
-    bv[threadIdx.x] = best; bi[threadIdx.x] = besti;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-      if (threadIdx.x < o) {
-        const float v2 = bv[threadIdx.x + o]; const long long i2 = bi[threadIdx.x + o];
-        if (i2 >= 0 && (v2 > bv[threadIdx.x] || (v2 == bv[threadIdx.x] && (bi[threadIdx.x] < 0 || i2 < bi[threadIdx.x])))) {
-          bv[threadIdx.x] = v2; bi[threadIdx.x] = i2;
-        }
+      if (!taken) {
+        const float v = probs[(long long)row_ids[r] * K + k];
+        if (topk_better(v, i, best, besti)) { best = v; besti = i; }
       }
-      __syncthreads();
+      r += dr; k += dk;
+      if (k >= K) { k -= K; ++r; }
     }
-    if (threadIdx.x == 0) {
-      chosen[j] = bi[0]; out_idx[j] = (int)bi[0]; out_score[j] = bv[0];
-      if (out_query) out_query[j] = row_ids[bi[0] / K];          // query id of the selected row: lets the mask kernel start
-    }                                                             // without a host round trip
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float v2 = __shfl_xor(best, off, 64);
+      const int i2 = __shfl_xor(besti, off, 64);
+      if (topk_better(v2, i2, best, besti)) { best = v2; besti = i2; }
+    }
+    if (lane == 0) { wv[wave] = best; wi[wave] = besti; }
+    __syncthreads();
+    if (wave == 0) {
+      best = lane < 16 ? wv[lane] : -INFINITY;
+      besti = lane < 16 ? wi[lane] : -1;
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        const float v2 = __shfl_xor(best, off, 64);
+        const int i2 = __shfl_xor(besti, off, 64);
+        if (topk_better(v2, i2, best, besti)) { best = v2; besti = i2; }
+      }
+      if (lane == 0) {
+        chosen[j] = besti; out_idx[j] = besti; out_score[j] = best;
+        if (out_query) out_query[j] = row_ids[besti / K];         // query id of the selected row: lets the mask kernel start
+      }                                                           // without a host round trip
+    }
     __syncthreads();
   }
   // entropy of each selected row: -sum p log p
-  for (int j = 0; j < topk; ++j) {
+  for (int j = wave; j < topk; j += 16) {
     const long long row = row_ids[chosen[j] / K];
     float e = 0.f;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) { const float p = probs[row * K + k]; e += -p * logf(p); }
-    bv[threadIdx.x] = e;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) { if (threadIdx.x < o) bv[threadIdx.x] += bv[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) out_entropy[j] = bv[0];
-    __syncthreads();
+    for (int k = lane; k < K; k += 64) { const float p = probs[row * K + k]; e += -p * logf(p); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
+    if (lane == 0) out_entropy[j] = e;
   }
 }
 
@@ -997,6 +1016,7 @@ extern "C" int ovis_topk_entropy_f32(const float* probs, const int* row_ids, int
                                      float* out_score, float* out_entropy, int* out_query, ovis_stream_t stream) {
   OVIS_REQUIRE(probs && row_ids && out_idx && out_score && out_entropy, "topk_entropy: null pointer");
   OVIS_REQUIRE(nrows > 0 && K > 0 && topk > 0 && topk <= 64 && (long long)nrows * K >= topk, "topk_entropy: need 0 < topk <= min(64, nrows*K)");
+  OVIS_REQUIRE((long long)nrows * K < (1ll << 31), "topk_entropy: more than 2^31 scores");
   hipLaunchKernelGGL(topk_entropy_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, probs, row_ids, nrows, K, topk, out_idx,
                      out_score, out_entropy, out_query);
   return ovis::check_launch("topk_entropy");

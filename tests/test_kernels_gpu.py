@@ -251,6 +251,25 @@ def test_aggregate_topk():
         assert abs(e - ent_ref[i]) < 1e-5
 
 
+@pytest.mark.parametrize("nrows,Q,K,topk", [(100, 100, 482, 10), (37, 200, 1203, 10), (3, 5, 2000, 64), (1, 4, 7, 7)])
+def test_topk_entropy_sizes_order_and_ties(nrows, Q, K, topk):
+    """flat top-k over the valid rows == torch.topk on the gathered rows (values in descending order, ties to the smaller
+    flat index), query ids, entropies; K below / above the workgroup size, topk up to the kernel's 64."""
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(nrows * K)
+    probs = torch.rand(Q, K, generator=g).softmax(-1)
+    rows = torch.randperm(Q, generator=g)[:nrows].sort().values
+    probs[rows[0], 3 % K] = probs[rows[-1], 5 % K] = 0.5            # an exact tie at the top
+    idx, score, ent, sel_q = ops.topk_entropy(probs.cuda(), rows.int().cuda(), topk)
+    flat = probs[rows].flatten()
+    order = sorted(range(flat.numel()), key=lambda i: (-float(flat[i]), i))[:topk]
+    assert idx.cpu().tolist() == order
+    assert torch.equal(score.cpu(), flat[order])
+    assert sel_q.cpu().tolist() == [int(rows[i // K]) for i in order]
+    ref_e = torch.stack([(-probs[rows[i // K]] * probs[rows[i // K]].log()).sum() for i in order])
+    assert (ent.cpu() - ref_e).abs().max() < 1e-5
+
+
 @pytest.mark.parametrize("sizes,scale", [([(4, 7), (8, 14), (15, 27)], 3.0), ([(23, 40), (46, 80), (92, 160)], 2.0),
                                          ([(23, 40), (46, 80), (92, 160)], 12.0), ([(5, 5), (9, 10), (17, 19)], 1.0)])
 def test_msda_encoder_tiled_lds_kernel_is_identical_to_direct_gather(sizes, scale):
