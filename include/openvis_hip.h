@@ -128,7 +128,9 @@ int ovis_pe_sine_f32(float* out, int T, int H, int W, int num_pos_feats, int thr
 
 /* ovis_gemm_nt_f16: same contract with fp16 A [M,K] / B [N,K] (K, lda, ldb multiples of 8), f32 accumulation,
  *   f32 bias / residual, C written as f32 (out_f16 == 0) or fp16.  Used for the CLIP ViT GEMMs only — the reference
- *   runs CLIP in fp16 on the GPU (adapter.py:108-111; clip.load on cuda). */
+ *   runs CLIP in fp16 on the GPU (adapter.py:108-111; clip.load on cuda).  On tiles with 16-byte aligned rows the f32
+ *   accumulators START at bias + residual (C = act((bias + residual) + sum_k a*b) in f32), so no epilogue load is
+ *   exposed; C may alias residual (each tile reads its residual block before it writes that block). */
 int ovis_gemm_nt_f16(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int M, int N,
                      int K, const float* bias, const float* residual, long long ldr, int act, int out_f16,
                      ovis_stream_t stream);
