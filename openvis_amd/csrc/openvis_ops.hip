@@ -508,7 +508,11 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
       txs[m] = make_tap(min(xlo + c, Wp - 1), usx, w);
       cin[m] = c < PW;
     }
-    // software pipeline: the 14 gathers of the next row are in flight while the current row is blended and stored
+    // software pipeline, 4 rows deep: four register sets are filled round-robin and NEVER copied (a `cur = nxt` copy of
+    // in-flight load results makes the compiler wait for them, which turned the previous 2-stage version into one exposed
+    // memory round trip per row: 24 per wavefront, most of the kernel's time).  Loads are issued unconditionally (row /
+    // column indices are clamped, surplus rows are simply not stored), so the counted vmcnt waits the compiler derives
+    // are the same on every path: a row's 14 gathers are only waited for when 42 younger ones are already in flight.
     struct RowLoads { float a[2], b[2], c[2], d[2]; unsigned r[2], g[2], bl[2]; Tap ty; };
     auto issue = [&](int r, RowLoads& L) {
       const int y = min(ylo + r, Hp - 1);
@@ -527,19 +531,32 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
         L.r[m] = in ? v0 : 0u; L.g[m] = in ? v1 : 0u; L.bl[m] = in ? v2 : 0u;
       }
     };
-    RowLoads cur, nxt;
-    if (wv < PR) issue(wv, cur);
-    for (int r = wv; r < PR; r += NW) {
-      if (r + NW < PR) issue(r + NW, nxt);
+    auto consume = [&](const RowLoads& L, int r) {
+      if (r >= PR) return;
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         if (cin[m]) {
-          const float u = cur.ty.l0 * (txs[m].l0 * cur.a[m] + txs[m].l1 * cur.b[m]) +
-                          cur.ty.l1 * (txs[m].l0 * cur.c[m] + txs[m].l1 * cur.d[m]);                      // == bilerp()
-          patch[r * PWs + lane + 64 * m] = make_uint2(cur.r[m] | (cur.g[m] << 8) | (cur.bl[m] << 16), __float_as_uint(fast_sigmoid(u)));
+          const float u = L.ty.l0 * (txs[m].l0 * L.a[m] + txs[m].l1 * L.b[m]) +
+                          L.ty.l1 * (txs[m].l0 * L.c[m] + txs[m].l1 * L.d[m]);                            // == bilerp()
+          patch[r * PWs + lane + 64 * m] = make_uint2(L.r[m] | (L.g[m] << 8) | (L.bl[m] << 16), __float_as_uint(fast_sigmoid(u)));
         }
       }
-      cur = nxt;
+    };
+    RowLoads L0, L1, L2, L3;
+    if (PR > 8 * NW) {                                            // tall patches (large boxes): 4 rows in flight per wavefront
+      issue(wv, L0); issue(wv + NW, L1); issue(wv + 2 * NW, L2); issue(wv + 3 * NW, L3);
+      for (int r = wv; r < PR; r += 4 * NW) {
+        consume(L0, r);          issue(r + 4 * NW, L0);
+        consume(L1, r + NW);     issue(r + 5 * NW, L1);
+        consume(L2, r + 2 * NW); issue(r + 6 * NW, L2);
+        consume(L3, r + 3 * NW); issue(r + 7 * NW, L3);
+      }
+    } else {                                                      // <= 8 rows per wavefront: two in flight, nothing surplus
+      issue(wv, L0); issue(wv + NW, L1);
+      for (int r = wv; r < PR; r += 2 * NW) {
+        consume(L0, r);      issue(r + 2 * NW, L0);
+        consume(L1, r + NW); issue(r + 3 * NW, L1);
+      }
     }
   }
   __syncthreads();
