@@ -759,50 +759,88 @@ __global__ void __launch_bounds__(1024)
 topk_entropy_kernel(const float* __restrict__ probs, const int* __restrict__ row_ids, int nrows, int K, int topk,
                     int* __restrict__ out_idx, float* __restrict__ out_score, float* __restrict__ out_entropy,
                     int* __restrict__ out_query) {
+  constexpr int ROWS_LDS = 2048;
   __shared__ float wv[16];
   __shared__ int wi[16];
   __shared__ int chosen[64];
+  __shared__ int rows_s[ROWS_LDS];                              // row ids next to the CUs: one global load per score, not two
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int total = nrows * K;
   const int r0 = tid / K, k0 = tid - r0 * K;
   const int dr = 1024 / K, dk = 1024 - dr * K;
-  for (int j = 0; j < topk; ++j) {
-    float best = -INFINITY;
-    int besti = -1;
+  const bool rows_in_lds = nrows <= ROWS_LDS;
+  if (rows_in_lds)
+    for (int i = tid; i < nrows; i += 1024) rows_s[i] = row_ids[i];
+  __syncthreads();
+  // Every thread keeps the best of ITS elements (flat indices tid, tid + 1024, ...); a selection is then one reduction over
+  // the 1024 candidates, and only the thread that owned the winner rescans its elements (minus the chosen ones).
+  // The scan is a chain of independent loads, unrolled so that 8 are in flight.
+  float best, second;                                           // the thread's best two remaining elements
+  int besti, secondi;
+  unsigned long long mine_taken = 0, mine_taken_hi = 0;         // bit o: this thread's o-th element (tid + 1024 o) was selected
+  auto scan = [&](int n_chosen) {
+    best = second = -INFINITY;
+    besti = secondi = -1;
     int r = r0, k = k0;
-    for (int i = tid; i < total; i += 1024) {
-      bool taken = false;
-      for (int c = 0; c < j; ++c) taken |= (chosen[c] == i);
-      if (!taken) {
-        const float v = probs[(long long)row_ids[r] * K + k];
-        if (topk_better(v, i, best, besti)) { best = v; besti = i; }
+    for (int i0 = tid, o0 = 0; i0 < total; i0 += 8 * 1024, o0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {                               // 8 independent loads in flight
+        const int i = i0 + u * 1024;
+        const int rc = i < total ? r : 0;
+        const int row = rows_in_lds ? rows_s[rc] : row_ids[rc];
+        v[u] = probs[(long long)row * K + (i < total ? k : 0)];
+        r += dr; k += dk;
+        if (k >= K) { k -= K; ++r; }
       }
-      r += dr; k += dk;
-      if (k >= K) { k -= K; ++r; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 1024, o = o0 + u;
+        bool taken = i >= total;
+        if (o < 64) taken |= ((mine_taken >> o) & 1ull) != 0;     // own selections: a register bit, no LDS walk
+        else if (o < 128) taken |= ((mine_taken_hi >> (o - 64)) & 1ull) != 0;
+        else for (int c = 0; c < n_chosen; ++c) taken |= (chosen[c] == i);
+        if (!taken) {
+          if (topk_better(v[u], i, best, besti)) { second = best; secondi = besti; best = v[u]; besti = i; }
+          else if (topk_better(v[u], i, second, secondi)) { second = v[u]; secondi = i; }
+        }
+      }
     }
+  };
+  scan(0);
+  for (int j = 0; j < topk; ++j) {
+    float wbest = best;
+    int wbesti = besti;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-      const float v2 = __shfl_xor(best, off, 64);
-      const int i2 = __shfl_xor(besti, off, 64);
-      if (topk_better(v2, i2, best, besti)) { best = v2; besti = i2; }
+      const float v2 = __shfl_xor(wbest, off, 64);
+      const int i2 = __shfl_xor(wbesti, off, 64);
+      if (topk_better(v2, i2, wbest, wbesti)) { wbest = v2; wbesti = i2; }
     }
-    if (lane == 0) { wv[wave] = best; wi[wave] = besti; }
+    if (lane == 0) { wv[wave] = wbest; wi[wave] = wbesti; }
     __syncthreads();
     if (wave == 0) {
-      best = lane < 16 ? wv[lane] : -INFINITY;
-      besti = lane < 16 ? wi[lane] : -1;
+      wbest = lane < 16 ? wv[lane] : -INFINITY;
+      wbesti = lane < 16 ? wi[lane] : -1;
 #pragma unroll
       for (int off = 8; off > 0; off >>= 1) {
-        const float v2 = __shfl_xor(best, off, 64);
-        const int i2 = __shfl_xor(besti, off, 64);
-        if (topk_better(v2, i2, best, besti)) { best = v2; besti = i2; }
+        const float v2 = __shfl_xor(wbest, off, 64);
+        const int i2 = __shfl_xor(wbesti, off, 64);
+        if (topk_better(v2, i2, wbest, wbesti)) { wbest = v2; wbesti = i2; }
       }
       if (lane == 0) {
-        chosen[j] = besti; out_idx[j] = besti; out_score[j] = best;
-        if (out_query) out_query[j] = row_ids[besti / K];         // query id of the selected row: lets the mask kernel start
+        chosen[j] = wbesti; out_idx[j] = wbesti; out_score[j] = wbest;
+        if (out_query) out_query[j] = row_ids[wbesti / K];        // query id of the selected row: lets the mask kernel start
       }                                                           // without a host round trip
     }
     __syncthreads();
+    if (besti == chosen[j] && j + 1 < topk) {                     // the winner's owner moves to its next candidate:
+      const int o = (besti - tid) >> 10;                          // the runner-up it already knows, or a rescan when that is
+      if (o < 64) mine_taken |= 1ull << o;                        // used up too (a thread winning three times is rare)
+      else if (o < 128) mine_taken_hi |= 1ull << (o - 64);
+      if (secondi >= 0 || total <= tid + 1024) { best = second; besti = secondi; second = -INFINITY; secondi = -1; }
+      else scan(j + 1);
+    }
   }
   // entropy of each selected row: -sum p log p
   for (int j = wave; j < topk; j += 16) {
