@@ -18,4 +18,4 @@ for name, side in (("full-frame boxes", None), ("200px boxes", 200)):
     cr = torch.tensor(crops, dtype=torch.int32).cuda()
     mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
     ms = timeit(lambda: ops.clip_crop_patches(frames, masks, cr, Hp, Wp, 224, 16, mean, std, out_f16=True), n=10)
-    print(os.environ.get("OVIS_CROP_EXP", "0"), name, len(crops), "crops", round(ms, 3), "ms")
+    print(name, len(crops), "crops", round(ms, 3), "ms")
