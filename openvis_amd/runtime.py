@@ -1,0 +1,73 @@
+"""Clip-level executor: independent clips of one model on several HIP streams.
+
+The reference evaluates one video per forward and parallelises over videos with one process per GPU
+(`InferenceSampler`, data/build.py:238-247).  Inside one GPU the path of a single clip is a chain of dependent launches
+whose small stages (per-frame decoder GEMMs, box read-back, top-k, the D2H copy of the output masks) leave most CUs idle;
+two clips in flight fill those holes.  `ClipPipeline` keeps one host thread and one HIP stream per slot: every kernel of
+`openvis_amd` is launched on torch's CURRENT stream, which is thread-local, so a clip's tensors live and die on its own
+stream and the caching allocator never hands a block to the other stream while it is in use.  Model weights and the
+shape-keyed caches (position encodings, window tables, bf16 weight planes) are read-only once filled, so the first call
+runs one clip alone (`warm`) before the slots start.  Results come back in input order and are bit-identical to a
+sequential run (tests/test_pipeline_gpu.py)."""
+import queue
+import threading
+
+import torch
+
+
+class ClipPipeline:
+    def __init__(self, model, n_streams=2):
+        if n_streams < 1:
+            raise ValueError("n_streams must be >= 1")
+        self.model, self.n = model, int(n_streams)
+        dev = torch.device(model.device)
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n)]
+        self._warm = False
+
+    def run(self, clips, **kw):
+        """clips: list of `batched_inputs` (one video each); returns [model(c, **kw) for c in clips], overlapped."""
+        clips = list(clips)
+        outs = [None] * len(clips)
+        first = 0
+        if not self._warm and clips:                    # fill the read-only caches without a concurrent writer
+            outs[0] = self.model(clips[0], **kw)
+            self._warm, first = True, 1
+        if self.n == 1 or len(clips) - first <= 1:
+            for i in range(first, len(clips)):
+                outs[i] = self.model(clips[i], **kw)
+            return outs
+        start = torch.cuda.Event()
+        start.record()                                  # the slots' streams wait for what the caller queued so far
+        todo = queue.SimpleQueue()
+        for i in range(first, len(clips)):
+            todo.put(i)
+        errors, done = [], [None] * self.n
+
+        def slot(w):
+            try:
+                torch.cuda.set_device(self.device)
+                with torch.cuda.stream(self.streams[w]):
+                    self.streams[w].wait_event(start)
+                    while not errors:
+                        try:
+                            i = todo.get_nowait()
+                        except queue.Empty:
+                            break
+                        outs[i] = self.model(clips[i], **kw)
+                    done[w] = torch.cuda.Event()
+                    done[w].record()
+            except BaseException as e:                  # re-raised in the caller's thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=slot, args=(w,), name=f"ovis-clip-slot-{w}") for w in range(self.n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        for e in done:
+            if e is not None:
+                torch.cuda.current_stream().wait_event(e)
+        return outs

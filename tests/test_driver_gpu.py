@@ -27,6 +27,18 @@ def test_train_net_eval_only_writes_ytvis_results(tmp_path):
         assert sum(rle.string_to_counts(seg["counts"])) == 360 * 640
 
 
+def test_train_net_with_videos_in_flight_matches_sequential(tmp_path):
+    outs = []
+    for streams in ("1", "2"):
+        out = tmp_path / f"res_{streams}.json"
+        cmd = [sys.executable, os.path.join(ROOT, "train_net.py"), "--eval-only", "--synthetic", "5", "--frames", "2", "--output", str(out),
+               "--streams", streams, "DATASETS.TEST", "['ytvis_2019_val']"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.load(open(out)))
+    assert outs[0] == outs[1] and len(outs[0]) == 50
+
+
 def test_train_net_refuses_training():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train_net.py"), "--synthetic", "1"], capture_output=True, text=True)
     assert r.returncode != 0 and "eval-only" in (r.stderr + r.stdout)

@@ -75,17 +75,19 @@ def worker(rank, world, args):
     else:
         videos = [(d, os.path.join(args.input, d)) for d in sorted(os.listdir(args.input)) if os.path.isdir(os.path.join(args.input, d))]
     results = []
-    for vi in D.inference_shard(len(videos), rank, world):
+
+    def load(vi):
         vid, path = videos[vi]
         if path is None:
             frames = [f for f in bench.synth_frames(args.frames, 360, 640, 1000 + vi, "cpu")]
             hw, fnames = (360, 640), [f"frame{i:04d}.jpg" for i in range(args.frames)]
         else:
             frames, hw, fnames = load_video_dir(path, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.get("MAX_SIZE_TEST", 1333), model.device)
-        inputs = [{"image": frames, "dataset_name": dataset, "height": hw[0], "width": hw[1], "video_id": vid, "length": len(frames),
-                   "seq_name": vid, "dataset": os.path.basename(os.path.normpath(args.input)) if args.input else "synthetic",
-                   "annotated_image_paths": fnames}]
-        out = model(inputs)
+        return [{"image": frames, "dataset_name": dataset, "height": hw[0], "width": hw[1], "video_id": vid, "length": len(frames),
+                 "seq_name": vid, "dataset": os.path.basename(os.path.normpath(args.input)) if args.input else "synthetic",
+                 "annotated_image_paths": fnames}]
+
+    def emit(inputs, out):
         if not out["pred_scores"]:
             out["pred_masks_rle"] = []
         # the evaluators then un-map contiguous ids to dataset ids (ytvis_eval.py:152-168, burst_eval.py:145-158); without
@@ -98,6 +100,20 @@ def worker(rank, world, args):
             for r in evals.instances_to_coco_json_video(inputs, out):
                 r["category_id"] += 1
                 results.append(r)
+
+    shard = list(D.inference_shard(len(videos), rank, world))
+    if args.streams > 1:
+        # several videos in flight on this GPU (openvis_amd/runtime.py): chunks bound what is decoded ahead
+        from openvis_amd.runtime import ClipPipeline
+        pipe = ClipPipeline(model, args.streams)
+        for c0 in range(0, len(shard), 4 * args.streams):
+            chunk = [load(vi) for vi in shard[c0:c0 + 4 * args.streams]]
+            for inputs, out in zip(chunk, pipe.run(chunk)):
+                emit(inputs, out)
+    else:
+        for vi in shard:
+            inputs = load(vi)
+            emit(inputs, model(inputs))
     if world > 1:
         import torch.distributed as dist
         gathered = [None] * world if rank == 0 else None
@@ -121,6 +137,7 @@ def main():
     ap.add_argument("--synthetic-text", action="store_true", help="random unit text embeddings even if the checkpoint has a text tower")
     ap.add_argument("--output", default="results.json")
     ap.add_argument("--port", type=int, default=29511)
+    ap.add_argument("--streams", type=int, default=1, help="videos in flight per GPU (HIP streams, openvis_amd/runtime.py)")
     ap.add_argument("opts", nargs=argparse.REMAINDER, default=[])
     args = ap.parse_args()
     if not args.eval_only:
