@@ -65,3 +65,34 @@ def test_pipeline_reraises_worker_errors():
     bad = [{"image": [torch.zeros(3, 90, 120, dtype=torch.uint8)], "dataset_name": "no_such_dataset"}]
     with pytest.raises(Exception):
         pipe.run(clips[:2] + [bad] + clips[2:])
+
+
+@pytest.mark.parametrize("arch", ["SANOnline", "BriVIS"])
+def test_pipelined_side_adapter_models_equal_sequential(arch):
+    """the SideAdapter meta-architectures (per-frame decoder, linker, BriVIS resampler) with two clips in flight"""
+    from openvis_amd import config, weights
+    from openvis_amd.catalog import MetadataCatalog
+    from openvis_amd.modeling.clip_adapter.side_adapter import SideAdapter
+    from openvis_amd.runtime import ClipPipeline
+    from tests.test_san_gpu import SAN_E2E_ARCH
+    Q = 100
+    cfg = config.get_cfg()
+    cfg.MODEL.META_ARCHITECTURE = arch
+    cfg.MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME = "SideAdapterFrameMultiScaleMaskedTransformerDecoder"
+    cfg.MODEL.CLIP_ADAPTER.CLIP_NUM_HEADS = 4
+    model = config.build_model(cfg)
+    model.clip_adapter = SideAdapter("tiny", broken_idx=3, merge_ids=[1, 2, 3], num_queries=Q, arch=SAN_E2E_ARCH, precision="fp16")
+    model.load_state_dict(weights.random_init(weights.brivis_r50_spec(SAN_E2E_ARCH, Q), seed=21))
+    names = [f"class_{i}" for i in range(9)]
+    MetadataCatalog.get("pipe_val").set(thing_classes=names)
+    g = torch.Generator().manual_seed(1)
+    base = torch.randn(1, 64, generator=g)
+    model.clip_adapter.set_text_features(names, torch.nn.functional.normalize(base + 0.05 * torch.randn(9, 64, generator=g), dim=-1))
+    clips = _clips(5, T=3)
+    ref = [model(c) for c in clips]
+    torch.cuda.synchronize()
+    outs = ClipPipeline(model, 2).run(clips)
+    torch.cuda.synchronize()
+    for a, b in zip(outs, ref):
+        assert a["pred_labels"] == b["pred_labels"] and a["pred_scores"] == b["pred_scores"]
+        assert all(torch.equal(ma, mb) for ma, mb in zip(a["pred_masks"], b["pred_masks"]))
