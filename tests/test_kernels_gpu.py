@@ -270,6 +270,42 @@ def test_topk_entropy_sizes_order_and_ties(nrows, Q, K, topk):
     assert (ent.cpu() - ref_e).abs().max() < 1e-5
 
 
+def test_topk_entropy_randomised_with_heavy_ties():
+    """scores quantised to a few levels (ties everywhere: the order is decided by the flat index), random sizes incl. more
+    than 128 elements per thread (beyond the kernel's own-selection bitmask) and threads that win several times"""
+    from openvis_amd import ops
+    rng = np.random.default_rng(11)
+    for case in range(24):
+        Q = int(rng.integers(1, 260))
+        K = int(rng.integers(1, 1300))
+        nrows = int(rng.integers(1, Q + 1))
+        topk = int(min(rng.integers(1, 65), nrows * K))
+        g = torch.Generator().manual_seed(case)
+        levels = int(rng.integers(2, 50))
+        probs = (torch.randint(1, levels + 1, (Q, K), generator=g).float() / (levels + 1)).contiguous()
+        if case % 3 == 0:                                    # one hot row: the same threads win again and again
+            probs[int(rng.integers(0, Q))] = 0.999
+        rows = torch.randperm(Q, generator=g)[:nrows].sort().values
+        idx, score, ent, sel_q = ops.topk_entropy(probs.cuda(), rows.int().cuda(), topk)
+        flat = probs[rows].flatten()
+        # descending value, ascending index on ties
+        order = sorted(range(flat.numel()), key=lambda i: (-float(flat[i]), i))[:topk] if flat.numel() < 20000 else None
+        if order is None:
+            v, _ = flat.sort(descending=True, stable=True)
+            assert torch.equal(score.cpu(), v[:topk])
+            got = idx.cpu().tolist()
+            assert len(set(got)) == topk and all(float(flat[i]) == float(s) for i, s in zip(got, score.cpu()))
+            for a, b in zip(got, got[1:]):                   # ties in ascending index order
+                assert float(flat[a]) > float(flat[b]) or a < b
+            cut = float(v[topk - 1])                         # every index below the last selected one with the cut value is in
+            last = max(i for i in got if float(flat[i]) == cut)
+            assert all((float(flat[i]) != cut) or (i in set(got)) for i in range(last))
+        else:
+            assert idx.cpu().tolist() == order, (case, Q, K, nrows, topk)
+            assert torch.equal(score.cpu(), flat[order])
+        assert sel_q.cpu().tolist() == [int(rows[i // K]) for i in idx.cpu().tolist()]
+
+
 @pytest.mark.parametrize("sizes,scale", [([(4, 7), (8, 14), (15, 27)], 3.0), ([(23, 40), (46, 80), (92, 160)], 2.0),
                                          ([(23, 40), (46, 80), (92, 160)], 12.0), ([(5, 5), (9, 10), (17, 19)], 1.0)])
 def test_msda_encoder_tiled_lds_kernel_is_identical_to_direct_gather(sizes, scale):
