@@ -105,6 +105,38 @@ class ClipVisual:
                 x = ops.gemm_nt(f, w[f"{i}.mlp.c_proj.weight"], w[f"{i}.mlp.c_proj.bias"], x.view(-1, C)).view(B, L, C)
         return x
 
+    def last_block_cls(self, x, i):
+        """resblock i evaluated for the CLASS TOKEN only -> f32 [B, C].  ln_post reads x[:, 0] alone (model.py:356-358), so in
+        the last block every token still contributes its key / value, but the query projection, the attention rows, the
+        output projection and the whole MLP are needed for one token per crop: [B] rows instead of [B*L] (the same
+        arithmetic per element as run_blocks, so the result matches it to the last bit of the GEMM's accumulation order)."""
+        w = self.w
+        B, L, C = x.shape
+        Hh = self.heads
+        D = C // Hh
+        f16 = self.precision == "fp16"
+        h = ops.layernorm(x, w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"], out_f16=f16)
+        hq = h[:, 0, :].contiguous()
+        bi = w[f"{i}.attn.in_proj_bias"]
+        xc = x[:, 0, :].contiguous()
+        if f16:
+            wi = w[f"{i}.attn.in_proj_weight.h"]
+            kv = ops.gemm_nt_f16(h.view(-1, C), wi[C:], bi[C:], out_f16=True)                   # [B*L, 2C]: keys | values
+            q = ops.gemm_nt_f16(hq, wi[:C], bi[:C], out_f16=True)                               # [B, C]
+            att = ops.attention_f16(q, kv, kv[:, C:], B, Hh, 1, L, D, C, C, L * 2 * C, 2 * C, L * 2 * C, 2 * C)
+            xc = ops.gemm_nt_f16(att.view(B, C), w[f"{i}.attn.out_proj.weight.h"], w[f"{i}.attn.out_proj.bias"], xc)
+            h2 = ops.layernorm(xc, w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"], out_f16=True)
+            f = ops.gemm_nt_f16(h2, w[f"{i}.mlp.c_fc.weight.h"], w[f"{i}.mlp.c_fc.bias"], None, ops.ACT_QUICKGELU, out_f16=True)
+            return ops.gemm_nt_f16(f, w[f"{i}.mlp.c_proj.weight.h"], w[f"{i}.mlp.c_proj.bias"], xc)
+        wi = w[f"{i}.attn.in_proj_weight"]
+        kv = ops.gemm_nt(h.view(-1, C), wi[C:], bi[C:])
+        q = ops.gemm_nt(hq, wi[:C], bi[:C])
+        att = ops.attention(q, kv, kv[:, C:], B, Hh, 1, L, D, C, C, L * 2 * C, 2 * C, L * 2 * C, 2 * C)
+        xc = ops.gemm_nt(att.view(B, C), w[f"{i}.attn.out_proj.weight"], w[f"{i}.attn.out_proj.bias"], xc)
+        h2 = ops.layernorm(xc, w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"])
+        f = ops.gemm_nt(h2, w[f"{i}.mlp.c_fc.weight"], w[f"{i}.mlp.c_fc.bias"], None, ops.ACT_QUICKGELU)
+        return ops.gemm_nt(f, w[f"{i}.mlp.c_proj.weight"], w[f"{i}.mlp.c_proj.bias"], xc)
+
     def head(self, tok):
         """ln_post + projection of token rows [N, C] -> [N, embed_dim] (model.py:358-361), exact f32."""
         w = self.w
@@ -114,17 +146,19 @@ class ClipVisual:
         """A: patch im2col matrix [M*G*G, 3*ps*ps] -> image features [M, embed_dim] (before L2 normalisation).
         patch_open uint8 [M, G*G]: the mask-prompt path (model.py:344-352) — after block d < mask_prompt_depth the
         closed patch tokens are reset to mask_embedding[d]."""
+        last = self.layers - 1
         if patch_open is None:
-            x = self.run_blocks(self.embed(A, M), 0, self.layers)
+            x = self.run_blocks(self.embed(A, M), 0, last)
         else:
             if self.mask_prompt_depth < 1:
                 raise ValueError("mask prompt requested on a tower built with mask_prompt_depth=0 (no mask_embedding)")
             x = self.embed(A, M, patch_open)
-            for i in range(self.layers):
+            for i in range(last):
                 x = self.run_blocks(x, i, i + 1)
                 if i + 1 < self.mask_prompt_depth:
                     ops.mask_prompt_select(x, patch_open, self.w["mask_embedding"][i + 1], 1)
-        return self.head(x[:, 0, :].contiguous())
+        # the mask prompt after the last block (depth > layers) only rewrites patch tokens, which nothing reads any more
+        return self.head(self.last_block_cls(x, last))
 
 
 class ClipAdapter:
