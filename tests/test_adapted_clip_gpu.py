@@ -177,3 +177,21 @@ def test_openvis_with_adapted_clip_adapter_end_to_end():
     d = np.array([np.abs(lg[ig[k]] - lr[ir[k]]).max() for k in common])
     assert np.median(d) < 1e-2 and (d < 1e-1).mean() > 0.97, (np.median(d), (d < 1e-1).mean())
     assert np.abs(lr - lp).max() > 0.5                                    # the prompt changes the logits on this clip
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("fp16", 2e-3)])
+@pytest.mark.parametrize("B", [1, 3, 70])
+def test_last_block_for_the_class_token_equals_the_full_block(precision, tol, B):
+    """ClipVisual.last_block_cls (queries / out-proj / MLP for token 0 only) against run_blocks on every token"""
+    from openvis_amd import weights
+    from openvis_amd.modeling.clip_adapter.adapter import ClipVisual
+    arch = dict(width=256, layers=3, heads=4, patch=16, resolution=64, embed_dim=64)
+    prefix = "clip_adapter.clip_model.visual."
+    sd = weights.random_init(weights.clip_visual_spec(**arch), seed=41)
+    vis = ClipVisual(**arch, precision=precision).load_state_dict(sd, prefix, "cuda")
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, 17, 256, generator=g).cuda()
+    full = vis.run_blocks(x.clone(), 2, 3)[:, 0, :]
+    cls = vis.last_block_cls(x.clone(), 2)
+    assert cls.shape == (B, 256)
+    assert (cls - full).abs().max().item() / full.abs().max().item() < tol
