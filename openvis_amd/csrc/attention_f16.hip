@@ -105,21 +105,26 @@ flash_attn_f16_kernel(AttnH a) {
       const f16x8 kk = *reinterpret_cast<const f16x8*>(&Ks[r32 * KROW + 16 * st + 8 * h]);
       s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kk, qf[st], s, 0, 0, 0);
     }
+    // unscaled scores: running max on the raw dot products, scale folded into the exponent's fma; only the last key
+    // tile can hold keys >= Nk
+    if (kt + 32 > a.Nk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+        s[r] = key < a.Nk ? s[r] : -INFINITY;
+      }
+    }
     float mt = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float x = key < a.Nk ? s[r] * scale_log2e : -INFINITY;
-      s[r] = x;
-      mt = fmaxf(mt, x);
-    }
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m_run, mt);       // finite: every tile holds at least one valid key
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+    const float moff = -m_new * scale_log2e;
     float ps = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = exp2f(s[r] - m_new);
+      const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale_log2e, moff));
       s[r] = p;
       ps += p;
     }
@@ -238,21 +243,26 @@ flash_attn_f16_seq_kernel(AttnH a) {
       const f16x8 kk = *reinterpret_cast<const f16x8*>(&Ks[(kt * 32 + r32) * KROW + 16 * st + 8 * h]);
       s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kk, qf[st], s, 0, 0, 0);
     }
+    // scores stay unscaled: the running max is tracked on the raw dot products (scale > 0 keeps the order) and the scale
+    // is folded into the exponent's fma; only the last key tile can hold keys >= Nk, so only it is masked
+    if (kt == nkt - 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        s[r] = key < a.Nk ? s[r] : -INFINITY;
+      }
+    }
     float mt = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float x = key < a.Nk ? s[r] * sl2 : -INFINITY;
-      s[r] = x;
-      mt = fmaxf(mt, x);
-    }
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m_run, mt);                        // finite: every key tile holds at least one valid key
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
+    const float moff = -m_new * sl2;
     float ps = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = __builtin_amdgcn_exp2f(s[r] - m_new);
+      const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, moff));
       s[r] = p;
       ps += p;
     }
