@@ -1,0 +1,65 @@
+"""GPU: BASELINE.json configs[1] -- the bench workload itself (openvis_R50, 720x1280 frames, 100 queries, the full
+architecture with ViT-B/16 @224) under the bench's precision policy (reference autocast restatement: "mixed" dense path +
+fp16 CLIP operands), on a 2-frame clip so that the CPU oracle finishes in seconds: mask IoU >= 0.999 against the f32 oracle,
+valid flags, CLIP logits, final masks (case C2)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c2_720p_clip_under_the_bench_policy_matches_oracle():
+    import bench
+    from openvis_amd import config, weights
+    from openvis_amd.catalog import MetadataCatalog
+    from oracle import torch_ref as TR
+
+    K, T = 40, 2
+    sd = weights.random_init(weights.openvis_spec("r50", None, 100), seed=42)
+    cfg = config.get_cfg()                                   # defaults: MODEL.PRECISION "mixed", CLIP_ADAPTER.PRECISION "fp16"
+    assert cfg.MODEL.PRECISION == "mixed" and cfg.MODEL.CLIP_ADAPTER.PRECISION == "fp16"
+    model = config.build_model(cfg)
+    model.load_state_dict(sd)
+    names = [f"class_{i}" for i in range(K)]
+    MetadataCatalog.get("synthetic_c2").set(thing_classes=names)
+    text = bench.synth_text(K, 512)
+    model.clip_adapter.set_text_features(names, text)
+    frames = bench.synth_frames(T, 720, 1280, 3, "cpu")
+    st, ref_st = {}, {}
+    out = model([{"image": [f for f in frames], "dataset_name": "synthetic_c2"}], stages=st)
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = TR.openvis_forward(frames, sd, text, stages=ref_st)
+
+    g, r = st["pred_masks"].cpu(), ref_st["pred_masks"]
+    assert g.shape == r.shape == (1, 100, T, 184, 320)
+    agree = ((g > 0) == (r > 0)).float().mean().item()
+    inter, union = ((g > 0) & (r > 0)).sum().item(), ((g > 0) | (r > 0)).sum().item()
+    assert agree > 0.999 and inter / max(union, 1) > 0.999, (agree, inter / max(union, 1))       # north star: mask IoU >= 0.999
+    vg, vr = st["valid"], ref_st["valid"].numpy()
+    assert (vg == vr).mean() > 0.99
+    lg, lr = st["crop_logits"].cpu().numpy(), ref_st["crop_logits"].numpy()
+    ig = {tuple(x): i for i, x in enumerate(np.argwhere(vg))}
+    ir = {tuple(x): i for i, x in enumerate(np.argwhere(vr))}
+    common = [k for k in ig if k in ir]
+    d = np.array([np.abs(lg[ig[k]] - lr[ir[k]]).max() for k in common])
+    # fp16 GEMM operands in the CLIP tower (the reference's GPU dtype) against the f32 oracle, x100 logits
+    assert len(common) > 0.95 * len(ir) and np.median(d) < 5e-2 and (d < 2e-1).mean() > 0.9, (np.median(d), (d < 2e-1).mean())
+    assert len(out["pred_masks"]) == 10 and tuple(out["pred_masks"][0].shape) == (T, 720, 1280)
+    rows_ref = ref_st["valid"].any(0).nonzero()[:, 0].tolist()
+    sg = {(q, l): i for i, (q, l) in enumerate(zip(out["pred_queries"], out["pred_labels"]))}
+    sr = {(rows_ref[q], l): i for i, (q, l) in enumerate(zip(ref["rows"], ref["pred_labels"]))}
+    both = set(sg) & set(sr)
+    assert len(both) >= 7, (sorted(sg), sorted(sr))
+    ious = []
+    for k in both:
+        a, b = out["pred_masks"][sg[k]].cpu().numpy().astype(bool), np.asarray(ref["pred_masks"][sr[k]]).astype(bool)
+        u = (a | b).sum()
+        ious.append(1.0 if u == 0 else (a & b).sum() / u)
+        assert abs(out["pred_scores"][sg[k]] - ref["pred_scores"][sr[k]]) < 2e-2
+    # random-init weights give near-zero mask logits (long, noisy boundaries): under the fp16-operand policy a single output
+    # mask may dip just under 0.999 against the f32 oracle; the mean over the outputs and the all-query IoU above hold it
+    print("C2 per-mask IoU:", [round(float(v), 5) for v in ious])
+    assert min(ious) > 0.998 and float(np.mean(ious)) > 0.999, ious
