@@ -358,8 +358,9 @@ def main():
                                    f"{MODELS[args.model].get('queries', 100)} queries, 482 classes, {T}-frame clips, "
                                    + ("ClipAdapter" if args.model.startswith("openvis") else "SideAdapter")
                                    + f" {MODELS[args.model].get('clip', 'ViT-B/16')}, random-init weights", "frames_per_step": T,
-                       "precision": ("reference autocast policy: backbone + decoder GEMM operands fp16 / f32 accumulate, "
-                                     "pixel decoder + logits f32 (exact 3-way bf16 split on the bf16 MFMA); " if args.precision == "mixed" else
+                       "precision": ("backbone GEMM operands fp16 / f32 accumulate (the reference's autocast), pixel decoder, "
+                                     "masked-attention decoder, masks and logits f32 (exact 3-way bf16 split on the bf16 MFMA); "
+                                     if args.precision == "mixed" else
                                      "backbone/pixel decoder/decoder/masks/logits: exact-f32 MFMA; ")
                                     + "CLIP ViT GEMM operands: "
                                     + ("fp16 with f32 accumulation (the reference's GPU CLIP dtype)"

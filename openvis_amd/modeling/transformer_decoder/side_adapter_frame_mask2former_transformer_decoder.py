@@ -6,6 +6,7 @@ The frame decoder plus the SAN attention-bias head: attn_features = attn_mlp(bil
 prediction head's biases are consumed at eval (aux_outputs are training-only), so they are evaluated once."""
 import torch
 
+from ...config import decoder_precision as _decoder_precision
 from ... import ops
 from ...registry import TRANSFORMER_DECODER_REGISTRY
 from .frame_mask2former_transformer_decoder import FrameMultiScaleMaskedTransformerDecoder
@@ -57,7 +58,7 @@ def _side_from_config(cls, cfg, in_channels, mask_classification):
                dim_feedforward=cfg.MODEL.MASK_FORMER.DIM_FEEDFORWARD, dec_layers=cfg.MODEL.MASK_FORMER.DEC_LAYERS - 1,
                pre_norm=cfg.MODEL.MASK_FORMER.PRE_NORM, mask_dim=cfg.MODEL.SEM_SEG_HEAD.MASK_DIM,
                enforce_input_project=cfg.MODEL.MASK_FORMER.ENFORCE_INPUT_PROJ, num_frames=cfg.INPUT.SAMPLING_FRAME_NUM,
-               precision="fp32" if cfg.MODEL.get("PRECISION", "mixed") == "fp32" else "fp16")
+               precision=_decoder_precision(cfg))
 
 
 @TRANSFORMER_DECODER_REGISTRY.register()

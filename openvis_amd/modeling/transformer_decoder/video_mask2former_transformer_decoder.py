@@ -9,6 +9,7 @@ Same constructor arguments / state-dict keys.  MI355X restructuring that does no
   * K/V of a level are projected with one GEMM each per layer; scores are never materialised (flash attention)."""
 import torch
 
+from ...config import decoder_precision as _decoder_precision
 from ... import ops
 from ...registry import TRANSFORMER_DECODER_REGISTRY
 
@@ -45,7 +46,7 @@ class VideoMultiScaleMaskedTransformerDecoder:
                    dec_layers=cfg.MODEL.MASK_FORMER.DEC_LAYERS - 1, pre_norm=cfg.MODEL.MASK_FORMER.PRE_NORM,
                    mask_dim=cfg.MODEL.SEM_SEG_HEAD.MASK_DIM, enforce_input_project=cfg.MODEL.MASK_FORMER.ENFORCE_INPUT_PROJ,
                    num_frames=cfg.INPUT.SAMPLING_FRAME_NUM,
-                   precision="fp32" if cfg.MODEL.get("PRECISION", "mixed") == "fp32" else "fp16")
+                   precision=_decoder_precision(cfg))
 
     def load_state_dict(self, sd, prefix="sem_seg_head.predictor.", device="cuda"):
         sd = dict(sd)

@@ -1,6 +1,6 @@
 """GPU: BASELINE.json configs[1] -- the bench workload itself (openvis_R50, 720x1280 frames, 100 queries, the full
 architecture with ViT-B/16 @224) under the bench's precision policy (reference autocast restatement: "mixed" dense path +
-fp16 CLIP operands), on a 2-frame clip so that the CPU oracle finishes in seconds: mask IoU >= 0.999 against the f32 oracle,
+f32 decoder + fp16 CLIP operands), on a 2-frame clip so that the CPU oracle finishes in seconds: mask IoU >= 0.999 against the f32 oracle,
 valid flags, CLIP logits, final masks (case C2)."""
 import numpy as np
 import pytest
@@ -17,8 +17,9 @@ def test_c2_720p_clip_under_the_bench_policy_matches_oracle():
 
     K, T = 40, 2
     sd = weights.random_init(weights.openvis_spec("r50", None, 100), seed=42)
-    cfg = config.get_cfg()                                   # defaults: MODEL.PRECISION "mixed", CLIP_ADAPTER.PRECISION "fp16"
+    cfg = config.get_cfg()                                   # defaults = what bench.py runs
     assert cfg.MODEL.PRECISION == "mixed" and cfg.MODEL.CLIP_ADAPTER.PRECISION == "fp16"
+    assert cfg.MODEL.MASK_FORMER.DECODER_PRECISION == "fp32"
     model = config.build_model(cfg)
     model.load_state_dict(sd)
     names = [f"class_{i}" for i in range(K)]
@@ -59,7 +60,7 @@ def test_c2_720p_clip_under_the_bench_policy_matches_oracle():
         u = (a | b).sum()
         ious.append(1.0 if u == 0 else (a & b).sum() / u)
         assert abs(out["pred_scores"][sg[k]] - ref["pred_scores"][sr[k]]) < 2e-2
-    # random-init weights give near-zero mask logits (long, noisy boundaries): under the fp16-operand policy a single output
-    # mask may dip just under 0.999 against the f32 oracle; the mean over the outputs and the all-query IoU above hold it
+    # bench policy: backbone fp16 operands, decoder f32 (MODEL.MASK_FORMER.DECODER_PRECISION): every output mask holds the
+    # north-star IoU; with an fp16-operand decoder two of the ten dip to 0.9984 (tools/exp_policy_mix.py)
     print("C2 per-mask IoU:", [round(float(v), 5) for v in ious])
-    assert min(ious) > 0.998 and float(np.mean(ious)) > 0.999, ious
+    assert min(ious) > 0.999, ious

@@ -24,8 +24,9 @@ def _frames(seed=0):
 
 # (dense-path policy, CLIP tower operand dtype): all-f32 parity mode, f32 dense + fp16 CLIP, and the reference's own
 # autocast policy ("mixed": backbone + decoder GEMM operands fp16 / f32 accumulate, pixel decoder f32, CLIP fp16)
-@pytest.fixture(scope="module", params=[("fp32", "fp32"), ("fp32", "fp16"), ("mixed", "fp16")],
-                ids=["f32", "f32+clip16", "mixed"])
+@pytest.fixture(scope="module", params=[("fp32", "fp32", "fp32"), ("fp32", "fp16", "fp32"), ("mixed", "fp16", "fp32"),
+                                        ("mixed", "fp16", "fp16")],
+                ids=["f32", "f32+clip16", "mixed", "mixed+decoder16"])
 def case(request):
     from openvis_amd import config, weights
     from openvis_amd.catalog import MetadataCatalog
@@ -35,9 +36,10 @@ def case(request):
     spec = (weights.resnet50_spec() + weights.pixel_decoder_spec() + weights.video_decoder_spec() +
             weights.clip_visual_spec(**CLIP_ARCH))
     sd = weights.random_init(spec, seed=7)
-    policy, clip_prec = request.param
+    policy, clip_prec, dec_prec = request.param
     cfg = config.get_cfg()
     cfg.MODEL.PRECISION = policy
+    cfg.MODEL.MASK_FORMER.DECODER_PRECISION = dec_prec         # "fp16": the autocast behaviour of the decoder
     model = config.build_model(cfg)
     model.clip_adapter = ClipAdapter("tiny", arch=CLIP_ARCH, precision=clip_prec)
     model.load_state_dict(sd)
@@ -58,7 +60,7 @@ def case(request):
         out_ref = TR.openvis_forward(frames, sd, text, stages=st_ref, clip_heads=CLIP_ARCH["heads"],
                                      clip_resolution=CLIP_ARCH["resolution"])
     return dict(out_gpu=out_gpu, out_ref=out_ref, st_gpu=st_gpu, st_ref=st_ref, precision=clip_prec, policy=policy,
-                tag=f"{policy}+clip_{clip_prec}")
+                tag=f"{policy}+clip_{clip_prec}" + ("+decoder_fp16" if (policy == "mixed" and dec_prec == "fp16") else ""))
 
 
 def _report(case, key, val):
