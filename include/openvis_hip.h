@@ -126,6 +126,13 @@ int ovis_add_bcast_f32(const float* a, const float* b, float* out, long long n, 
 int ovis_pe_sine_f32(float* out, int T, int H, int W, int num_pos_feats, int three_d, const float* add_c,
                      ovis_stream_t stream);
 
+/* Kernel selection of ovis_gemm_nt_f16 for problems of >= 256 tiles of 256x256 (the CLIP ViT GEMMs; replaces nothing in
+ * the reference, torch picks cuBLAS algorithms implicitly).  mode 1 (default): the ping-pong kernel (gemm_f16_pp.hip:
+ * the two wavefronts of a SIMD run half a phase apart, LDS-DMA 4 half-tiles ahead, 16x16x32 MFMA); mode 0: the lock-step
+ * 256x256 kernel of round 1 (gemm_f16.hip).  raster_group > 0: N tiles per column group of the tile raster;
+ * desync_ns: start offset spread over the persistent workgroups that own one tile fewer.  Process-wide, not thread-safe. */
+int ovis_set_f16_gemm_mode(int mode, int raster_group, int desync_ns);
+
 /* ovis_gemm_nt_f16: same contract with fp16 A [M,K] / B [N,K] (K, lda, ldb multiples of 8), f32 accumulation,
  *   f32 bias / residual, C written as f32 (out_f16 == 0) or fp16.  Used for the CLIP ViT GEMMs only — the reference
  *   runs CLIP in fp16 on the GPU (adapter.py:108-111; clip.load on cuda).  On tiles with 16-byte aligned rows the f32

@@ -405,6 +405,13 @@ cast_f32_f16_kernel(const float4* __restrict__ x, uint2* __restrict__ y, long lo
 
 }  // namespace
 
+namespace ovis {   // gemm_f16_pp.hip: the ping-pong 256x256 kernel for the big CLIP GEMMs
+bool gemm_f16_pp_eligible(const void* C, long long lda, long long ldb, long long ldc, int M, int N, int K, const float* bias,
+                          const float* residual, long long ldr, int out_f16, bool act_is_none);
+int gemm_f16_pp_launch(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int M, int N, int K,
+                       const float* bias, const float* residual, long long ldr, int act, int out_f16, hipStream_t s);
+}
+
 extern "C" int ovis_gemm_nt_f16(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int M,
                                 int N, int K, const float* bias, const float* residual, long long ldr, int act,
                                 int out_f16, ovis_stream_t stream) {
@@ -418,6 +425,8 @@ extern "C" int ovis_gemm_nt_f16(const void* A, long long lda, const void* B, lon
   const _Float16* a = reinterpret_cast<const _Float16*>(A);
   const _Float16* b = reinterpret_cast<const _Float16*>(B);
   hipStream_t s = (hipStream_t)stream;
+  if (ovis::gemm_f16_pp_eligible(C, lda, ldb, ldc, M, N, K, bias, residual, ldr, out_f16, act == 0))
+    return ovis::gemm_f16_pp_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, out_f16, s);
   const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128);
   const long long blocks256 = (long long)ovis::cdiv(M, 256) * ovis::cdiv(N, 256);
   if (blocks256 >= 256 && K % 64 == 0) {

@@ -1,0 +1,197 @@
+// gemm_lab: standalone (no torch) correctness + timing harness for ovis_gemm_nt_f16 on the CLIP ViT shapes.
+//   build:  make -C openvis_amd/csrc lab      ->  build/gemm_lab
+//   run  :  build/gemm_lab [check] [time] [variants...]
+// Variants are (mode, raster_group, desync_ns) triples of ovis_set_f16_gemm_mode; timing is interleaved rounds of all
+// variants in one process on uniform random [-1,1) operands (cdna_hip_programming.md rules 24/25).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../include/openvis_hip.h"
+extern "C" int ovis_pp_debug(int flags, unsigned long long* stamps);   // lab-only entry of gemm_f16_pp.hip
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+#define OVIS_OKAY(x) do { int r_ = (x); if (r_ != 0) { printf("ovis error %d: %s at %s:%d\n", r_, ovis_last_error(), __FILE__, __LINE__); exit(3); } } while (0)
+
+__device__ inline unsigned hash32(unsigned x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+
+// kind 0: uniform [-scale, scale); kind 1: integers in {-1, 0, 1}
+__global__ void fill_f16(_Float16* p, long long n, unsigned seed, int kind, float scale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned h = hash32((unsigned)i * 2654435761U + seed);
+    p[i] = kind == 1 ? (_Float16)(float)((int)(h % 3u) - 1) : (_Float16)(((h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale);
+  }
+}
+__global__ void fill_f32(float* p, long long n, unsigned seed, int kind, float scale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned h = hash32((unsigned)i * 2246822519U + seed);
+    p[i] = kind == 1 ? (float)((int)(h % 5u) - 2) : ((h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale;
+  }
+}
+// naive reference: one thread per output, f32 fmaf chain over k (exact on the integer data)
+__global__ void ref_gemm(const _Float16* A, const _Float16* B, float* C, int M, int N, int K, const float* bias, const float* R, int act) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * N) return;
+  const int m = (int)(i / N), n = (int)(i % N);
+  float s = (bias ? bias[n] : 0.f) + (R ? R[i] : 0.f);
+  for (int k = 0; k < K; ++k) s = fmaf((float)A[(long long)m * K + k], (float)B[(long long)n * K + k], s);
+  if (act == 1) s = fmaxf(s, 0.f);
+  else if (act == 2) s = s / (1.f + expf(-1.702f * s));
+  C[i] = s;
+}
+__global__ void diff_kernel(const float* ref, const void* out, int out_f16, long long n, float* maxabs, unsigned long long* nbad, float tol_abs, float tol_rel) {
+  float mx = 0.f; unsigned long long bad = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float o = out_f16 ? (float)((const _Float16*)out)[i] : ((const float*)out)[i];
+    const float d = fabsf(o - ref[i]);
+    if (!(d <= tol_abs + tol_rel * fabsf(ref[i]))) ++bad;
+    mx = fmaxf(mx, d == d ? d : 1e30f);
+  }
+  atomicMax((int*)maxabs, __float_as_int(mx));
+  if (bad) atomicAdd(nbad, bad);
+}
+
+struct Variant { int mode, grp, desync, dbg; std::string name; };
+
+int main(int argc, char** argv) {
+  bool do_check = false, do_time = false, do_trace = false;
+  std::vector<Variant> variants;
+  int iters = 10, rounds = 3;
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "check")) do_check = true;
+    else if (!strcmp(argv[i], "time")) do_time = true;
+    else if (!strncmp(argv[i], "iters=", 6)) iters = atoi(argv[i] + 6);
+    else if (!strncmp(argv[i], "rounds=", 7)) rounds = atoi(argv[i] + 7);
+    else if (!strcmp(argv[i], "trace")) do_trace = true;
+    else { Variant v; v.dbg = 0; if (sscanf(argv[i], "%d,%d,%d,%d", &v.mode, &v.grp, &v.desync, &v.dbg) >= 3) { v.name = argv[i]; variants.push_back(v); } }
+  }
+  if (variants.empty()) { variants.push_back({0, 0, 0, 0, "0,0,0"}); variants.push_back({1, 6, 0, 0, "1,6,0"}); }
+  hipStream_t s; HIP_OK(hipStreamCreate(&s));
+  float* d_max; unsigned long long* d_bad;
+  HIP_OK(hipMalloc(&d_max, 4)); HIP_OK(hipMalloc(&d_bad, 8));
+  int fails = 0;
+
+  if (do_check) {
+    struct Case { int M, N, K, act, out16, bias, res, kind; };
+    const Case cases[] = {
+      {8192 + 37, 2304, 768, 0, 1, 1, 0, 1},      // QKV shape, ragged M, exact integers
+      {8192 + 37, 2304, 768, 0, 1, 1, 0, 0},      // random floats
+      {7000, 3072, 768, 2, 1, 1, 0, 0},           // fc1 + QuickGELU
+      {22000, 768, 3072, 0, 0, 1, 1, 1},          // fc2: f32 out, residual, exact integers
+      {22000, 768, 768, 0, 0, 1, 1, 0},           // out-proj: f32 out, residual
+      {9000, 2056, 832, 0, 0, 0, 0, 0},           // ragged N (8-multiple), odd K steps (13), no bias
+      {9000, 2056, 832, 1, 1, 1, 0, 0},           // ReLU, fp16 out, ragged N
+    };
+    for (const Case& c : cases) {
+      _Float16 *A, *B; float *bias = nullptr, *R = nullptr, *ref; void* C;
+      const long long MN = (long long)c.M * c.N;
+      HIP_OK(hipMalloc(&A, (size_t)c.M * c.K * 2)); HIP_OK(hipMalloc(&B, (size_t)c.N * c.K * 2));
+      HIP_OK(hipMalloc(&ref, MN * 4)); HIP_OK(hipMalloc(&C, MN * 4));
+      fill_f16<<<2048, 256, 0, s>>>(A, (long long)c.M * c.K, 11u, c.kind, 1.f);
+      fill_f16<<<2048, 256, 0, s>>>(B, (long long)c.N * c.K, 23u, c.kind, c.kind ? 1.f : 1.f / sqrtf((float)c.K));
+      if (c.bias) { HIP_OK(hipMalloc(&bias, c.N * 4)); fill_f32<<<64, 256, 0, s>>>(bias, c.N, 5u, c.kind, 1.f); }
+      if (c.res) { HIP_OK(hipMalloc(&R, MN * 4)); fill_f32<<<2048, 256, 0, s>>>(R, MN, 7u, c.kind, 1.f); }
+      ref_gemm<<<(unsigned)((MN + 255) / 256), 256, 0, s>>>(A, B, ref, c.M, c.N, c.K, bias, R, c.act);
+      for (const Variant& v : variants) {
+        OVIS_OKAY(ovis_set_f16_gemm_mode(v.mode, v.grp, v.desync));
+        if (v.dbg) continue;
+        for (int rep = 0; rep < 3; ++rep) {                       // repeated: a race shows up as run-to-run differences
+          HIP_OK(hipMemsetAsync(C, 0xff, MN * 4, s));
+          OVIS_OKAY(ovis_gemm_nt_f16(A, c.K, B, c.K, C, c.N, c.M, c.N, c.K, bias, R, c.N, c.act, c.out16, s));
+          HIP_OK(hipMemsetAsync(d_max, 0, 4, s)); HIP_OK(hipMemsetAsync(d_bad, 0, 8, s));
+          const float tol_abs = c.kind ? 0.f : (c.out16 ? 2e-2f : 2e-3f), tol_rel = c.kind ? 0.f : (c.out16 ? 2e-3f : 1e-4f);
+          diff_kernel<<<1024, 256, 0, s>>>(ref, C, c.out16, MN, d_max, d_bad, tol_abs, tol_rel);
+          float mx; unsigned long long bad;
+          HIP_OK(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, s)); HIP_OK(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, s));
+          HIP_OK(hipStreamSynchronize(s));
+          const bool ok = bad == 0;
+          if (!ok) ++fails;
+          if (rep == 0 || !ok)
+            printf("check M=%d N=%d K=%d act=%d out16=%d bias=%d res=%d %s variant=%s rep=%d: max|d|=%.3g bad=%llu %s\n", c.M, c.N, c.K, c.act,
+                   c.out16, c.bias, c.res, c.kind ? "int" : "rnd", v.name.c_str(), rep, mx, bad, ok ? "OK" : "FAIL");
+        }
+      }
+      HIP_OK(hipFree(A)); HIP_OK(hipFree(B)); HIP_OK(hipFree(ref)); HIP_OK(hipFree(C));
+      if (bias) HIP_OK(hipFree(bias));
+      if (R) HIP_OK(hipFree(R));
+    }
+  }
+
+  if (do_time) {
+    struct Shape { int M, N, K, act, out16, res; const char* name; };
+    const Shape shapes[] = {
+      {98500, 2304, 768, 0, 1, 0, "qkv"}, {98500, 3072, 768, 2, 1, 0, "fc1"},
+      {98500, 768, 768, 0, 0, 1, "outproj"}, {98500, 768, 3072, 0, 0, 1, "fc2"},
+      {4096, 4096, 4096, 0, 1, 0, "4k"}, {8192, 8192, 8192, 0, 1, 0, "8k"},
+    };
+    hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    for (const Shape& sh : shapes) {
+      _Float16 *A, *B; float *bias, *R = nullptr; void* C;
+      const long long MN = (long long)sh.M * sh.N;
+      HIP_OK(hipMalloc(&A, (size_t)sh.M * sh.K * 2)); HIP_OK(hipMalloc(&B, (size_t)sh.N * sh.K * 2));
+      HIP_OK(hipMalloc(&C, MN * (sh.out16 ? 2 : 4))); HIP_OK(hipMalloc(&bias, sh.N * 4));
+      fill_f16<<<2048, 256, 0, s>>>(A, (long long)sh.M * sh.K, 11u, 0, 1.f);
+      fill_f16<<<2048, 256, 0, s>>>(B, (long long)sh.N * sh.K, 23u, 0, 1.f / sqrtf((float)sh.K));
+      fill_f32<<<64, 256, 0, s>>>(bias, sh.N, 5u, 0, 1.f);
+      if (sh.res) { HIP_OK(hipMalloc(&R, MN * 4)); fill_f32<<<2048, 256, 0, s>>>(R, MN, 7u, 0, 1.f); }
+      std::vector<std::vector<double>> ms(variants.size());
+      for (int r = 0; r < rounds + 1; ++r)
+        for (size_t vi = 0; vi < variants.size(); ++vi) {
+          const Variant& v = variants[vi];
+          OVIS_OKAY(ovis_set_f16_gemm_mode(v.mode, v.grp, v.desync));
+          ovis_pp_debug(v.dbg, nullptr);
+          HIP_OK(hipEventRecord(e0, s));
+          for (int it = 0; it < iters; ++it)
+            OVIS_OKAY(ovis_gemm_nt_f16(A, sh.K, B, sh.K, C, sh.N, sh.M, sh.N, sh.K, bias, R, sh.N, sh.act, sh.out16, s));
+          HIP_OK(hipEventRecord(e1, s)); HIP_OK(hipEventSynchronize(e1));
+          float t; HIP_OK(hipEventElapsedTime(&t, e0, e1));
+          if (r > 0) ms[vi].push_back(t / iters);                 // round 0 = warm-up
+        }
+      for (size_t vi = 0; vi < variants.size(); ++vi) {
+        std::sort(ms[vi].begin(), ms[vi].end());
+        const double med = ms[vi][ms[vi].size() / 2], mn = ms[vi][0];
+        const double fl = 2.0 * sh.M * sh.N * sh.K;
+        printf("time %-8s M=%d N=%d K=%d variant=%-10s median %.4f ms (%.0f TF)  min %.4f ms (%.0f TF)\n", sh.name, sh.M, sh.N, sh.K,
+               variants[vi].name.c_str(), med, fl / med / 1e9, mn, fl / mn / 1e9);
+      }
+
+      if (do_trace)
+        for (const Variant& v : variants) {
+          if (v.mode != 1) continue;
+          const size_t nst = 256 * 16 * 2 * 4;
+          unsigned long long* d_st; HIP_OK(hipMalloc(&d_st, nst * 8)); HIP_OK(hipMemsetAsync(d_st, 0, nst * 8, s));
+          OVIS_OKAY(ovis_set_f16_gemm_mode(v.mode, v.grp, v.desync));
+          ovis_pp_debug(v.dbg, d_st);
+          OVIS_OKAY(ovis_gemm_nt_f16(A, sh.K, B, sh.K, C, sh.N, sh.M, sh.N, sh.K, bias, R, sh.N, sh.act, sh.out16, s));
+          ovis_pp_debug(0, nullptr);
+          std::vector<unsigned long long> st(nst);
+          HIP_OK(hipMemcpyAsync(st.data(), d_st, nst * 8, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
+          unsigned long long t0 = ~0ull, t1 = 0;
+          for (size_t i = 0; i < nst; i += 4) if (st[i]) { t0 = std::min(t0, st[i]); t1 = std::max(t1, st[i + 2]); }
+          printf("trace %s variant=%s: first tile begin -> last epilogue end %.2f us (100 MHz ticks)\n", sh.name, v.name.c_str(), (t1 - t0) * 0.01);
+          for (int it = 0; it < 16; ++it) {
+            double kl[2] = {0, 0}, ep[2] = {0, 0}, gap[2] = {0, 0}, beg[2] = {0, 0}; int n[2] = {0, 0}; double bmin = 1e30, bmax = 0;
+            for (int b = 0; b < 256; ++b) for (int g = 0; g < 2; ++g) {
+              const unsigned long long* x = &st[((size_t)(b * 16 + it) * 2 + g) * 4];
+              if (!x[0] || !x[2]) continue;
+              kl[g] += (x[1] - x[0]) * 0.01; ep[g] += (x[2] - x[1]) * 0.01; beg[g] += (x[0] - t0) * 0.01; ++n[g];
+              bmin = std::min(bmin, (x[0] - t0) * 0.01); bmax = std::max(bmax, (x[0] - t0) * 0.01);
+              if (it + 1 < 16) { const unsigned long long* y = &st[((size_t)(b * 16 + it + 1) * 2 + g) * 4]; if (y[0]) gap[g] += (y[0] - x[2]) * 0.01; }
+            }
+            if (n[0]) printf("  it %2d (%3d wg): begin %.1f us [%.1f..%.1f]  G0 kloop %.2f epi %.2f | G1 kloop %.2f epi %.2f\n", it, n[0], beg[0] / n[0], bmin, bmax,
+                             kl[0] / n[0], ep[0] / n[0], kl[1] / std::max(n[1], 1), ep[1] / std::max(n[1], 1));
+          }
+          HIP_OK(hipFree(d_st));
+        }
+      HIP_OK(hipFree(A)); HIP_OK(hipFree(B)); HIP_OK(hipFree(C)); HIP_OK(hipFree(bias));
+      if (R) HIP_OK(hipFree(R));
+    }
+  }
+  printf("gemm_lab done, %d failing checks\n", fails);
+  return fails ? 1 : 0;
+}
