@@ -130,7 +130,8 @@ int ovis_pe_sine_f32(float* out, int T, int H, int W, int num_pos_feats, int thr
  * the reference, torch picks cuBLAS algorithms implicitly).  mode 1 (default): the ping-pong kernel (gemm_f16_pp.hip:
  * the two wavefronts of a SIMD run half a phase apart, LDS-DMA 4 half-tiles ahead, 16x16x32 MFMA); mode 0: the lock-step
  * 256x256 kernel of round 1 (gemm_f16.hip).  raster_group > 0: N tiles per column group of the tile raster;
- * desync_ns: start offset spread over the persistent workgroups that own one tile fewer.  Process-wide, not thread-safe. */
+ * desync_ns: start offsets of the 32 persistent workgroups of an XCD are spread over [0, desync_ns) (< 0: automatic, 24 us
+ * for the residual GEMMs, 0 otherwise).  Process-wide, not thread-safe. */
 int ovis_set_f16_gemm_mode(int mode, int raster_group, int desync_ns);
 
 /* ovis_gemm_nt_f16: same contract with fp16 A [M,K] / B [N,K] (K, lda, ldb multiples of 8), f32 accumulation,

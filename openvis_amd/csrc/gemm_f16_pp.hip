@@ -17,13 +17,25 @@
 //   * LDS = 2 K-step buffers x 4 half-tiles (A rows of the two M-halves, B rows of the two N-halves; 16 KB each) filled
 //     by global_load_lds_dwordx4 (one half-tile per phase, 2 wave-instructions per wavefront).  The DMA runs 4-5 phases
 //     ahead of its first read: the only waits are counted `s_waitcnt vmcnt(8)` (4 half-tiles stay in flight), never 0;
-//   * the stream of K steps runs across output tiles: the first 1.5 K steps of the next tile are in flight before the
-//     epilogue of the current one starts, and the waits of the first K step after an epilogue leave its stores in flight;
+//   * the stream of K steps runs across output tiles: BOTH K steps of the next tile are in flight before the epilogue of the
+//     current one starts (its stores sit behind them in the in-order vmcnt queue and get two K steps to drain), and the
+//     waits of those two K steps count the stores as "younger" instead of waiting for them;
+//   * tile transition: G0 waits one slot for G1's last MFMAs, then all 8 wavefronts convert + store in the same slot (a
+//     wavefront issues a 1-KB store every ~100 ns whatever the others do; two groups storing in turn cost twice the time);
+//     row block outer / column pair inner store order, so that the two 64-byte halves of a 128-byte line are written by
+//     consecutive instructions (5-6 % on the whole GEMM against the other order: partial-line writes);
+//   * accumulators start at the bias (+ the f32 residual) instead of zero: the epilogue only activates, converts, stores;
+//   * edge tiles are shifted inside the matrix (loads) and masked (stores): DMA addresses = lane constant + tile base;
+//     the workgroup's tile list (bases, owned / computed rows and columns) is built once in LDS;
 //   * LDS rows are 128 B (a full cache line per DMA'd row segment); the 16-byte chunk index is XOR-swizzled with
 //     (row>>1)&7 on the DMA's per-lane SOURCE address and on the fragment read (conflict-free ds_read_b128);
 //   * the weight rows of a wavefront's N range are DMA'd in a permuted order (n = 32j + 8q + 4e + r for MFMA row 4q + r of
 //     tile 2j + e), so that a lane ends up with 8 consecutive output columns: one 16-byte store per fp16 row segment;
-//   * bias lives in LDS for the whole launch (read with ds_read, so the epilogue never touches the vmcnt queue's loads).
+//   * bias lives in LDS for the whole launch (read with ds_read, so it never touches the vmcnt queue).
+// Measured (tools/gemm_lab.cpp, interleaved with gemm_f16_256_kernel in one process, M = 98 500): QKV 999 vs 889 TF, fc1 1013 vs
+// 860, out-proj 549 vs 480, fc2 991 vs 851; 4096^3 1291-1350 vs 1135-1145.  The K loop itself runs at 1.43 us per 64-deep step
+// (~1390 TF); what is left on the K = 768 shapes is the per-tile epilogue (activation + conversion VALU, 16-32 stores per
+// wavefront) and, for the residual GEMMs, the 128 MB burst of residual loads + C stores every round of tiles.
 //
 // Race argument (the hardware orders an LDS-DMA write against a ds_read only through the issuing wavefront's vmcnt wait
 // followed by a barrier the reader has passed).  Slots are the intervals between barriers; group G0 = wavefronts 0-3 reads
@@ -36,6 +48,7 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 #include <hip/hip_fp16.h>
+#include <type_traits>
 
 namespace {
 
@@ -46,7 +59,10 @@ constexpr int PP_HT = 128 * 128;           // bytes of a half-tile: 128 rows x 6
 constexpr int PP_BUF = 4 * PP_HT;          // one K step: A0 A1 B0 B1
 constexpr int PP_BIAS = 2 * PP_BUF;        // bias (f32) behind the two buffers
 constexpr int PP_LDS = 160 * 1024;
-constexpr int PP_MAX_BIAS_N = (PP_LDS - PP_BIAS) / 4;
+constexpr int PP_TAB = PP_LDS - 4096;      // this workgroup's tile list: 128 entries of 32 bytes
+constexpr int PP_MAX_TILES = 128;
+constexpr int PP_MAX_BIAS_N = (PP_TAB - PP_BIAS) / 4;
+struct PPTile { long long a_off, b_off; int bm, bml, bn, bnl; };   // DMA bases (bytes) of the shifted tile; rows / columns owned and computed
 
 struct PPArgs {
   const _Float16* A; const _Float16* B; void* C; const float* bias; const float* R;
@@ -55,7 +71,7 @@ struct PPArgs {
   int tiles_m, tiles_n, n_tiles;
   int grp_w, grp_rem;                       // raster: column groups of grp_w (+1 for the first grp_rem groups) N tiles
   int desync_ns;                            // start offset spread over the workgroups that own one tile fewer (ns)
-  int dbg;                                  // lab only: 1 = skip the epilogue stores, 2 = skip the epilogue arithmetic too
+  int dbg;                                  // lab only: 1 = skip the epilogue stores, 2 = skip the epilogue arithmetic too, 4 = nt stores, 8 = per-workgroup desync
   unsigned long long* stamps;               // lab only: s_memrealtime stamps [workgroup][tile iteration < 16][2 groups][4]
 };
 
@@ -77,11 +93,6 @@ gemm_f16_pp_kernel(const PPArgs p) {
   const int nblk = gridDim.x;
   const int nk = p.K >> 6;
 
-  for (int i = tid * 4; i < p.N; i += 512 * 4)                   // zeros when there is no bias: no branch in the epilogue
-    *reinterpret_cast<float4*>(lds + PP_BIAS + i * 4) =
-        p.bias ? *reinterpret_cast<const float4*>(p.bias + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-
   // logical tile index -> (m tile, n tile): column groups of <= grp_w + 1 N tiles, M-panel-major inside a group; the 32
   // workgroups of an XCD take 32 consecutive logical tiles per round, i.e. a (32 / w) x w block of the output: they
   // share (32 / w + w) operand panels through that XCD's L2 (w ~ 5-6 minimises it; 9-12 N tiles in one row do not).
@@ -94,27 +105,52 @@ gemm_f16_pp_kernel(const PPArgs p) {
     tm = u / w; tn = n0 + (u - tm * w);
   };
 
-  // ---- DMA source rows of this lane (byte offsets from A / B; two 8-row groups per half-tile and wavefront) ----
+  // bias (zeros when there is none: no branch in the epilogue) and this workgroup's tile list go to LDS once; a tile
+  // change in the main loop is then one broadcast ds_read_b128 instead of two integer divisions
+  const int first = (int)ovis::xcd_remap(blockIdx.x, nblk);
+  const int n_my = (p.n_tiles - first + nblk - 1) / nblk;
+  for (int i = tid * 4; i < p.N; i += 512 * 4)
+    *reinterpret_cast<float4*>(lds + PP_BIAS + i * 4) =
+        p.bias ? *reinterpret_cast<const float4*>(p.bias + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < n_my; i += 512) {
+    int tm, tn;
+    tile_mn(first + i * nblk, tm, tn);
+    PPTile t;
+    t.bm = tm * 256; t.bn = tn * 256; t.bml = min(t.bm, p.M - 256); t.bnl = min(t.bn, p.N - 256);
+    t.a_off = (long long)t.bml * p.lda * 2; t.b_off = (long long)t.bnl * p.ldb * 2;
+    *reinterpret_cast<PPTile*>(lds + PP_TAB + i * 32) = t;
+  }
+  __syncthreads();
+  // wave-uniform copy of entry i.  Inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of an ordinary LDS load here
+  // (LDS-DMA in flight may alias it for all the compiler knows), which drains the whole DMA pipeline at every tile change.
+  auto tile_entry = [&](int i) {
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    u32x4 lo, hi;
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(lds + PP_TAB) + i * 32;   // LDS byte address
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory");
+    PPTile t;
+    t.a_off = ((long long)__builtin_amdgcn_readfirstlane(lo.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(lo.x);
+    t.b_off = ((long long)__builtin_amdgcn_readfirstlane(lo.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(lo.z);
+    t.bm = __builtin_amdgcn_readfirstlane(hi.x); t.bml = __builtin_amdgcn_readfirstlane(hi.y);
+    t.bn = __builtin_amdgcn_readfirstlane(hi.z); t.bnl = __builtin_amdgcn_readfirstlane(hi.w);
+    return t;
+  };
+
+  // ---- DMA sources: a lane-constant byte offset per (half-tile, 8-row group) + a wave-uniform tile base ----
+  // Edge tiles are SHIFTED inside the matrix for the loads (rows min(256 t, M - 256) ...) and their stores are masked to
+  // the rows / columns that belong to the tile: no per-lane clamping, so a tile change costs scalar arithmetic only.
   const int dr = lane >> 3;                                       // row inside the 8-row group
-  unsigned offA0[2], offA1[2], offB0[2], offB1[2];
-  auto rows_a = [&](int tm, int i, unsigned (&off)[2]) {
+  unsigned voA[2][2], voB[2][2];                                  // [half-tile i / j][group g]
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int mr = 16 * (wave & 3) + 8 * g + dr;                // half-tile row = 64 wr + mr
-      const int c = (lane & 7) ^ ((q + 4 * g) & 7);               // logical chunk held by this lane's slot: ((row>>1)&7)
-      const int m = min(tm * 256 + wr * 128 + i * 64 + mr, p.M - 1);
-      off[g] = (unsigned)((long long)m * p.lda * 2 + c * 16);
-    }
-  };
-  auto rows_b = [&](int tn, int j, unsigned (&off)[2]) {
+  for (int g = 0; g < 2; ++g) {
+    const int c = (lane & 7) ^ ((q + 4 * g) & 7);                 // logical chunk held by this lane's slot: ((row>>1)&7)
+    const int i16 = 8 * g + dr;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int i16 = 8 * g + dr, e = wave & 1;                   // half-tile row = 32 (wave>>1) + 16 e + i16
-      const int c = (lane & 7) ^ ((q + 4 * g) & 7);
-      const int n = min(tn * 256 + (wave >> 1) * 64 + 32 * j + 8 * (i16 >> 2) + 4 * e + (i16 & 3), p.N - 1);
-      off[g] = (unsigned)((long long)n * p.ldb * 2 + c * 16);
+    for (int h = 0; h < 2; ++h) {
+      voA[h][g] = (unsigned)((long long)(wr * 128 + h * 64 + 16 * (wave & 3) + i16) * p.lda * 2 + c * 16);          // half-tile row 64 wr + 16 (wave&3) + i16
+      voB[h][g] = (unsigned)((long long)((wave >> 1) * 64 + 32 * h + 8 * (i16 >> 2) + 4 * (wave & 1) + (i16 & 3)) * p.ldb * 2 + c * 16);
     }
-  };
+  }
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Bb = reinterpret_cast<const char*>(p.B);
   unsigned char* dma_dst = lds + wave * 2048;                      // + buffer + half-tile + g * 1024
@@ -122,7 +158,6 @@ gemm_f16_pp_kernel(const PPArgs p) {
     PP_GLDS(base + off[0] + kt * 128, dma_dst + dst_off);
     PP_GLDS(base + off[1] + kt * 128, dma_dst + dst_off + 1024);
   };
-
   // ---- fragment read addresses -----------------------------------------------------------------------------
   const unsigned rd0 = (unsigned)(l15 * 128 + ((q ^ sw) << 4));    // k block 0; k block 1 = ^ 64
   const unsigned a_rd = rd0 + wr * 64 * 128;
@@ -159,160 +194,191 @@ gemm_f16_pp_kernel(const PPArgs p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- the two DMA cursors: c1 = K step s+1 (half-tiles B1, A1), c2 = K step s+2 (A0, B0) -------------------
-  const int first = (int)ovis::xcd_remap(blockIdx.x, nblk);
-  int c1_tile = first, c1_kt = 0, c2_tile = first, c2_kt = 0;
-  {
-    int tm, tn;
-    tile_mn(first, tm, tn);
-    rows_a(tm, 0, offA0); rows_a(tm, 1, offA1); rows_b(tn, 0, offB0); rows_b(tn, 1, offB1);
-  }
+  // ---- the two DMA cursors: c1 = next K step of the half-tiles B1, A1; c2 = next K step of A0, B0 (one step further ahead) ----
+  int c1_i = 0, c1_kt = 0, c2_i = 0, c2_kt = 0;                   // tile ordinal + K step
+  const char *c1a, *c1b, *c2a, *c2b;
+  { const PPTile t = tile_entry(0); c1a = c2a = Ab + t.a_off; c1b = c2b = Bb + t.b_off; }
+  // (tile change: called AFTER a phase's MFMAs were issued, where the wavefront has nothing else to do)
   auto advance1 = [&]() {
-    if (++c1_kt == nk) {
-      c1_kt = 0; c1_tile += nblk;
-      if (c1_tile < p.n_tiles) { int tm, tn; tile_mn(c1_tile, tm, tn); rows_a(tm, 1, offA1); rows_b(tn, 1, offB1); }
-    }
+    if (++c1_kt == nk) { c1_kt = 0; if (++c1_i < n_my) { const PPTile t = tile_entry(c1_i); c1a = Ab + t.a_off; c1b = Bb + t.b_off; } }
   };
   auto advance2 = [&]() {
-    if (++c2_kt == nk) {
-      c2_kt = 0; c2_tile += nblk;
-      if (c2_tile < p.n_tiles) { int tm, tn; tile_mn(c2_tile, tm, tn); rows_a(tm, 0, offA0); rows_b(tn, 0, offB0); }
-    }
+    if (++c2_kt == nk) { c2_kt = 0; if (++c2_i < n_my) { const PPTile t = tile_entry(c2_i); c2a = Ab + t.a_off; c2b = Bb + t.b_off; } }
   };
   // (past the last tile the cursors keep re-loading the last tile's rows into slots nobody reads: the vmcnt counts stay uniform)
+  auto issue_b1 = [&](unsigned buf) { issue(c1b, voB[1], c1_kt, buf + 3 * PP_HT); };
+  auto issue_a1 = [&](unsigned buf) { issue(c1a, voA[1], c1_kt, buf + 1 * PP_HT); };
+  auto issue_a0 = [&](unsigned buf) { issue(c2a, voA[0], c2_kt, buf + 0 * PP_HT); };
+  auto issue_b0 = [&](unsigned buf) { issue(c2b, voB[0], c2_kt, buf + 2 * PP_HT); };
 
   if (p.desync_ns > 0) {
-    // workgroups that own one tile fewer than the others may start late for free: spreads the epilogue store bursts
-    const int rem = p.n_tiles % nblk;
-    if (rem && first >= rem) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();           // 100 MHz
-      const unsigned long long wait = (unsigned long long)p.desync_ns * (unsigned)(first - rem + 1) / (unsigned)(nblk - rem) / 10;
-      while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
+    // lab knob: start offsets (dbg bit 3 clear: the 32 workgroups of every XCD spread over [0, desync_ns); set: whole XCDs)
+    unsigned long long wait = (unsigned long long)p.desync_ns * (((blockIdx.x >> 3) & 31u) * 8u + (blockIdx.x & 7u)) / 2560;   // 100 MHz ticks
+    if (p.dbg & 8) wait = (unsigned long long)p.desync_ns * (blockIdx.x & 7u) / 80;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
   }
 
-  // prologue: K step 0 (buffer 0) completely, A0/B0 of K step 1 (buffer 1)
-  issue(Ab, offA0, 0, 0 * PP_HT); issue(Bb, offB0, 0, 2 * PP_HT);
-  advance2();
-  issue(Bb, offB1, 0, 3 * PP_HT); issue(Ab, offA1, 0, 1 * PP_HT);
-  advance1();
-  issue(Ab, offA0, c2_kt, PP_BUF + 0 * PP_HT); issue(Bb, offB0, c2_kt, PP_BUF + 2 * PP_HT);
-  advance2();
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                  // A0, B0 of K step 0
-  if (wr == 1) PP_BARRIER();                                       // wavefronts 4-7 run one slot behind
+  // ---- epilogue of one tile: a lane owns one output row per 16-row block and 8 consecutive columns per column pair ----
+  constexpr int ESZ = OUT_F16 ? 2 : 4;
+  // Row block outer, column pair inner: the two 64-byte halves of a 128-byte line come from CONSECUTIVE store instructions.
+  // (Column pair outer -- the halves 8 instructions apart -- measured 5-6 % slower on the whole GEMM: partial-line writes.)
+  auto epilogue_rows = [&](auto pred_tag, int bm, int bml, int bn, int bnl) {
+    constexpr bool PRED = decltype(pred_tag)::value;                 // edge tile: mask the rows / columns of the neighbour tile
+    const int row0 = bml + wr * 128 + l15, col0 = bnl + wc * 64 + 8 * q;
+    char* cp = reinterpret_cast<char*>(p.C) + ((long long)row0 * p.ldc + col0) * ESZ;
+    const long long row_step = 16 * p.ldc * ESZ;
+    auto act4 = [&](f32x4& x) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (ACT == 1) x[e] = fmaxf(x[e], 0.f);
+        else if constexpr (ACT == 2) x[e] = ovis::quick_gelu(x[e]);
+        else if constexpr (ACT == 3) x[e] = ovis::gelu_erf(x[e]);
+      }
+    };
+    auto pack8 = [&](const f32x4& x0, const f32x4& x1) {
+      using f32x2 = __attribute__((ext_vector_type(2))) float;
+      using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+      const f16x2 h0 = __builtin_convertvector(f32x2{x0[0], x0[1]}, f16x2), h1 = __builtin_convertvector(f32x2{x0[2], x0[3]}, f16x2);
+      const f16x2 h2 = __builtin_convertvector(f32x2{x1[0], x1[1]}, f16x2), h3 = __builtin_convertvector(f32x2{x1[2], x1[3]}, f16x2);
+      return make_uint4(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), __builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3));
+    };
+    auto put = [&](int mb, int j) {
+      f32x4 x0 = acc[mb][2 * j], x1 = acc[mb][2 * j + 1];
+      act4(x0); act4(x1);
+      char* c = cp + mb * row_step + j * 32 * ESZ;
+      const bool ok = !PRED || (col0 + 32 * j >= bn && row0 + mb * 16 >= bm);
+      if constexpr (OUT_F16) {
+        const uint4 o = pack8(x0, x1);
+        if (p.dbg & 1) asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+        else if (ok) *reinterpret_cast<uint4*>(c) = o;
+      } else {
+        if (p.dbg & 1) asm volatile("" :: "v"(x0[0]), "v"(x0[3]), "v"(x1[0]), "v"(x1[3]));
+        else if (ok) { *reinterpret_cast<f32x4*>(c) = x0; *reinterpret_cast<f32x4*>(c + 16) = x1; }
+      }
+    };
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) put(mb, j);
+  };
+  // ... followed by the start value of the next tile's accumulators: bias + residual (gemm_epilogue.h) or zero
+  auto acc_init = [&](int bml, int bnl) {
+    if constexpr (HAS_R) {
+      const float* rp = p.R + (long long)(bml + wr * 128 + l15) * p.ldr + bnl + wc * 64 + 8 * q;
+      const int col0 = bnl + wc * 64 + 8 * q;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(lds + PP_BIAS + (col0 + 32 * j + 4 * e) * 4);
+#pragma unroll
+          for (int mb = 0; mb < 8; ++mb)
+            acc[mb][2 * j + e] = *reinterpret_cast<const f32x4*>(rp + (long long)mb * 16 * p.ldr + 32 * j + 4 * e) + bv;
+        }
+    } else {                                                         // accumulators start at the bias: nothing to add in the epilogue
+      const int col0 = bnl + wc * 64 + 8 * q;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(lds + PP_BIAS + (col0 + 32 * (nb >> 1) + 4 * (nb & 1)) * 4);
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) acc[mb][nb] = bv;
+      }
+    }
+  };
+
+  // prologue: K steps 0 and 1 completely (both buffers).  Every tile starts in this state: the DMA of the first two K
+  // steps of the NEXT tile is issued before the epilogue's stores (the in-order vmcnt queue then lets the stores drain
+  // under two K steps of compute: no load that is waited for before the end of K step 1 is younger than a store).
+  issue_a0(0); issue_b0(0); advance2(); issue_b1(0); issue_a1(0); advance1();
+  issue_a0(PP_BUF); issue_b0(PP_BUF); advance2(); issue_b1(PP_BUF); issue_a1(PP_BUF); advance1();
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                 // A0, B0 of K step 0
+  if (wr == 1) PP_BARRIER();                                       // wavefronts 4-7 (G1) run one slot behind wavefronts 0-3 (G0)
+  PP_BARRIER();
+  // read segment of phase 1 of the first K step
+  read_b(2 * PP_HT, 0, bf0);
+  read_a(0, 0);
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                 // B1 of K step 0 (5 younger half-tiles)
   PP_BARRIER();
 
-  constexpr int NS = OUT_F16 ? 16 : (HAS_R ? 55 : 32);             // younger vm ops of one epilogue (+ residual loads) per lane, 8 + NS <= 63
+  constexpr int NS = OUT_F16 ? 16 : (HAS_R ? 53 : 32);             // vm ops of one epilogue (+ residual loads) per lane; 10 + NS <= 63
+#define PP_WAIT(n_first, n_later) do { if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_first) : "memory"); \
+                                       else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_later) : "memory"); } while (0)
   unsigned s = 0;                                                    // global K step counter (buffer = s & 1)
-  for (int tile = first; tile < p.n_tiles; tile += nblk) {
-    int tm, tn;
-    tile_mn(tile, tm, tn);
-    const int bm = tm * 256, bn = tn * 256;
-    const int it = (tile - first) / nblk;
+  { const PPTile t = tile_entry(0); acc_init(t.bml, t.bnl); }
+  for (int it = 0; it < n_my; ++it) {
     unsigned long long* st = (p.stamps && it < 16 && (wave & 3) == 0 && lane == 0) ? p.stamps + ((blockIdx.x * 16 + it) * 2 + wr) * 4 : nullptr;
     if (st) st[0] = __builtin_amdgcn_s_memrealtime();
-    const int n_lane = bn + wc * 64 + 8 * q;                         // + 32 j: first of this lane's 8 columns
-    if constexpr (HAS_R) {                                           // accumulators start at bias + residual (gemm_epilogue.h)
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) {
-        const long long m = min((long long)bm + wr * 128 + mb * 16 + l15, (long long)p.M - 1);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int n = min(n_lane + 32 * j, p.N - 8);
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const float4 rv = *reinterpret_cast<const float4*>(p.R + m * p.ldr + n + 4 * e);
-            const float4 bv = *reinterpret_cast<const float4*>(lds + PP_BIAS + (n + 4 * e) * 4);
-            acc[mb][2 * j + e] = f32x4{rv.x + bv.x, rv.y + bv.y, rv.z + bv.z, rv.w + bv.w};
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    unsigned long long* ks = (st && it >= 2 && it < 6) ? p.stamps + 256 * 16 * 2 * 4 + (blockIdx.x * 2 + wr) * 64 + (it - 2) * 16 : nullptr;
 
+    // vm ops YOUNGER than the half-tile a wait is for (8 = four half-tiles), per K step of the tile; NS = the previous
+    // epilogue's stores, which sit behind the early-issued B1/A1 of K step 1:
+    //   kt = 0: (phase 1: in the tile transition below), 8 + NS, 8 + NS;   kt = 1: 8 + NS, 8 + NS, 8;   kt >= 2: 8
     for (int kt = 0; kt < nk; ++kt, ++s) {
       const unsigned cur = (s & 1) * PP_BUF, oth = PP_BUF - cur;
-      const bool after_epi = kt == 0 && tile != first;               // this tile's first K step: the epilogue's stores are younger than every load these waits need
       // ---- phase 1: quadrant (0,0) ----
-      read_b(cur + 2 * PP_HT, 0, bf0);
-      read_a(cur, 0);
-      issue(Bb, offB1, c1_kt, oth + 3 * PP_HT);
-      if (after_epi) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + NS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      PP_BARRIER();
+      if (kt) {
+        read_b(cur + 2 * PP_HT, 0, bf0);
+        read_a(cur, 0);
+        issue_b1(oth);
+        if (kt == 1) PP_WAIT(8, 8 + NS); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        PP_BARRIER();
+      }
       mma(0, 0, bf0);
       PP_BARRIER();
       // ---- phase 2: quadrant (0,1) ----
       read_b(cur + 2 * PP_HT, 1, bf1);
-      issue(Ab, offA1, c1_kt, oth + 1 * PP_HT);
-      advance1();
-      if (after_epi) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + NS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (kt) issue_a1(oth);
+      if (kt < 2) PP_WAIT(8, 8 + NS); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       PP_BARRIER();
       mma(0, 1, bf1);
+      if (kt) advance1();
       PP_BARRIER();
       // ---- phase 3: quadrant (1,1) ----
       read_a(cur, 1);
-      issue(Ab, offA0, c2_kt, cur + 0 * PP_HT);
+      issue_a0(cur);
       PP_BARRIER();
       mma(1, 1, bf1);
       PP_BARRIER();
       // ---- phase 4: quadrant (1,0), no LDS reads ----
-      issue(Bb, offB0, c2_kt, cur + 2 * PP_HT);
-      advance2();
-      if (after_epi) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + NS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      issue_b0(cur);
+      if (kt == 0) PP_WAIT(8, 8 + NS); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       PP_BARRIER();
       mma(1, 0, bf0);
+      advance2();
       PP_BARRIER();
+      if (ks && kt < 16) ks[kt] = __builtin_amdgcn_s_memrealtime();
     }
-
     if (st) st[1] = __builtin_amdgcn_s_memrealtime();
-    // ---- epilogue: lane = one output row per 16-row block, 8 consecutive columns per column pair ----
-    if (p.dbg < 2)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n_lane + 32 * j;
-      float bv[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-      if constexpr (!HAS_R) {
-        const int nc = min(n, p.N - 8);
-        const float4 b0 = *reinterpret_cast<const float4*>(lds + PP_BIAS + nc * 4);
-        const float4 b1 = *reinterpret_cast<const float4*>(lds + PP_BIAS + nc * 4 + 16);
-        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-      }
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) {
-        const long long m = (long long)bm + wr * 128 + mb * 16 + l15;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          v[e] = acc[mb][2 * j + (e >> 2)][e & 3] + bv[e];
-          if constexpr (ACT == 1) v[e] = fmaxf(v[e], 0.f);
-          else if constexpr (ACT == 2) v[e] = ovis::quick_gelu(v[e]);
-          else if constexpr (ACT == 3) v[e] = ovis::gelu_erf(v[e]);
-        }
-        const bool ok = m < p.M && n < p.N && p.dbg == 0;                          // N % 8 == 0: a lane's 8 columns are inside or outside together
-        if constexpr (OUT_F16) {
-          f16x8 o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
-          if (ok) *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(p.C) + m * p.ldc + n) = o;
-        } else {
-          if (ok) {
-            float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
-            *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
-          }
-        }
-      }
+
+    // ---- tile transition.  B1 / A1 of the next tile's K step 1 go out first (slots of buffer (s+1) & 1: last read 2 and 3
+    // phases ago), i.e. BEFORE this wavefront's stores.  G0 then waits one slot for G1's last MFMAs so that BOTH groups run
+    // their epilogue in the same slot (a wavefront issues a 1-KB store every ~100 ns whatever the others do: two groups
+    // storing one after the other cost twice the time); G1 reads its phase 1 under G0's first MFMAs of the next tile.
+    const PPTile t = tile_entry(it);
+    const int bm = t.bm, bn = t.bn, bml = t.bml, bnl = t.bnl;        // rows / columns this tile owns (stores) and computed (shifted edge tiles)
+    const bool has_next = it + 1 < n_my;
+    int nbml = bml, nbnl = bnl;
+    if (has_next) { const PPTile tn_ = tile_entry(it + 1); nbml = tn_.bml; nbnl = tn_.bnl; }
+    { const unsigned nb1 = (s & 1) * PP_BUF ^ PP_BUF; issue_b1(nb1); issue_a1(nb1); advance1(); }
+    // slots:  G0: [last MFMAs] | (idle)      | epilogue, phase-1 reads | MFMAs of phase 1 ...
+    //         G1: [phase-4 reads] | last MFMAs | epilogue               | phase-1 reads   | MFMAs ...
+    if (wr == 0) PP_BARRIER();
+    if (wr == 1 && !(p.dbg & 16)) __builtin_amdgcn_s_setprio(1);     // the younger wavefronts 4-7 lose every arbitration against 0-3 otherwise
+    if ((p.dbg & 3) < 2) {
+      if (bm == bml && bn == bnl) epilogue_rows(std::false_type{}, bm, bml, bn, bnl);
+      else epilogue_rows(std::true_type{}, bm, bml, bn, bnl);
     }
+    if (has_next) acc_init(nbml, nbnl);
     if (st) st[2] = __builtin_amdgcn_s_memrealtime();
+    if (wr == 1) { __builtin_amdgcn_s_setprio(0); PP_BARRIER(); }
+    {                                                                // read segment of the next tile's phase 1 (fragment registers are free again)
+      const unsigned cur = (s & 1) * PP_BUF;
+      read_b(cur + 2 * PP_HT, 0, bf0);
+      read_a(cur, 0);
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(10 + NS) : "memory");   // B1 of the next tile's K step 0: 5 younger half-tiles + the epilogue
+    }
+    PP_BARRIER();
   }
   if (wr == 0) PP_BARRIER();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -320,7 +386,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
 
 int g_f16_gemm_mode = 1;          // 1: ping-pong kernel for eligible problems, 0: gemm_f16_256_kernel (gemm_f16.hip)
 int g_pp_grp = 6;                 // raster: at most this many N tiles per column group
-int g_pp_desync_ns = 0;
+int g_pp_desync_ns = -1;          // < 0: automatic
 int g_pp_dbg = 0;
 unsigned long long* g_pp_stamps = nullptr;
 
@@ -333,8 +399,9 @@ bool gemm_f16_pp_eligible(const void* C, long long lda, long long ldb, long long
   if (g_f16_gemm_mode != 1) return false;
   if (!((out_f16 && !residual) || (!out_f16 && act_is_none))) return false;   // instantiated combinations
   const long long blocks256 = (long long)cdiv(M, 256) * cdiv(N, 256);
-  if (blocks256 < 256 || K % 64 != 0 || K < 128 || N % 8 != 0) return false;
-  if ((long long)M * lda * 2 >= (1ll << 32) || (long long)N * ldb * 2 >= (1ll << 32)) return false;   // 32-bit DMA row offsets
+  if (blocks256 > 256ll * PP_MAX_TILES) return false;
+  if (blocks256 < 256 || K % 64 != 0 || K < 128 || N % 8 != 0 || M < 256 || N < 256) return false;
+  if (256 * lda * 2 >= (1ll << 31) || 256 * ldb * 2 >= (1ll << 31)) return false;                      // 32-bit DMA row offsets inside a tile
   if (bias && (N > PP_MAX_BIAS_N || (reinterpret_cast<uintptr_t>(bias) & 15))) return false;
   if (reinterpret_cast<uintptr_t>(C) & 15) return false;
   if (out_f16 ? (ldc % 8 != 0) : (ldc % 4 != 0)) return false;
@@ -350,7 +417,10 @@ int gemm_f16_pp_launch(const void* A, long long lda, const void* B, long long ld
   p.tiles_m = (int)cdiv(M, 256); p.tiles_n = (int)cdiv(N, 256); p.n_tiles = p.tiles_m * p.tiles_n;
   const int groups = (int)cdiv(p.tiles_n, g_pp_grp > 0 ? g_pp_grp : p.tiles_n);
   p.grp_w = p.tiles_n / groups; p.grp_rem = p.tiles_n % groups;
-  p.desync_ns = g_pp_desync_ns; p.dbg = g_pp_dbg; p.stamps = g_pp_stamps;
+  // residual GEMMs: every round of tiles ends in a 128 MB burst (residual loads + C stores); starting the 32 workgroups of
+  // an XCD spread over 24 us de-phases the bursts (+4 % out-proj, +1.5 % fc2; -1 % on the fp16-output shapes, hence only here)
+  p.desync_ns = g_pp_desync_ns >= 0 ? g_pp_desync_ns : (residual ? 24000 : 0);
+  p.dbg = g_pp_dbg; p.stamps = g_pp_stamps;
   const int grid = p.n_tiles < 256 ? p.n_tiles : 256;              // one persistent workgroup per CU (MI355X: 256 CUs)
 #define PP_LAUNCH(O, A_, R_) hipLaunchKernelGGL((gemm_f16_pp_kernel<O, A_, R_>), dim3(grid), dim3(512), 0, s, p)
   if (out_f16 && !residual) {
@@ -369,7 +439,7 @@ int gemm_f16_pp_launch(const void* A, long long lda, const void* B, long long ld
 
 extern "C" int ovis_set_f16_gemm_mode(int mode, int raster_group, int desync_ns) {
   OVIS_REQUIRE(mode == 0 || mode == 1, "set_f16_gemm_mode: mode must be 0 (gemm_f16_256_kernel) or 1 (ping-pong kernel)");
-  OVIS_REQUIRE(raster_group >= 0 && raster_group <= 64 && desync_ns >= 0, "set_f16_gemm_mode: bad tuning value");
+  OVIS_REQUIRE(raster_group >= 0 && raster_group <= 64, "set_f16_gemm_mode: bad tuning value");
   g_f16_gemm_mode = mode;
   if (raster_group > 0) g_pp_grp = raster_group;
   g_pp_desync_ns = desync_ns;

@@ -99,7 +99,8 @@ int main(int argc, char** argv) {
       ref_gemm<<<(unsigned)((MN + 255) / 256), 256, 0, s>>>(A, B, ref, c.M, c.N, c.K, bias, R, c.act);
       for (const Variant& v : variants) {
         OVIS_OKAY(ovis_set_f16_gemm_mode(v.mode, v.grp, v.desync));
-        if (v.dbg) continue;
+        if (v.dbg & 3) continue;                                  // variants that skip the stores cannot be checked
+        ovis_pp_debug(v.dbg, nullptr);
         for (int rep = 0; rep < 3; ++rep) {                       // repeated: a race shows up as run-to-run differences
           HIP_OK(hipMemsetAsync(C, 0xff, MN * 4, s));
           OVIS_OKAY(ovis_gemm_nt_f16(A, c.K, B, c.K, C, c.N, c.M, c.N, c.K, bias, R, c.N, c.act, c.out16, s));
@@ -163,7 +164,7 @@ int main(int argc, char** argv) {
       if (do_trace)
         for (const Variant& v : variants) {
           if (v.mode != 1) continue;
-          const size_t nst = 256 * 16 * 2 * 4;
+          const size_t nst = 256 * 16 * 2 * 4 + 256 * 2 * 64;
           unsigned long long* d_st; HIP_OK(hipMalloc(&d_st, nst * 8)); HIP_OK(hipMemsetAsync(d_st, 0, nst * 8, s));
           OVIS_OKAY(ovis_set_f16_gemm_mode(v.mode, v.grp, v.desync));
           ovis_pp_debug(v.dbg, d_st);
@@ -172,7 +173,7 @@ int main(int argc, char** argv) {
           std::vector<unsigned long long> st(nst);
           HIP_OK(hipMemcpyAsync(st.data(), d_st, nst * 8, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
           unsigned long long t0 = ~0ull, t1 = 0;
-          for (size_t i = 0; i < nst; i += 4) if (st[i]) { t0 = std::min(t0, st[i]); t1 = std::max(t1, st[i + 2]); }
+          for (size_t i = 0; i < 256 * 16 * 2 * 4; i += 4) if (st[i]) { t0 = std::min(t0, st[i]); t1 = std::max(t1, st[i + 2]); }
           printf("trace %s variant=%s: first tile begin -> last epilogue end %.2f us (100 MHz ticks)\n", sh.name, v.name.c_str(), (t1 - t0) * 0.01);
           for (int it = 0; it < 16; ++it) {
             double kl[2] = {0, 0}, ep[2] = {0, 0}, gap[2] = {0, 0}, beg[2] = {0, 0}; int n[2] = {0, 0}; double bmin = 1e30, bmax = 0;
@@ -185,6 +186,23 @@ int main(int argc, char** argv) {
             }
             if (n[0]) printf("  it %2d (%3d wg): begin %.1f us [%.1f..%.1f]  G0 kloop %.2f epi %.2f | G1 kloop %.2f epi %.2f\n", it, n[0], beg[0] / n[0], bmin, bmax,
                              kl[0] / n[0], ep[0] / n[0], kl[1] / std::max(n[1], 1), ep[1] / std::max(n[1], 1));
+          }
+          {   // per-K-step durations of tile iterations 2..5 (mean over workgroups, group 0): dt[kt] = end(kt) - end(kt-1); dt[0] = end(0) - tile begin
+            const int nks = std::min(sh.K / 64, 16);
+            for (int it = 2; it < 6; ++it) {
+              printf("  ksteps it %d:", it);
+              for (int kt = 0; kt < nks; ++kt) {
+                double sum = 0; int n = 0;
+                for (int b = 0; b < 256; ++b) {
+                  const unsigned long long* k = &st[256 * 16 * 2 * 4 + (size_t)(b * 2 + 0) * 64 + (it - 2) * 16];
+                  const unsigned long long* x = &st[((size_t)(b * 16 + it) * 2 + 0) * 4];
+                  if (!k[kt] || !x[0]) continue;
+                  sum += (k[kt] - (kt ? k[kt - 1] : x[0])) * 0.01; ++n;
+                }
+                printf(" %.2f", n ? sum / n : 0.0);
+              }
+              printf("\n");
+            }
           }
           HIP_OK(hipFree(d_st));
         }
