@@ -133,6 +133,9 @@ int ovis_pe_sine_f32(float* out, int T, int H, int W, int num_pos_feats, int thr
  * desync_ns: start offsets of the 32 persistent workgroups of an XCD are spread over [0, desync_ns) (< 0: automatic, 24 us
  * for the residual GEMMs, 0 otherwise).  Process-wide, not thread-safe. */
 int ovis_set_f16_gemm_mode(int mode, int raster_group, int desync_ns);
+/* Name of the kernel ovis_gemm_nt_f16 launches for this problem (static string; for profiles and bench.py's roofline). */
+const char* ovis_gemm_nt_f16_kernel(const void* C, long long lda, long long ldb, long long ldc, int M, int N, int K,
+                                    const float* bias, const float* residual, long long ldr, int act, int out_f16);
 
 /* ovis_gemm_nt_f16: same contract with fp16 A [M,K] / B [N,K] (K, lda, ldb multiples of 8), f32 accumulation,
  *   f32 bias / residual, C written as f32 (out_f16 == 0) or fp16.  Used for the CLIP ViT GEMMs only — the reference

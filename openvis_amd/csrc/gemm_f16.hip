@@ -450,6 +450,21 @@ extern "C" int ovis_gemm_nt_f16(const void* A, long long lda, const void* B, lon
   return ovis::check_launch("gemm_nt_f16");
 }
 
+extern "C" const char* ovis_gemm_nt_f16_kernel(const void* C, long long lda, long long ldb, long long ldc, int M, int N, int K,
+                                               const float* bias, const float* residual, long long ldr, int act, int out_f16) {
+  // same decision tree as ovis_gemm_nt_f16 (names as rocprofv3 prints them, without the anonymous namespace)
+  if (ovis::gemm_f16_pp_eligible(C, lda, ldb, ldc, M, N, K, bias, residual, ldr, out_f16, act == 0))
+    return out_f16 ? (act == 0 ? "gemm_f16_pp_kernel<true,0,false>" : act == 1 ? "gemm_f16_pp_kernel<true,1,false>" :
+                      act == 2 ? "gemm_f16_pp_kernel<true,2,false>" : "gemm_f16_pp_kernel<true,3,false>")
+                   : (residual ? "gemm_f16_pp_kernel<false,0,true>" : "gemm_f16_pp_kernel<false,0,false>");
+  const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128);
+  const long long blocks256 = (long long)ovis::cdiv(M, 256) * ovis::cdiv(N, 256);
+  if (blocks256 >= 256 && K % 64 == 0) return out_f16 ? "gemm_f16_256_kernel<true>" : "gemm_f16_256_kernel<false>";
+  if (blocks128 >= 128 && K % BKH == 0) return out_f16 ? "gemm_f16_glds_kernel<true>" : "gemm_f16_glds_kernel<false>";
+  if (blocks128 >= 128) return out_f16 ? "gemm_f16_kernel<128,128,true>" : "gemm_f16_kernel<128,128,false>";
+  return out_f16 ? "gemm_f16_kernel<64,64,true>" : "gemm_f16_kernel<64,64,false>";
+}
+
 extern "C" int ovis_cast_f32_to_f16(const float* x, void* y, long long n, ovis_stream_t stream) {
   OVIS_REQUIRE(x && y && n > 0 && n % 4 == 0, "cast_f32_to_f16: n must be a positive multiple of 4");
   hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(ovis::cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,

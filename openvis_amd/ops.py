@@ -117,14 +117,12 @@ def gemm_nt_f16(a, w, bias=None, residual=None, act=ACT_NONE, out_f16=False):
     M = a2.shape[0]
     out = torch.empty((M, N), dtype=torch.float16 if out_f16 else torch.float32, device=a.device)
     r2 = residual.reshape(-1, N) if residual is not None else None
-    # mirrors the dispatch in csrc/gemm_f16.hip (names = the kernels rocprofv3 reports)
-    o = "true" if out_f16 else "false"
-    if ((M + 255) // 256) * ((N + 255) // 256) >= 256 and K % 64 == 0:
-        kname = f"gemm_f16_256_kernel<{o}>"
-    elif ((M + 127) // 128) * ((N + 127) // 128) >= 128:
-        kname = f"gemm_f16_glds_kernel<{o}>" if K % 64 == 0 else f"gemm_f16_kernel<128,128,{o}>"
-    else:
-        kname = f"gemm_f16_kernel<64,64,{o}>"
+    kname = ""
+    if PROFILE is not None:                     # the kernel the library picks (name as rocprofv3 reports it)
+        fn = _lib.lib().ovis_gemm_nt_f16_kernel
+        fn.restype = ctypes.c_char_p
+        kname = fn(_lib._conv(out), _ll(K), _ll(w.stride(0)), _ll(N), M, N, K, _lib._conv(bias), _lib._conv(r2), _ll(N), act,
+                   int(out_f16)).decode()
     with _Prof(kname, 2.0 * M * N * K):
         _lib.call("ovis_gemm_nt_f16", a2, _ll(K), w, _ll(w.stride(0)), out, _ll(N), M, N, K, bias, r2, _ll(N), act,
                   int(out_f16), _lib.stream_ptr())
