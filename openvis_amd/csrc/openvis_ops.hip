@@ -4,6 +4,7 @@
 // full-resolution intermediates the reference materialises ([Q,T,Hp,Wp] fp32 masks, x8-replicated
 // boolean masks, per-mask host loops).
 #include "common.h"
+#include <atomic>
 
 #pragma clang fp contract(off)
 
@@ -435,8 +436,11 @@ clip_crop_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ m
   const int G = R / ps;
   const long long row = (long long)m * G * G + (py / ps) * G + (px / ps);
   const int col = (py % ps) * ps + (px % ps);
-  // mask prompt (model.py:332-333): ceil(avg-pooled mask region) == 1 iff any bin of the patch is > 0 (values are >= 0)
-  if (patch_open && mk > 0.f) patch_open[row] = 1;
+  // mask prompt (model.py:332-333): ceil(avg-pooled mask region) == 1 iff any bin of the patch is > 0 (values are >= 0).
+  // The reference's mask regions are fp16 (roi_align(valid_masks.half(), ...), mask_adapted_adapter.py:113): a soft-mask
+  // value below 2^-25 (logit < -17.3) IS zero there, which is what closes the background patches of a real checkpoint;
+  // an f32 sigmoid never reaches 0, so the test is made on the value rounded to fp16.
+  if (patch_open && (_Float16)mk > (_Float16)0.f) patch_open[row] = 1;
   if (out_f16) {
     _Float16* ap = reinterpret_cast<_Float16*>(Av) + row * lda + col;
     ap[0] = (_Float16)r0; ap[ps * ps] = (_Float16)r1; ap[2 * ps * ps] = (_Float16)r2;
@@ -631,8 +635,11 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
   const int G = R / ps;
   const long long row = (long long)m * G * G + (py / ps) * G + (px / ps);
   const int col = (py % ps) * ps + (px % ps);
-  // mask prompt (model.py:332-333): ceil(avg-pooled mask region) == 1 iff any bin of the patch is > 0 (values are >= 0)
-  if (patch_open && mk > 0.f) patch_open[row] = 1;
+  // mask prompt (model.py:332-333): ceil(avg-pooled mask region) == 1 iff any bin of the patch is > 0 (values are >= 0).
+  // The reference's mask regions are fp16 (roi_align(valid_masks.half(), ...), mask_adapted_adapter.py:113): a soft-mask
+  // value below 2^-25 (logit < -17.3) IS zero there, which is what closes the background patches of a real checkpoint;
+  // an f32 sigmoid never reaches 0, so the test is made on the value rounded to fp16.
+  if (patch_open && (_Float16)mk > (_Float16)0.f) patch_open[row] = 1;
   if (out_f16) {
     _Float16* ap = reinterpret_cast<_Float16*>(Av) + row * lda + col;
     ap[0] = (_Float16)r0; ap[ps * ps] = (_Float16)r1; ap[2 * ps * ps] = (_Float16)r2;
@@ -993,12 +1000,16 @@ static int clip_crop_impl(const uint8_t* frames, const float* masks, const int* 
   const int p16 = args(16), p8 = args(8);
   const bool grid_ok = bin_max <= (float)CROP_GMAX;
   if (grid_ok && resolution % 16 == 0 && (size_t)p16 * (p16 + 1) * 8 <= 76 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute is per DEVICE (a process may drive several GPUs) and the ClipPipeline slot threads call this concurrently:
+    // one atomic flag per device ordinal; setting it twice is harmless
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    OVIS_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "clip_crop: hipGetDevice failed");
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
       OVIS_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&clip_crop_tiled_kernel<16, 16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 76 * 1024) == hipSuccess,
                    "clip_crop: cannot raise the dynamic LDS limit");
-      attr_set = true;
+      attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((clip_crop_tiled_kernel<16, 16>), dim3((unsigned)((long long)M * (resolution / 16) * (resolution / 16))), dim3(256),
                        (size_t)p16 * (p16 + 1) * 8, (hipStream_t)stream, frames, masks, crops, A, patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp,

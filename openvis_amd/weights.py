@@ -266,16 +266,72 @@ def random_init(spec, seed=42):
     return sd
 
 
+class _ArrayUnpickler(__import__("pickle").Unpickler):
+    """Unpickler for detectron2 model-zoo `.pkl` files that resolves only what such a file needs (numpy array
+    reconstruction, OrderedDict, builtin containers): a MODEL.WEIGHTS path must not be able to run arbitrary code."""
+    _ALLOWED = {("collections", "OrderedDict"), ("numpy", "ndarray"), ("numpy", "dtype"),
+                ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+                ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("builtins", "set"),
+                ("builtins", "frozenset"), ("builtins", "bytearray"), ("builtins", "complex")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise __import__("pickle").UnpicklingError(f"checkpoint pickle refers to {module}.{name}: refused")
+
+
+_C2_SUFFIX = (("_bn_riv", ".norm.running_var"), ("_bn_rm", ".norm.running_mean"), ("_bn_s", ".norm.weight"),
+              ("_bn_b", ".norm.bias"), ("_w", ".weight"), ("_b", ".bias"))
+_C2_BRANCH = {"branch2a": "conv1", "branch2b": "conv2", "branch2c": "conv3", "branch1": "shortcut"}
+
+
+def _c2_resnet_name(k):
+    """Caffe2 / MSRA ResNet blob name -> detectron2 module name (detectron2 checkpoint/c2_model_loading.py
+    convert_basic_c2_names, ResNet rows): conv1_w -> stem.conv1.weight, res_conv1_bn_s -> stem.conv1.norm.weight,
+    res2_0_branch2a_w -> res2.0.conv1.weight, res3_0_branch1_bn_b -> res3.0.shortcut.norm.bias.  None: not a backbone blob."""
+    for suf, rep in _C2_SUFFIX:
+        if k.endswith(suf):
+            stem, tail = k[:-len(suf)], rep
+            break
+    else:
+        return None
+    if stem in ("conv1", "res_conv1"):
+        return "stem.conv1" + tail
+    parts = stem.split("_")
+    if len(parts) == 3 and parts[0].startswith("res") and parts[0][3:].isdigit() and parts[1].isdigit() and parts[2] in _C2_BRANCH:
+        return f"{parts[0]}.{parts[1]}.{_C2_BRANCH[parts[2]]}{tail}"
+    return None
+
+
 def load_checkpoint(path):
     """State dict of a reference checkpoint: a torch `.pth` / `.pt` file ({"model": state_dict} as DetectionCheckpointer
-    writes it, or a bare state dict) or a detectron2 model-zoo `.pkl` (pickle of {"model": {key: numpy array}, ...})."""
+    writes it, or a bare state dict; loaded with weights_only=True) or a detectron2 model-zoo `.pkl` (pickle of
+    {"model": {key: numpy array}, "matching_heuristics": True, ...}; read by an unpickler restricted to array data).
+    A backbone-only pickle (MODEL.WEIGHTS: detectron2://ImageNetPretrained/MSRA/R-50.pkl in the reference's Base.yaml) has
+    un-prefixed Caffe2 or detectron2 names, which DetectionCheckpointer resolves with its matching heuristics: here the
+    Caffe2 ResNet names are converted and every backbone key gets the `backbone.` prefix of the meta-architectures."""
     if path.endswith(".pkl"):
-        import pickle
         import numpy as np
         with open(path, "rb") as f:
-            data = pickle.load(f, encoding="latin1")
-        model = data.get("model", data)
-        return {k: torch.from_numpy(np.ascontiguousarray(v)) if not torch.is_tensor(v) else v
-                for k, v in model.items() if not k.startswith("__")}
-    ck = torch.load(path, map_location="cpu")
+            data = _ArrayUnpickler(f, encoding="latin1").load()
+        model = data.get("model", data) if isinstance(data, dict) else data
+        out = {}
+        heur = isinstance(data, dict) and bool(data.get("matching_heuristics", False))
+        for k, v in model.items():
+            if k.startswith("__"):
+                continue
+            t = torch.from_numpy(np.ascontiguousarray(v)) if not torch.is_tensor(v) else v
+            if not k.startswith(("backbone.", "sem_seg_head.", "clip_adapter.", "resampler.", "brownian_criterion.")):
+                c2 = _c2_resnet_name(k)
+                if c2 is not None:
+                    k = "backbone." + c2
+                elif (heur and "." in k) or k.startswith(("stem.", "res2.", "res3.", "res4.", "res5.")):
+                    k = "backbone." + k
+                else:
+                    continue                      # fc1000 / optimizer blobs of a classification checkpoint
+            out[k] = t
+        return out
+    ck = torch.load(path, map_location="cpu", weights_only=True)
     return ck.get("model", ck) if isinstance(ck, dict) else ck

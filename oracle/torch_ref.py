@@ -12,9 +12,14 @@ State-dict key names are the reference's.  Pinning status
   * detectron2 ResNet-50 / ImageList / BitMasks boxes, torchvision roi_align: the sources are NOT
     under /root/reference (un-vendored third-party deps: detectron2 v0.6 per INSTALL.md:9-13,
     torchvision 0.11) -> restated from their published semantics; "parity unpinned" for those rows.
-  * dtype: the reference's GPU path casts crops to fp16 (clip_adapter/adapter.py:108-111) and runs
-    under autocast; this oracle follows the CPU (fp32) semantics of the same statements with the
-    `.cuda()` / `.half()` casts dropped.
+  * dtype: the reference's GPU path casts crops to fp16 (clip_adapter/adapter.py:108-111: `.half()` on frames,
+    boxes and the soft mask) and runs under autocast; this oracle follows the fp32 semantics of the same
+    statements with the `.cuda()` / `.half()` casts dropped ("the fp32 oracle must state which
+    it follows" -- crops, roi_align and the blend are f32 here).  ONE consequence of the fp16 cast is
+    discrete and is restated: the mask-prompt tower opens a patch iff its pooled mask region is > 0
+    (model.py:332-333), and in fp16 a soft-mask value below 2^-25 (logit < -17.3) is exactly 0 -- that is what
+    closes background patches on a real checkpoint.  clip_visual() therefore rounds the mask regions to fp16
+    before pooling them (mask_adapted_adapter.py:113).
 """
 import math
 
@@ -512,7 +517,8 @@ def clip_visual(x, W, prefix="clip_adapter.clip_model.visual.", heads=12, m=None
     x = F.conv2d(x, W[p + "conv1.weight"], None, stride=patch)
     x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
     if m is not None:
-        m = F.avg_pool2d(m.float().reshape(m.shape[0], 1, m.shape[-2], m.shape[-1]), patch, stride=patch)
+        m = m.half().float()     # the reference's mask regions are fp16 (mask_adapted_adapter.py:113): < 2^-25 is 0
+        m = F.avg_pool2d(m.reshape(m.shape[0], 1, m.shape[-2], m.shape[-1]), patch, stride=patch)
         m = torch.ceil(m.reshape(m.shape[0], -1).unsqueeze(-1))                # [M, G*G, 1]
         mask_embedding = W[p + "mask_embedding"]
         if mask_embedding.shape[1] == 1:

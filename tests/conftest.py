@@ -9,3 +9,18 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`pytest tests` on a box without a GPU (or without the built library) skips the gpu-marked tests instead of
+    failing ~200 of them; `-m gpu` on the GPU box runs them (and they fail loudly if the HIP library is missing THERE)."""
+    import pytest
+    gpu_items = [i for i in items if i.get_closest_marker("gpu")]
+    if not gpu_items:
+        return
+    import torch
+    if torch.cuda.is_available():
+        return                                  # on a GPU box a missing libopenvis_hip.so must fail, not skip
+    skip = pytest.mark.skip(reason="needs a real MI355X (torch.cuda.is_available() is False)")
+    for i in gpu_items:
+        i.add_marker(skip)

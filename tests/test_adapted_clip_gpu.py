@@ -112,9 +112,44 @@ def test_adapted_clip_adapter_vs_oracle(precision, tol, fwd):
     # the pooled mask itself: bit-exact 0/1 pattern, with closed patches present
     _, patch_open = ops.clip_crop_patches_masked(frames.cuda(), masks.cuda(), torch.from_numpy(crops).cuda(), Hp, Wp, 64, 16,
                                                  PIXEL_MEAN, PIXEL_STD)
-    ref_open = torch.ceil(F.avg_pool2d(mregions, 16, 16)).reshape(len(crops), -1)
+    ref_open = torch.ceil(F.avg_pool2d(mregions.half().float(), 16, 16)).reshape(len(crops), -1)
     assert torch.equal(patch_open.cpu().float(), ref_open)
     assert 0 < int(ref_open.sum()) < ref_open.numel()
+
+
+def test_mask_prompt_closes_background_patches_like_the_fp16_reference():
+    """Real checkpoints put background logits near -20: the reference's fp16 mask regions (mask_adapted_adapter.py:113)
+    are exactly 0 there, so ceil(avg_pool(m)) closes those patches (model.py:332-338).  An f32 sigmoid never is 0: a kernel
+    that tests `mask > 0` in f32 opens every in-frame patch and the mask prompt degenerates to the plain ViT.  Expected
+    pattern: roi_align of the fp16-rounded soft mask, rounded to fp16 again (the reference's tensors), pooled, ceil'ed."""
+    from openvis_amd import ops
+    from openvis_amd.modeling.clip_adapter.adapter import PIXEL_MEAN, PIXEL_STD
+    from oracle import torch_ref as TR
+    g = torch.Generator().manual_seed(11)
+    T, Q, H, W, Hp, Wp = 2, 4, 96, 128, 96, 128
+    frames = (torch.rand(T, 3, H, W, generator=g) * 255).to(torch.uint8)
+    masks = torch.full((Q, T, Hp // 4, Wp // 4), -22.0) + torch.randn(Q, T, Hp // 4, Wp // 4, generator=g)
+    masks[0, :, 3:9, 4:20] = 8.0                       # four objects of different shapes inside the frame
+    masks[1, :, 10:22, 24:29] = 7.0
+    masks[2, :, 2:20, 2:6] = 9.0
+    masks[3, :, 12:15, 8:27] = 6.0
+    up = F.interpolate(masks, size=(Hp, Wp), mode="bilinear", align_corners=False)
+    part = up.sigmoid().transpose(0, 1).contiguous()
+    _, valid, boxes, m32 = TR.clip_crops(frames, part, resolution=64, return_mask_regions=True)
+    _, _, _, m16 = TR.clip_crops(frames, part.half().float(), resolution=64, return_mask_regions=True)
+    ref_open = torch.ceil(F.avg_pool2d(m16.half().float(), 16, 16)).reshape(m16.shape[0], -1)
+    f32_open = torch.ceil(F.avg_pool2d(m32, 16, 16)).reshape(m32.shape[0], -1)
+    bx = ops.mask_bbox(masks.cuda(), Hp, Wp).cpu().numpy()                # as ClipAdapter.preprocess_boxes
+    ok = bx[..., 2] >= 0
+    assert (ok == valid.numpy()).all()
+    crops = torch.from_numpy(np.concatenate([np.argwhere(ok), bx[ok]], axis=1).astype(np.int32))
+    _, patch_open = ops.clip_crop_patches_masked(frames.cuda(), masks.cuda(), crops.cuda(), Hp, Wp, 64, 16, PIXEL_MEAN, PIXEL_STD)
+    got = patch_open.cpu().float()
+    assert torch.equal(got, ref_open), (got != ref_open).sum().item()
+    assert int((f32_open != ref_open).sum()) >= 8      # the f32 rule opens background patches the reference closes
+    assert 0 < int(ref_open.sum()) < ref_open.numel()
+    # and the oracle's tower follows the same rule
+    assert torch.equal(torch.ceil(F.avg_pool2d(m32.half().float(), 16, 16)).reshape(m32.shape[0], -1), ref_open)
 
 
 def test_bg_adapters_append_the_non_object_row():

@@ -57,13 +57,58 @@ def test_load_checkpoint_pth_and_pkl(tmp_path):
     import pickle
     import numpy as np
     import torch
-    sd = {"backbone.stem.conv1.weight": torch.randn(4, 3, 7, 7), "x.bias": torch.randn(5)}
+    sd = {"backbone.stem.conv1.weight": torch.randn(4, 3, 7, 7), "sem_seg_head.x.bias": torch.randn(5)}
     torch.save({"model": sd, "iteration": 3}, tmp_path / "m.pth")
     with open(tmp_path / "m.pkl", "wb") as f:
         pickle.dump({"model": {k: v.numpy() for k, v in sd.items()}, "__author__": "x", "matching_heuristics": True}, f)
     for name in ("m.pth", "m.pkl"):
         got = weights.load_checkpoint(str(tmp_path / name))
         assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+
+
+def test_backbone_only_pickles_get_the_backbone_prefix(tmp_path):
+    """detectron2 model-zoo ImageNet pickles (Base.yaml MODEL.WEIGHTS: .../MSRA/R-50.pkl) carry Caffe2 blob names or
+    un-prefixed detectron2 names; DetectionCheckpointer's matching heuristics map them onto `backbone.*`."""
+    import pickle
+    import numpy as np
+    import torch
+    c2 = {"conv1_w": np.zeros((64, 3, 7, 7), np.float32), "res_conv1_bn_s": np.ones(64, np.float32),
+          "res2_0_branch2a_w": np.zeros((64, 64, 1, 1), np.float32), "res2_0_branch2a_bn_b": np.zeros(64, np.float32),
+          "res3_0_branch1_w": np.zeros((512, 256, 1, 1), np.float32), "res3_0_branch1_bn_rm": np.zeros(512, np.float32),
+          "res5_2_branch2c_bn_riv": np.ones(2048, np.float32), "fc1000_w": np.zeros((1000, 2048), np.float32),
+          "fc1000_b": np.zeros(1000, np.float32)}
+    with open(tmp_path / "c2.pkl", "wb") as f:
+        pickle.dump({"model": c2, "__author__": "MSRA", "matching_heuristics": True}, f)
+    got = weights.load_checkpoint(str(tmp_path / "c2.pkl"))
+    assert set(got) == {"backbone.stem.conv1.weight", "backbone.stem.conv1.norm.weight", "backbone.res2.0.conv1.weight",
+                        "backbone.res2.0.conv1.norm.bias", "backbone.res3.0.shortcut.weight",
+                        "backbone.res3.0.shortcut.norm.running_mean", "backbone.res5.2.conv3.norm.running_var"}
+    d2 = {"stem.conv1.weight": np.zeros((64, 3, 7, 7), np.float32), "res4.5.conv2.norm.bias": np.zeros(256, np.float32)}
+    with open(tmp_path / "d2.pkl", "wb") as f:
+        pickle.dump({"model": d2, "matching_heuristics": True}, f)
+    assert set(weights.load_checkpoint(str(tmp_path / "d2.pkl"))) == {"backbone." + k for k in d2}
+    r50 = {k for k, _ in weights.openvis_spec("r50", dict(width=64, layers=1, heads=1, patch=16, resolution=32, embed_dim=16), 100)}
+    assert {k for k in got} <= r50                             # every converted name is a key of the R50 models
+
+
+def test_checkpoint_files_cannot_execute_code(tmp_path):
+    """MODEL.WEIGHTS is user-supplied: a pickle that refers to anything but array data is refused (.pkl), torch.load
+    runs with weights_only=True (.pth)."""
+    import os
+    import pickle
+    import pytest
+    import torch
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > /dev/null",))
+    with open(tmp_path / "evil.pkl", "wb") as f:
+        pickle.dump({"model": {"x": Evil()}}, f)
+    with pytest.raises(pickle.UnpicklingError):
+        weights.load_checkpoint(str(tmp_path / "evil.pkl"))
+    torch.save({"model": {"x": Evil()}}, tmp_path / "evil.pth")
+    with pytest.raises(Exception):
+        weights.load_checkpoint(str(tmp_path / "evil.pth"))
 
 
 def test_evaluator_handoff_formats():
