@@ -5,8 +5,10 @@
    offline decoder attends over all frames of a clip, so the path shards by clip with no data-path collective,
    SURVEY.md §8(e); "scaling": "weak".)
 
-A "step" is one full eval forward of the OpenVIS meta-architecture over one synthetic 5-frame 720p clip
-(uint8 frames already resident in HBM): pre-process -> ResNet-50 -> MSDeformAttn pixel decoder -> 9-layer
+A "step" is one full eval forward of the OpenVIS meta-architecture over one synthetic 5-frame 720p clip, exactly what
+SURVEY.md 8(d) defines as the metric: `model(batched_inputs)` wall-clock INCLUDING the H2D copy of the uint8 frames (from
+pinned host memory, as a DataLoader(pin_memory=True) delivers them) and the D2H copy of the 10 output masks: H2D ->
+pre-process -> ResNet-50 -> MSDeformAttn pixel decoder -> 9-layer
 masked-attention decoder -> mask boxes -> CLIP ViT-B/16 on every valid (frame, query) crop -> class aggregation ->
 top-10 -> output masks copied to the host.  Random-init weights of the real architecture (no network for
 checkpoints), 482 synthetic class embeddings (burst_val size).  Prints ONE JSON line on rank 0.
@@ -109,57 +111,68 @@ def _usable_cpus(cap=32):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(sd, text, n_crops=4):
-    """The oracle (CPU port of the reference path, oracle/torch_ref.py) on a BOUNDED sample of the 720p workload:
-    one 720x1280 frame; backbone, FPN/mask features, the 9-layer decoder and the x4 mask upsample are run in full,
-    the 6 identical MSDeformAttn encoder layers are timed as (t(3 layers) - t(1 layer)) / 2 and scaled, and CLIP
-    ViT-B/16 is timed on `n_crops` crops and scaled to the frame's number of valid crops."""
+def cpu_baseline(sd, iters=3):
+    """BASELINE.md section 3 / SURVEY.md 8(d): the oracle (CPU port of the reference path, oracle/torch_ref.py, fp32) on C1 =
+    BASELINE.json configs[0]: ONE 480x854 frame (seed 0), 100 queries, K = 40 classes, the COMPLETE forward (nothing
+    extrapolated): 1 warm-up + `iters` timed iterations, median s/frame, per-stage split of the median iteration."""
     from oracle import torch_ref as TR
     import torch.nn.functional as F
-    # threads: torch's own default for this host (respects affinity); oversubscribing a quota'd container with
-    # os.cpu_count() threads makes the CPU leg pathologically slow
     cores = _usable_cpus()
     torch.set_num_threads(cores)
-    frames = synth_frames(1, H720, W720, 0, "cpu")
-    tm = lambda: time.perf_counter()
-    with torch.no_grad():
-        t0 = tm()
-        images, (H, W) = TR.preprocess([f for f in frames])
-        feats = TR.resnet50(images, sd)
-        t_backbone = tm() - t0
-        TR.pixel_decoder(feats, sd, n_layers=1)             # warm-up (allocator, thread pools)
-        t0 = tm()
-        mf, _, ms = TR.pixel_decoder(feats, sd, n_layers=1)
-        t_pd1 = tm() - t0
-        t0 = tm()
-        TR.pixel_decoder(feats, sd, n_layers=3)
-        t_pd3 = tm() - t0
-        t_layer = max(t_pd3 - t_pd1, 0.0) / 2.0
-        t0 = tm()
-        _, pm = TR.video_decoder(ms, mf, sd)
-        mask_pred = F.interpolate(pm[0], size=images.shape[-2:], mode="bilinear", align_corners=False)
-        part = mask_pred.sigmoid().transpose(0, 1).contiguous()
-        valid = (part > 0.5).sum(dim=(-1, -2)) > 0
-        t_dec = tm() - t0
-        n_valid = int(valid.sum())
-        t0 = tm()
-        regions, v2, _ = TR.clip_crops(frames, part[:, :n_crops])
-        feat = TR.clip_encode_image(regions, sd)
-        _ = 100.0 * feat @ text.T
-        n_done = max(int(v2.sum()), 1)
-        t_clip = (tm() - t0) / n_done
-    sec_per_frame = t_backbone + t_pd1 + 5 * t_layer + t_dec + t_clip * n_valid
-    return {"value": round(1.0 / sec_per_frame, 5), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/torch_ref.py fp32, 1 frame 720x1280: backbone {t_backbone:.1f}s + pixel decoder "
-                      f"(1 layer {t_pd1:.1f}s + 5 x {t_layer:.1f}s) + decoder/upsample {t_dec:.1f}s + CLIP ViT-B/16 "
-                      f"{t_clip:.2f}s/crop (timed on {n_done}) x {n_valid} valid crops = {sec_per_frame:.1f} s/frame"}
+    frames = synth_frames(1, 480, 854, 0, "cpu")
+    text = synth_text(40, 512)
+    pc = time.perf_counter
+
+    def one():
+        t = {}
+        with torch.no_grad():
+            t0 = pc()
+            images, (H, W) = TR.preprocess([f for f in frames])
+            feats = TR.resnet50(images, sd)
+            t["backbone"] = pc() - t0; t0 = pc()
+            mask_features, _, ms = TR.pixel_decoder(feats, sd)
+            t["pixel_decoder"] = pc() - t0; t0 = pc()
+            _, pred_masks = TR.video_decoder(ms, mask_features, sd)
+            t["decoder"] = pc() - t0; t0 = pc()
+            mask_pred = F.interpolate(pred_masks[0], size=images.shape[-2:], mode="bilinear", align_corners=False)
+            t["mask_upsample"] = pc() - t0; t0 = pc()
+            probs, vmasks, extras = TR.open_vocabulary_inference(mask_pred, frames, text, sd)
+            t["clip_crops_logits"] = pc() - t0; t0 = pc()
+            TR.inference_video(pred_masks.shape[1], text.shape[0], probs, vmasks, (H, W), H, W)
+            t["topk_output_masks"] = pc() - t0
+        t["n_valid_crops"] = int(extras["valid"].sum()) if "valid" in extras else -1
+        return t
+
+    one()                                                             # warm-up (allocator, thread pools)
+    runs = [one() for _ in range(iters)]
+    tot = lambda r: sum(v for k, v in r.items() if k != "n_valid_crops")
+    runs.sort(key=tot)
+    med = runs[len(runs) // 2]
+    return {"value": round(1.0 / tot(med), 5), "unit": "frames/s", "cores": cores, "kind": "port",
+            "os_cpu_count": os.cpu_count(), "torch_num_threads": torch.get_num_threads(),
+            "s_per_frame_median": round(tot(med), 3), "s_per_frame_all": [round(tot(r), 3) for r in runs],
+            "stage_s": {k: round(v, 3) for k, v in med.items() if k != "n_valid_crops"},
+            "sample": f"oracle/torch_ref.py fp32, C1 = BASELINE.json configs[0]: one 480x854 frame, 100 queries, 40 classes, "
+                      f"complete eval forward ({med['n_valid_crops']} valid crops through CLIP ViT-B/16), 1 warm-up + {iters} "
+                      f"timed iterations, median; threads = min(torch default, affinity, cgroup quota, 32)"}
+
+
+def _respawn_ranks(args):
+    """`python bench.py --gpus N` without torchrun: start the N ranks as CHILD processes (torch.distributed.run) before
+    anything touches the GPU, and exit with their code.  (Never exec: the GPU boxes refuse an exec after GPU init.)"""
+    import subprocess
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100,
+                    help="timed steps (default 100 = 5 s of GPU work: long enough for the driver's 5 s GPU-busy sampling)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=1,
                     help="clips in flight per GPU (openvis_amd.runtime.ClipPipeline: one HIP stream + host thread each); "
@@ -175,6 +188,12 @@ def main():
     ap.add_argument("--precision", default="mixed", choices=["mixed", "fp32"],
                     help="dense-path policy: mixed = the reference's autocast policy, fp32 = exact f32 everywhere")
     args = ap.parse_args()
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != env_world:
+        if env_world == 1 and args.gpus > 1:
+            _respawn_ranks(args)                              # does not return
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
 
     from openvis_amd import distributed as D
     # OVIS_BENCH_TEST_RIG=1 (tests only): all ranks on cuda:0 with a gloo rendezvous, to exercise the N > 1 control flow on a
@@ -191,15 +210,17 @@ def main():
     res = args.resolution or (1080 if args.model.endswith("_swinl") else 720)
     FH, FW = res, res * 16 // 9                          # frame size of this run
     fwd_kw = {}
+    # clips live in PINNED HOST memory (what a DataLoader(pin_memory=True) hands to the model); every timed step uploads its
+    # uint8 frames (13.8 MB per 720p clip) inside model.forward -- SURVEY.md 8(d): the metric includes that copy
     if frame_sharded:
         # ONE clip, contiguous frame blocks per rank, all-gather of query embeddings before the linker
         fr = D.inference_shard(T, rank, world)
         fwd_kw = {"frame_range": (fr.start, fr.stop)}
-        clips = [synth_frames(T, FH, FW, 1000 + i, device) for i in range(2)]
+        clips = [synth_frames(T, FH, FW, 1000 + i, "cpu").pin_memory() for i in range(2)]
     else:
         # clip-level sharding (InferenceSampler layout): 2*world clips, each rank owns a contiguous shard
         my_clips = D.inference_shard(2 * world, rank, world)
-        clips = [synth_frames(T, FH, FW, 1000 + i, device) for i in my_clips]
+        clips = [synth_frames(T, FH, FW, 1000 + i, "cpu").pin_memory() for i in my_clips]
     inputs = [[{"image": [f for f in c], "dataset_name": "synthetic_burst_val"}] for c in clips]
     _model = model
     model = (lambda inp, **kw: _model(inp, **fwd_kw, **kw)) if fwd_kw else _model
@@ -273,19 +294,35 @@ def main():
         peak, peak_note = PEAK_F16_MFMA_TFLOPS, "fp16 dense MFMA peak"
     else:
         peak, peak_note = PEAK_F32_MFMA_TFLOPS, "f32 MFMA peak"
-    # HBM traffic of that kernel from the committed PMC passes of this same command (tools/pmc_traffic.py:
-    # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs); null if no summary is committed
-    traffic, pmc = None, {}
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_bench.json")))["kernels"]
-        for k, v in pmc.items():
-            if dom[0].split("<")[0] in k and (("ILb1E" in k) == ("<true>" in dom[0]) or "ILb" not in k):
-                traffic = v["hbm_bytes_per_launch"]
-                break
-    except Exception:
-        traffic = None
+    # HBM traffic of that kernel: PMC passes of this same command (tools/pmc_traffic.py: FETCH_SIZE x2 gfx950 correction +
+    # WRITE_SIZE, separate --pmc runs) committed under profiles/rNN/ -- a STATIC figure (bench.py cannot run rocprofv3 on
+    # itself), tagged with the file and the commit it was collected at; null if no summary has this kernel
+    def _norm(k):
+        return k.replace("(anonymous namespace)::", "").replace("void ", "").replace(" ", "")
+
+    pmc, pmc_src = {}, None
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_bench.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            pmc = {_norm(k): v for k, v in d["kernels"].items()}
+            pmc_src = {"file": os.path.relpath(f, ROOT), "commit": d.get("commit"), "static": True}
+            break
+        except Exception:
+            continue
+
+    def _pmc_lookup(name):
+        v = pmc.get(_norm(name))
+        if v is None and "<" not in name:                     # un-templated kernels: prefix match
+            v = next((x for k, x in pmc.items() if k.startswith(_norm(name))), None)
+        return v
+
+    tv = _pmc_lookup(dom[0])
+    traffic = tv["hbm_bytes_per_launch"] if tv else None
     roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "peak_note": peak_note, "traffic": traffic,
+                "traffic_source": pmc_src if traffic is not None else None,
+                "traffic_split": ({"fetch": tv["fetch_bytes_per_launch"], "write": tv["write_bytes_per_launch"]} if tv else None),
                 "measured": (f"HIP events per launch, in situ: {args.steps} clips with {args.streams} in flight (launches of "
                              "different clips share the GPU)" if pipelined else "HIP events per launch, one clip on one stream"),
                 "launches_per_step": n_launch // n_situ, "avg_launch_ms": round(secs / n_launch * 1e3, 4),
@@ -296,6 +333,11 @@ def main():
                 "all_gemm_kernels": {k: {"launches": v[0], "ms": round(v[2] * 1e3, 3), "TFLOPs": round(v[1] / v[2] / 1e12, 1)}
                                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])},
                 "all_gemm_kernels_note": "one isolated clip: launches, summed ms, rate"}
+    fam = [v for k, v in agg.items() if k.split("<")[0] == kbase]
+    if len(fam) > 1:                                          # every instantiation of the dominant kernel's template together
+        fl, sc, nl = sum(v[1] for v in fam), sum(v[2] for v in fam), sum(v[0] for v in fam)
+        roofline["family"] = {"kernel": kbase + "<*>", "launches_per_step": nl, "ms_per_step": round(sc * 1e3, 3),
+                              "achieved": round(fl / sc / 1e12, 2), "frac": round(fl / sc / 1e12 / peak, 4)}
 
     # stage breakdown (untimed extra pass, OpenVIS only): wall time of each stage with a device sync after it
     stage_ms = None
@@ -332,14 +374,8 @@ def main():
         kname, (kn, kbytes, ksecs) = max(hbm_situ.items(), key=lambda kv: kv[1][2])
         gbs = kbytes / ksecs / 1e9
         kiso = hbm.get(kname, (kn, kbytes, ksecs))
-        ktraffic = None
-        try:
-            for k, v in pmc.items():
-                if kname.split("<")[0] in k:
-                    ktraffic = v["hbm_bytes_per_launch"]
-                    break
-        except Exception:
-            ktraffic = None
+        kv = _pmc_lookup(kname)
+        ktraffic = kv["hbm_bytes_per_launch"] if kv else None
         roofline_k1 = {"kernel": kname, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": ktraffic, "launches_per_step": kn // n_situ,
                        "avg_launch_ms": round(ksecs / kn * 1e3, 4), "algorithmic_mb_per_launch": round(kbytes / kn / 1e6, 2),
@@ -350,7 +386,7 @@ def main():
         line = {
             "metric": ("frames/sec (whole node) OpenVIS R50 720p inference" if args.model == "openvis" and res == 720 else
                        f"frames/sec (whole node) {args.model} {bb_name} {res}p inference"), "value": round(frames_total / elapsed, 3),
-            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "frames/s", "n_gpus": world, "world_size_seen": D.world_size(), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if frame_sharded else "weak",
             "vs_baseline": None, "dtype": "f16" if (_model.clip_adapter.precision == "fp16" or args.precision == "mixed") else "f32", "data": "synthetic",
@@ -372,7 +408,7 @@ def main():
             "stage_ms_note": "one clip alone, device sync after every stage (clips in flight overlap these stages)",
         }
         if not args.no_cpu_baseline and world == 1 and args.model == "openvis":
-            line["cpu_baseline"] = cpu_baseline(sd, text)
+            line["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist

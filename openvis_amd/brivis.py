@@ -37,9 +37,11 @@ class BriVIS(SANOnline):
         self.resampler.load_state_dict(sd, "resampler.", self.device)
         return self
 
-    def forward(self, batched_inputs, stages=None, frame_range=None):
+    def forward(self, batched_inputs, stages=None, frame_range=None, gather_masks_to=None):
         """frame_range=(begin, end): this rank's contiguous frame block of the clip (frame-sharded mode; requires an
-        initialised process group). Default: all frames on this rank."""
+        initialised process group). Default: all frames on this rank.  gather_masks_to=r: the selected output masks of all
+        frames are gathered on rank r (the other ranks return `pred_masks: []`); None: every rank keeps the masks of its
+        own frames (`pred_masks_frames` names them) for a sharded evaluator."""
         dataset_name = list(set(x["dataset_name"] for x in batched_inputs))[0]
         class_names = self.get_class_name_list(dataset_name)
         self.sem_seg_head.num_classes = len(class_names)
@@ -47,9 +49,17 @@ class BriVIS(SANOnline):
         T_total = len(all_frames)
         b0, b1 = frame_range if frame_range is not None else (0, T_total)
         frames = self._frames_to_device([{"image": all_frames[b0:b1]}])
-        io, images, image_size, padded = self.image_outputs(frames, class_names)          # brivis.py:149-171
+        # the ONE exchange (C5) starts on a side stream as soon as the decoder has produced the local query embeddings; the
+        # CLIP back pass of the local frames (per_window's post_encode_image) runs under it
+        gather = []
+        on_embeds = ((lambda e: gather.append(D.all_gather_frames_async(e[0], T_total) if e[0].shape[0] == b1 - b0 else None))
+                     if frame_range is not None else None)
+        io, images, image_size, padded = self.image_outputs(frames, class_names, on_embeds=on_embeds)   # brivis.py:149-171
         emb_local = io["pred_embeds"][0]                                                   # [t_local,Q,C]
-        emb = D.all_gather_frames(emb_local, T_total) if frame_range is not None else emb_local   # C5: the one exchange
+        if frame_range is None:
+            emb = emb_local
+        else:                                          # (several windows: the hook saw partial blocks -> gather the whole block now)
+            emb = gather[0].wait() if len(gather) == 1 and gather[0] is not None else D.all_gather_frames(emb_local, T_total)
         idx, frame_embeds = batch_video_match_via_embeds(emb.unsqueeze(0))                 # brivis.py:173
         x = self.resampler.temporal(frame_embeds[0])                                       # [T,Q,C], replicated
         n = self.clip_adapter.num_heads
@@ -62,8 +72,17 @@ class BriVIS(SANOnline):
                                pred_embeds=emb_out))
         inp = batched_inputs[0]
         row_ids = np.arange(self.num_queries, dtype=np.int32)
-        return self.inference_video(self.num_queries, len(class_names), probs, row_ids, pred_masks, padded, image_size,
-                                    inp.get("height", image_size[0]), inp.get("width", image_size[1]))
+        self.mask_gather = None
+        if frame_range is not None and gather_masks_to is not None:
+            self.mask_gather = lambda m: D.gather_frame_masks(m, T_total, gather_masks_to)
+        try:
+            out = self.inference_video(self.num_queries, len(class_names), probs, row_ids, pred_masks, padded, image_size,
+                                       inp.get("height", image_size[0]), inp.get("width", image_size[1]))
+        finally:
+            self.mask_gather = None
+        if frame_range is not None and gather_masks_to is None:
+            out["pred_masks_frames"] = (b0, b1)
+        return out
 
     __call__ = forward
 

@@ -2,7 +2,12 @@
 
 OpenVIS' offline decoder attends over every frame of a clip, so the unit of parallelism is the CLIP: ranks own
 contiguous shards of the clip list exactly like detectron2's InferenceSampler (openvis/data/build.py:238-247) and
-there is no collective on the data path.  The only collective is the scalar MAX used for timing."""
+there is no collective on the data path.  The only collective is the scalar MAX used for timing.
+
+The online models (BriVIS) also shard ONE clip by frames: all_gather_frames_async (query embeddings, on a side stream),
+all_reduce_sum (per-query logit sums) and gather_frame_masks (the selected output masks to the output rank).  Ranks are
+started by torch.distributed.run / bench.py's child spawn BEFORE anything touches the GPU, and every rank calls
+torch.cuda.set_device(LOCAL_RANK) before its first HIP call (bench.py main)."""
 import os
 
 import torch
@@ -56,24 +61,102 @@ def sum_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
-def all_gather_frames(local, total_frames):
-    """All-gather of per-frame rows over contiguous frame shards: `local` is this rank's
-    [t_local, ...] block of a [total_frames, ...] tensor sharded with `inference_shard`; blocks are padded to the
-    largest shard so ONE all_gather moves everything (<= 512 KB per rank for [5,100,256] f32 — latency-bound)."""
+def world_size():
+    """World size the process group actually has (1 without one) -- bench.py prints it next to --gpus."""
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One extra HIP stream per device for collectives that overlap the compute stream."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
+
+
+class _FramesGather:
+    """Handle of an all-gather of per-frame rows that may still be in flight; wait() -> [total_frames, ...] on the
+    caller's current stream."""
+
+    def __init__(self, out, sizes, tmax, device, work=None, side=None):
+        self.out, self.sizes, self.tmax, self.device, self.work, self.side = out, sizes, tmax, device, work, side
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()                                    # the CURRENT stream waits for the collective
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.out.record_stream(torch.cuda.current_stream())
+            self.work = None
+        if self.sizes is None:
+            return self.out
+        o = self.out.view((len(self.sizes), self.tmax) + tuple(self.out.shape[1:]))
+        if all(n == self.tmax for n in self.sizes):
+            return o.reshape((-1,) + tuple(self.out.shape[1:])).to(self.device)
+        return torch.cat([o[r, :n] for r, n in enumerate(self.sizes)], dim=0).to(self.device)
+
+
+def all_gather_frames_async(local, total_frames):
+    """All-gather of per-frame rows over contiguous frame shards (the ONE exchange of the frame-sharded
+    path): `local` is this rank's [t_local, ...] block of a [total_frames, ...] tensor sharded with `inference_shard`.
+    Blocks are padded to the largest shard so ONE all_gather_into_tensor moves everything (512 KB per rank for [5,100,256]
+    f32: latency-bound, ~4 MB over xGMI).  On RCCL the pad + collective run on a SIDE stream, so whatever the caller
+    launches on its own stream before wait() (the CLIP back pass of the local frames) overlaps the exchange."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
-        return local
+        return _FramesGather(local, None, 0, local.device)
     world = dist.get_world_size()
     sizes = [len(inference_shard(total_frames, r, world)) for r in range(world)]
     tmax = max(sizes)
-    pad = local.new_zeros((tmax,) + tuple(local.shape[1:]))
-    pad[: local.shape[0]] = local
+    assert local.shape[0] == sizes[dist.get_rank()], (local.shape, sizes, dist.get_rank())
     dev = local.device
-    if dist.get_backend() == "gloo" and local.is_cuda:          # test rigs without RCCL: stage through the host
-        pad = pad.cpu()
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad.contiguous())
-    return torch.cat([o[:n] for o, n in zip(out, sizes)], dim=0).to(dev)
+    if dist.get_backend() == "gloo":                            # CPU tests / one-GPU test rigs: synchronous, staged through the host
+        pad = torch.zeros((tmax,) + tuple(local.shape[1:]), dtype=local.dtype)
+        pad[: local.shape[0]] = local.detach().cpu()
+        out = torch.empty((world * tmax,) + tuple(local.shape[1:]), dtype=local.dtype)
+        dist.all_gather_into_tensor(out, pad)
+        return _FramesGather(out, sizes, tmax, dev)
+    side, main = _side_stream(dev), torch.cuda.current_stream()
+    side.wait_stream(main)                                      # `local` is produced on the caller's stream
+    with torch.cuda.stream(side):
+        pad = local.new_zeros((tmax,) + tuple(local.shape[1:]))
+        pad[: local.shape[0]] = local
+        out = local.new_empty((world * tmax,) + tuple(local.shape[1:]))
+        work = dist.all_gather_into_tensor(out, pad, async_op=True)
+    local.record_stream(side)
+    return _FramesGather(out, sizes, tmax, dev, work, side)
+
+
+def all_gather_frames(local, total_frames):
+    """Synchronous form of all_gather_frames_async."""
+    return all_gather_frames_async(local, total_frames).wait()
+
+
+def gather_frame_masks(masks, total_frames, dst=0):
+    """Frame-sharded output hand-off: masks uint8 [n, t_local, H, W] of this rank's frames -> on rank `dst` the masks of ALL
+    frames [n, total_frames, H, W] (device tensor), None on the other ranks (10 x t_local x H x W bytes
+    per rank, 9.2 MB per 720p frame).  Without a process group: the input."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return masks
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [len(inference_shard(total_frames, r, world)) for r in range(world)]
+    tmax = max(sizes)
+    n = masks.shape[0]
+    dev = masks.device
+    staged = dist.get_backend() == "gloo"
+    src = masks.detach().cpu() if staged else masks
+    pad = src.new_zeros((tmax, n) + tuple(masks.shape[2:]))
+    pad[: masks.shape[1]] = src.transpose(0, 1)
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad.contiguous(), bufs, dst=dst)
+    if rank != dst:
+        return None
+    full = torch.cat([b[:k] for b, k in zip(bufs, sizes)], dim=0)       # [T, n, H, W]
+    return full.transpose(0, 1).contiguous().to(dev)
 
 
 def all_reduce_sum(t):

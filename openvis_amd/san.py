@@ -98,7 +98,7 @@ class SANOnline(MinVIS):
     def get_class_name_list(self, dataset_name):
         return [c.strip() for c in MetadataCatalog.get(dataset_name).thing_classes]
 
-    def image_outputs(self, frames, class_names):
+    def image_outputs(self, frames, class_names, on_embeds=None):
         """frames uint8 [T,3,H,W] -> per-frame head outputs incl. pred_logits [1,T,Q,K+1] (san.py:211-231); long videos
         go through windows of MODEL.MASK_FORMER.TEST.WINDOW_SIZE frames (san.py:285-307)."""
         T, _, H, W = frames.shape
@@ -111,6 +111,8 @@ class SANOnline(MinVIS):
             images, _, _ = self.preprocess(fr)
             mg_feats, clip_tokens = self.clip_adapter.front_encode_image(fr, padded)          # san.py:221
             outputs = self.sem_seg_head(self.backbone(images), extra_feats=mg_feats)
+            if on_embeds is not None:                   # frame-sharded BriVIS: the query all-gather starts here (side stream)
+                on_embeds(outputs["pred_embeds"])
             clip_feats = self.clip_adapter.post_encode_image(clip_tokens, outputs["class_attn_biases"][0])   # san.py:230
             outputs["pred_logits"] = self.clip_adapter.cal_sim_logits(text_feats, clip_feats).unsqueeze(0)   # [1,t,Q,K+1]
             outputs["clip_tokens"], outputs["images"] = clip_tokens, images

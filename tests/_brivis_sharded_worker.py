@@ -35,10 +35,14 @@ def main():
     inp = [{"image": [f for f in frames], "dataset_name": "synthetic_shard"}]
     fr = D.inference_shard(T, rank, world)
     st = {}
-    out = model(inp, stages=st, frame_range=(fr.start, fr.stop) if world > 1 else None)
+    gather_to = int(os.environ["OVIS_GATHER_TO"]) if "OVIS_GATHER_TO" in os.environ else None
+    out = model(inp, stages=st, frame_range=(fr.start, fr.stop) if world > 1 else None, gather_masks_to=gather_to)
     res = {"rank": rank, "world": world, "range": [fr.start, fr.stop], "labels": out["pred_labels"], "scores": out["pred_scores"],
            "queries": out["pred_queries"], "indices": st["indices"].cpu().tolist(), "probs": st["probs"].cpu().tolist(),
-           "mask_sums": [int(m.sum()) for m in out["pred_masks"]], "mask_shape": list(out["pred_masks"][0].shape)}
+           "mask_sums": [int(m.sum()) for m in out["pred_masks"]],
+           "mask_shape": list(out["pred_masks"][0].shape) if len(out["pred_masks"]) else [],
+           "frame_sums": [int(v) for v in torch.stack(list(out["pred_masks"])).sum(dim=(0, 2, 3))] if len(out["pred_masks"]) else [],
+           "mask_frames": list(out.get("pred_masks_frames", []))}
     json.dump(res, open(f"{out_path}.{rank}", "w"))
     D.barrier()
 

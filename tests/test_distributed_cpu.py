@@ -82,3 +82,48 @@ def test_shard_edge_cases():
     assert list(inference_shard(0, 0, 4)) == []
     assert [len(inference_shard(3, r, 8)) for r in range(8)] == [1, 1, 1, 0, 0, 0, 0, 0]
     assert [list(inference_shard(36, r, 8)) for r in (0, 7)] == [[0, 1, 2, 3, 4], [32, 33, 34, 35]]
+
+
+def _worker_c4(rank, world, port, T, out):
+    """One rank of the C4 layout (BASELINE.json configs[3]): the control flow of BriVIS.forward(frame_range=...) with the
+    per-frame GPU work replaced by a deterministic function of the frame index (openvis_amd/brivis.py:47-84)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from openvis_amd import distributed as D
+    D.init_from_env("gloo")
+    assert D.world_size() == world
+    Q, C, K1, H, W, n = 6, 8, 5, 4, 6, 3
+    g = torch.Generator().manual_seed(0)
+    embeds = torch.randn(T, Q, C, generator=g)                   # what every frame's decoder would produce
+    logits = torch.randn(T, Q, K1, generator=g)
+    masks = (torch.rand(n, T, H, W, generator=g) > 0.5).to(torch.uint8)
+    mine = D.inference_shard(T, rank, world)
+    b0, b1 = mine.start, mine.stop
+    h = D.all_gather_frames_async(embeds[b0:b1].clone(), T)      # starts "on the side stream"
+    local = logits[b0:b1].mean(0) * (float(b1 - b0) / float(T))  # classify_sharded: weighted local mean ...
+    emb = h.wait()
+    total = D.all_reduce_sum(local.clone())                      # ... all-reduced = mean over ALL frames
+    full = D.gather_frame_masks(masks[:, b0:b1].contiguous(), T, dst=0)
+    ok_masks = (full is None) if rank != 0 else bool(torch.equal(full, masks))
+    out.put((rank, b1 - b0, bool(torch.equal(emb, embeds)), float((total - logits.mean(0)).abs().max()), ok_masks))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_c4_layout_world_size_8_end_to_end():
+    """36 frames over 8 ranks = 5,5,5,5,4,4,4,4: padded all-gather of the query embeddings gives every
+    rank the full sequence in frame order, the weighted logit all-reduce equals the mean over all 36 frames, and the
+    selected masks of all frames arrive on rank 0 in frame order."""
+    world, T = 8, 36
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c4, args=(r, world, port, T, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert [r[1] for r in res] == [5, 5, 5, 5, 4, 4, 4, 4]
+    assert all(r[2] for r in res)
+    assert all(r[3] < 1e-6 for r in res)
+    assert all(r[4] for r in res)

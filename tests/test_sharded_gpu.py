@@ -13,10 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(world, out, port):
+def _run(world, out, port, extra_env=None):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_brivis_sharded_worker.py"), out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     for p in procs:
@@ -37,6 +38,12 @@ def test_two_rank_frame_sharded_brivis_equals_single_rank(tmp_path):
     assert two[0]["mask_shape"][0] == 4 and two[1]["mask_shape"][0] == 3 and single["mask_shape"][0] == 7
     # the union of the ranks' masks is the single-rank result (pixel counts per instance add up)
     assert [a + b for a, b in zip(two[0]["mask_sums"], two[1]["mask_sums"])] == single["mask_sums"]
+    assert two[0]["mask_frames"] == [0, 4] and two[1]["mask_frames"] == [4, 7]
+    # output hand-off to ONE rank: rank 0 receives the selected masks of all 7 frames in frame order
+    g = _run(2, str(tmp_path / "gather"), 29643, {"OVIS_GATHER_TO": "0"})
+    assert g[0]["mask_shape"] == single["mask_shape"] and g[0]["mask_sums"] == single["mask_sums"]
+    assert g[0]["frame_sums"] == single["frame_sums"]
+    assert g[1]["mask_shape"] == [] and g[1]["labels"] == single["labels"]
 
 
 @pytest.mark.parametrize("model,scaling", [("openvis", "weak"), ("brivis", "strong")])
