@@ -283,11 +283,21 @@ def main():
     n_situ = args.steps if pipelined else 1                  # clips behind the in-situ sums
     if not pipelined:
         agg_situ, hbm_situ = agg, hbm
-    dom = max(agg_situ.items(), key=lambda kv: kv[1][2])
-    n_launch, flops, secs = dom[1]
+    # "The dominant kernel" = the kernel TEMPLATE with the largest summed launch time (rocprofv3 lists every instantiation as
+    # its own row -- <out dtype, activation, residual> for the fp16 GEMM --, but it is one piece of code); the line carries
+    # the aggregate over its instantiations and every instantiation's own row for the cross-check against rocprofv3.
+    def _families(a):
+        fam = {}
+        for k, v in a.items():
+            f = fam.setdefault(k.split("<")[0], [0, 0.0, 0.0, {}])
+            f[0] += v[0]; f[1] += v[1]; f[2] += v[2]; f[3][k] = v
+        return fam
+
+    fam_situ, fam_iso = _families(agg_situ), _families(agg)
+    kbase, (n_launch, flops, secs, members) = max(fam_situ.items(), key=lambda kv: kv[1][2])
+    dom = (kbase + "<*>" if len(members) > 1 else next(iter(members)), None)
     achieved = flops / secs / 1e12
-    iso = agg.get(dom[0], dom[1])
-    kbase = dom[0].split("<")[0]
+    iso = fam_iso.get(kbase, (n_launch, flops, secs))
     if "f32x3" in kbase:      # f32 product = 6 bf16 MFMA products of the exact 3-way split: ceiling = bf16 peak / 6
         peak, peak_note = round(PEAK_F16_MFMA_TFLOPS / 6.0, 1), "bf16 dense MFMA peak / 6 (six bf16 products per f32 product)"
     elif "f16" in kbase:
@@ -317,7 +327,12 @@ def main():
             v = next((x for k, x in pmc.items() if k.startswith(_norm(name))), None)
         return v
 
-    tv = _pmc_lookup(dom[0])
+    # per launch like `achieved`: launch-weighted mean over the instantiations
+    tvs = [(_pmc_lookup(k), v[0]) for k, v in members.items()]
+    tv = None
+    if tvs and all(t is not None for t, _ in tvs):
+        nl = sum(n for _, n in tvs)
+        tv = {f: round(sum(t[f] * n for t, n in tvs) / nl) for f in ("hbm_bytes_per_launch", "fetch_bytes_per_launch", "write_bytes_per_launch")}
     traffic = tv["hbm_bytes_per_launch"] if tv else None
     roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "peak_note": peak_note, "traffic": traffic,
@@ -330,14 +345,14 @@ def main():
                 "isolated": {"achieved": round(iso[1] / iso[2] / 1e12, 2), "frac": round(iso[1] / iso[2] / 1e12 / peak, 4),
                              "avg_launch_ms": round(iso[2] / iso[0] * 1e3, 4),
                              "note": "the same kernel with one clip alone on the GPU"},
+                "instantiations": {k: {"launches_per_step": v[0] // n_situ, "avg_launch_ms": round(v[2] / v[0] * 1e3, 4),
+                                       "gflop_per_launch": round(v[1] / v[0] / 1e9, 2), "achieved": round(v[1] / v[2] / 1e12, 1),
+                                       "frac": round(v[1] / v[2] / 1e12 / peak, 4),
+                                       "traffic": (_pmc_lookup(k) or {}).get("hbm_bytes_per_launch")}
+                                   for k, v in sorted(members.items(), key=lambda kv: -kv[1][2])},
                 "all_gemm_kernels": {k: {"launches": v[0], "ms": round(v[2] * 1e3, 3), "TFLOPs": round(v[1] / v[2] / 1e12, 1)}
                                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])},
                 "all_gemm_kernels_note": "one isolated clip: launches, summed ms, rate"}
-    fam = [v for k, v in agg.items() if k.split("<")[0] == kbase]
-    if len(fam) > 1:                                          # every instantiation of the dominant kernel's template together
-        fl, sc, nl = sum(v[1] for v in fam), sum(v[2] for v in fam), sum(v[0] for v in fam)
-        roofline["family"] = {"kernel": kbase + "<*>", "launches_per_step": nl, "ms_per_step": round(sc * 1e3, 3),
-                              "achieved": round(fl / sc / 1e12, 2), "frac": round(fl / sc / 1e12 / peak, 4)}
 
     # stage breakdown (untimed extra pass, OpenVIS only): wall time of each stage with a device sync after it
     stage_ms = None
