@@ -383,6 +383,7 @@ def main():
                     "A16_topk_masks_d2h": round(t_out, 2)}
 
     bb_name = {"r50": "R50", "swin_l": "Swin-L"}[MODELS[args.model].get("backbone", "r50")]
+    bb_prec = _model.backbone.precision
     # K1 (deformable sampling): HBM roofline of the gather kernel, same live HIP-event measurement
     roofline_k1 = None
     if hbm_situ:
@@ -404,18 +405,16 @@ def main():
             "unit": "frames/s", "n_gpus": world, "world_size_seen": D.world_size(), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if frame_sharded else "weak",
-            "vs_baseline": None, "dtype": "f16" if (_model.clip_adapter.precision == "fp16" or args.precision == "mixed") else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16" if "fp16" in (bb_prec, _model.clip_adapter.precision) else "f32", "data": "synthetic",
             "config": {"workload": f"{args.model} {bb_name} {res}p ({FH}x{FW} -> {(FH + 31) // 32 * 32}x{(FW + 31) // 32 * 32}), "
                                    f"{MODELS[args.model].get('queries', 100)} queries, 482 classes, {T}-frame clips, "
                                    + ("ClipAdapter" if args.model.startswith("openvis") else "SideAdapter")
                                    + f" {MODELS[args.model].get('clip', 'ViT-B/16')}, random-init weights", "frames_per_step": T,
-                       "precision": ("backbone GEMM operands fp16 / f32 accumulate (the reference's autocast), pixel decoder, "
-                                     "masked-attention decoder, masks and logits f32 (exact 3-way bf16 split on the bf16 MFMA); "
-                                     if args.precision == "mixed" else
-                                     "backbone/pixel decoder/decoder/masks/logits: exact-f32 MFMA; ")
-                                    + "CLIP ViT GEMM operands: "
-                                    + ("fp16 with f32 accumulation (the reference's GPU CLIP dtype)"
-                                       if _model.clip_adapter.precision == "fp16" else "f32"),
+                       "precision": (f"backbone GEMM operands {bb_prec}" + (" / f32 accumulate (the reference's autocast)" if bb_prec == "fp16" else
+                                     " (exact 3-way bf16 split on the bf16 MFMA)") + "; pixel decoder, masked-attention decoder, masks and "
+                                     "logits f32; CLIP ViT GEMM operands " +
+                                     ("fp16 with f32 accumulation (the reference's GPU CLIP dtype)" if _model.clip_adapter.precision == "fp16"
+                                      else "f32") + (f"; resampler {_model.resampler.precision}" if hasattr(_model, "resampler") else "")),
                        "valid_crops_per_clip": n_valid,
                        "parallelism": (f"frame-sharded x{world} + RCCL all-gather" if frame_sharded else f"clip-replicas x{world}")
                                       + (f", {args.streams} clips in flight per GPU (HIP streams)" if args.streams > 1 and not frame_sharded else "")},

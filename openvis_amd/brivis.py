@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .config import resampler_precision
 from . import distributed as D
 from .modeling.minvis import batch_video_match_via_embeds
 from .modeling.resampler import TemporalInstanceResampler
@@ -29,7 +30,7 @@ class BriVIS(SANOnline):
         args = SANOnline.from_config(cfg)
         args["resampler"] = TemporalInstanceResampler(
             hidden_dim=256, feed_dim=2048, nheads=8, nlayers=6,                        # hard-coded, brivis.py:47
-            precision="fp32" if cfg.MODEL.get("PRECISION", "mixed") == "fp32" else "fp16")
+            precision=resampler_precision(cfg))
         return args
 
     def load_state_dict(self, sd):

@@ -66,6 +66,13 @@ def get_cfg():
             #             pixel decoder forced f32, msdeformattn.py:329),  "fp32" = exact f32 everywhere.
             #   The transformer decoder follows MASK_FORMER.DECODER_PRECISION below.
             "PRECISION": "mixed",
+            # not reference keys -- per-stage operand dtype under "mixed" ("auto" = chosen per meta-architecture so that every
+            # query mask keeps IoU >= 0.999 against the f32 oracle at 720p; tools/exp_policy_mix.py, exp_policy_mix_san.py):
+            #   OpenVIS / OpenVISOnline: backbone fp16 operands (masks depend on backbone + pixel decoder + decoder only);
+            #   SAN / SANOnline / BriVIS: the side adapter injects CLIP features into the pixel decoder, and fp16 operands in
+            #   EITHER the backbone or the side adapter's ViT put every query below 0.999 (SANOnline 0.9866-0.9974, BriVIS
+            #   0.9975-0.9987; tracks and logits are unaffected) -> backbone, side adapter and resampler run f32 operands.
+            "BACKBONE_PRECISION": "auto", "RESAMPLER_PRECISION": "auto",
             "PIXEL_MEAN": [123.675, 116.280, 103.530], "PIXEL_STD": [58.395, 57.120, 57.375],
             "BACKBONE": {"NAME": "build_resnet_backbone", "FREEZE_AT": 0},
             "RESNETS": {"DEPTH": 50, "STRIDE_IN_1X1": False, "OUT_FEATURES": ["res2", "res3", "res4", "res5"],
@@ -101,7 +108,9 @@ def get_cfg():
                              "MASK_PROMPT_FWD": True,
                              # not a reference key: GEMM operand dtype of the CLIP tower on MI355X ("fp16" as the
                              # reference's GPU CLIP, or "fp32")
-                             "PRECISION": "fp16"},
+                             "PRECISION": "fp16",
+                             # SideAdapter (SAN / SANOnline / BriVIS) tower: "auto" = fp32 (see BACKBONE_PRECISION)
+                             "SIDE_PRECISION": "auto"},
         },
         "INPUT": {"SAMPLING_FRAME_NUM": 2, "MIN_SIZE_TEST": 360, "MAX_SIZE_TEST": 1333, "FORMAT": "RGB"},
         "DATASETS": {"TEST": ["burst_val"]},
@@ -117,6 +126,32 @@ def build_model(cfg):
     model = cls(**cls.from_config(cfg))
     model.output_rle = bool(cfg.MODEL.MASK_FORMER.TEST.get("OUTPUT_RLE", False))
     return model
+
+
+SIDE_ADAPTER_ARCHS = ("SAN", "SANOnline", "BriVIS")
+
+
+def _stage_precision(cfg, value, side_default):
+    if cfg.MODEL.get("PRECISION", "mixed") == "fp32":
+        return "fp32"
+    if value in ("fp16", "fp32"):
+        return value
+    return side_default if cfg.MODEL.META_ARCHITECTURE in SIDE_ADAPTER_ARCHS else "fp16"
+
+
+def backbone_precision(cfg):
+    """GEMM operand dtype of the backbone (MODEL.BACKBONE_PRECISION; see get_cfg)."""
+    return _stage_precision(cfg, cfg.MODEL.get("BACKBONE_PRECISION", "auto"), "fp32")
+
+
+def side_adapter_precision(cfg):
+    """GEMM operand dtype of the SideAdapter's CLIP tower (MODEL.CLIP_ADAPTER.SIDE_PRECISION)."""
+    return _stage_precision(cfg, cfg.MODEL.CLIP_ADAPTER.get("SIDE_PRECISION", "auto"), "fp32")
+
+
+def resampler_precision(cfg):
+    """GEMM operand dtype of BriVIS' TemporalInstanceResampler (MODEL.RESAMPLER_PRECISION)."""
+    return _stage_precision(cfg, cfg.MODEL.get("RESAMPLER_PRECISION", "auto"), "fp32")
 
 
 def decoder_precision(cfg):

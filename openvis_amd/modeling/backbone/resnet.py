@@ -6,6 +6,8 @@ weights/bias at load time and ReLU / residual-add fused in the epilogue.  State-
 (`stem.conv1.{weight,norm.*}`, `res{2..5}.{i}.conv{1,2,3}.*`, `shortcut.*`)."""
 import torch
 
+from ...config import backbone_precision as _backbone_precision
+
 from ... import ops
 from ...registry import BACKBONE_REGISTRY
 
@@ -87,4 +89,4 @@ class ResNet:
 @BACKBONE_REGISTRY.register()
 def build_resnet_backbone(cfg, input_shape=None):
     return ResNet(cfg.MODEL.RESNETS.DEPTH, cfg.MODEL.RESNETS.OUT_FEATURES,
-                  precision="fp32" if cfg.MODEL.get("PRECISION", "mixed") == "fp32" else "fp16")
+                  precision=_backbone_precision(cfg))

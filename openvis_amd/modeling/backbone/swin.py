@@ -13,6 +13,7 @@ State-dict keys are the reference's (`patch_embed.proj`, `layers.{i}.blocks.{j}.
 attn.relative_position_bias_table,norm2,mlp.fc1,mlp.fc2}`, `layers.{i}.downsample.{norm,reduction}`, `norm{i}`)."""
 import torch
 
+from ...config import backbone_precision as _backbone_precision
 from ... import ops
 from ...registry import BACKBONE_REGISTRY
 
@@ -150,4 +151,4 @@ def D2SwinTransformer(cfg, input_shape=None):
     s = cfg.MODEL.SWIN
     return SwinTransformer(s.PATCH_SIZE, s.EMBED_DIM, s.DEPTHS, s.NUM_HEADS, s.WINDOW_SIZE, s.MLP_RATIO, s.QKV_BIAS, s.QK_SCALE,
                            s.APE, s.PATCH_NORM, s.OUT_FEATURES,
-                           precision="fp32" if cfg.MODEL.get("PRECISION", "mixed") == "fp32" else "fp16")
+                           precision=_backbone_precision(cfg))

@@ -5,6 +5,7 @@ the CLIP back blocks classify every query with [SOS] tokens, the MinVIS tracker 
 import numpy as np
 import torch
 
+from .config import side_adapter_precision
 from . import ops
 from .catalog import MetadataCatalog
 from .modeling.clip_adapter.side_adapter import SideAdapter
@@ -16,7 +17,7 @@ from .registry import META_ARCH_REGISTRY
 def _build_side_adapter(cfg):
     return SideAdapter(cfg.MODEL.CLIP_ADAPTER.CLIP_MODEL_NAME, broken_idx=cfg.MODEL.CLIP_ADAPTER.BROKEN_ID,
                        merge_ids=cfg.MODEL.CLIP_ADAPTER.MERGE_IDS, num_queries=cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES,
-                       precision=cfg.MODEL.CLIP_ADAPTER.get("PRECISION", "fp16"))
+                       precision=side_adapter_precision(cfg))
 
 
 def _classify(pred_logits):

@@ -1,0 +1,135 @@
+"""TEST INFRASTRUCTURE ONLY -- golden vectors at WORKLOAD size for BASELINE.json configs[2], [3], [4]:
+the f32 CPU oracle (oracle/torch_ref.py, pinned against the reference's own modules by tests/test_oracle_*.py) is run
+ONCE in the build container on seeded synthetic inputs, and what the GPU tests compare against is committed as data:
+
+  tests/golden/c3_san_online_720p.npz    SANOnline R50 + SideAdapter ViT-B/16, 2 frames of 720x1280
+  tests/golden/c4_brivis_720p_36f.npz    BriVIS R50, ONE 36-frame 720p clip (linker over all 36 frames, resampler, heads)
+  tests/golden/c5_brivis_swinl_1080p.npz BriVIS Swin-L (embed 192, depths 2/2/18/2, window 12) + SideAdapter ViT-L/14@336,
+                                         1 frame of 1080x1920
+
+Inputs are NOT stored: frames = bench.synth_frames(T, H, W, seed), weights = weights.random_init(spec, seed 42), text =
+bench.synth_text(40, E) -- all seeded torch CPU generators, identical on the GPU box (same image).  Stored per case: tracker
+indices [T,Q], class probabilities [Q,K], per-frame logits of a few queries, the top-10 (row, label, score), positive-pixel
+counts of every (frame, query) mask, and the sign bits of the mask logits (np.packbits) for all queries on a frame subset.
+
+  python oracle/make_golden_workload.py c3 c4 c5        (c4: ~10 min and ~12 GB on 8 cores; frames go through the oracle in
+                                                         chunks of 4 -- every per-frame stage is frame-independent)
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import bench
+from openvis_amd import weights
+from openvis_amd.modeling.clip_adapter.adapter import _CLIP_ARCH
+from oracle import torch_ref as TR
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+K, Q = 40, 100
+
+
+def image_outputs_chunked(frames, W, text, chunk, **kw):
+    """san_online_image_outputs over frame chunks (identical results: nothing before the linker mixes frames)."""
+    outs = []
+    for b in range(0, frames.shape[0], chunk):
+        t0 = time.time()
+        with torch.no_grad():
+            o = TR.san_online_image_outputs(frames[b:b + chunk], W, text, **kw)
+        outs.append(o)
+        print(f"  frames {b}..{min(b + chunk, frames.shape[0]) - 1}: {time.time() - t0:.1f} s", flush=True)
+    io = dict(outs[0])
+    for k in ("pred_masks",):
+        io[k] = torch.cat([o[k] for o in outs], dim=2)                      # [1,Q,T,h,w]
+    for k in ("pred_embeds", "pred_logits"):
+        io[k] = torch.cat([o[k] for o in outs], dim=1)                      # [1,T,Q,*]
+    for k in ("mask_feats", "attn_feats", "images"):
+        io[k] = torch.cat([o[k] for o in outs], dim=0)
+    io.pop("class_attn_biases", None)
+    cb = [o["clip_bk"] for o in outs]
+    io["clip_bk"] = tuple(torch.cat([c[i] for c in cb], dim=(1 if i == 0 else 0)) for i in range(len(cb[0])))
+    return io
+
+
+def pack(mask_logits):
+    """sign bits of [..., h, w] logits -> uint8, 8 pixels per byte."""
+    return np.packbits((mask_logits > 0).numpy().astype(np.uint8), axis=-1)
+
+
+def save(name, **arrays):
+    path = os.path.join(GOLDEN, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB", flush=True)
+
+
+def topk_arrays(res):
+    return dict(top_rows=np.asarray(res["rows"], np.int32), top_labels=np.asarray(res["pred_labels"], np.int32),
+                top_scores=np.asarray(res["pred_scores"], np.float32), top_entropys=np.asarray(res["pred_entropys"], np.float32))
+
+
+def c3():
+    T = 2
+    sd = weights.random_init(weights.san_spec("r50", None, Q), seed=42)
+    frames = bench.synth_frames(T, 720, 1280, 3, "cpu")
+    text = bench.synth_text(K, 512)
+    st = {}
+    with torch.no_grad():
+        res = TR.san_online_forward(frames, sd, text, stages=st)
+    pm = st["pred_masks"][0]                                               # [Q,T,h,w]
+    save("c3_san_online_720p.npz", indices=st["indices"].numpy().astype(np.int16), probs=st["probs"].numpy(),
+         logits=st["pred_logits"][0].numpy().astype(np.float32), mask_bits=pack(pm), mask_shape=np.array(pm.shape),
+         mask_counts=(pm > 0).sum(dim=(-1, -2)).numpy().astype(np.int32), **topk_arrays(res))
+
+
+def brivis_case(name, frames, sd, text, chunk, keep_frames, **kw):
+    nq = kw.get("num_queries", Q)
+    io = image_outputs_chunked(frames, sd, text, chunk, **kw)
+    images, (H, Wd) = io["images"], io["image_size"]
+    with torch.no_grad():
+        idx, frame_embeds = TR.video_match_via_embeds(io["pred_embeds"][0])
+        x = TR.resampler_forward(frame_embeds.unsqueeze(0), sd)
+        masks, biases, emb = TR.resampler_heads(x, io["mask_feats"], io["attn_feats"], sd)
+        sos = TR.san_post_encode_image(io["clip_bk"], biases, sd, broken_idx=kw.get("broken_idx", 9), num_sos=nq)
+        logits = TR.san_cal_sim_logits(io["text_feats"], sos, sd)                        # [T,Q,K+1]
+        probs = F.softmax(logits.mean(dim=0), dim=-1)[:, :-1]
+        pred_masks = masks.permute(1, 0, 2, 3)                                           # [Q,T,h,w]
+        # top-10 on the low-res masks is what the GPU test compares; the full-size output masks of the SUBSET frames only
+        mask_pred = F.interpolate(pred_masks[:, keep_frames], size=images.shape[-2:], mode="bilinear", align_corners=False)
+        res = TR.inference_video(nq, text.shape[0], probs, mask_pred, (H, Wd), H, Wd)
+    save(name, indices=idx.numpy().astype(np.int16), probs=probs.numpy(), logits_subset=logits[keep_frames].numpy().astype(np.float32),
+         keep_frames=np.asarray(keep_frames, np.int32), mask_bits=pack(pred_masks[:, keep_frames]),
+         mask_shape=np.array(pred_masks[:, keep_frames].shape), mask_counts=(pred_masks > 0).sum(dim=(-1, -2)).numpy().astype(np.int32),
+         pred_embeds_checksum=emb.double().abs().sum(dim=(1, 2)).numpy(), **topk_arrays(res))
+
+
+def c4():
+    T = 36
+    sd = weights.random_init(weights.brivis_spec("r50", None, Q), seed=42)
+    frames = bench.synth_frames(T, 720, 1280, 1000, "cpu")               # bench.py --model brivis, clip 0
+    text = bench.synth_text(K, 512)
+    brivis_case("c4_brivis_720p_36f.npz", frames, sd, text, 4, [0, 17, 35])
+
+
+def c5():
+    arch = _CLIP_ARCH["ViT-L/14@336px"]
+    a = weights.SWIN_ARCH["swin_l"]
+    sd = weights.random_init(weights.brivis_spec("swin_l", arch, Q), seed=42)
+    frames = bench.synth_frames(1, 1080, 1920, 1000, "cpu")
+    text = bench.synth_text(K, arch["embed_dim"])
+    bb = lambda images, W: TR.swin(images, W, a["embed_dim"], a["depths"], a["num_heads"], a["window"])
+    brivis_case("c5_brivis_swinl_1080p.npz", frames, sd, text, 1, [0], broken_idx=21, merge_ids=(6, 12, 18), resolution=336,
+                clip_heads=arch["width"] // 64, num_queries=Q, backbone_fn=bb)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    for case in sys.argv[1:] or ["c3", "c4", "c5"]:
+        t0 = time.time()
+        print(f"== {case}", flush=True)
+        {"c3": c3, "c4": c4, "c5": c5}[case]()
+        print(f"== {case} done in {time.time() - t0:.0f} s", flush=True)

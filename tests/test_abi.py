@@ -33,3 +33,22 @@ def test_invalid_arguments_are_rejected_before_launch():
 def test_no_torch_types_in_abi_signatures():
     src = open(os.path.join(ROOT, "include", "openvis_hip.h")).read()
     assert not re.search(r"at::|torch::|Tensor", src)
+
+
+def test_b1_is_a_compiled_torch_extension_with_dispatcher_ops():
+    """B1: the module the reference imports (ops/functions/ms_deform_attn_func.py:22, built from
+    src/vision.cpp:18-21) is a compiled extension with at::Tensor arguments, and the op is registered with the dispatcher."""
+    import pytest
+    import torch
+    import MultiScaleDeformableAttention as MSDA
+    assert MSDA.__file__.endswith(".so")
+    assert callable(MSDA.ms_deform_attn_forward) and callable(MSDA.ms_deform_attn_backward)
+    v, ss, lsi = torch.zeros(1, 6, 8, 32), torch.tensor([[2, 3]]), torch.tensor([0])
+    loc, w = torch.zeros(1, 4, 8, 1, 4, 2), torch.zeros(1, 4, 8, 1, 4)
+    for fn in (MSDA.ms_deform_attn_forward, torch.ops.ovis_mi.ms_deform_attn_forward):
+        with pytest.raises(RuntimeError, match="Not implemented on the CPU"):          # ms_deform_attn.h:43
+            fn(v, ss, lsi, loc, w, 64)
+    with pytest.raises(NotImplementedError):
+        MSDA.ms_deform_attn_backward(v, ss, lsi, loc, w, v, 64)
+    m = lambda t: t.to("meta")                                                          # fake-tensor / torch.compile shape inference
+    assert torch.ops.ovis_mi.ms_deform_attn_forward(m(v), m(ss), m(lsi), m(loc), m(w), 64).shape == (1, 4, 256)

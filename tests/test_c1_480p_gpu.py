@@ -44,7 +44,10 @@ def test_c1_single_480p_frame_matches_oracle():
     ir = {tuple(x): i for i, x in enumerate(np.argwhere(vr))}
     common = [k for k in ig if k in ir]
     d = np.array([np.abs(lg[ig[k]] - lr[ir[k]]).max() for k in common])
-    assert len(common) > 0 and np.median(d) < 2e-2 and (d < 1e-1).mean() > 0.97, (np.median(d), d.max())   # 1e-3 on the cosine
+    assert len(common) > 0 and np.median(d) < 2e-2
+    from tests._logits import logit_errors_by_box
+    d_same, d_diff = logit_errors_by_box(st, ref_st)           # the bound (1e-3 on the cosine) on every crop with an identical box
+    assert len(d_same) >= 0.97 * (len(d_same) + len(d_diff)) and d_same.max() <= 1e-1, (len(d_same), len(d_diff), d_same.max())
     # final output: 10 masks at 480x854, IoU per matched (query, label)
     assert len(out["pred_masks"]) == 10 and tuple(out["pred_masks"][0].shape) == (1, 480, 854)
     sg = {(q, l): i for i, (q, l) in enumerate(zip(out["pred_queries"], out["pred_labels"]))}

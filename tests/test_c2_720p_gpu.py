@@ -47,7 +47,11 @@ def test_c2_720p_clip_under_the_bench_policy_matches_oracle():
     common = [k for k in ig if k in ir]
     d = np.array([np.abs(lg[ig[k]] - lr[ir[k]]).max() for k in common])
     # fp16 GEMM operands in the CLIP tower (the reference's GPU dtype) against the f32 oracle, x100 logits
-    assert len(common) > 0.95 * len(ir) and np.median(d) < 5e-2 and (d < 2e-1).mean() > 0.9, (np.median(d), (d < 2e-1).mean())
+    assert len(common) > 0.95 * len(ir) and np.median(d) < 5e-2
+    from tests._logits import logit_errors_by_box
+    d_same, d_diff = logit_errors_by_box(st, ref_st)           # the bound (1e-3 on the cosine) on every crop with an identical box
+    print("C2 logits: %d crops with identical boxes, max err %.4f (x100 scale); %d crops with a moved box" % (len(d_same), d_same.max(), len(d_diff)))
+    assert len(d_same) >= 0.95 * (len(d_same) + len(d_diff)) and d_same.max() <= 1e-1, (len(d_same), len(d_diff), d_same.max())
     assert len(out["pred_masks"]) == 10 and tuple(out["pred_masks"][0].shape) == (T, 720, 1280)
     rows_ref = ref_st["valid"].any(0).nonzero()[:, 0].tolist()
     sg = {(q, l): i for i, (q, l) in enumerate(zip(out["pred_queries"], out["pred_labels"]))}

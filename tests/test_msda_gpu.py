@@ -104,3 +104,23 @@ def test_error_behaviour_matches_reference():
         MSDA.ms_deform_attn_forward(c(v).half(), c(sh), c(lsi), c(loc).half(), c(w).half(), 128)
     with pytest.raises(NotImplementedError):
         MSDA.ms_deform_attn_backward(c(v), c(sh), c(lsi), c(loc), c(w), c(v), 128)
+
+
+def test_reference_call_sequence_and_dispatcher_op_give_the_same_bits():
+    """The reference-shaped call chain MSDeformAttnFunction.apply -> MSDA.ms_deform_attn_forward (func.py:34-39) and the
+    dispatcher op torch.ops.ovis_mi.ms_deform_attn_forward run the same kernel on the caller's current stream."""
+    import MultiScaleDeformableAttention as MSDA
+    from openvis_amd.modeling.pixel_decoder.ops.functions.ms_deform_attn_func import MSDeformAttnFunction
+    assert MSDA.__file__.endswith(".so")
+    v, sh, lsi, loc, w = [torch.from_numpy(a).cuda() for a in _encoder_inputs(5, [(6, 9), (3, 5)], M=8, D=32)]
+    a = MSDeformAttnFunction.apply(v, sh, lsi, loc, w, 128)
+    b = torch.ops.ovis_mi.ms_deform_attn_forward(v, sh, lsi, loc, w, 128)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        c = MSDA.ms_deform_attn_forward(v, sh, lsi, loc, w, 128)
+    side.synchronize()
+    torch.cuda.synchronize()
+    ref = oracle_msda.msda_forward(*[t.cpu().numpy() for t in (v, sh, lsi, loc, w)])
+    for o in (a, b, c):
+        assert np.array_equal(o.cpu().numpy(), ref)

@@ -11,6 +11,7 @@ def _sources():
             if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
                 yield os.path.join(d, f)
     yield os.path.join(ROOT, "MultiScaleDeformableAttention.py")
+    yield os.path.join(ROOT, "openvis_amd", "csrc", "torch_ext", "msda_module.cpp")
     yield os.path.join(ROOT, "train_net.py")
 
 

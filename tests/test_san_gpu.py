@@ -95,8 +95,12 @@ def test_resampler_matches_reference():
 SAN_E2E_ARCH = dict(width=256, layers=4, heads=4, patch=16, resolution=64, embed_dim=64)
 
 
-@pytest.mark.parametrize("arch_name,policy", [("SANOnline", "fp32"), ("SANOnline", "mixed"), ("BriVIS", "fp32"), ("BriVIS", "mixed")])
+@pytest.mark.parametrize("arch_name,policy", [("SANOnline", "fp32"), ("SANOnline", "default"), ("SANOnline", "fp16"),
+                                              ("BriVIS", "fp32"), ("BriVIS", "default"), ("BriVIS", "fp16")])
 def test_san_brivis_end_to_end(arch_name, policy):
+    """policy "default" = the config defaults bench.py times (MODEL.PRECISION mixed, whose per-stage "auto" choice for the
+    side-adapter architectures is f32 operands: tools/exp_policy_mix_san.py) and must meet the fp32 bounds; "fp16" forces
+    fp16 operands in backbone / side adapter / resampler (the reference's autocast) to keep those code paths covered."""
     from openvis_amd import config, weights
     from openvis_amd.catalog import MetadataCatalog
     from openvis_amd.modeling.clip_adapter.side_adapter import SideAdapter
@@ -110,10 +114,14 @@ def test_san_brivis_end_to_end(arch_name, policy):
     cfg.MODEL.META_ARCHITECTURE = arch_name
     cfg.MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME = "SideAdapterFrameMultiScaleMaskedTransformerDecoder"
     cfg.MODEL.CLIP_ADAPTER.CLIP_NUM_HEADS = 4
-    cfg.MODEL.PRECISION = policy
+    cfg.MODEL.PRECISION = "fp32" if policy == "fp32" else "mixed"
+    if policy == "fp16":
+        cfg.MODEL.BACKBONE_PRECISION = cfg.MODEL.RESAMPLER_PRECISION = cfg.MODEL.CLIP_ADAPTER.SIDE_PRECISION = "fp16"
     model = config.build_model(cfg)
-    model.clip_adapter = SideAdapter("tiny", broken_idx=3, merge_ids=[1, 2, 3], num_queries=Q, arch=SAN_E2E_ARCH,
-                                     precision="fp32" if policy == "fp32" else "fp16")
+    side_prec = config.side_adapter_precision(cfg)
+    assert (model.backbone.precision, side_prec) == (("fp16", "fp16") if policy == "fp16" else ("fp32", "fp32"))
+    model.clip_adapter = SideAdapter("tiny", broken_idx=3, merge_ids=[1, 2, 3], num_queries=Q, arch=SAN_E2E_ARCH, precision=side_prec)
+    policy = "mixed" if policy == "fp16" else "fp32"          # bounds below: the default policy must meet the fp32 ones
     model.load_state_dict(sd)
     names = [f"class_{i}" for i in range(K)]
     MetadataCatalog.get("synthetic_val").set(thing_classes=names)
@@ -187,10 +195,14 @@ def test_san_offline_end_to_end(policy):
     cfg.MODEL.META_ARCHITECTURE = "SAN"
     cfg.MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME = "SideAdapterVideoMultiScaleMaskedTransformerDecoder"
     cfg.MODEL.CLIP_ADAPTER.CLIP_NUM_HEADS = 4
-    cfg.MODEL.PRECISION = policy
+    cfg.MODEL.PRECISION = "fp32" if policy == "fp32" else "mixed"
+    if policy == "fp16":
+        cfg.MODEL.BACKBONE_PRECISION = cfg.MODEL.RESAMPLER_PRECISION = cfg.MODEL.CLIP_ADAPTER.SIDE_PRECISION = "fp16"
     model = config.build_model(cfg)
-    model.clip_adapter = SideAdapter("tiny", broken_idx=3, merge_ids=[1, 2, 3], num_queries=Q, arch=SAN_E2E_ARCH,
-                                     precision="fp32" if policy == "fp32" else "fp16")
+    side_prec = config.side_adapter_precision(cfg)
+    assert (model.backbone.precision, side_prec) == (("fp16", "fp16") if policy == "fp16" else ("fp32", "fp32"))
+    model.clip_adapter = SideAdapter("tiny", broken_idx=3, merge_ids=[1, 2, 3], num_queries=Q, arch=SAN_E2E_ARCH, precision=side_prec)
+    policy = "mixed" if policy == "fp16" else "fp32"          # bounds below: the default policy must meet the fp32 ones
     model.load_state_dict(sd)
     names = [f"class_{i}" for i in range(K)]
     MetadataCatalog.get("synthetic_val").set(thing_classes=names)
