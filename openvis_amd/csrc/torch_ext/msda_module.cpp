@@ -8,8 +8,9 @@
 // the calling thread like the reference (cuda.cu:70).  backward: the eval-only tier does not build the col2im kernels.
 #include <torch/extension.h>
 #include <torch/library.h>
-#include <c10/hip/HIPStream.h>
-#include <c10/hip/HIPGuard.h>
+// ROCm builds of torch present the HIP device under the "cuda" device type: guards and streams are the *MasqueradingAsCUDA forms
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include "../../../include/openvis_hip.h"
 
 namespace {
@@ -45,9 +46,9 @@ at::Tensor ms_deform_attn_forward(const at::Tensor& value, const at::Tensor& spa
   check_forward_args(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step);
   const int batch = (int)value.size(0), spatial_size = (int)value.size(1), num_heads = (int)value.size(2), channels = (int)value.size(3);
   const int num_levels = (int)spatial_shapes.size(0), num_query = (int)sampling_loc.size(1), num_point = (int)sampling_loc.size(4);
-  c10::hip::HIPGuard guard(value.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(value.device());
   at::Tensor out = at::empty({batch, num_query, (int64_t)num_heads * channels}, value.options());      // fully overwritten (cuda.cu:59 zero-inits)
-  hipStream_t stream = c10::hip::getCurrentHIPStream().stream();
+  hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
   int rc;
   if (value.scalar_type() == at::kFloat)
     rc = ovis_msda_forward_f32(value.data_ptr<float>(), spatial_shapes.data_ptr<int64_t>(), level_start_index.data_ptr<int64_t>(),
