@@ -24,8 +24,7 @@ class SwinTransformer:
     def __init__(self, patch_size=4, embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window_size=7, mlp_ratio=4.0,
                  qkv_bias=True, qk_scale=None, ape=False, patch_norm=True, out_features=("res2", "res3", "res4", "res5"),
                  precision="fp16"):
-        if ape:
-            raise NotImplementedError("absolute position embedding (MODEL.SWIN.APE) is not used by any shipped config")
+        self.ape = bool(ape)                         # MODEL.SWIN.APE (swin.py:567-578): no shipped config sets it
         if patch_size != 4:
             raise NotImplementedError("MODEL.SWIN.PATCH_SIZE != 4")
         self.patch_size, self.embed_dim, self.depths, self.num_heads = patch_size, embed_dim, tuple(depths), tuple(num_heads)
@@ -70,6 +69,9 @@ class SwinTransformer:
                 names += [f"norm{i}.weight", f"norm{i}.bias"]
         for n in names:
             w[n] = g(n)
+        # absolute position embedding [1,E,h0,w0] (pretrain grid): kept on the host; the table for an input size is a
+        # weight-derived constant like the relative position bias tables (built once per size in _ape_table)
+        self._ape = sd[prefix + "absolute_pos_embed"].float() if self.ape else None
         self.w16 = {k: ops.cast_f16(v) for k, v in w.items()
                     if self.precision == "fp16" and k.endswith(".weight") and v.dim() == 2 and "norm" not in k}
         self._tables = {}
@@ -82,6 +84,14 @@ class SwinTransformer:
         if x.dtype == torch.float16:
             return ops.gemm_nt_f16(x, self.w16[name + ".weight"], b, residual, act, out_f16=out_f16)
         return ops.gemm_nt(x, self.w[name + ".weight"], b, residual, act)
+
+    def _ape_table(self, H, W, device):
+        """absolute_pos_embed bicubically interpolated to the patch grid (swin.py:706-712) as [H,W,E] NHWC, cached per size."""
+        k = ("ape", H, W)
+        if k not in self._tables:
+            t = torch.nn.functional.interpolate(self._ape, size=(H, W), mode="bicubic")        # constant preparation, once per size
+            self._tables[k] = t[0].permute(1, 2, 0).contiguous().to(device)
+        return self._tables[k]
 
     def _stage_tables(self, i, j, B, H, W, device):
         """(relative position bias [heads,N,ld] of block (i,j), shift mask [B*nW,N,ld] or None) -- cached per geometry."""
@@ -129,6 +139,8 @@ class SwinTransformer:
         x = ops.conv2d_nhwc(x, w["patch_embed.proj.weight"], self.patch_size, 0, w["patch_embed.proj.bias"])
         if self.patch_norm:
             x = ops.layernorm(x, w["patch_embed.norm.weight"], w["patch_embed.norm.bias"])
+        if self.ape:
+            x = ops.add_bcast(x, self._ape_table(x.shape[1], x.shape[2], x.device))               # x + ape (swin.py:713)
         feats = {}
         for i, depth in enumerate(self.depths):
             for j in range(depth):

@@ -352,6 +352,24 @@ def gen_swin():
     print("wrote swin.npz", {k: tuple(v.shape) for k, v in out.items()})
 
 
+def gen_swin_ape():
+    """Reference SwinTransformer.forward with ape=True (backbone/swin.py:567-578, 706-713): the absolute position embedding of
+    the 56x56 pretrain grid (pretrain_img_size 224) is interpolated bicubically to the 16x26 patch grid of the input."""
+    from tests._synth import synth_inputs
+    sw = R.ref("openvis.modeling.backbone.swin")
+    cfg = dict(embed_dim=32, depths=[1, 1, 1, 1], num_heads=[1, 2, 4, 8], window_size=5)
+    m = sw.SwinTransformer(pretrain_img_size=224, patch_size=4, in_chans=3, drop_path_rate=0.0, ape=True, **cfg)
+    m.eval()
+    spec = _load_synth(m, 161)
+    x = synth_inputs([(2, 3, 64, 104)], 162)[0]
+    with torch.no_grad():
+        out = m(x)
+    np.savez_compressed(os.path.join(GOLD, "swin_ape.npz"), spec=_spec_arrays(spec), seeds=np.array([161, 162]),
+                        cfg=np.array([cfg["embed_dim"], cfg["window_size"]] + cfg["depths"] + cfg["num_heads"]),
+                        **{k: v.numpy() for k, v in out.items()})
+    print("wrote swin_ape.npz", {k: tuple(v.shape) for k, v in out.items()})
+
+
 TEXT_NOUNS = ["person", "traffic light", "hot dog", "teddy bear", "skateboard", "giant_panda", "earless_seal", "ape"]
 
 
@@ -399,7 +417,7 @@ def gen_clip_text():
     print("wrote clip_text.npz", tokens.shape, ens.shape)
 
 
-GENERATORS = {"sidevideo": gen_side_video_decoder, "text": gen_clip_text, "swin": gen_swin, "msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "san": gen_side_adapter, "resampler": gen_resampler, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual, "clipmask": gen_clip_visual_mask_prompt,
+GENERATORS = {"sidevideo": gen_side_video_decoder, "text": gen_clip_text, "swin": gen_swin, "swinape": gen_swin_ape, "msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "san": gen_side_adapter, "resampler": gen_resampler, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual, "clipmask": gen_clip_visual_mask_prompt,
               "pe": gen_position_encodings}
 
 if __name__ == "__main__":

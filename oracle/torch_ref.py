@@ -98,6 +98,9 @@ def swin(x, W, embed_dim, depths, num_heads, ws, prefix="backbone.", patch_norm=
     x = x.flatten(2).transpose(1, 2)                                                             # [B, H*W, C]
     if patch_norm:
         x = F.layer_norm(x, (C,), W[prefix + "patch_embed.norm.weight"], W[prefix + "patch_embed.norm.bias"])
+    if prefix + "absolute_pos_embed" in W:                                                       # ape=True (swin.py:567-578, 706-713)
+        ape = F.interpolate(W[prefix + "absolute_pos_embed"], size=(H, Wd), mode="bicubic")
+        x = x + ape.flatten(2).transpose(1, 2)
     outs = {}
     for i, depth in enumerate(depths):
         C = embed_dim * 2 ** i

@@ -108,6 +108,27 @@ def test_swin_window12_720p_stage_shapes_vs_oracle():
         assert (got - ref[k]).abs().max() < 5e-5, (k, (got - ref[k]).abs().max())
 
 
+def test_swin_absolute_position_embedding_matches_oracle():
+    """MODEL.SWIN.APE (swin.py:567-578, 706-713): absolute_pos_embed [1,E,h0,w0] is interpolated bicubically to the patch grid
+    and added after the patch embedding."""
+    from openvis_amd import weights
+    from openvis_amd.modeling.backbone.swin import SwinTransformer
+    from oracle import torch_ref as TR
+    E, depths, heads, ws = 32, (1, 1, 1, 1), (1, 2, 4, 8), 7
+    spec = weights.swin_spec("backbone.", E, depths, heads, ws) + [("backbone.absolute_pos_embed", (1, E, 14, 14))]
+    Wd = weights.random_init(spec, seed=9)
+    x = synth_inputs([(2, 3, 96, 160)], 4)[0]
+    with torch.no_grad():
+        ref = TR.swin(x, Wd, E, depths, heads, ws)
+        plain = TR.swin(x, {k: v for k, v in Wd.items() if k != "backbone.absolute_pos_embed"}, E, depths, heads, ws)
+    m = SwinTransformer(4, E, depths, heads, ws, ape=True, precision="fp32").load_state_dict(Wd)
+    out = m(_nhwc4(x))
+    for k in ref:
+        got = out[k].permute(0, 3, 1, 2).cpu()
+        assert (got - ref[k]).abs().max() < 5e-5, (k, (got - ref[k]).abs().max())
+    assert (ref["res2"] - plain["res2"]).abs().max() > 1e-2          # the embedding is not a no-op on this fixture
+
+
 def test_san_online_with_swin_backbone_end_to_end():
     """SANOnline on a small Swin backbone (window 7, head_dim 32) + small side-adapter CLIP vs the oracle, exact-f32 policy."""
     from openvis_amd import config, weights
