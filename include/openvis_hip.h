@@ -70,6 +70,18 @@ int ovis_conv2d_nhwc_f32_w3(const float* x, const float* w, const void* w3, long
                             int Cout, int KH, int KW, int stride, int pad, const float* bias, const float* residual, int act,
                             ovis_stream_t stream);
 
+/* f32-grade GEMM from PRE-SPLIT operands (gemm_f16_pp.hip, X3 mode): A3 [3][M][lda] and W3 [3][N][ldb] are the exact 3-way bf16
+ * splits of the f32 operands (plane strides in elements; ovis_split_f32_to_bf16x3[_v8], or a producer that writes planes), the
+ * ping-pong kernel runs the six plane-pair products as one K axis of 6 K.  C: f32 [M,ldc] (out_planes 0; bias / residual / ReLU
+ * as ovis_gemm_nt_f32) or, out_planes 1, the three bf16 planes of the result (no residual) -- the operand format of the next
+ * GEMM, so a chain of linear layers never materialises its f32 intermediate (the FFN of msdeformattn.py:118-121).
+ * Shapes: ovis_gemm_x3pp_eligible(M, N, K, has_bias) != 0 (>= 256 tiles of 256x256, K % 64 == 0, N % 8 == 0). */
+int ovis_gemm_x3pp_eligible(int M, int N, int K, int has_bias);
+int ovis_split_f32_to_bf16x3_v8(const float* x, void* planes, long long n, ovis_stream_t stream);
+int ovis_gemm_nt_bf16x3_planes(const void* A3, long long lda, long long planeA, const void* W3, long long ldb, long long planeB,
+                               void* C, long long ldc, long long planeC, int M, int N, int K, const float* bias,
+                               const float* residual, long long ldr, int act, int out_planes, ovis_stream_t stream);
+
 /* ---- Dense layers and convolutions on the f32 matrix cores ---------------------------------
  * Replace the cuBLAS/cuDNN work behind the reference's nn.Linear / Conv2d modules on the path, e.g.
  *   ops/modules/ms_deform_attn.py:98-104,124 (value_proj, sampling_offsets, attention_weights, output_proj),

@@ -67,6 +67,7 @@ struct PPTile { long long a_off, b_off; int bm, bml, bn, bnl; };   // DMA bases 
 struct PPArgs {
   const _Float16* A; const _Float16* B; void* C; const float* bias; const float* R;
   long long lda, ldb, ldc, ldr;
+  long long planeA, planeB, planeC;          // X3: bytes between the bf16 planes of A / B (and of C when the output is planes)
   int M, N, K, act;
   int tiles_m, tiles_n, n_tiles;
   int grp_w, grp_rem;                       // raster: column groups of grp_w (+1 for the first grp_rem groups) N tiles
@@ -81,7 +82,12 @@ struct PPArgs {
 #define PP_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); \
                           __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <bool OUT_F16, int ACT, bool HAS_R>
+// OUT: 0 f32, 1 fp16, 2 three bf16 planes (the exact split of the f32 result, operand format of the X3 mode).
+// X3 : f32-grade GEMM on the bf16 matrix cores (gemm_f32x3.h): A and B arrive as the exact 3-way bf16 split of the f32 operands
+//      (planes [3][rows][ld]); the K loop runs over the six plane pairs (a2 b0, a0 b2, a1 b1, a1 b0, a0 b1, a0 b0: smallest terms
+//      first) x K, i.e. this is the same kernel on a K axis of 6 K -- the split costs no VALU work in the loop.  Accumulators start
+//      at zero and bias / residual are added in the epilogue (an O(1) start value would cost the f32-grade error bound).
+template <int OUT, int ACT, bool HAS_R, bool X3>
 __global__ void __launch_bounds__(512)
 gemm_f16_pp_kernel(const PPArgs p) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[PP_LDS];   // ONE LDS object (a second one de-pipelines the DMA)
@@ -91,7 +97,8 @@ gemm_f16_pp_kernel(const PPArgs p) {
   const int wr = wave >> 2, wc = wave & 3;
   const int l15 = lane & 15, q = lane >> 4, sw = l15 >> 1;
   const int nblk = gridDim.x;
-  const int nk = p.K >> 6;
+  const int nk1 = p.K >> 6;                                        // K steps of one plane pair
+  const int nk = X3 ? 6 * nk1 : nk1;
 
   // logical tile index -> (m tile, n tile): column groups of <= grp_w + 1 N tiles, M-panel-major inside a group; the 32
   // workgroups of an XCD take 32 consecutive logical tiles per round, i.e. a (32 / w) x w block of the output: they
@@ -188,28 +195,44 @@ gemm_f16_pp_kernel(const PPArgs p) {
       for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int e = 0; e < 2; ++e)
-          acc[i * 4 + mb][j * 2 + e] =
-              __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[e][kb], af[mb][kb], acc[i * 4 + mb][j * 2 + e], 0, 0, 0);
+          if constexpr (X3) {
+            using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+            acc[i * 4 + mb][j * 2 + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, bf[e][kb]), __builtin_bit_cast(bf16x8, af[mb][kb]), acc[i * 4 + mb][j * 2 + e], 0, 0, 0);
+          } else {
+            acc[i * 4 + mb][j * 2 + e] =
+                __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[e][kb], af[mb][kb], acc[i * 4 + mb][j * 2 + e], 0, 0, 0);
+          }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
 
   // ---- the two DMA cursors: c1 = next K step of the half-tiles B1, A1; c2 = next K step of A0, B0 (one step further ahead) ----
-  int c1_i = 0, c1_kt = 0, c2_i = 0, c2_kt = 0;                   // tile ordinal + K step
-  const char *c1a, *c1b, *c2a, *c2b;
-  { const PPTile t = tile_entry(0); c1a = c2a = Ab + t.a_off; c1b = c2b = Bb + t.b_off; }
+  // (X3: a cursor also walks the six plane pairs; pair t reads plane PA[t] of A and PB[t] of B, 2 bits each in the codes below)
+  struct Cur { int i, kt, k, t; const char *ta, *tb, *a, *b; };     // tile ordinal, K step of the tile, K step of the pair, pair
+  auto planes = [&](Cur& c) {
+    if constexpr (X3) { c.a = c.ta + ((82 >> (2 * c.t)) & 3) * p.planeA; c.b = c.tb + ((280 >> (2 * c.t)) & 3) * p.planeB; }
+    else { c.a = c.ta; c.b = c.tb; }
+  };
+  Cur c1, c2;
+  { const PPTile t = tile_entry(0); c1.i = c1.kt = c1.k = c1.t = 0; c1.ta = Ab + t.a_off; c1.tb = Bb + t.b_off; planes(c1); c2 = c1; }
   // (tile change: called AFTER a phase's MFMAs were issued, where the wavefront has nothing else to do)
-  auto advance1 = [&]() {
-    if (++c1_kt == nk) { c1_kt = 0; if (++c1_i < n_my) { const PPTile t = tile_entry(c1_i); c1a = Ab + t.a_off; c1b = Bb + t.b_off; } }
+  auto advance = [&](Cur& c) {
+    ++c.k;
+    if (X3 && c.k == nk1) { c.k = 0; ++c.t; if (c.t < 6) planes(c); }
+    if (++c.kt == nk) {
+      c.kt = c.k = c.t = 0;
+      if (++c.i < n_my) { const PPTile t = tile_entry(c.i); c.ta = Ab + t.a_off; c.tb = Bb + t.b_off; }
+      planes(c);
+    }
   };
-  auto advance2 = [&]() {
-    if (++c2_kt == nk) { c2_kt = 0; if (++c2_i < n_my) { const PPTile t = tile_entry(c2_i); c2a = Ab + t.a_off; c2b = Bb + t.b_off; } }
-  };
+  auto advance1 = [&]() { advance(c1); };
+  auto advance2 = [&]() { advance(c2); };
   // (past the last tile the cursors keep re-loading the last tile's rows into slots nobody reads: the vmcnt counts stay uniform)
-  auto issue_b1 = [&](unsigned buf) { issue(c1b, voB[1], c1_kt, buf + 3 * PP_HT); };
-  auto issue_a1 = [&](unsigned buf) { issue(c1a, voA[1], c1_kt, buf + 1 * PP_HT); };
-  auto issue_a0 = [&](unsigned buf) { issue(c2a, voA[0], c2_kt, buf + 0 * PP_HT); };
-  auto issue_b0 = [&](unsigned buf) { issue(c2b, voB[0], c2_kt, buf + 2 * PP_HT); };
+  auto issue_b1 = [&](unsigned buf) { issue(c1.b, voB[1], c1.k, buf + 3 * PP_HT); };
+  auto issue_a1 = [&](unsigned buf) { issue(c1.a, voA[1], c1.k, buf + 1 * PP_HT); };
+  auto issue_a0 = [&](unsigned buf) { issue(c2.a, voA[0], c2.k, buf + 0 * PP_HT); };
+  auto issue_b0 = [&](unsigned buf) { issue(c2.b, voB[0], c2.k, buf + 2 * PP_HT); };
 
   if (p.desync_ns > 0) {
     // lab knob: start offsets (dbg bit 3 clear: the 32 workgroups of every XCD spread over [0, desync_ns); set: whole XCDs)
@@ -220,7 +243,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
   }
 
   // ---- epilogue of one tile: a lane owns one output row per 16-row block and 8 consecutive columns per column pair ----
-  constexpr int ESZ = OUT_F16 ? 2 : 4;
+  constexpr int ESZ = OUT == 0 ? 4 : 2;
   // Row block outer, column pair inner: the two 64-byte halves of a 128-byte line come from CONSECUTIVE store instructions.
   // (Column pair outer -- the halves 8 instructions apart -- measured 5-6 % slower on the whole GEMM: partial-line writes.)
   auto epilogue_rows = [&](auto pred_tag, int bm, int bml, int bn, int bnl) {
@@ -243,15 +266,41 @@ gemm_f16_pp_kernel(const PPArgs p) {
       const f16x2 h2 = __builtin_convertvector(f32x2{x1[0], x1[1]}, f16x2), h3 = __builtin_convertvector(f32x2{x1[2], x1[3]}, f16x2);
       return make_uint4(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), __builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3));
     };
+    const float* rp = nullptr;
+    if constexpr (X3 && HAS_R) rp = p.R + (long long)row0 * p.ldr + col0;
     auto put = [&](int mb, int j) {
       f32x4 x0 = acc[mb][2 * j], x1 = acc[mb][2 * j + 1];
+      if constexpr (X3) {                                            // bias / residual enter here, not as the accumulators' start value
+        x0 += *reinterpret_cast<const f32x4*>(lds + PP_BIAS + (col0 + 32 * j) * 4);
+        x1 += *reinterpret_cast<const f32x4*>(lds + PP_BIAS + (col0 + 32 * j) * 4 + 16);
+        if constexpr (HAS_R) {
+          x0 += *reinterpret_cast<const f32x4*>(rp + (long long)mb * 16 * p.ldr + 32 * j);
+          x1 += *reinterpret_cast<const f32x4*>(rp + (long long)mb * 16 * p.ldr + 32 * j + 4);
+        }
+      }
       act4(x0); act4(x1);
       char* c = cp + mb * row_step + j * 32 * ESZ;
       const bool ok = !PRED || (col0 + 32 * j >= bn && row0 + mb * 16 >= bm);
-      if constexpr (OUT_F16) {
+      if constexpr (OUT == 1) {
         const uint4 o = pack8(x0, x1);
         if (p.dbg & 1) asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
         else if (ok) *reinterpret_cast<uint4*>(c) = o;
+      } else if constexpr (OUT == 2) {                               // exact 3-way bf16 split of the f32 result, one 16-byte store per plane
+        using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+        bf16x8 h0, h1, h2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = e < 4 ? x0[e & 3] : x1[e & 3];
+          const __bf16 a0 = (__bf16)v;
+          const float r1 = v - (float)a0;
+          const __bf16 a1 = (__bf16)r1;
+          h0[e] = a0; h1[e] = a1; h2[e] = (__bf16)(r1 - (float)a1);
+        }
+        if (ok) {
+          *reinterpret_cast<bf16x8*>(c) = h0;
+          *reinterpret_cast<bf16x8*>(c + p.planeC) = h1;
+          *reinterpret_cast<bf16x8*>(c + 2 * p.planeC) = h2;
+        }
       } else {
         if (p.dbg & 1) asm volatile("" :: "v"(x0[0]), "v"(x0[3]), "v"(x1[0]), "v"(x1[3]));
         else if (ok) { *reinterpret_cast<f32x4*>(c) = x0; *reinterpret_cast<f32x4*>(c + 16) = x1; }
@@ -264,7 +313,12 @@ gemm_f16_pp_kernel(const PPArgs p) {
   };
   // ... followed by the start value of the next tile's accumulators: bias + residual (gemm_epilogue.h) or zero
   auto acc_init = [&](int bml, int bnl) {
-    if constexpr (HAS_R) {
+    if constexpr (X3) {
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if constexpr (HAS_R) {
       const float* rp = p.R + (long long)(bml + wr * 128 + l15) * p.ldr + bnl + wc * 64 + 8 * q;
       const int col0 = bnl + wc * 64 + 8 * q;
 #pragma unroll
@@ -301,7 +355,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
   asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                 // B1 of K step 0 (5 younger half-tiles)
   PP_BARRIER();
 
-  constexpr int NS = OUT_F16 ? 16 : (HAS_R ? 53 : 32);             // vm ops of one epilogue (+ residual loads) per lane; 10 + NS <= 63
+  constexpr int NS = OUT == 1 ? 16 : OUT == 2 ? 48 : (HAS_R ? 53 : 32);   // vm ops of one epilogue (+ residual loads) per lane; 10 + NS <= 63
 #define PP_WAIT(n_first, n_later) do { if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_first) : "memory"); \
                                        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_later) : "memory"); } while (0)
   unsigned s = 0;                                                    // global K step counter (buffer = s & 1)
@@ -422,12 +476,13 @@ int gemm_f16_pp_launch(const void* A, long long lda, const void* B, long long ld
   p.desync_ns = g_pp_desync_ns >= 0 ? g_pp_desync_ns : (residual ? 24000 : 0);
   p.dbg = g_pp_dbg; p.stamps = g_pp_stamps;
   const int grid = p.n_tiles < 256 ? p.n_tiles : 256;              // one persistent workgroup per CU (MI355X: 256 CUs)
-#define PP_LAUNCH(O, A_, R_) hipLaunchKernelGGL((gemm_f16_pp_kernel<O, A_, R_>), dim3(grid), dim3(512), 0, s, p)
+  p.planeA = p.planeB = p.planeC = 0;
+#define PP_LAUNCH(O, A_, R_) hipLaunchKernelGGL((gemm_f16_pp_kernel<O, A_, R_, false>), dim3(grid), dim3(512), 0, s, p)
   if (out_f16 && !residual) {
-    if (act == 0) PP_LAUNCH(true, 0, false); else if (act == 1) PP_LAUNCH(true, 1, false);
-    else if (act == 2) PP_LAUNCH(true, 2, false); else PP_LAUNCH(true, 3, false);
+    if (act == 0) PP_LAUNCH(1, 0, false); else if (act == 1) PP_LAUNCH(1, 1, false);
+    else if (act == 2) PP_LAUNCH(1, 2, false); else PP_LAUNCH(1, 3, false);
   } else if (!out_f16 && act == 0) {
-    if (residual) PP_LAUNCH(false, 0, true); else PP_LAUNCH(false, 0, false);
+    if (residual) PP_LAUNCH(0, 0, true); else PP_LAUNCH(0, 0, false);
   } else {
     return fail(OVIS_EINVAL, "gemm_nt_f16 (ping-pong): no instantiation for out_f16=%d act=%d residual=%d", out_f16, act, residual != nullptr);
   }
@@ -435,7 +490,70 @@ int gemm_f16_pp_launch(const void* A, long long lda, const void* B, long long ld
   return check_launch("gemm_nt_f16 (ping-pong)");
 }
 
+// x [n] f32 -> planes [3][n] bf16 with x == p0 + p1 + p2 exactly, 8 elements per thread (16-byte stores)
+__global__ void __launch_bounds__(256)
+x3_split8_kernel(const float4* __restrict__ x, uint4* __restrict__ p0, uint4* __restrict__ p1, uint4* __restrict__ p2, long long n8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const float4 a = x[2 * i], b = x[2 * i + 1];
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  union { __bf16 h[8]; uint4 u; } o0, o1, o2;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h0 = (__bf16)v[e];
+    const float r1 = v[e] - (float)h0;
+    const __bf16 h1 = (__bf16)r1;
+    o0.h[e] = h0; o1.h[e] = h1; o2.h[e] = (__bf16)(r1 - (float)h1);
+  }
+  p0[i] = o0.u; p1[i] = o1.u; p2[i] = o2.u;
+}
+
 }  // namespace ovis
+
+extern "C" int ovis_gemm_x3pp_eligible(int M, int N, int K, int has_bias) {
+  const long long blocks256 = (long long)ovis::cdiv(M, 256) * ovis::cdiv(N, 256);
+  return blocks256 >= 256 && blocks256 <= 256ll * PP_MAX_TILES && K % 64 == 0 && K >= 64 && N % 8 == 0 && M >= 256 && N >= 256 &&
+         (!has_bias || N <= PP_MAX_BIAS_N) && 256ll * K * 2 < (1ll << 31);
+}
+
+extern "C" int ovis_split_f32_to_bf16x3_v8(const float* x, void* planes, long long n, ovis_stream_t stream) {
+  OVIS_REQUIRE(x && planes && n > 0 && n % 8 == 0, "split_f32_to_bf16x3_v8: n must be a positive multiple of 8");
+  OVIS_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(planes)) & 15) == 0, "split_f32_to_bf16x3_v8: 16-byte alignment");
+  char* pl = reinterpret_cast<char*>(planes);
+  hipLaunchKernelGGL(ovis::x3_split8_kernel, dim3(ovis::cdiv(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(x), reinterpret_cast<uint4*>(pl), reinterpret_cast<uint4*>(pl + n * 2),
+                     reinterpret_cast<uint4*>(pl + n * 4), n / 8);
+  return ovis::check_launch("split_f32_to_bf16x3_v8");
+}
+
+extern "C" int ovis_gemm_nt_bf16x3_planes(const void* A3, long long lda, long long planeA, const void* W3, long long ldb, long long planeB,
+                                          void* C, long long ldc, long long planeC, int M, int N, int K, const float* bias,
+                                          const float* residual, long long ldr, int act, int out_planes, ovis_stream_t stream) {
+  OVIS_REQUIRE(A3 && W3 && C, "gemm_nt_bf16x3_planes: null pointer");
+  OVIS_REQUIRE(ovis_gemm_x3pp_eligible(M, N, K, bias != nullptr), "gemm_nt_bf16x3_planes: shape not eligible (M=%d N=%d K=%d)", M, N, K);
+  OVIS_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % (out_planes ? 8 : 4) == 0, "gemm_nt_bf16x3_planes: bad leading dimensions");
+  OVIS_REQUIRE(((reinterpret_cast<uintptr_t>(A3) | reinterpret_cast<uintptr_t>(W3) | reinterpret_cast<uintptr_t>(C)) & 15) == 0 &&
+               (planeA * 2) % 16 == 0 && (planeB * 2) % 16 == 0 && (!out_planes || (planeC * 2) % 16 == 0), "gemm_nt_bf16x3_planes: 16-byte alignment");
+  OVIS_REQUIRE((act == 0 || act == 1) && !(out_planes && residual), "gemm_nt_bf16x3_planes: act must be none / ReLU; plane output has no residual");
+  OVIS_REQUIRE(!residual || (ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(residual) & 15) == 0), "gemm_nt_bf16x3_planes: residual alignment");
+  OVIS_REQUIRE(!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0, "gemm_nt_bf16x3_planes: bias alignment");
+  PPArgs p;
+  p.A = reinterpret_cast<const _Float16*>(A3); p.B = reinterpret_cast<const _Float16*>(W3); p.C = C; p.bias = bias; p.R = residual;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.M = M; p.N = N; p.K = K; p.act = act;
+  p.planeA = planeA * 2; p.planeB = planeB * 2; p.planeC = planeC * 2;         // bytes
+  p.tiles_m = (int)ovis::cdiv(M, 256); p.tiles_n = (int)ovis::cdiv(N, 256); p.n_tiles = p.tiles_m * p.tiles_n;
+  const int groups = (int)ovis::cdiv(p.tiles_n, g_pp_grp > 0 ? g_pp_grp : p.tiles_n);
+  p.grp_w = p.tiles_n / groups; p.grp_rem = p.tiles_n % groups;
+  p.desync_ns = g_pp_desync_ns > 0 ? g_pp_desync_ns : 0; p.dbg = g_pp_dbg; p.stamps = g_pp_stamps;
+  const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
+  hipStream_t s = (hipStream_t)stream;
+#define PP_LAUNCH(O, A_, R_) hipLaunchKernelGGL((gemm_f16_pp_kernel<O, A_, R_, true>), dim3(grid), dim3(512), 0, s, p)
+  if (out_planes) { if (act == 1) PP_LAUNCH(2, 1, false); else PP_LAUNCH(2, 0, false); }
+  else if (residual) { if (act == 1) PP_LAUNCH(0, 1, true); else PP_LAUNCH(0, 0, true); }
+  else { if (act == 1) PP_LAUNCH(0, 1, false); else PP_LAUNCH(0, 0, false); }
+#undef PP_LAUNCH
+  return ovis::check_launch("gemm_nt_bf16x3_planes");
+}
 
 extern "C" int ovis_set_f16_gemm_mode(int mode, int raster_group, int desync_ns) {
   OVIS_REQUIRE(mode == 0 || mode == 1, "set_f16_gemm_mode: mode must be 0 (gemm_f16_256_kernel) or 1 (ping-pong kernel)");

@@ -560,3 +560,30 @@ def mean_over_dim0(x):
     y = torch.empty(x.shape[1:], dtype=torch.float32, device=x.device)
     _lib.call("ovis_mean_dim0_f32", x, y, x.shape[0], _ll(y.numel()), _lib.stream_ptr())
     return y
+
+
+# ---- f32-grade GEMM on pre-split bf16 planes (csrc/gemm_f16_pp.hip, X3 mode) ---------------------------------------------
+def x3pp_eligible(M, N, K, has_bias=True):
+    return bool(_lib.lib().ovis_gemm_x3pp_eligible(int(M), int(N), int(K), int(bool(has_bias))))
+
+
+def split_planes(x):
+    """f32 [..., K] -> bf16 [3, ..., K] with x == p0 + p1 + p2 exactly (the operand format of gemm_nt_planes)."""
+    _chk(x)
+    p = torch.empty((3,) + tuple(x.shape), dtype=torch.bfloat16, device=x.device)
+    _lib.call("ovis_split_f32_to_bf16x3_v8", x, p, _ll(x.numel()), _lib.stream_ptr())
+    return p
+
+
+def gemm_nt_planes(a3, w3, bias=None, residual=None, act=ACT_NONE, out_planes=False):
+    """a3 bf16 [3,M,K], w3 bf16 [3,N,K] (exact 3-way splits) -> f32 [M,N] or, out_planes, bf16 [3,M,N]: act(a w^T + bias + residual)
+    with f32-grade accuracy on the ping-pong bf16 MFMA kernel (six plane-pair products as one K axis of 6 K)."""
+    _chk(a3, w3, bias, residual)
+    _, M, K = a3.shape
+    N = w3.shape[1]
+    out = torch.empty((3, M, N), dtype=torch.bfloat16, device=a3.device) if out_planes else \
+        torch.empty((M, N), dtype=torch.float32, device=a3.device)
+    with _Prof(f"gemm_f16_pp_kernel<{2 if out_planes else 0},{act},{'true' if residual is not None else 'false'},true>", 2.0 * M * N * K):
+        _lib.call("ovis_gemm_nt_bf16x3_planes", a3, _ll(K), _ll(M * K), w3, _ll(K), _ll(N * K), out, _ll(N), _ll(M * N), M, N, K, bias,
+                  residual, _ll(N), act, int(out_planes), _lib.stream_ptr())
+    return out

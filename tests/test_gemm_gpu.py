@@ -139,3 +139,26 @@ def test_presplit_weight_planes_give_identical_results(gemm_modes):
     assert torch.equal(ops.conv2d_nhwc(x, cwt, 1, 1, b[:256].contiguous(), None, 1), ops.conv2d_nhwc(x, cwt, 1, 1, b[:256].contiguous(), None, 1, cw=True))
     small = torch.randn(100, 256, generator=g).cuda()                     # small problems keep using the f32 weights
     assert torch.equal(ops.gemm_nt(small, w, b), ops.gemm_nt(small, w, b, cw=True))
+
+
+@pytest.mark.parametrize("N,K,act,res,planes", [(256, 256, 0, True, False), (520, 192, 1, False, False), (512, 128, 1, False, True)])
+def test_gemm_on_presplit_bf16_planes_is_f32_grade(N, K, act, res, planes):
+    """ovis_gemm_nt_bf16x3_planes (gemm_f16_pp.hip, X3 mode): operands given as their exact 3-way bf16 split, the six plane-pair
+    products run as one K axis of 6 K on the ping-pong kernel; f32 output or the split of the result (chained linear layers)."""
+    from openvis_amd import ops
+    M = 66000 + 37
+    assert ops.x3pp_eligible(M, N, K)
+    g = torch.Generator().manual_seed(N + K)
+    a = (torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, 1, generator=g))).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    r = torch.randn(M, N, generator=g).cuda() if res else None
+    a3, w3 = ops.split_planes(a), ops.split_planes(w)
+    assert torch.equal(a3.float().sum(0), a)                                     # the split is exact
+    out = ops.gemm_nt_planes(a3, w3, b, r, act, out_planes=planes)
+    ref = a.double() @ w.double().T + b.double() + (r.double() if res else 0)
+    scale = a.double().abs() @ w.double().abs().T + b.double().abs() + (r.double().abs() if res else 0)
+    if act:
+        ref = ref.relu()
+    got = out.double().sum(0) if planes else out.double()
+    assert ((got - ref).abs() / scale).max().item() < 1e-6

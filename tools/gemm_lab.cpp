@@ -56,10 +56,106 @@ __global__ void diff_kernel(const float* ref, const void* out, int out_f16, long
   if (bad) atomicAdd(nbad, bad);
 }
 
+// ---- x3 (f32-grade GEMM on bf16 planes) -------------------------------------------------------------------------------
+__global__ void ref_gemm_f64(const float* A, const float* B, double* C, double* S, int M, int N, int K, const float* bias, const float* R, int act) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * N) return;
+  const int m = (int)(i / N), n = (int)(i % N);
+  double s = (bias ? (double)bias[n] : 0.0) + (R ? (double)R[i] : 0.0), sc = fabs(s);
+  for (int k = 0; k < K; ++k) { const double a = A[(long long)m * K + k], b = B[(long long)n * K + k]; s += a * b; sc += fabs(a * b); }
+  if (act == 1) s = s > 0 ? s : 0;
+  C[i] = s; S[i] = sc;
+}
+__global__ void x3_err_kernel(const double* ref, const double* scale, const float* out, const __bf16* planes, long long plane, long long n, float* maxerr) {
+  float mx = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double o = out ? (double)out[i] : (double)(float)planes[i] + (double)(float)planes[plane + i] + (double)(float)planes[2 * plane + i];
+    const double e = fabs(o - ref[i]) / scale[i];
+    mx = fmaxf(mx, e == e ? (float)e : 1e30f);
+  }
+  atomicMax((int*)maxerr, __float_as_int(mx));
+}
+
+static int run_x3(hipStream_t s, bool do_time) {
+  int fails = 0;
+  float* d_max; HIP_OK(hipMalloc(&d_max, 4));
+  struct Case { int M, N, K, act, res, out_planes; const char* name; };
+  const Case cases[] = {{66000 + 37, 256, 256, 0, 1, 0, "value/out proj"}, {66000 + 37, 1024, 256, 1, 0, 0, "FFN1 f32 out"},
+                        {66000 + 37, 1024, 256, 1, 0, 1, "FFN1 planes out"}, {66000 + 37, 256, 1024, 0, 1, 0, "FFN2"}, {33000, 520, 320, 0, 0, 0, "ragged"}};
+  for (const Case& c : cases) {
+    const long long MN = (long long)c.M * c.N, MK = (long long)c.M * c.K, NK = (long long)c.N * c.K;
+    float *A, *W, *bias, *R = nullptr, *C; double *ref, *sc; __bf16 *A3, *W3, *C3 = nullptr;
+    HIP_OK(hipMalloc(&A, MK * 4)); HIP_OK(hipMalloc(&W, NK * 4)); HIP_OK(hipMalloc(&bias, c.N * 4)); HIP_OK(hipMalloc(&C, MN * 4));
+    HIP_OK(hipMalloc(&ref, MN * 8)); HIP_OK(hipMalloc(&sc, MN * 8)); HIP_OK(hipMalloc(&A3, MK * 6)); HIP_OK(hipMalloc(&W3, NK * 6));
+    fill_f32<<<2048, 256, 0, s>>>(A, MK, 3u, 0, 4.f); fill_f32<<<512, 256, 0, s>>>(W, NK, 9u, 0, 1.f / sqrtf((float)c.K)); fill_f32<<<8, 256, 0, s>>>(bias, c.N, 5u, 0, 1.f);
+    if (c.res) { HIP_OK(hipMalloc(&R, MN * 4)); fill_f32<<<2048, 256, 0, s>>>(R, MN, 7u, 0, 2.f); }
+    if (c.out_planes) HIP_OK(hipMalloc(&C3, MN * 6));
+    ref_gemm_f64<<<(unsigned)((MN + 255) / 256), 256, 0, s>>>(A, W, ref, sc, c.M, c.N, c.K, bias, R, c.act);
+    OVIS_OKAY(ovis_split_f32_to_bf16x3_v8(A, A3, MK, s)); OVIS_OKAY(ovis_split_f32_to_bf16x3_v8(W, W3, NK, s));
+    for (int rep = 0; rep < 2; ++rep) {
+      HIP_OK(hipMemsetAsync(c.out_planes ? (void*)C3 : (void*)C, 0xff, c.out_planes ? MN * 6 : MN * 4, s));
+      OVIS_OKAY(ovis_gemm_nt_bf16x3_planes(A3, c.K, MK, W3, c.K, NK, c.out_planes ? (void*)C3 : (void*)C, c.N, MN, c.M, c.N, c.K, bias, R, c.N, c.act, c.out_planes, s));
+      HIP_OK(hipMemsetAsync(d_max, 0, 4, s));
+      x3_err_kernel<<<1024, 256, 0, s>>>(ref, sc, c.out_planes ? nullptr : C, C3, MN, MN, d_max);
+      float mx; HIP_OK(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
+      const bool ok = mx < 2e-6f;
+      if (!ok) ++fails;
+      if (rep == 0 || !ok) printf("x3 check %-16s M=%d N=%d K=%d act=%d res=%d planes=%d: max err / sum|ab| = %.3g %s\n", c.name, c.M, c.N, c.K, c.act, c.res, c.out_planes, mx, ok ? "OK" : "FAIL");
+    }
+    // the shipped bf16x3 kernel (pre-split weights, activation split in the loop) on the same data
+    OVIS_OKAY(ovis_gemm_nt_f32_w3(A, c.K, W, c.K, W3, NK, C, c.N, c.M, c.N, c.K, bias, R, c.N, c.act, s));
+    HIP_OK(hipMemsetAsync(d_max, 0, 4, s));
+    x3_err_kernel<<<1024, 256, 0, s>>>(ref, sc, C, nullptr, 0, MN, d_max);
+    float mx; HIP_OK(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
+    printf("x3 check %-16s legacy gemm_f32x3_kernel: max err / sum|ab| = %.3g\n", c.name, mx);
+    HIP_OK(hipFree(A)); HIP_OK(hipFree(W)); HIP_OK(hipFree(bias)); HIP_OK(hipFree(C)); HIP_OK(hipFree(ref)); HIP_OK(hipFree(sc)); HIP_OK(hipFree(A3)); HIP_OK(hipFree(W3));
+    if (R) HIP_OK(hipFree(R));
+    if (C3) HIP_OK(hipFree(C3));
+  }
+  if (do_time) {
+    hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    struct Shape { int M, N, K, act, res; const char* name; };
+    const Shape shapes[] = {{96600, 256, 256, 0, 1, "proj256"}, {96600, 288, 256, 0, 0, "offs288"}, {96600, 544, 256, 0, 0, "fused544"}, {96600, 1024, 256, 1, 0, "ffn1"},
+                            {96600, 256, 1024, 0, 1, "ffn2"}, {294400, 256, 256, 0, 0, "maskfeat"}, {96600, 256, 2048, 0, 0, "inproj2048"}};
+    for (const Shape& sh : shapes) {
+      const long long MN = (long long)sh.M * sh.N, MK = (long long)sh.M * sh.K, NK = (long long)sh.N * sh.K;
+      float *A, *W, *bias, *R = nullptr, *C; __bf16 *A3, *W3, *C3;
+      HIP_OK(hipMalloc(&A, MK * 4)); HIP_OK(hipMalloc(&W, NK * 4)); HIP_OK(hipMalloc(&bias, sh.N * 4)); HIP_OK(hipMalloc(&C, MN * 4));
+      HIP_OK(hipMalloc(&A3, MK * 6)); HIP_OK(hipMalloc(&W3, NK * 6)); HIP_OK(hipMalloc(&C3, MN * 6));
+      fill_f32<<<2048, 256, 0, s>>>(A, MK, 3u, 0, 4.f); fill_f32<<<512, 256, 0, s>>>(W, NK, 9u, 0, 1.f / sqrtf((float)sh.K)); fill_f32<<<8, 256, 0, s>>>(bias, sh.N, 5u, 0, 1.f);
+      if (sh.res) { HIP_OK(hipMalloc(&R, MN * 4)); fill_f32<<<2048, 256, 0, s>>>(R, MN, 7u, 0, 2.f); }
+      OVIS_OKAY(ovis_split_f32_to_bf16x3_v8(W, W3, NK, s));
+      const bool elig = ovis_gemm_x3pp_eligible(sh.M, sh.N, sh.K, 1) != 0;
+      double t[4] = {1e30, 1e30, 1e30, 1e30};
+      for (int r = 0; r < 4; ++r)
+        for (int v = 0; v < 4; ++v) {
+          if (v > 0 && !elig) continue;
+          HIP_OK(hipEventRecord(e0, s));
+          for (int it = 0; it < 10; ++it) {
+            if (v == 0) OVIS_OKAY(ovis_gemm_nt_f32_w3(A, sh.K, W, sh.K, W3, NK, C, sh.N, sh.M, sh.N, sh.K, bias, R, sh.N, sh.act, s));
+            else if (v == 1) OVIS_OKAY(ovis_split_f32_to_bf16x3_v8(A, A3, MK, s));
+            else if (v == 2) OVIS_OKAY(ovis_gemm_nt_bf16x3_planes(A3, sh.K, MK, W3, sh.K, NK, C, sh.N, MN, sh.M, sh.N, sh.K, bias, R, sh.N, sh.act, 0, s));
+            else if (!sh.res) OVIS_OKAY(ovis_gemm_nt_bf16x3_planes(A3, sh.K, MK, W3, sh.K, NK, C3, sh.N, MN, sh.M, sh.N, sh.K, bias, nullptr, sh.N, sh.act, 1, s));
+          }
+          HIP_OK(hipEventRecord(e1, s)); HIP_OK(hipEventSynchronize(e1));
+          float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+          if (r > 0) t[v] = std::min(t[v], (double)ms / 10);
+        }
+      const double fl = 2.0 * sh.M * sh.N * sh.K;
+      printf("x3 time %-10s M=%d N=%d K=%d: legacy %.4f ms (%.0f TF f32-eq) | split A %.4f ms | pp f32-out %.4f ms (%.0f TF) | pp planes-out %.4f ms\n", sh.name,
+             sh.M, sh.N, sh.K, t[0], fl / t[0] / 1e9, t[1], t[2], fl / t[2] / 1e9, sh.res ? 0.0 : t[3]);
+      HIP_OK(hipFree(A)); HIP_OK(hipFree(W)); HIP_OK(hipFree(bias)); HIP_OK(hipFree(C)); HIP_OK(hipFree(A3)); HIP_OK(hipFree(W3)); HIP_OK(hipFree(C3));
+      if (R) HIP_OK(hipFree(R));
+    }
+  }
+  HIP_OK(hipFree(d_max));
+  return fails;
+}
+
 struct Variant { int mode, grp, desync, dbg; std::string name; };
 
 int main(int argc, char** argv) {
-  bool do_check = false, do_time = false, do_trace = false;
+  bool do_check = false, do_time = false, do_trace = false, do_x3 = false;
   std::vector<Variant> variants;
   int iters = 10, rounds = 3;
   for (int i = 1; i < argc; ++i) {
@@ -68,6 +164,7 @@ int main(int argc, char** argv) {
     else if (!strncmp(argv[i], "iters=", 6)) iters = atoi(argv[i] + 6);
     else if (!strncmp(argv[i], "rounds=", 7)) rounds = atoi(argv[i] + 7);
     else if (!strcmp(argv[i], "trace")) do_trace = true;
+    else if (!strcmp(argv[i], "x3")) do_x3 = true;
     else { Variant v; v.dbg = 0; if (sscanf(argv[i], "%d,%d,%d,%d", &v.mode, &v.grp, &v.desync, &v.dbg) >= 3) { v.name = argv[i]; variants.push_back(v); } }
   }
   if (variants.empty()) { variants.push_back({0, 0, 0, 0, "0,0,0"}); variants.push_back({1, 6, 0, 0, "1,6,0"}); }
@@ -75,6 +172,7 @@ int main(int argc, char** argv) {
   float* d_max; unsigned long long* d_bad;
   HIP_OK(hipMalloc(&d_max, 4)); HIP_OK(hipMalloc(&d_bad, 8));
   int fails = 0;
+  if (do_x3) fails += run_x3(s, true);
 
   if (do_check) {
     struct Case { int M, N, K, act, out16, bias, res, kind; };
