@@ -232,15 +232,6 @@ int ovis_mask_bbox(const float* masks, int* boxes, int Q, int T, int h, int w, i
 int ovis_clip_crop_patches(const uint8_t* frames, const float* masks, const int* crops, void* A, int out_f16, int M,
                            int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int resolution, int patch,
                            long long lda, const float* mean3_host, const float* std3_host, ovis_stream_t stream);
-/* A9 as the reference materialises it, in fp16: soft [T,Q,Hp,Wp] = half(sigmoid(x4 bilinear upsample of masks [Q,T,h,w])) -- the
- * `valid_masks.half()` tensor of adapter.py:88-111 -- written in the same pass that finds the boxes (as ovis_mask_bbox), and the crop
- * kernel that reads it (patch_open NULL, or the AdaptedClipAdapter byte map as in ovis_clip_crop_patches_masked).  One evaluation of
- * the upsample per pixel instead of one per crop and source pixel. */
-int ovis_mask_bbox_soft(const float* masks, int* boxes, void* soft_f16, int Q, int T, int h, int w, int Hp, int Wp, ovis_stream_t stream);
-int ovis_clip_crop_patches_soft(const uint8_t* frames, const void* soft_f16, const int* crops, void* A, unsigned char* patch_open,
-                                int out_f16, int M, int Q, int T, int H, int W, int Hp, int Wp, int resolution, int patch,
-                                long long lda, const float* mean3_host, const float* std3_host, ovis_stream_t stream);
-
 /* As ovis_clip_crop_patches, for AdaptedClipAdapter (mask_adapted_adapter.py:79-123, 143-147): additionally writes
  *   patch_open[m*G*G + py*G + px] = ceil(AvgPool2d(patch)(mask_region)) (model.py:332-333) as 0/1 bytes -- 1 iff any bin of
  *   the patch has a positive mask_region value.  patch_open (device, M*G*G bytes) is cleared by the call. */

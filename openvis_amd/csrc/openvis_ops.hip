@@ -340,47 +340,6 @@ mask_bbox_kernel(const float* __restrict__ masks, int* __restrict__ boxes, int Q
   }
 }
 
-// A9 as the reference has it, in fp16: soft [T,Q,Hp,Wp] = half(sigmoid(x4 bilinear upsample of the logits)) -- the tensor
-// `valid_masks.half()` that the reference's roi_align reads (adapter.py:88-111) -- written in the same pass that finds the boxes
-// (one evaluation of the upsample per pixel instead of one in mask_bbox_kernel plus one per crop and source pixel in the crop
-// kernel: 2.8 + 0.5 ms -> 1.3 ms per 720p clip).  0.94 GB per 5-frame 720p clip; 8 consecutive pixels per lane = 16-byte stores.
-__global__ void __launch_bounds__(256)
-mask_bbox_soft_kernel(const float* __restrict__ masks, int* __restrict__ boxes, _Float16* __restrict__ soft, int Q, int T, int h, int w,
-                      int Hp, int Wp, int rows_per_blk) {
-  const int tq = blockIdx.y;              // t*Q + q
-  const int t = tq / Q, q = tq % Q;
-  const float* mp = masks + ((long long)q * T + t) * h * w;
-  _Float16* sp = soft + (long long)tq * Hp * Wp;
-  const float sy = (float)h / (float)Hp, sx = (float)w / (float)Wp;
-  const int y_begin = blockIdx.x * rows_per_blk, y_end = min(Hp, y_begin + rows_per_blk);
-  int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
-  for (int xb = threadIdx.x * 8; xb < Wp; xb += blockDim.x * 8) {      // Wp % 8 == 0 (padded to a multiple of 32)
-    Tap tx[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) tx[e] = make_tap(xb + e, sx, w);
-    for (int y = y_begin; y < y_end; ++y) {
-      const Tap ty = make_tap(y, sy, h);
-      union { _Float16 hv[8]; uint4 u; } o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float u = bilerp(mp, w, ty, tx[e]);
-        if (mask_on(u)) { x0 = min(x0, xb + e); x1 = max(x1, xb + e); y0 = min(y0, y); y1 = max(y1, y); }
-        o.hv[e] = (_Float16)fast_sigmoid(u);
-      }
-      *reinterpret_cast<uint4*>(sp + (long long)y * Wp + xb) = o.u;
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    x0 = min(x0, __shfl_xor(x0, o, 64)); y0 = min(y0, __shfl_xor(y0, o, 64));
-    x1 = max(x1, __shfl_xor(x1, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
-  }
-  if ((threadIdx.x & 63) == 0 && x1 >= 0) {
-    atomicMin(&boxes[tq * 4 + 0], x0); atomicMin(&boxes[tq * 4 + 1], y0);
-    atomicMax(&boxes[tq * 4 + 2], x1); atomicMax(&boxes[tq * 4 + 3], y1);
-  }
-}
-
 // =================================================================================================
 // A10 (second half): CLIP input crops.  adapter.py:96-116 + 140-143:
 //   square box [x0,y0,x0+s,y0+s], s = max(x1+1-x0, y1+1-y0); roi_align(frame) and roi_align(sigmoid mask)
@@ -499,9 +458,7 @@ constexpr int CROP_GMAX = 8;       // samples per bin and axis the tiled kernel 
 constexpr int CROP_WMAX = CROP_GMAX + 2;   // source pixels one bin can touch along an axis
 struct AxisW { short fbase, mbase, fn, mn; float fw[CROP_WMAX], mw[CROP_WMAX]; };
 
-// SOFT: `masks` is the fp16 soft-mask tensor [T,Q,Hp,Wp] of mask_bbox_soft_kernel instead of the low-res logits [Q,T,h,w]: staging a
-// source pixel is one 2-byte load instead of four gathers + bilerp + sigmoid.
-template <int TY, int TX, bool SOFT>
+template <int TY, int TX>
 __global__ void __launch_bounds__(TY * TX)
 clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ masks, const int* __restrict__ crops,
                        void* __restrict__ Av, unsigned char* __restrict__ patch_open, int out_f16, int M, int Q, int T, int H,
@@ -526,7 +483,6 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
   const uint8_t* fp = frames + (long long)t * 3 * H * W;
   const long long plane = (long long)H * W;
   const float* mp = masks + ((long long)q * T + t) * h * w;
-  const _Float16* sp = reinterpret_cast<const _Float16*>(masks) + ((long long)t * Q + q) * Hp * Wp;      // SOFT
   const float usy = (float)h / (float)Hp, usx = (float)w / (float)Wp;
 
   // source rectangle of this tile: sample coordinates are monotone in (bin index, sample index)
@@ -571,8 +527,7 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
       const uint8_t* frow = fp + (long long)(yin ? y : 0) * W;
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        if constexpr (SOFT) L.a[m] = (float)sp[(long long)y * Wp + min(xlo + lane + 64 * m, Wp - 1)];
-        else { L.a[m] = r0[txs[m].i0]; L.b[m] = r0[txs[m].i1]; L.c[m] = r1[txs[m].i0]; L.d[m] = r1[txs[m].i1]; }
+        L.a[m] = r0[txs[m].i0]; L.b[m] = r0[txs[m].i1]; L.c[m] = r1[txs[m].i0]; L.d[m] = r1[txs[m].i1];
         const int x = xlo + lane + 64 * m;
         const bool in = yin && x < W;
         const int xc = in ? x : 0;
@@ -585,11 +540,9 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         if (cin[m]) {
-          float sv;
-          if constexpr (SOFT) sv = L.a[m];
-          else sv = fast_sigmoid(L.ty.l0 * (txs[m].l0 * L.a[m] + txs[m].l1 * L.b[m]) +
-                                 L.ty.l1 * (txs[m].l0 * L.c[m] + txs[m].l1 * L.d[m]));                   // == sigmoid(bilerp())
-          patch[r * PWs + lane + 64 * m] = make_uint2(L.r[m] | (L.g[m] << 8) | (L.bl[m] << 16), __float_as_uint(sv));
+          const float u = L.ty.l0 * (txs[m].l0 * L.a[m] + txs[m].l1 * L.b[m]) +
+                          L.ty.l1 * (txs[m].l0 * L.c[m] + txs[m].l1 * L.d[m]);                            // == bilerp()
+          patch[r * PWs + lane + 64 * m] = make_uint2(L.r[m] | (L.g[m] << 8) | (L.bl[m] << 16), __float_as_uint(fast_sigmoid(u)));
         }
       }
     };
@@ -1037,8 +990,7 @@ extern "C" int ovis_mask_bbox(const float* masks, int* boxes, int Q, int T, int 
 
 static int clip_crop_impl(const uint8_t* frames, const float* masks, const int* crops, void* A, unsigned char* patch_open,
                           int out_f16, int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int resolution,
-                          int patch, long long lda, const float* mean3_host, const float* std3_host, ovis_stream_t stream,
-                          bool soft = false) {
+                          int patch, long long lda, const float* mean3_host, const float* std3_host, ovis_stream_t stream) {
   OVIS_REQUIRE(frames && masks && crops && A && mean3_host && std3_host, "clip_crop: null pointer");
   OVIS_REQUIRE(M > 0 && resolution > 0 && patch > 0 && resolution % patch == 0, "clip_crop: bad sizes");
   OVIS_REQUIRE(lda >= 3ll * patch * patch, "clip_crop: lda smaller than a patch row (3*patch*patch)");
@@ -1054,52 +1006,25 @@ static int clip_crop_impl(const uint8_t* frames, const float* masks, const int* 
     int dev = 0;
     OVIS_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "clip_crop: hipGetDevice failed");
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-      OVIS_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&clip_crop_tiled_kernel<16, 16, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 76 * 1024) == hipSuccess &&
-                   hipFuncSetAttribute(reinterpret_cast<const void*>(&clip_crop_tiled_kernel<16, 16, true>),
+      OVIS_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&clip_crop_tiled_kernel<16, 16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 76 * 1024) == hipSuccess,
                    "clip_crop: cannot raise the dynamic LDS limit");
       attr_set[dev].store(true, std::memory_order_release);
     }
-#define CROP_LAUNCH(TY_, S_, PD_, NT_) hipLaunchKernelGGL((clip_crop_tiled_kernel<TY_, TY_, S_>), dim3((unsigned)((long long)M * (resolution / TY_) * (resolution / TY_))), \
-      dim3(NT_), (size_t)PD_ * (PD_ + 1) * 8, (hipStream_t)stream, frames, masks, crops, A, patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, lda, \
-      PD_, PD_, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2])
-    if (soft) CROP_LAUNCH(16, true, p16, 256); else CROP_LAUNCH(16, false, p16, 256);
+    hipLaunchKernelGGL((clip_crop_tiled_kernel<16, 16>), dim3((unsigned)((long long)M * (resolution / 16) * (resolution / 16))), dim3(256),
+                       (size_t)p16 * (p16 + 1) * 8, (hipStream_t)stream, frames, masks, crops, A, patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
+                       resolution, patch, lda, p16, p16, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
   } else if (grid_ok && resolution % 8 == 0 && (size_t)p8 * (p8 + 1) * 8 <= 64 * 1024) {
-    if (soft) CROP_LAUNCH(8, true, p8, 64); else CROP_LAUNCH(8, false, p8, 64);
-#undef CROP_LAUNCH
+    hipLaunchKernelGGL((clip_crop_tiled_kernel<8, 8>), dim3((unsigned)((long long)M * (resolution / 8) * (resolution / 8))), dim3(64),
+                       (size_t)p8 * (p8 + 1) * 8, (hipStream_t)stream, frames, masks, crops, A, patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
+                       resolution, patch, lda, p8, p8, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
   } else {
-    OVIS_REQUIRE(!soft, "clip_crop (soft masks): box / resolution outside the tiled kernel's range");
     const long long total = (long long)M * resolution * resolution;
     hipLaunchKernelGGL(clip_crop_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, frames, masks, crops, A,
                        patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, lda, mean3_host[0], mean3_host[1], mean3_host[2],
                        std3_host[0], std3_host[1], std3_host[2]);
   }
   return ovis::check_launch("clip_crop");
-}
-
-extern "C" int ovis_mask_bbox_soft(const float* masks, int* boxes, void* soft_f16, int Q, int T, int h, int w, int Hp, int Wp,
-                                   ovis_stream_t stream) {
-  OVIS_REQUIRE(masks && boxes && soft_f16, "mask_bbox_soft: null pointer");
-  OVIS_REQUIRE(Q > 0 && T > 0 && h > 0 && w > 0 && Hp >= h && Wp >= w && Wp % 8 == 0, "mask_bbox_soft: bad sizes (Wp % 8 == 0)");
-  OVIS_REQUIRE((reinterpret_cast<uintptr_t>(soft_f16) & 15) == 0, "mask_bbox_soft: soft must be 16-byte aligned");
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(bbox_init_kernel, dim3(ovis::cdiv(T * Q * 4, 256)), dim3(256), 0, s, boxes, T * Q * 4);
-  const int rows_per_blk = 16;
-  hipLaunchKernelGGL(mask_bbox_soft_kernel, dim3(ovis::cdiv(Hp, rows_per_blk), T * Q), dim3(256), 0, s, masks, boxes,
-                     reinterpret_cast<_Float16*>(soft_f16), Q, T, h, w, Hp, Wp, rows_per_blk);
-  return ovis::check_launch("mask_bbox_soft");
-}
-
-extern "C" int ovis_clip_crop_patches_soft(const uint8_t* frames, const void* soft_f16, const int* crops, void* A, unsigned char* patch_open,
-                                           int out_f16, int M, int Q, int T, int H, int W, int Hp, int Wp, int resolution, int patch,
-                                           long long lda, const float* mean3_host, const float* std3_host, ovis_stream_t stream) {
-  if (patch_open) {
-    const int G = resolution / (patch > 0 ? patch : 1);
-    OVIS_REQUIRE(hipMemsetAsync(patch_open, 0, (size_t)M * G * G, (hipStream_t)stream) == hipSuccess, "clip_crop_patches_soft: memset failed");
-  }
-  return clip_crop_impl(frames, reinterpret_cast<const float*>(soft_f16), crops, A, patch_open, out_f16, M, Q, T, H, W, Hp / 4, Wp / 4, Hp, Wp,
-                        resolution, patch, lda, mean3_host, std3_host, stream, true);
 }
 
 extern "C" int ovis_clip_crop_patches(const uint8_t* frames, const float* masks, const int* crops, void* A, int out_f16,

@@ -210,50 +210,31 @@ class ClipAdapter:
         return torch.stack([self.text_cache[w] for w in noun_list]).contiguous()
 
     # ---- image side ------------------------------------------------------------------------
-    def preprocess_boxes(self, masks_lowres, Hp, Wp, soft=False):
+    def preprocess_boxes(self, masks_lowres, Hp, Wp):
         """valid flags + crop list from the mask logits (adapter.py:86-102). One small D2H copy, as the reference's
-        BitMasks.get_bounding_boxes host loop (adapter.py:94).  soft: also return the fp16 soft-mask tensor [T,Q,Hp,Wp]
-        (`valid_masks.half()`, adapter.py:88-111) written by the same pass."""
-        soft_t = None
-        if soft:
-            boxes_d, soft_t = ops.mask_bbox_soft(masks_lowres, Hp, Wp)
-        else:
-            boxes_d = ops.mask_bbox(masks_lowres, Hp, Wp)
-        boxes = boxes_d.cpu().numpy()                                         # [T,Q,4]
+        BitMasks.get_bounding_boxes host loop (adapter.py:94)."""
+        boxes = ops.mask_bbox(masks_lowres, Hp, Wp).cpu().numpy()             # [T,Q,4]
         valid = boxes[..., 2] >= 0                                            # [T,Q]
         tq = np.argwhere(valid)                                               # (t, q) lexicographic
         crops = np.concatenate([tq, boxes[valid]], axis=1).astype(np.int32) if len(tq) else np.zeros((0, 6), np.int32)
-        return (valid, crops, soft_t) if soft else (valid, crops)
+        return valid, crops
 
     def forward(self, frames, text, masks_lowres, padded_hw):
         """frames uint8 [T,3,H,W] (device); masks_lowres [Q,T,h,w] logits; returns (sim_logits [M,K] or None, valid [T,Q],
-        crops int32 [M,6]).  With fp16 tower operands (the reference's GPU dtype) the soft masks are materialised once in
-        fp16, exactly the tensor the reference crops from; the exact-f32 policy samples the f32 logits on the fly."""
+        crops int32 [M,6])."""
         Hp, Wp = padded_hw
-        use_soft = self.precision == "fp16" and Wp % 8 == 0 and Hp == 4 * masks_lowres.shape[2] and Wp == 4 * masks_lowres.shape[3]
-        if use_soft:
-            valid, crops, soft = self.preprocess_boxes(masks_lowres, Hp, Wp, soft=True)
-        else:
-            valid, crops = self.preprocess_boxes(masks_lowres, Hp, Wp)
+        valid, crops = self.preprocess_boxes(masks_lowres, Hp, Wp)
         if crops.shape[0] == 0:
             return None, valid, crops
         crops_d = torch.from_numpy(crops).to(self.device)
-        f16 = self.precision == "fp16"
         if self.mask_prompt_fwd:                                              # mask_adapted_adapter.py:68-69
-            if use_soft:
-                A, patch_open = ops.clip_crop_patches_soft(frames, soft, crops_d, self.input_resolution, self.arch["patch"],
-                                                           PIXEL_MEAN, PIXEL_STD, out_f16=f16, masked=True)
-            else:
-                A, patch_open = ops.clip_crop_patches_masked(frames, masks_lowres, crops_d, Hp, Wp, self.input_resolution,
-                                                             self.arch["patch"], PIXEL_MEAN, PIXEL_STD, out_f16=f16)
+            A, patch_open = ops.clip_crop_patches_masked(frames, masks_lowres, crops_d, Hp, Wp, self.input_resolution,
+                                                         self.arch["patch"], PIXEL_MEAN, PIXEL_STD,
+                                                         out_f16=(self.precision == "fp16"))
             feat = self.visual.forward_patches(A, crops.shape[0], patch_open)
         else:
-            if use_soft:
-                A = ops.clip_crop_patches_soft(frames, soft, crops_d, self.input_resolution, self.arch["patch"], PIXEL_MEAN,
-                                               PIXEL_STD, out_f16=f16)
-            else:
-                A = ops.clip_crop_patches(frames, masks_lowres, crops_d, Hp, Wp, self.input_resolution, self.arch["patch"],
-                                          PIXEL_MEAN, PIXEL_STD, out_f16=f16)
+            A = ops.clip_crop_patches(frames, masks_lowres, crops_d, Hp, Wp, self.input_resolution, self.arch["patch"],
+                                      PIXEL_MEAN, PIXEL_STD, out_f16=(self.precision == "fp16"))
             feat = self.visual.forward_patches(A, crops.shape[0])
         text_features = self.encode_text(text)
         feat = ops.l2norm_rows(feat, 100.0)                                   # normalize, then temperature (:144,146)

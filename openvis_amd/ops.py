@@ -400,31 +400,6 @@ def mask_bbox(masks, Hp, Wp):
     return boxes
 
 
-def mask_bbox_soft(masks, Hp, Wp):
-    """masks [Q,T,h,w] logits -> (boxes int32 [T,Q,4] as mask_bbox, soft fp16 [T,Q,Hp,Wp] = half(sigmoid(x4 upsample))): the
-    reference's `valid_masks.half()` (adapter.py:88-111), produced in the pass that finds the boxes."""
-    _chk(masks)
-    Q, T, h, w = masks.shape
-    boxes = torch.empty((T, Q, 4), dtype=torch.int32, device=masks.device)
-    soft = torch.empty((T, Q, Hp, Wp), dtype=torch.float16, device=masks.device)
-    _lib.call("ovis_mask_bbox_soft", masks, boxes, soft, Q, T, h, w, Hp, Wp, _lib.stream_ptr())
-    return boxes, soft
-
-
-def clip_crop_patches_soft(frames, soft, crops, resolution, patch, mean, std, out_f16=False, masked=False):
-    """Crops from the fp16 soft-mask tensor of mask_bbox_soft: patch matrix A (and, masked, patch_open uint8 [M, G*G])."""
-    _chk(frames, soft, crops)
-    T, _, H, W = frames.shape
-    _, Q, Hp, Wp = soft.shape
-    M = crops.shape[0]
-    G = resolution // patch
-    A = _patch_matrix(M * G * G, patch, out_f16, frames.device)
-    patch_open = torch.empty((M, G * G), dtype=torch.uint8, device=frames.device) if masked else None
-    _lib.call("ovis_clip_crop_patches_soft", frames, soft, crops, A, patch_open, int(out_f16), M, Q, T, H, W, Hp, Wp, resolution, patch,
-              _ll(A.shape[1]), _f3(mean), _f3(std), _lib.stream_ptr())
-    return (A, patch_open) if masked else A
-
-
 def clip_crop_patches(frames, masks, crops, Hp, Wp, resolution, patch, mean, std, out_f16=False):
     _chk(frames, masks, crops)
     T, _, H, W = frames.shape

@@ -360,32 +360,3 @@ def test_clip_patch14_tower_and_crops_vs_oracle(precision, tol):
         ref = 100.0 * feat @ text.T
     assert (valid == v2.numpy()).all()
     assert (logits.cpu() - ref).abs().max().item() < tol * 100, (logits.cpu() - ref).abs().max().item()
-
-
-def test_soft_mask_prepass_and_soft_crops_match_the_on_the_fly_path():
-    """ovis_mask_bbox_soft / ovis_clip_crop_patches_soft: the fp16 soft-mask tensor (adapter.py:88-111 `valid_masks.half()`) written by
-    the box pass, and the crop kernel that reads it, against the f32-logit path (boxes identical, soft == half(sigmoid(upsample)),
-    crop pixels within the fp16 rounding of the mask values)."""
-    from openvis_amd import ops
-    from openvis_amd.modeling.clip_adapter.adapter import PIXEL_MEAN, PIXEL_STD
-    g = torch.Generator().manual_seed(7)
-    T, Q, H, W, Hp, Wp = 2, 5, 150, 230, 160, 256
-    frames = (torch.rand(T, 3, H, W, generator=g) * 255).to(torch.uint8).cuda()
-    masks = (torch.randn(Q, T, Hp // 4, Wp // 4, generator=g) * 4).cuda()
-    masks[0] = -9.0
-    masks[0, :, 5:20, 8:40] = 7.0
-    boxes = ops.mask_bbox(masks, Hp, Wp)
-    boxes2, soft = ops.mask_bbox_soft(masks, Hp, Wp)
-    assert torch.equal(boxes, boxes2)
-    up = F.interpolate(masks.cpu(), size=(Hp, Wp), mode="bilinear", align_corners=False).sigmoid().transpose(0, 1)
-    assert (soft.cpu().float() - up).abs().max().item() < 6e-4                      # half rounding (+ fast sigmoid 1e-6)
-    bx = boxes.cpu().numpy()
-    ok = bx[..., 2] >= 0
-    crops = torch.from_numpy(np.concatenate([np.argwhere(ok), bx[ok]], axis=1).astype(np.int32)).cuda()
-    for f16 in (False, True):
-        a = ops.clip_crop_patches(frames, masks, crops, Hp, Wp, 64, 16, PIXEL_MEAN, PIXEL_STD, out_f16=f16)
-        b = ops.clip_crop_patches_soft(frames, soft, crops, 64, 16, PIXEL_MEAN, PIXEL_STD, out_f16=f16)
-        assert a.shape == b.shape and (a.float() - b.float()).abs().max().item() < (4e-3 if f16 else 2e-3)
-    _, po_a = ops.clip_crop_patches_masked(frames, masks, crops, Hp, Wp, 64, 16, PIXEL_MEAN, PIXEL_STD)
-    _, po_b = ops.clip_crop_patches_soft(frames, soft, crops, 64, 16, PIXEL_MEAN, PIXEL_STD, masked=True)
-    assert (po_a != po_b).float().mean().item() < 0.02                               # only bins whose mean sits at the fp16 underflow edge
