@@ -61,7 +61,7 @@ MODELS = {   # --model: META_ARCHITECTURE, decoder, weight spec, backbone, CLIP 
 }
 
 
-def build_model(device, seed=42, clip_precision="fp16", precision="mixed", model_name="openvis"):
+def build_model(device, seed=42, clip_precision="fp16", precision="mixed", model_name="openvis", f32_split="bf16x3"):
     from openvis_amd import config, weights
     from openvis_amd.catalog import MetadataCatalog
     from openvis_amd.modeling.clip_adapter.adapter import _CLIP_ARCH
@@ -83,6 +83,7 @@ def build_model(device, seed=42, clip_precision="fp16", precision="mixed", model
         cfg.MODEL.SWIN.EMBED_DIM, cfg.MODEL.SWIN.DEPTHS = a["embed_dim"], list(a["depths"])
         cfg.MODEL.SWIN.NUM_HEADS, cfg.MODEL.SWIN.WINDOW_SIZE = list(a["num_heads"]), a["window"]
     cfg.MODEL.PRECISION = precision
+    cfg.MODEL.F32_GEMM_SPLIT = f32_split
     model = config.build_model(cfg)
     model.device = torch.device(device)
     sd = weights.random_init(getattr(weights, m["spec"])(backbone, _CLIP_ARCH[clip], queries), seed=seed)
@@ -187,6 +188,8 @@ def main():
                     help="frame height (16:9); default 720, *_swinl models: 1080 (BASELINE.json configs[4])")
     ap.add_argument("--precision", default="mixed", choices=["mixed", "fp32"],
                     help="dense-path policy: mixed = the reference's autocast policy, fp32 = exact f32 everywhere")
+    ap.add_argument("--f32-split", default="bf16x3", choices=["bf16x3", "bf16x2", "f32"],
+                    help="MODEL.F32_GEMM_SPLIT: how large f32 GEMMs reach the MFMA (bf16x3 = f32-grade, the default)")
     args = ap.parse_args()
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != env_world:
@@ -204,7 +207,7 @@ def main():
     device = torch.device("cuda", 0 if rig else local_rank)
 
     from openvis_amd import ops
-    model, sd, text = build_model(device, clip_precision=args.clip_precision, precision=args.precision, model_name=args.model)
+    model, sd, text = build_model(device, clip_precision=args.clip_precision, precision=args.precision, model_name=args.model, f32_split=args.f32_split)
     frame_sharded = args.model.startswith("brivis") and world > 1
     T = args.frames or (36 if args.model.startswith("brivis") else T_CLIP)
     res = args.resolution or (1080 if args.model.endswith("_swinl") else 720)
@@ -414,7 +417,8 @@ def main():
                                      " (exact 3-way bf16 split on the bf16 MFMA)") + "; pixel decoder, masked-attention decoder, masks and "
                                      "logits f32; CLIP ViT GEMM operands " +
                                      ("fp16 with f32 accumulation (the reference's GPU CLIP dtype)" if _model.clip_adapter.precision == "fp16"
-                                      else "f32") + (f"; resampler {_model.resampler.precision}" if hasattr(_model, "resampler") else "")),
+                                      else "f32") + (f"; resampler {_model.resampler.precision}" if hasattr(_model, "resampler") else "")
+                                     + ("" if args.f32_split == "bf16x3" else f"; large f32 GEMMs: {args.f32_split} (MODEL.F32_GEMM_SPLIT, opt-in)")),
                        "valid_crops_per_clip": n_valid,
                        "parallelism": (f"frame-sharded x{world} + RCCL all-gather" if frame_sharded else f"clip-replicas x{world}")
                                       + (f", {args.streams} clips in flight per GPU (HIP streams)" if args.streams > 1 and not frame_sharded else "")},

@@ -73,6 +73,12 @@ def get_cfg():
             #   EITHER the backbone or the side adapter's ViT put every query below 0.999 (SANOnline 0.9866-0.9974, BriVIS
             #   0.9975-0.9987; tracks and logits are unaffected) -> backbone, side adapter and resampler run f32 operands.
             "BACKBONE_PRECISION": "auto", "RESAMPLER_PRECISION": "auto",
+            # not a reference key -- how a LARGE f32 GEMM/conv is put on the MFMA (csrc/gemm_f32x3.h; process-wide, applied by
+            # build_model): "bf16x3" (default) = the six-product split, f32-grade (rel. err ~1e-7); "bf16x2" = three products,
+            # 16 significand bits per operand (rel. err ~1e-5: 64 x finer than autocast's fp16 operands) for ~5 % of the step --
+            # opt-in; at 720p every query mask keeps the same IoU vs the f32 oracle (profiles/r02/bf16x2.txt); "f32" = the
+            # native f32 MFMA for every size.
+            "F32_GEMM_SPLIT": "bf16x3",
             "PIXEL_MEAN": [123.675, 116.280, 103.530], "PIXEL_STD": [58.395, 57.120, 57.375],
             "BACKBONE": {"NAME": "build_resnet_backbone", "FREEZE_AT": 0},
             "RESNETS": {"DEPTH": 50, "STRIDE_IN_1X1": False, "OUT_FEATURES": ["res2", "res3", "res4", "res5"],
@@ -123,11 +129,17 @@ def build_model(cfg):
     from . import openvis, san, brivis  # noqa: F401  (registers the meta-architectures)
     from .registry import META_ARCH_REGISTRY
     cls = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)
+    split = cfg.MODEL.get("F32_GEMM_SPLIT", "bf16x3")
+    if split not in F32_GEMM_SPLITS:
+        raise ValueError(f"MODEL.F32_GEMM_SPLIT must be one of {sorted(F32_GEMM_SPLITS)}, got {split!r}")
+    from . import ops
+    ops.set_f32_gemm_mode(F32_GEMM_SPLITS[split])
     model = cls(**cls.from_config(cfg))
     model.output_rle = bool(cfg.MODEL.MASK_FORMER.TEST.get("OUTPUT_RLE", False))
     return model
 
 
+F32_GEMM_SPLITS = {"f32": 0, "bf16x3": 1, "bf16x2": 2}
 SIDE_ADAPTER_ARCHS = ("SAN", "SANOnline", "BriVIS")
 
 

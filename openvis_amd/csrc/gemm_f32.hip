@@ -161,7 +161,7 @@ int launch_gemm(LoaderA la, const float* B, long long ldb, float* C, long long l
     hipLaunchKernelGGL((gemm_f32_kernel<BM_, BN_, LoaderA, VB_>), dim3(tm * tn, batch), dim3(256), 0, stream, la, B,  \
                        ldb, C, ldc, M, N, K, bias, R, ldr, act, tn, a_bs, b_bs, c_bs);                              \
   }
-  if (blocks128 >= 256 && vecb && g_f32_gemm_mode == 1) {
+  if (blocks128 >= 256 && vecb && g_f32_gemm_mode >= 1) {
     ovis::launch_gemm_f32x3(la, B, ldb, C, ldc, M, N, K, bias, R, ldr, act, stream, batch, a_bs, b_bs, c_bs);
   } else if (blocks128 >= 256) {
     if (vecb) GEMM_LAUNCH(128, 128, true) else GEMM_LAUNCH(128, 128, false)
@@ -174,8 +174,10 @@ int launch_gemm(LoaderA la, const float* B, long long ldb, float* C, long long l
 
 }  // namespace
 
+namespace ovis { int x3_planes() { return g_f32_gemm_mode == 2 ? 2 : 3; } }
+
 extern "C" int ovis_set_f32_gemm_mode(int mode) {
-  OVIS_REQUIRE(mode == 0 || mode == 1, "set_f32_gemm_mode: mode must be 0 (native f32 MFMA) or 1 (bf16x3 split)");
+  OVIS_REQUIRE(mode >= 0 && mode <= 2, "set_f32_gemm_mode: mode must be 0 (native f32 MFMA), 1 (bf16x3 split) or 2 (bf16x2: 3 products)");
   g_f32_gemm_mode = mode;
   return 0;
 }
@@ -240,7 +242,7 @@ extern "C" int ovis_gemm_nt_f32_w3(const float* A, long long lda, const float* B
   const bool veca = (K % 8 == 0) && ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0) && ldb % 8 == 0 && (((uintptr_t)W3 & 15) == 0) &&
                     plane % 8 == 0;
   const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128);
-  if (!(veca && blocks128 >= 256 && g_f32_gemm_mode == 1))           // small / unaligned / exact-chain mode: the f32 copy
+  if (!(veca && blocks128 >= 256 && g_f32_gemm_mode >= 1))           // small / unaligned / exact-chain mode: the f32 copy
     return ovis_gemm_nt_f32(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, stream);
   OVIS_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldb >= K && ldc >= N && act >= 0 && act <= 3 && (!residual || ldr >= N),
                "gemm_nt_f32_w3: bad sizes");
@@ -258,7 +260,7 @@ extern "C" int ovis_conv2d_nhwc_f32_w3(const float* x, const float* w, const voi
   const long long blocks128 = ovis::cdiv(M, 128) * (long long)ovis::cdiv(Cout, 128);
   const bool ok = Cin % 4 == 0 && K % 8 == 0 && (((uintptr_t)x | (uintptr_t)w3) & 15) == 0 && plane % 8 == 0 && OH > 0 && OW > 0 &&
                   M < (1ll << 31);
-  if (!(ok && blocks128 >= 256 && g_f32_gemm_mode == 1))
+  if (!(ok && blocks128 >= 256 && g_f32_gemm_mode >= 1))
     return ovis_conv2d_nhwc_f32(x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act, stream);
   OVIS_REQUIRE(act >= 0 && act <= 3, "conv2d_nhwc_f32_w3: unknown activation %d", act);
   ConvA la{x, ConvGeom{H, W, Cin, OH, OW, KH, KW, stride, pad}, (int)M, K};

@@ -51,15 +51,18 @@ struct PlanesB {
   __device__ __forceinline__ void advance(long long elems) { P += elems; }
 };
 
-template <int BM, int BN, typename LoaderA, typename LoaderB = DenseA<true>>
+// NP = 3: the six products above (f32-grade).  NP = 2 ("bf16x2"): planes 0 and 1 only and the three products a1 b0, a0 b1, a0 b0:
+// both operands are then carried with 16 significand bits (relative error 2^-17 = 7.6e-6 per operand -- 64 x finer than the fp16
+// operands of autocast, 32 x finer than the TF32 cuDNN uses for the reference's f32 convolutions by default) at half the MFMA work.
+template <int BM, int BN, typename LoaderA, typename LoaderB = DenseA<true>, int NP = 3>
 __global__ void __launch_bounds__(256)
 gemm_f32x3_kernel(LoaderA la, LoaderB lb, float* __restrict__ C, long long ldc, int M, int N, int K,
                   const float* __restrict__ bias, const float* __restrict__ R, long long ldr, int act, int tiles_n,
                   long long a_bs, long long b_bs, long long c_bs) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_IT = BM / 64, B_IT = BN / 64;   // thread stages rows srow + 64 i, 8 consecutive k each
-  __shared__ __attribute__((aligned(16))) __bf16 As[3][BM * X3_ROW];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[3][BN * X3_ROW];
+  __shared__ __attribute__((aligned(16))) __bf16 As[NP][BM * X3_ROW];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[NP][BN * X3_ROW];
 
   if (gridDim.y > 1) {
     la.advance((long long)blockIdx.y * a_bs);
@@ -97,7 +100,7 @@ gemm_f32x3_kernel(LoaderA la, LoaderB lb, float* __restrict__ C, long long ldc, 
         const __bf16* p = lb.P + (okb[i][0] ? (long long)n * lb.ldb + k : 0);
         qb[i].p0 = *reinterpret_cast<const uint4*>(p);
         qb[i].p1 = *reinterpret_cast<const uint4*>(p + lb.plane);
-        qb[i].p2 = *reinterpret_cast<const uint4*>(p + 2 * lb.plane);
+        if constexpr (NP == 3) qb[i].p2 = *reinterpret_cast<const uint4*>(p + 2 * lb.plane);
       }
     }
   };
@@ -111,7 +114,7 @@ gemm_f32x3_kernel(LoaderA la, LoaderB lb, float* __restrict__ C, long long ldc, 
         const bool ok = okb[i][0];
         sb[i].p0 = make_uint4(ok ? qb[i].p0.x : 0u, ok ? qb[i].p0.y : 0u, ok ? qb[i].p0.z : 0u, ok ? qb[i].p0.w : 0u);
         sb[i].p1 = make_uint4(ok ? qb[i].p1.x : 0u, ok ? qb[i].p1.y : 0u, ok ? qb[i].p1.z : 0u, ok ? qb[i].p1.w : 0u);
-        sb[i].p2 = make_uint4(ok ? qb[i].p2.x : 0u, ok ? qb[i].p2.y : 0u, ok ? qb[i].p2.z : 0u, ok ? qb[i].p2.w : 0u);
+        if constexpr (NP == 3) sb[i].p2 = make_uint4(ok ? qb[i].p2.x : 0u, ok ? qb[i].p2.y : 0u, ok ? qb[i].p2.z : 0u, ok ? qb[i].p2.w : 0u);
       }
     }
   };
@@ -121,14 +124,14 @@ gemm_f32x3_kernel(LoaderA la, LoaderB lb, float* __restrict__ C, long long ldc, 
       const int o = (srow + i * 64) * X3_ROW + scol;
       *reinterpret_cast<uint4*>(&As[0][o]) = sa[i].p0;
       *reinterpret_cast<uint4*>(&As[1][o]) = sa[i].p1;
-      *reinterpret_cast<uint4*>(&As[2][o]) = sa[i].p2;
+      if constexpr (NP == 3) *reinterpret_cast<uint4*>(&As[2][o]) = sa[i].p2;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int o = (srow + i * 64) * X3_ROW + scol;
       *reinterpret_cast<uint4*>(&Bs[0][o]) = sb[i].p0;
       *reinterpret_cast<uint4*>(&Bs[1][o]) = sb[i].p1;
-      *reinterpret_cast<uint4*>(&Bs[2][o]) = sb[i].p2;
+      if constexpr (NP == 3) *reinterpret_cast<uint4*>(&Bs[2][o]) = sb[i].p2;
     }
   };
 
@@ -145,9 +148,9 @@ gemm_f32x3_kernel(LoaderA la, LoaderB lb, float* __restrict__ C, long long ldc, 
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0};   // six products, smallest first
   constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
   auto mma_step = [&](int s) {
-    x3_bf16x8 af[3][TM], bf[3][TN];
+    x3_bf16x8 af[NP][TM], bf[NP][TN];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NP; ++p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
         af[p][i] = *reinterpret_cast<const x3_bf16x8*>(&As[p][(wr * (BM / 2) + i * 32 + r32) * X3_ROW + h * 16 + s * 8]);
@@ -157,7 +160,7 @@ gemm_f32x3_kernel(LoaderA la, LoaderB lb, float* __restrict__ C, long long ldc, 
     }
     // the (i,j) loop is innermost so consecutive MFMAs hit different accumulators
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = (NP == 3 ? 0 : 3); t < 6; ++t)                 // NP == 2: a1 b0, a0 b1, a0 b0
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -191,11 +194,17 @@ gemm_f32x3_kernel(LoaderA la, LoaderB lb, float* __restrict__ C, long long ldc, 
   }
 }
 
+int x3_planes();   // gemm_f32.hip: 3 (f32-grade, default) or 2 ("bf16x2", ovis_set_f32_gemm_mode(2))
+
 template <typename LoaderA>
 inline void launch_gemm_f32x3(LoaderA la, const float* B, long long ldb, float* C, long long ldc, int M, int N, int K,
                               const float* bias, const float* R, long long ldr, int act, hipStream_t stream, int batch,
                               long long a_bs, long long b_bs, long long c_bs) {
   const int tm = cdiv(M, 128), tn = cdiv(N, 128);
+  if (x3_planes() == 2)
+    hipLaunchKernelGGL((gemm_f32x3_kernel<128, 128, LoaderA, DenseA<true>, 2>), dim3(tm * tn, batch), dim3(256), 0, stream, la,
+                       DenseA<true>{B, ldb, N, K}, C, ldc, M, N, K, bias, R, ldr, act, tn, a_bs, b_bs, c_bs);
+  else
   hipLaunchKernelGGL((gemm_f32x3_kernel<128, 128, LoaderA>), dim3(tm * tn, batch), dim3(256), 0, stream, la,
                      DenseA<true>{B, ldb, N, K}, C, ldc, M, N, K, bias, R, ldr, act, tn, a_bs, b_bs, c_bs);
 }
@@ -205,6 +214,10 @@ template <typename LoaderA>
 inline void launch_gemm_f32x3_w3(LoaderA la, const void* W3, long long ldb, long long plane, float* C, long long ldc, int M, int N,
                                  int K, const float* bias, const float* R, long long ldr, int act, hipStream_t stream) {
   const int tm = cdiv(M, 128), tn = cdiv(N, 128);
+  if (x3_planes() == 2)
+    hipLaunchKernelGGL((gemm_f32x3_kernel<128, 128, LoaderA, PlanesB, 2>), dim3(tm * tn, 1), dim3(256), 0, stream, la,
+                       PlanesB{(const __bf16*)W3, ldb, plane, N, K}, C, ldc, M, N, K, bias, R, ldr, act, tn, 0ll, 0ll, 0ll);
+  else
   hipLaunchKernelGGL((gemm_f32x3_kernel<128, 128, LoaderA, PlanesB>), dim3(tm * tn, 1), dim3(256), 0, stream, la,
                      PlanesB{(const __bf16*)W3, ldb, plane, N, K}, C, ldc, M, N, K, bias, R, ldr, act, tn, 0ll, 0ll, 0ll);
 }

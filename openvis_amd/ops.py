@@ -21,7 +21,7 @@ _F32_GEMM_MODE = 1
 
 def _gemm_variant(M, N, loader, K=4, batch=1):
     big = ((M + 127) // 128) * ((N + 127) // 128) * batch >= 256       # mirrors launch_gemm() in csrc/gemm_f32.hip
-    if big and _F32_GEMM_MODE == 1 and K % 4 == 0:
+    if big and _F32_GEMM_MODE >= 1 and K % 4 == 0:
         return f"gemm_f32x3_kernel<128,128,{loader}>"
     return f"gemm_f32_kernel<{'128,128' if big else '64,64'},{loader}>"
 
@@ -97,7 +97,7 @@ def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None, cw
                       _lib.stream_ptr())
         return out.view(*a.shape[:-1], N)
     with _Prof(_gemm_variant(M, N, "DenseA", K), 2.0 * M * N * K):
-        if cw and w.is_contiguous() and K % 8 == 0 and _F32_GEMM_MODE == 1 and ((M + 127) // 128) * ((N + 127) // 128) >= 256:
+        if cw and w.is_contiguous() and K % 8 == 0 and _F32_GEMM_MODE >= 1 and ((M + 127) // 128) * ((N + 127) // 128) >= 256:
             _lib.call("ovis_gemm_nt_f32_w3", a2, _ll(K), w, _ll(K), w3_of(w), _ll(w.numel()), out, _ll(N), M, N, K, bias, r2,
                       _ll(N), act, _lib.stream_ptr())
         else:
@@ -237,7 +237,7 @@ def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE, w
                       _lib.stream_ptr())
         return y
     with _Prof(_gemm_variant(N * OH * OW, Cout, "ConvA", KH * KW * Cin), 2.0 * N * OH * OW * Cout * KH * KW * Cin):
-        if cw and (KH * KW * Cin) % 8 == 0 and _F32_GEMM_MODE == 1:
+        if cw and (KH * KW * Cin) % 8 == 0 and _F32_GEMM_MODE >= 1:
             _lib.call("ovis_conv2d_nhwc_f32_w3", x, w, w3_of(w), _ll(w.numel()), y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias,
                       residual, act, _lib.stream_ptr())
         else:

@@ -1,7 +1,7 @@
 """GPU: BASELINE.json configs[1] -- the bench workload itself (openvis_R50, 720x1280 frames, 100 queries, the full
 architecture with ViT-B/16 @224) under the bench's precision policy (reference autocast restatement: "mixed" dense path +
 f32 decoder + fp16 CLIP operands), on a 2-frame clip so that the CPU oracle finishes in seconds: mask IoU >= 0.999 against the f32 oracle,
-valid flags, CLIP logits, final masks (case C2)."""
+valid flags, CLIP logits over the bench's 482 classes, final masks (case C2)."""
 import numpy as np
 import pytest
 import torch
@@ -15,7 +15,7 @@ def test_c2_720p_clip_under_the_bench_policy_matches_oracle():
     from openvis_amd.catalog import MetadataCatalog
     from oracle import torch_ref as TR
 
-    K, T = 40, 2
+    K, T = 482, 2                                           # the bench's label space (burst_val size)
     sd = weights.random_init(weights.openvis_spec("r50", None, 100), seed=42)
     cfg = config.get_cfg()                                   # defaults = what bench.py runs
     assert cfg.MODEL.PRECISION == "mixed" and cfg.MODEL.CLIP_ADAPTER.PRECISION == "fp16"

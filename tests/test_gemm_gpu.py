@@ -97,6 +97,30 @@ def test_large_gemm_bf16x3_split_is_f32_grade(gemm_modes, M, N, K):
     assert errs[1] <= 2.0 * errs[0] + 1e-8, errs
 
 
+def test_large_gemm_bf16x2_opt_in_carries_16_operand_bits(gemm_modes):
+    # MODEL.F32_GEMM_SPLIT "bf16x2" (mode 2): three products of the two leading bf16 planes -- operands rounded to 16
+    # significand bits (2^-17 relative each), products and sums in f32: error between the f32 grade and 1e-4 of fp16 operands
+    ops = gemm_modes
+    M, N, K = 96600, 256, 256
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, 1, generator=g))
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    ac, wc = a.cuda(), w.cuda()
+    ref = ac.double() @ wc.double().T
+    row_scale = ac.double().abs() @ wc.double().abs().T
+    errs = {}
+    for mode in (1, 2):
+        ops.set_f32_gemm_mode(mode)
+        errs[mode] = ((ops.gemm_nt(ac, wc).double() - ref).abs() / row_scale).max().item()
+    assert errs[1] < 2e-6 and 2e-6 < errs[2] < 2 * 2.0 ** -17, errs
+    # integers below 2^16 are exact in two planes
+    ai = (torch.arange(70000 * 72).reshape(70000, 72) % 251 - 125).float()
+    wi = (torch.arange(130 * 72).reshape(130, 72) % 97 - 48).float()
+    assert torch.equal(ops.gemm_nt(ai.cuda(), wi.cuda()).cpu(), (ai.double() @ wi.double().T).float())
+    with pytest.raises(Exception):
+        ops.set_f32_gemm_mode(3)
+
+
 def test_large_gemm_bf16x3_integer_exact(gemm_modes):
     ops = gemm_modes
     M, N, K = 70000, 130, 72
