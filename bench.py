@@ -61,7 +61,7 @@ MODELS = {   # --model: META_ARCHITECTURE, decoder, weight spec, backbone, CLIP 
 }
 
 
-def build_model(device, seed=42, clip_precision="fp16", precision="mixed", model_name="openvis", f32_split="bf16x3"):
+def build_model(device, seed=42, clip_precision="fp16", precision="mixed", model_name="openvis", f32_split="auto"):
     from openvis_amd import config, weights
     from openvis_amd.catalog import MetadataCatalog
     from openvis_amd.modeling.clip_adapter.adapter import _CLIP_ARCH
@@ -188,8 +188,9 @@ def main():
                     help="frame height (16:9); default 720, *_swinl models: 1080 (BASELINE.json configs[4])")
     ap.add_argument("--precision", default="mixed", choices=["mixed", "fp32"],
                     help="dense-path policy: mixed = the reference's autocast policy, fp32 = exact f32 everywhere")
-    ap.add_argument("--f32-split", default="bf16x3", choices=["bf16x3", "bf16x2", "f32"],
-                    help="MODEL.F32_GEMM_SPLIT: how large f32 GEMMs reach the MFMA (bf16x3 = f32-grade, the default)")
+    ap.add_argument("--f32-split", default="auto", choices=["auto", "bf16x3", "bf16x2", "f32"],
+                    help="MODEL.F32_GEMM_SPLIT: how large f32 GEMMs reach the bf16 MFMA (auto: bf16x2 under --precision mixed, "
+                         "the f32-grade bf16x3 under fp32)")
     args = ap.parse_args()
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != env_world:
@@ -207,6 +208,7 @@ def main():
     device = torch.device("cuda", 0 if rig else local_rank)
 
     from openvis_amd import ops
+    f32_split = args.f32_split if args.f32_split != "auto" else ("bf16x3" if args.precision == "fp32" else "bf16x2")
     model, sd, text = build_model(device, clip_precision=args.clip_precision, precision=args.precision, model_name=args.model, f32_split=args.f32_split)
     frame_sharded = args.model.startswith("brivis") and world > 1
     T = args.frames or (36 if args.model.startswith("brivis") else T_CLIP)
@@ -301,8 +303,9 @@ def main():
     dom = (kbase + "<*>" if len(members) > 1 else next(iter(members)), None)
     achieved = flops / secs / 1e12
     iso = fam_iso.get(kbase, (n_launch, flops, secs))
-    if "f32x3" in kbase:      # f32 product = 6 bf16 MFMA products of the exact 3-way split: ceiling = bf16 peak / 6
-        peak, peak_note = round(PEAK_F16_MFMA_TFLOPS / 6.0, 1), "bf16 dense MFMA peak / 6 (six bf16 products per f32 product)"
+    if "f32x3" in kbase:      # one f32 product = 6 (bf16x3) or 3 (bf16x2) bf16 MFMA products: ceiling = bf16 peak / that
+        nprod = 3 if f32_split == "bf16x2" else 6
+        peak, peak_note = round(PEAK_F16_MFMA_TFLOPS / nprod, 1), f"bf16 dense MFMA peak / {nprod} ({f32_split}: {nprod} bf16 products per f32 product)"
     elif "f16" in kbase:
         peak, peak_note = PEAK_F16_MFMA_TFLOPS, "fp16 dense MFMA peak"
     else:
@@ -328,6 +331,35 @@ def main():
         v = pmc.get(_norm(name))
         if v is None and "<" not in name:                     # un-templated kernels: prefix match
             v = next((x for k, x in pmc.items() if k.startswith(_norm(name))), None)
+        if v is None and "<" in name:
+            # the bench label names <BM,BN,LoaderA>; rocprofv3 also prints the B loader / plane count (and the ovis:: scope):
+            # launch-weighted mean over the instantiations that share the label's template arguments
+            def _targs(k):
+                k = k.replace("ovis::", "")
+                if "<" not in k:
+                    return k, []
+                b, rest = k.split("<", 1)
+                out, depth, cur = [], 0, ""
+                for ch in rest[:rest.rfind(">")]:
+                    if ch == "," and depth == 0:
+                        out.append(cur)
+                        cur = ""
+                        continue
+                    depth += ch == "<"
+                    depth -= ch == ">"
+                    cur += ch
+                return b, out + [cur]
+            base, targs = _targs(_norm(name))
+            hits = []
+            for k, x in pmc.items():
+                b, ta = _targs(k)
+                if b == base and len(ta) >= len(targs) and all(a.startswith(t) for a, t in zip(ta, targs)):
+                    hits.append(x)
+            if hits:
+                nl = sum(h["launches"] for h in hits)
+                v = {f: round(sum(h[f] * h["launches"] for h in hits) / nl) for f in
+                     ("hbm_bytes_per_launch", "fetch_bytes_per_launch", "write_bytes_per_launch")}
+                v["launches"] = nl
         return v
 
     # per launch like `achieved`: launch-weighted mean over the instantiations
@@ -351,7 +383,10 @@ def main():
                 "instantiations": {k: {"launches_per_step": v[0] // n_situ, "avg_launch_ms": round(v[2] / v[0] * 1e3, 4),
                                        "gflop_per_launch": round(v[1] / v[0] / 1e9, 2), "achieved": round(v[1] / v[2] / 1e12, 1),
                                        "frac": round(v[1] / v[2] / 1e12 / peak, 4),
-                                       "traffic": (_pmc_lookup(k) or {}).get("hbm_bytes_per_launch")}
+                                       "traffic": (_pmc_lookup(k) or {}).get("hbm_bytes_per_launch"),
+                                       # PMC bytes / this launch time: how close the instantiation sits to the HBM roof instead
+                                       "traffic_gbps": (round((_pmc_lookup(k) or {}).get("hbm_bytes_per_launch") / (v[2] / v[0]) / 1e9, 1)
+                                                        if (_pmc_lookup(k) or {}).get("hbm_bytes_per_launch") else None)}
                                    for k, v in sorted(members.items(), key=lambda kv: -kv[1][2])},
                 "all_gemm_kernels": {k: {"launches": v[0], "ms": round(v[2] * 1e3, 3), "TFLOPs": round(v[1] / v[2] / 1e12, 1)}
                                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])},
@@ -418,7 +453,7 @@ def main():
                                      "logits f32; CLIP ViT GEMM operands " +
                                      ("fp16 with f32 accumulation (the reference's GPU CLIP dtype)" if _model.clip_adapter.precision == "fp16"
                                       else "f32") + (f"; resampler {_model.resampler.precision}" if hasattr(_model, "resampler") else "")
-                                     + ("" if args.f32_split == "bf16x3" else f"; large f32 GEMMs: {args.f32_split} (MODEL.F32_GEMM_SPLIT, opt-in)")),
+                                     + f"; large f32 GEMMs/convs as {f32_split} on the bf16 MFMA (MODEL.F32_GEMM_SPLIT)"),
                        "valid_crops_per_clip": n_valid,
                        "parallelism": (f"frame-sharded x{world} + RCCL all-gather" if frame_sharded else f"clip-replicas x{world}")
                                       + (f", {args.streams} clips in flight per GPU (HIP streams)" if args.streams > 1 and not frame_sharded else "")},

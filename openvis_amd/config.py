@@ -73,12 +73,17 @@ def get_cfg():
             #   EITHER the backbone or the side adapter's ViT put every query below 0.999 (SANOnline 0.9866-0.9974, BriVIS
             #   0.9975-0.9987; tracks and logits are unaffected) -> backbone, side adapter and resampler run f32 operands.
             "BACKBONE_PRECISION": "auto", "RESAMPLER_PRECISION": "auto",
-            # not a reference key -- how a LARGE f32 GEMM/conv is put on the MFMA (csrc/gemm_f32x3.h; process-wide, applied by
-            # build_model): "bf16x3" (default) = the six-product split, f32-grade (rel. err ~1e-7); "bf16x2" = three products,
-            # 16 significand bits per operand (rel. err ~1e-5: 64 x finer than autocast's fp16 operands) for ~5 % of the step --
-            # opt-in; at 720p every query mask keeps the same IoU vs the f32 oracle (profiles/r02/bf16x2.txt); "f32" = the
-            # native f32 MFMA for every size.
-            "F32_GEMM_SPLIT": "bf16x3",
+            # not a reference key -- how a LARGE f32 GEMM/conv is put on the bf16 MFMA (csrc/gemm_f32x3.h; process-wide, applied
+            # by build_model):
+            #   "bf16x3" = six products of the exact 3-way bf16 split, f32-grade (rel. err ~1e-7);
+            #   "bf16x2" = three products of the two leading planes: 16 significand bits per operand (rel. err < 2^-16, 64 x
+            #              finer than autocast's fp16 operands, 32 x finer than the TF32 the reference's f32 convolutions get
+            #              from cuDNN by default), products and sums in f32, half the MFMA work;
+            #   "f32"    = the native f32 MFMA (an fmaf chain) for every size;
+            #   "auto"   = "bf16x2" under MODEL.PRECISION "mixed", "bf16x3" under "fp32".  Measured at 720p against the f32
+            #              oracle (profiles/r02/bf16x2.txt): per-query mask IoU min 0.99928 vs 0.99927 (OpenVIS), 0.99964 vs
+            #              0.99988 (SANOnline), tracks identical, cosine error unchanged at 2e-7 -- for 5 % of the step.
+            "F32_GEMM_SPLIT": "auto",
             "PIXEL_MEAN": [123.675, 116.280, 103.530], "PIXEL_STD": [58.395, 57.120, 57.375],
             "BACKBONE": {"NAME": "build_resnet_backbone", "FREEZE_AT": 0},
             "RESNETS": {"DEPTH": 50, "STRIDE_IN_1X1": False, "OUT_FEATURES": ["res2", "res3", "res4", "res5"],
@@ -129,17 +134,26 @@ def build_model(cfg):
     from . import openvis, san, brivis  # noqa: F401  (registers the meta-architectures)
     from .registry import META_ARCH_REGISTRY
     cls = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)
-    split = cfg.MODEL.get("F32_GEMM_SPLIT", "bf16x3")
+    split = f32_gemm_split(cfg)
     if split not in F32_GEMM_SPLITS:
         raise ValueError(f"MODEL.F32_GEMM_SPLIT must be one of {sorted(F32_GEMM_SPLITS)}, got {split!r}")
-    from . import ops
-    ops.set_f32_gemm_mode(F32_GEMM_SPLITS[split])
     model = cls(**cls.from_config(cfg))
+    model.f32_gemm_mode = F32_GEMM_SPLITS[split]          # applied at the start of every forward (VideoMaskFormer._frames_to_device)
     model.output_rle = bool(cfg.MODEL.MASK_FORMER.TEST.get("OUTPUT_RLE", False))
     return model
 
 
 F32_GEMM_SPLITS = {"f32": 0, "bf16x3": 1, "bf16x2": 2}
+
+
+def f32_gemm_split(cfg):
+    """MODEL.F32_GEMM_SPLIT with "auto" resolved (see get_cfg)."""
+    split = cfg.MODEL.get("F32_GEMM_SPLIT", "auto")
+    if split == "auto":
+        return "bf16x3" if cfg.MODEL.get("PRECISION", "mixed") == "fp32" else "bf16x2"
+    return split
+
+
 SIDE_ADAPTER_ARCHS = ("SAN", "SANOnline", "BriVIS")
 
 

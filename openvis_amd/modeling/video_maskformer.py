@@ -44,10 +44,17 @@ class VideoMaskFormer:
     def eval(self):
         return self
 
+    f32_gemm_mode = None      # MODEL.F32_GEMM_SPLIT resolved by config.build_model (None: leave the library's setting alone)
+
     def _frames_to_device(self, batched_inputs):
         """list of T uint8 [3,H,W] -> one uint8 [T,3,H,W] device tensor (openvis.py:57-60).  Host frames are copied
         frame by frame straight into the device tensor (async from pinned memory, e.g. DataLoader(pin_memory=True)): no
-        host-side torch.stack pass (a 13.8 MB memcpy per 720p clip) and no pageable staging copy."""
+        host-side torch.stack pass (a 13.8 MB memcpy per 720p clip) and no pageable staging copy.
+
+        First call of every forward: also (re)applies this model's f32-GEMM split, a process-wide library setting, so that
+        a model's results never depend on which model ran before it."""
+        if self.f32_gemm_mode is not None and ops.f32_gemm_mode() != self.f32_gemm_mode:
+            ops.set_f32_gemm_mode(self.f32_gemm_mode)
         frames = [f for video in batched_inputs for f in video["image"]]
         f0 = frames[0]
         if any(f.dtype != torch.uint8 for f in frames):

@@ -53,8 +53,13 @@ def _chk(*ts):
             raise _lib.OvisError("openvis_amd ops need contiguous HIP device tensors (no CPU fallback)")
 
 
+def f32_gemm_mode():
+    return _F32_GEMM_MODE
+
+
 def set_f32_gemm_mode(mode):
-    """0: native f32 MFMA for every f32 GEMM/conv; 1 (default): large problems use the exact bf16x3 split (gemm_f32x3.h)."""
+    """0: native f32 MFMA for every f32 GEMM/conv; 1 (library default): large problems use the exact bf16x3 split (gemm_f32x3.h);
+    2: the same kernel with the two leading planes only (bf16x2, three products).  Process-wide (MODEL.F32_GEMM_SPLIT)."""
     global _F32_GEMM_MODE
     _lib.call("ovis_set_f32_gemm_mode", int(mode))
     _F32_GEMM_MODE = int(mode)

@@ -15,9 +15,10 @@ import json
 import sys
 
 
-def short(k):
-    k = k.replace("(anonymous namespace)::", "").replace("void ", "")
-    return k.split("(")[0][:90]
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_traffic import short            # noqa: E402  (demangles the names rocprofv3 leaves mangled)
 
 
 if __name__ == "__main__":

@@ -6,6 +6,7 @@ exactly half of the bytes of a wide coalesced read stream -> doubled here (state
 import collections
 import csv
 import glob
+import os
 import json
 import sys
 
@@ -19,7 +20,54 @@ def load(d, name):
     return acc
 
 
+def demangle(k):
+    """rocprofv3 leaves kernels with _Float16 parameters mangled (binutils' c++filt does not know DF16_ either): decode the
+    name and its template arguments -- integers, bools and (possibly templated) struct names are all this library uses."""
+    if not k.startswith("_ZN12_GLOBAL__N_1"):
+        return k
+    pos = len("_ZN12_GLOBAL__N_1")
+
+    def ident(p):
+        n = 0
+        while k[p].isdigit():
+            n, p = n * 10 + int(k[p]), p + 1
+        return k[p:p + n], p + n
+
+    def targs(p):                                  # at 'I'
+        out, p = [], p + 1
+        while k[p] != "E":
+            if k[p] == "L":                        # literal: Li128E / Lb1E
+                q = k.index("E", p)
+                out.append(("true" if k[p + 2:q] == "1" else "false") if k[p + 1] == "b" else k[p + 2:q])
+                p = q + 1
+            elif k[p] == "N":                      # nested name N4ovis6DenseAI...EE
+                p += 1
+                parts = []
+                while k[p] != "E":
+                    if k[p] == "I":
+                        a, p = targs(p)
+                        parts[-1] += "<" + ", ".join(a) + ">"
+                    else:
+                        nm, p = ident(p)
+                        parts.append(nm)
+                out.append("::".join(parts))
+                p += 1
+            else:
+                raise ValueError(k)
+        return out, p + 1
+
+    try:
+        name, pos = ident(pos)
+        if k[pos] == "I":
+            a, pos = targs(pos)
+            name += "<" + ", ".join(a) + ">"
+        return name
+    except (ValueError, IndexError):
+        return k
+
+
 def short(k):
+    k = demangle(k)
     k = k.replace("(anonymous namespace)::", "").replace("void ", "")
     return k.split("(")[0][:90]
 

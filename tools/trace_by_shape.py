@@ -6,13 +6,15 @@ import os
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_traffic import demangle
+
 d, out = sys.argv[1], sys.argv[2]
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 agg = defaultdict(lambda: [0, 0])
 for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"]
-        name = name[:110]
+        name = demangle(r["Kernel_Name"]).replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:110]
         key = (name, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")), r.get("LDS_Block_Size", ""))
         a = agg[key]
         a[0] += 1
