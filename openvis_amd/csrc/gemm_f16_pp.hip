@@ -48,6 +48,7 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 #include <hip/hip_fp16.h>
+#include <mutex>
 #include <type_traits>
 
 namespace {
@@ -74,6 +75,7 @@ struct PPArgs {
   int desync_ns;                            // start offset spread over the workgroups that own one tile fewer (ns)
   int dbg;                                  // lab only: 1 = skip the epilogue stores, 2 = skip the epilogue arithmetic too, 4 = nt stores, 8 = per-workgroup desync
   unsigned long long* stamps;               // lab only: s_memrealtime stamps [workgroup][tile iteration < 16][2 groups][4]
+  void* dump;                               // 2 KB scratch that the masked lanes of edge tiles store to (never read)
 };
 
 #define PP_GLDS(src, dst) \
@@ -141,6 +143,13 @@ gemm_f16_pp_kernel(const PPArgs p) {
     t.bm = __builtin_amdgcn_readfirstlane(hi.x); t.bml = __builtin_amdgcn_readfirstlane(hi.y);
     t.bn = __builtin_amdgcn_readfirstlane(hi.z); t.bnl = __builtin_amdgcn_readfirstlane(hi.w);
     return t;
+  };
+
+  // 8 consecutive bias values (columns col .. col + 7) from LDS.  Inline asm for the same reason as tile_entry: in front of an
+  // ordinary LDS load of the bias hipcc waits for vmcnt(0) -- every store of the epilogue and both K steps of the next tile.
+  auto bias8 = [&](int col, f32x4& b0, f32x4& b1) {
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(lds + PP_BIAS) + col * 4;
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b0), "=&v"(b1) : "v"(addr) : "memory");
   };
 
   // ---- DMA sources: a lane-constant byte offset per (half-tile, 8-row group) + a wave-uniform tile base ----
@@ -244,13 +253,22 @@ gemm_f16_pp_kernel(const PPArgs p) {
 
   // ---- epilogue of one tile: a lane owns one output row per 16-row block and 8 consecutive columns per column pair ----
   constexpr int ESZ = OUT == 0 ? 4 : 2;
+  const unsigned lane_c = (unsigned)(((long long)(wr * 128 + l15) * p.ldc + wc * 64 + 8 * q) * ESZ);
   // Row block outer, column pair inner: the two 64-byte halves of a 128-byte line come from CONSECUTIVE store instructions.
   // (Column pair outer -- the halves 8 instructions apart -- measured 5-6 % slower on the whole GEMM: partial-line writes.)
   auto epilogue_rows = [&](auto pred_tag, int bm, int bml, int bn, int bnl) {
     constexpr bool PRED = decltype(pred_tag)::value;                 // edge tile: mask the rows / columns of the neighbour tile
     const int row0 = bml + wr * 128 + l15, col0 = bnl + wc * 64 + 8 * q;
-    char* cp = reinterpret_cast<char*>(p.C) + ((long long)row0 * p.ldc + col0) * ESZ;
-    const long long row_step = 16 * p.ldc * ESZ;
+    // wave-uniform tile base + 32-bit lane offset (one VGPR live across the K loop; 256 rows of C stay far below 4 GB)
+    char* cp = reinterpret_cast<char*>(p.C) + ((long long)bml * p.ldc + bnl) * ESZ;
+    if (p.dbg & 32) cp = reinterpret_cast<char*>(p.C) + (long long)((blockIdx.x & 7) * 256) * p.ldc * ESZ;   // lab: every tile of a workgroup stores to the same 256 rows (L2-resident)
+    const unsigned row_step = (unsigned)(16 * p.ldc * ESZ);
+    unsigned lane_off = lane_c;
+    asm volatile("" : "+v"(lane_off));                               // opaque: the per-row offsets are not worth 16 registers across the K loop
+    // Every store below must be ISSUED by every wavefront, with at least one active lane: the counted vmcnt waits of the K loop
+    // count them as younger operations.  Masked lanes of an edge tile therefore write to the library's dump buffer instead of
+    // being switched off (a wavefront whose lanes are all masked would otherwise skip the instruction).
+    char* dump = reinterpret_cast<char*>(p.dump) + lane * 32;
     auto act4 = [&](f32x4& x) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -271,16 +289,18 @@ gemm_f16_pp_kernel(const PPArgs p) {
     auto put = [&](int mb, int j) {
       f32x4 x0 = acc[mb][2 * j], x1 = acc[mb][2 * j + 1];
       if constexpr (X3) {                                            // bias / residual enter here, not as the accumulators' start value
-        x0 += *reinterpret_cast<const f32x4*>(lds + PP_BIAS + (col0 + 32 * j) * 4);
-        x1 += *reinterpret_cast<const f32x4*>(lds + PP_BIAS + (col0 + 32 * j) * 4 + 16);
+        f32x4 b0, b1;
+        bias8(col0 + 32 * j, b0, b1);
+        x0 += b0; x1 += b1;
         if constexpr (HAS_R) {
           x0 += *reinterpret_cast<const f32x4*>(rp + (long long)mb * 16 * p.ldr + 32 * j);
           x1 += *reinterpret_cast<const f32x4*>(rp + (long long)mb * 16 * p.ldr + 32 * j + 4);
         }
       }
       act4(x0); act4(x1);
-      char* c = cp + mb * row_step + j * 32 * ESZ;
-      const bool ok = !PRED || (col0 + 32 * j >= bn && row0 + mb * 16 >= bm);
+      char* c = cp + (lane_off + (unsigned)mb * row_step + (unsigned)(j * 32 * ESZ));
+      if constexpr (PRED) { if (!(col0 + 32 * j >= bn && row0 + mb * 16 >= bm)) c = dump; }
+      constexpr bool ok = true;
       if constexpr (OUT == 1) {
         const uint4 o = pack8(x0, x1);
         if (p.dbg & 1) asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
@@ -296,11 +316,10 @@ gemm_f16_pp_kernel(const PPArgs p) {
           const __bf16 a1 = (__bf16)r1;
           h0[e] = a0; h1[e] = a1; h2[e] = (__bf16)(r1 - (float)a1);
         }
-        if (ok) {
-          *reinterpret_cast<bf16x8*>(c) = h0;
-          *reinterpret_cast<bf16x8*>(c + p.planeC) = h1;
-          *reinterpret_cast<bf16x8*>(c + 2 * p.planeC) = h2;
-        }
+        const long long pc = (PRED && c == dump) ? 0 : p.planeC;
+        *reinterpret_cast<bf16x8*>(c) = h0;
+        *reinterpret_cast<bf16x8*>(c + pc) = h1;
+        *reinterpret_cast<bf16x8*>(c + 2 * pc) = h2;
       } else {
         if (p.dbg & 1) asm volatile("" :: "v"(x0[0]), "v"(x0[3]), "v"(x1[0]), "v"(x1[3]));
         else if (ok) { *reinterpret_cast<f32x4*>(c) = x0; *reinterpret_cast<f32x4*>(c + 16) = x1; }
@@ -322,21 +341,25 @@ gemm_f16_pp_kernel(const PPArgs p) {
       const float* rp = p.R + (long long)(bml + wr * 128 + l15) * p.ldr + bnl + wc * 64 + 8 * q;
       const int col0 = bnl + wc * 64 + 8 * q;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j) {
+        f32x4 bv[2];
+        bias8(col0 + 32 * j, bv[0], bv[1]);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(lds + PP_BIAS + (col0 + 32 * j + 4 * e) * 4);
+        for (int e = 0; e < 2; ++e)
 #pragma unroll
           for (int mb = 0; mb < 8; ++mb)
-            acc[mb][2 * j + e] = *reinterpret_cast<const f32x4*>(rp + (long long)mb * 16 * p.ldr + 32 * j + 4 * e) + bv;
-        }
+            acc[mb][2 * j + e] = *reinterpret_cast<const f32x4*>(rp + (long long)mb * 16 * p.ldr + 32 * j + 4 * e) + bv[e];
+      }
     } else {                                                         // accumulators start at the bias: nothing to add in the epilogue
       const int col0 = bnl + wc * 64 + 8 * q;
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(lds + PP_BIAS + (col0 + 32 * (nb >> 1) + 4 * (nb & 1)) * 4);
+      for (int j = 0; j < 2; ++j) {
+        f32x4 bv[2];
+        bias8(col0 + 32 * j, bv[0], bv[1]);
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb) acc[mb][nb] = bv;
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int mb = 0; mb < 8; ++mb) acc[mb][2 * j + e] = bv[e];
       }
     }
   };
@@ -358,16 +381,18 @@ gemm_f16_pp_kernel(const PPArgs p) {
   constexpr int NS = OUT == 1 ? 16 : OUT == 2 ? 48 : (HAS_R ? 53 : 32);   // vm ops of one epilogue (+ residual loads) per lane; 10 + NS <= 63
 #define PP_WAIT(n_first, n_later) do { if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_first) : "memory"); \
                                        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_later) : "memory"); } while (0)
+#define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
+  // vm ops YOUNGER than the half-tile a wait is for (8 = four half-tiles), per K step of the tile; NS = the previous
+  // epilogue's stores, which sit behind the early-issued B1/A1 of K step 1:
+  //   kt = 0: (phase 1: in the tile transition below), 8 + NS, 8 + NS;   kt = 1: 8 + NS, 8 + NS, 8;   kt >= 2: 8
+  // (the first tile of a workgroup has no stores in front of it: PP_WAIT's first argument)
+  static_assert(10 + NS <= 63, "vmcnt is a 6-bit field");
   unsigned s = 0;                                                    // global K step counter (buffer = s & 1)
   { const PPTile t = tile_entry(0); acc_init(t.bml, t.bnl); }
   for (int it = 0; it < n_my; ++it) {
     unsigned long long* st = (p.stamps && it < 16 && (wave & 3) == 0 && lane == 0) ? p.stamps + ((blockIdx.x * 16 + it) * 2 + wr) * 4 : nullptr;
     if (st) st[0] = __builtin_amdgcn_s_memrealtime();
     unsigned long long* ks = (st && it >= 2 && it < 6) ? p.stamps + 256 * 16 * 2 * 4 + (blockIdx.x * 2 + wr) * 64 + (it - 2) * 16 : nullptr;
-
-    // vm ops YOUNGER than the half-tile a wait is for (8 = four half-tiles), per K step of the tile; NS = the previous
-    // epilogue's stores, which sit behind the early-issued B1/A1 of K step 1:
-    //   kt = 0: (phase 1: in the tile transition below), 8 + NS, 8 + NS;   kt = 1: 8 + NS, 8 + NS, 8;   kt >= 2: 8
     for (int kt = 0; kt < nk; ++kt, ++s) {
       const unsigned cur = (s & 1) * PP_BUF, oth = PP_BUF - cur;
       // ---- phase 1: quadrant (0,0) ----
@@ -375,7 +400,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
         read_b(cur + 2 * PP_HT, 0, bf0);
         read_a(cur, 0);
         issue_b1(oth);
-        if (kt == 1) PP_WAIT(8, 8 + NS); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (kt == 1) PP_WAIT(8, 8 + NS); else PP_VMCNT(8);
         PP_BARRIER();
       }
       mma(0, 0, bf0);
@@ -383,7 +408,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
       // ---- phase 2: quadrant (0,1) ----
       read_b(cur + 2 * PP_HT, 1, bf1);
       if (kt) issue_a1(oth);
-      if (kt < 2) PP_WAIT(8, 8 + NS); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (kt < 2) PP_WAIT(8, 8 + NS); else PP_VMCNT(8);
       PP_BARRIER();
       mma(0, 1, bf1);
       if (kt) advance1();
@@ -396,7 +421,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
       PP_BARRIER();
       // ---- phase 4: quadrant (1,0), no LDS reads ----
       issue_b0(cur);
-      if (kt == 0) PP_WAIT(8, 8 + NS); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (kt == 0) PP_WAIT(8, 8 + NS); else PP_VMCNT(8);
       PP_BARRIER();
       mma(1, 0, bf0);
       advance2();
@@ -406,8 +431,8 @@ gemm_f16_pp_kernel(const PPArgs p) {
     if (st) st[1] = __builtin_amdgcn_s_memrealtime();
 
     // ---- tile transition.  B1 / A1 of the next tile's K step 1 go out first (slots of buffer (s+1) & 1: last read 2 and 3
-    // phases ago), i.e. BEFORE this wavefront's stores.  G0 then waits one slot for G1's last MFMAs so that BOTH groups run
-    // their epilogue in the same slot (a wavefront issues a 1-KB store every ~100 ns whatever the others do: two groups
+    // phases ago), i.e. BEFORE this wavefront's (remaining) stores.  G0 then waits one slot for G1's last MFMAs so that BOTH
+    // groups run their epilogue in the same slot (a wavefront issues a 1-KB store every ~100 ns whatever the others do: two groups
     // storing one after the other cost twice the time); G1 reads its phase 1 under G0's first MFMAs of the next tile.
     const PPTile t = tile_entry(it);
     const int bm = t.bm, bn = t.bn, bml = t.bml, bnl = t.bnl;        // rows / columns this tile owns (stores) and computed (shifted edge tiles)
@@ -430,12 +455,23 @@ gemm_f16_pp_kernel(const PPArgs p) {
       const unsigned cur = (s & 1) * PP_BUF;
       read_b(cur + 2 * PP_HT, 0, bf0);
       read_a(cur, 0);
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(10 + NS) : "memory");   // B1 of the next tile's K step 0: 5 younger half-tiles + the epilogue
+      PP_VMCNT(10 + NS);                                             // B1 of the next tile's K step 0: 5 younger half-tiles + the epilogue
     }
     PP_BARRIER();
   }
   if (wr == 0) PP_BARRIER();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// One 4 KB device buffer per device, allocated at the first launch there and kept for the life of the process.
+void* pp_dump_buffer() {
+  static void* buf[64] = {};
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!buf[dev] && hipMalloc(&buf[dev], 4096) != hipSuccess) buf[dev] = nullptr;
+  return buf[dev];
 }
 
 int g_f16_gemm_mode = 1;          // 1: ping-pong kernel for eligible problems, 0: gemm_f16_256_kernel (gemm_f16.hip)
@@ -475,6 +511,8 @@ int gemm_f16_pp_launch(const void* A, long long lda, const void* B, long long ld
   // an XCD spread over 24 us de-phases the bursts (+4 % out-proj, +1.5 % fc2; -1 % on the fp16-output shapes, hence only here)
   p.desync_ns = g_pp_desync_ns >= 0 ? g_pp_desync_ns : (residual ? 24000 : 0);
   p.dbg = g_pp_dbg; p.stamps = g_pp_stamps;
+  p.dump = pp_dump_buffer();
+  if (!p.dump) return fail(OVIS_EINVAL, "gemm_nt_f16 (ping-pong): cannot allocate the 4 KB dump buffer");
   const int grid = p.n_tiles < 256 ? p.n_tiles : 256;              // one persistent workgroup per CU (MI355X: 256 CUs)
   p.planeA = p.planeB = p.planeC = 0;
 #define PP_LAUNCH(O, A_, R_) hipLaunchKernelGGL((gemm_f16_pp_kernel<O, A_, R_, false>), dim3(grid), dim3(512), 0, s, p)
@@ -545,6 +583,8 @@ extern "C" int ovis_gemm_nt_bf16x3_planes(const void* A3, long long lda, long lo
   const int groups = (int)ovis::cdiv(p.tiles_n, g_pp_grp > 0 ? g_pp_grp : p.tiles_n);
   p.grp_w = p.tiles_n / groups; p.grp_rem = p.tiles_n % groups;
   p.desync_ns = g_pp_desync_ns > 0 ? g_pp_desync_ns : 0; p.dbg = g_pp_dbg; p.stamps = g_pp_stamps;
+  p.dump = pp_dump_buffer();
+  OVIS_REQUIRE(p.dump, "gemm_nt_bf16x3_planes: cannot allocate the 4 KB dump buffer");
   const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
   hipStream_t s = (hipStream_t)stream;
 #define PP_LAUNCH(O, A_, R_) hipLaunchKernelGGL((gemm_f16_pp_kernel<O, A_, R_, true>), dim3(grid), dim3(512), 0, s, p)
