@@ -65,6 +65,14 @@ class VideoMaskFormer:
         if all(f.is_cuda for f in frames):
             return torch.stack(frames).to(self.device).contiguous()
         x = torch.empty((len(frames),) + tuple(f0.shape), dtype=torch.uint8, device=self.device)
+        nb = f0.numel()
+        if (not f0.is_cuda and all(f.is_contiguous() and f.untyped_storage().data_ptr() == f0.untyped_storage().data_ptr()
+                                   and f.storage_offset() == f0.storage_offset() + i * nb for i, f in enumerate(frames))):
+            # the frames are consecutive slices of ONE host buffer (a collated / stacked clip): one copy instead of T -- every
+            # async copy costs the host ~0.1 ms of launch latency during which the GPU has nothing queued (tools/trace_gaps.py)
+            whole = torch.empty(0, dtype=torch.uint8).set_(f0.untyped_storage(), f0.storage_offset(), x.shape)
+            x.copy_(whole, non_blocking=True)
+            return x
         for i, f in enumerate(frames):
             x[i].copy_(f, non_blocking=True)
         return x
@@ -112,13 +120,25 @@ class VideoMaskFormer:
                 return {"image_size": (output_height, output_width), "pred_entropys": ent.cpu().tolist(),
                         "pred_scores": score.cpu().tolist(), "pred_labels": [i % K for i in idx.cpu().tolist()],
                         "pred_masks": [], "pred_queries": sel_q.cpu().tolist()}
-        # D2H of the 10 output masks (video_maskformer.py:283): pinned staging buffer from torch's caching host
-        # allocator + one async copy; uint8 {0,1} is re-viewed as bool (no host-side conversion pass).
-        host = torch.empty(masks.shape, dtype=torch.uint8, pin_memory=True)
-        host.copy_(masks, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        masks_cpu = host.view(torch.bool)
-        labels = [i % K for i in idx.cpu().tolist()]                          # video_maskformer.py:269-270
-        return {"image_size": (output_height, output_width), "pred_entropys": ent.cpu().tolist(),
-                "pred_scores": score.cpu().tolist(), "pred_labels": labels, "pred_masks": [m for m in masks_cpu],
-                "pred_queries": sel_q.cpu().tolist()}
+        # D2H of the 10 output masks and of the top-10 scalars (video_maskformer.py:267-283): pinned staging buffers from torch's
+        # caching host allocator, async copies on the hand-off side stream behind the last kernel; uint8 {0,1} is re-viewed as
+        # bool (no host-side conversion pass).  Nobody waits here: the VideoOutput does when a field is read (output.py).
+        from ..output import VideoOutput, copy_stream
+        cur, side = torch.cuda.current_stream(), copy_stream(masks.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            host = torch.empty(masks.shape, dtype=torch.uint8, pin_memory=True)
+            host.copy_(masks, non_blocking=True)
+            small = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (idx, score, ent, sel_q)]
+            for h_, t in zip(small, (idx, score, ent, sel_q)):
+                h_.copy_(t, non_blocking=True)
+                t.record_stream(side)
+            masks.record_stream(side)
+            done = torch.cuda.Event()
+            done.record(side)
+
+        def finish():
+            i_, s_, e_, q_ = (h_.tolist() for h_ in small)
+            return {"pred_entropys": e_, "pred_scores": s_, "pred_labels": [i % K for i in i_],      # video_maskformer.py:269-270
+                    "pred_masks": [m for m in host.view(torch.bool)], "pred_queries": q_}
+        return VideoOutput({"image_size": (output_height, output_width)}, done, finish)

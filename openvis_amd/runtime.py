@@ -70,4 +70,7 @@ class ClipPipeline:
         for e in done:
             if e is not None:
                 torch.cuda.current_stream().wait_event(e)
+        for o in outs:                                  # deferred device -> host hand-off (output.py): complete on return
+            if hasattr(o, "wait"):
+                o.wait()
         return outs
