@@ -89,9 +89,17 @@ struct PPArgs {
 //      (planes [3][rows][ld]); the K loop runs over the six plane pairs (a2 b0, a0 b2, a1 b1, a1 b0, a0 b1, a0 b0: smallest terms
 //      first) x K, i.e. this is the same kernel on a K axis of 6 K -- the split costs no VALU work in the loop.  Accumulators start
 //      at zero and bias / residual are added in the epilogue (an O(1) start value would cost the f32-grade error bound).
-template <int OUT, int ACT, bool HAS_R, bool X3>
+// FA : "f32 A" mode (round 2; bf16x2 of gemm_f32x3.h on this schedule): A is the f32 activation matrix itself, DMA'd as f32 (a K
+//      step is 32 floats = the same 128-byte LDS rows, same swizzle); B are the two leading bf16 planes of the constant weight
+//      (64-byte rows, 16 rows per DMA instruction, plane 0 / plane 1 of a wavefront's 16 rows side by side: a fragment read is a
+//      linear 1 KB -> conflict-free without a swizzle).  A wavefront reads its f32 fragment (8 consecutive k per lane), splits it
+//      into hi / lo bf16 in registers (3 VALU per element) and issues the three products a1 b0, a0 b1, a0 b0 -- no split pass over
+//      A in memory, no plane stores to LDS, and the DMA pipeline / barrier protocol / vmcnt accounting of the fp16 kernel unchanged
+//      (every half-tile is still two DMA instructions per wavefront).
+template <int OUT, int ACT, bool HAS_R, bool X3, bool FA = false>
 __global__ void __launch_bounds__(512)
 gemm_f16_pp_kernel(const PPArgs p) {
+  static_assert(!(FA && X3) && (!FA || OUT == 0), "f32-A mode: f32 output, no plane walking");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[PP_LDS];   // ONE LDS object (a second one de-pipelines the DMA)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -99,7 +107,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
   const int wr = wave >> 2, wc = wave & 3;
   const int l15 = lane & 15, q = lane >> 4, sw = l15 >> 1;
   const int nblk = gridDim.x;
-  const int nk1 = p.K >> 6;                                        // K steps of one plane pair
+  const int nk1 = FA ? p.K >> 5 : p.K >> 6;                        // K steps of one plane pair (FA: 32 floats per step)
   const int nk = X3 ? 6 * nk1 : nk1;
 
   // logical tile index -> (m tile, n tile): column groups of <= grp_w + 1 N tiles, M-panel-major inside a group; the 32
@@ -126,7 +134,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
     tile_mn(first + i * nblk, tm, tn);
     PPTile t;
     t.bm = tm * 256; t.bn = tn * 256; t.bml = min(t.bm, p.M - 256); t.bnl = min(t.bn, p.N - 256);
-    t.a_off = (long long)t.bml * p.lda * 2; t.b_off = (long long)t.bnl * p.ldb * 2;
+    t.a_off = (long long)t.bml * p.lda * (FA ? 4 : 2); t.b_off = (long long)t.bnl * p.ldb * 2;
     *reinterpret_cast<PPTile*>(lds + PP_TAB + i * 32) = t;
   }
   __syncthreads();
@@ -163,41 +171,78 @@ gemm_f16_pp_kernel(const PPArgs p) {
     const int i16 = 8 * g + dr;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      voA[h][g] = (unsigned)((long long)(wr * 128 + h * 64 + 16 * (wave & 3) + i16) * p.lda * 2 + c * 16);          // half-tile row 64 wr + 16 (wave&3) + i16
-      voB[h][g] = (unsigned)((long long)((wave >> 1) * 64 + 32 * h + 8 * (i16 >> 2) + 4 * (wave & 1) + (i16 & 3)) * p.ldb * 2 + c * 16);
+      voA[h][g] = (unsigned)((long long)(wr * 128 + h * 64 + 16 * (wave & 3) + i16) * p.lda * (FA ? 4 : 2) + c * 16);   // half-tile row 64 wr + 16 (wave&3) + i16
+      if constexpr (FA) {     // instruction g = plane g; 16 rows x 64 B: lane -> (row lane>>2, 16-byte chunk lane&3)
+        const int r16 = lane >> 2;
+        voB[h][g] = (unsigned)(g * p.planeB + (long long)((wave >> 1) * 64 + 32 * h + 8 * (r16 >> 2) + 4 * (wave & 1) + (r16 & 3)) * p.ldb * 2 + (lane & 3) * 16);
+      } else {
+        voB[h][g] = (unsigned)((long long)((wave >> 1) * 64 + 32 * h + 8 * (i16 >> 2) + 4 * (wave & 1) + (i16 & 3)) * p.ldb * 2 + c * 16);
+      }
     }
   }
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Bb = reinterpret_cast<const char*>(p.B);
   unsigned char* dma_dst = lds + wave * 2048;                      // + buffer + half-tile + g * 1024
-  auto issue = [&](const char* base, const unsigned (&off)[2], int kt, int dst_off) {
-    PP_GLDS(base + off[0] + kt * 128, dma_dst + dst_off);
-    PP_GLDS(base + off[1] + kt * 128, dma_dst + dst_off + 1024);
+  constexpr int B_STEP = FA ? 64 : 128;                            // bytes of one K step in a B row (A: 128 in every mode)
+  auto issue = [&](const char* base, const unsigned (&off)[2], int kbytes, int dst_off) {
+    PP_GLDS(base + off[0] + kbytes, dma_dst + dst_off);
+    PP_GLDS(base + off[1] + kbytes, dma_dst + dst_off + 1024);
   };
   // ---- fragment read addresses -----------------------------------------------------------------------------
-  const unsigned rd0 = (unsigned)(l15 * 128 + ((q ^ sw) << 4));    // k block 0; k block 1 = ^ 64
+  const unsigned rd0 = FA ? (unsigned)(l15 * 128 + (((2 * q) ^ sw) << 4))      // floats 8q .. 8q+3 of the row; 8q+4 .. 8q+7 = ^ 16
+                          : (unsigned)(l15 * 128 + ((q ^ sw) << 4));            // k block 0; k block 1 = ^ 64
   const unsigned a_rd = rd0 + wr * 64 * 128;
-  const unsigned b_rd = rd0 + wc * 32 * 128;                      // callers add the B0 slot (2 * PP_HT)
+  const unsigned b_rd = FA ? (unsigned)(wc * 2 * 2048 + l15 * 64 + q * 16)      // + e * 2048 + plane * 1024
+                           : rd0 + wc * 32 * 128;                               // callers add the B0 slot (2 * PP_HT)
 
   f32x4 acc[8][4];
-  f16x8 af[4][2], bf0[2][2], bf1[2][2];
+  f16x8 af[4][2], bf0[2][2], bf1[2][2];                            // FA: second index = bf16 plane (0 hi, 1 lo) instead of k block
   auto read_a = [&](unsigned buf, int i) {
+    if constexpr (FA) {
+      using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-      af[mb][0] = *reinterpret_cast<const f16x8*>(lds + buf + i * PP_HT + mb * 2048 + a_rd);
-      af[mb][1] = *reinterpret_cast<const f16x8*>(lds + buf + i * PP_HT + mb * 2048 + (a_rd ^ 64));
+      for (int mb = 0; mb < 4; ++mb) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(lds + buf + i * PP_HT + mb * 2048 + a_rd);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(lds + buf + i * PP_HT + mb * 2048 + (a_rd ^ 16));
+        bf16x8 h0, h1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = e < 4 ? x0[e & 3] : x1[e & 3];
+          const __bf16 a0 = (__bf16)v;
+          h0[e] = a0; h1[e] = (__bf16)(v - (float)a0);
+        }
+        af[mb][0] = __builtin_bit_cast(f16x8, h0); af[mb][1] = __builtin_bit_cast(f16x8, h1);
+      }
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        af[mb][0] = *reinterpret_cast<const f16x8*>(lds + buf + i * PP_HT + mb * 2048 + a_rd);
+        af[mb][1] = *reinterpret_cast<const f16x8*>(lds + buf + i * PP_HT + mb * 2048 + (a_rd ^ 64));
+      }
     }
   };
   auto read_b = [&](unsigned buf, int j, f16x8 (&bf)[2][2]) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       bf[e][0] = *reinterpret_cast<const f16x8*>(lds + buf + j * PP_HT + e * 2048 + b_rd);
-      bf[e][1] = *reinterpret_cast<const f16x8*>(lds + buf + j * PP_HT + e * 2048 + (b_rd ^ 64));
+      bf[e][1] = *reinterpret_cast<const f16x8*>(lds + buf + j * PP_HT + e * 2048 + (FA ? b_rd + 1024 : (b_rd ^ 64)));
     }
   };
   auto mma = [&](int i, int j, const f16x8 (&bf)[2][2]) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (FA) {
+      using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+      constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};        // a1 b0, a0 b1, a0 b0: smallest terms first
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            acc[i * 4 + mb][j * 2 + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, bf[e][PB2[t]]), __builtin_bit_cast(bf16x8, af[mb][PA2[t]]), acc[i * 4 + mb][j * 2 + e], 0, 0, 0);
+    } else {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -212,6 +257,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
             acc[i * 4 + mb][j * 2 + e] =
                 __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[e][kb], af[mb][kb], acc[i * 4 + mb][j * 2 + e], 0, 0, 0);
           }
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -238,10 +284,10 @@ gemm_f16_pp_kernel(const PPArgs p) {
   auto advance1 = [&]() { advance(c1); };
   auto advance2 = [&]() { advance(c2); };
   // (past the last tile the cursors keep re-loading the last tile's rows into slots nobody reads: the vmcnt counts stay uniform)
-  auto issue_b1 = [&](unsigned buf) { issue(c1.b, voB[1], c1.k, buf + 3 * PP_HT); };
-  auto issue_a1 = [&](unsigned buf) { issue(c1.a, voA[1], c1.k, buf + 1 * PP_HT); };
-  auto issue_a0 = [&](unsigned buf) { issue(c2.a, voA[0], c2.k, buf + 0 * PP_HT); };
-  auto issue_b0 = [&](unsigned buf) { issue(c2.b, voB[0], c2.k, buf + 2 * PP_HT); };
+  auto issue_b1 = [&](unsigned buf) { issue(c1.b, voB[1], c1.k * B_STEP, buf + 3 * PP_HT); };
+  auto issue_a1 = [&](unsigned buf) { issue(c1.a, voA[1], c1.k * 128, buf + 1 * PP_HT); };
+  auto issue_a0 = [&](unsigned buf) { issue(c2.a, voA[0], c2.k * 128, buf + 0 * PP_HT); };
+  auto issue_b0 = [&](unsigned buf) { issue(c2.b, voB[0], c2.k * B_STEP, buf + 2 * PP_HT); };
 
   if (p.desync_ns > 0) {
     // lab knob: start offsets (dbg bit 3 clear: the 32 workgroups of every XCD spread over [0, desync_ns); set: whole XCDs)
@@ -526,6 +572,42 @@ int gemm_f16_pp_launch(const void* A, long long lda, const void* B, long long ld
   }
 #undef PP_LAUNCH
   return check_launch("gemm_nt_f16 (ping-pong)");
+}
+
+// ---- f32-A mode (bf16x2): A f32 [M,K], W as bf16 planes [>=2][N][ldb] (the first two of ovis_split_f32_to_bf16x3) ----
+bool gemm_f32a_pp_eligible(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C, long long ldc,
+                           int M, int N, int K, const float* bias, const float* residual, long long ldr, int act) {
+  if (act != 0 && act != 1) return false;
+  const long long tiles_n = cdiv(N, 256), blocks256 = (long long)cdiv(M, 256) * tiles_n;
+  if (blocks256 < 256 || blocks256 > 256ll * PP_MAX_TILES || M < 256 || N < 256) return false;
+  if (tiles_n * 256 * 100 > (long long)N * 115) return false;           // > 15 % of the columns computed for nothing (N = 288: 78 %)
+  if (K % 32 != 0 || K < 64 || N % 8 != 0) return false;
+  if (lda % 4 != 0 || ldb % 8 != 0 || plane % 8 != 0 || ldc % 4 != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W3) | reinterpret_cast<uintptr_t>(C)) & 15) return false;
+  if (256 * lda * 4 >= (1ll << 31) || plane * 2 + 256 * ldb * 2 >= (1ll << 31)) return false;           // 32-bit DMA offsets inside a tile
+  if (bias && (N > PP_MAX_BIAS_N || (reinterpret_cast<uintptr_t>(bias) & 15))) return false;
+  if (residual && ((ldr % 4 != 0) || (reinterpret_cast<uintptr_t>(residual) & 15))) return false;
+  return true;
+}
+
+int gemm_f32a_pp_launch(const float* A, long long lda, const void* W3, long long ldb, long long plane, float* C, long long ldc, int M, int N,
+                        int K, const float* bias, const float* residual, long long ldr, int act, hipStream_t s) {
+  PPArgs p;
+  p.A = reinterpret_cast<const _Float16*>(A); p.B = reinterpret_cast<const _Float16*>(W3); p.C = C; p.bias = bias; p.R = residual;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.M = M; p.N = N; p.K = K; p.act = act;
+  p.planeA = 0; p.planeB = plane * 2; p.planeC = 0;                  // bytes
+  p.tiles_m = (int)cdiv(M, 256); p.tiles_n = (int)cdiv(N, 256); p.n_tiles = p.tiles_m * p.tiles_n;
+  const int groups = (int)cdiv(p.tiles_n, g_pp_grp > 0 ? g_pp_grp : p.tiles_n);
+  p.grp_w = p.tiles_n / groups; p.grp_rem = p.tiles_n % groups;
+  p.desync_ns = g_pp_desync_ns > 0 ? g_pp_desync_ns : 0; p.dbg = g_pp_dbg; p.stamps = g_pp_stamps;
+  p.dump = pp_dump_buffer();
+  if (!p.dump) return fail(OVIS_EINVAL, "gemm_nt_f32 (ping-pong, f32 A): cannot allocate the 4 KB dump buffer");
+  const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
+#define PP_LAUNCH(A_, R_) hipLaunchKernelGGL((gemm_f16_pp_kernel<0, A_, R_, false, true>), dim3(grid), dim3(512), 0, s, p)
+  if (residual) { if (act == 1) PP_LAUNCH(1, true); else PP_LAUNCH(0, true); }
+  else { if (act == 1) PP_LAUNCH(1, false); else PP_LAUNCH(0, false); }
+#undef PP_LAUNCH
+  return check_launch("gemm_nt_f32 (ping-pong, f32 A, bf16x2)");
 }
 
 // x [n] f32 -> planes [3][n] bf16 with x == p0 + p1 + p2 exactly, 8 elements per thread (16-byte stores)

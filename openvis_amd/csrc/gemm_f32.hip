@@ -174,7 +174,26 @@ int launch_gemm(LoaderA la, const float* B, long long ldb, float* C, long long l
 
 }  // namespace
 
-namespace ovis { int x3_planes() { return g_f32_gemm_mode == 2 ? 2 : 3; } }
+namespace ovis {
+int x3_planes() { return g_f32_gemm_mode == 2 ? 2 : 3; }
+// gemm_f16_pp.hip: the ping-pong kernel's f32-A mode (bf16x2 only)
+bool gemm_f32a_pp_eligible(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C, long long ldc,
+                           int M, int N, int K, const float* bias, const float* residual, long long ldr, int act);
+int gemm_f32a_pp_launch(const float* A, long long lda, const void* W3, long long ldb, long long plane, float* C, long long ldc, int M, int N,
+                        int K, const float* bias, const float* residual, long long ldr, int act, hipStream_t s);
+}
+static int g_f32a_pp = 1;      // lab switch (ovis_set_f32a_pp): 0 keeps bf16x2 on gemm_f32x3_kernel
+
+extern "C" int ovis_set_f32a_pp(int on) { g_f32a_pp = on ? 1 : 0; return OVIS_OK; }
+
+// the kernel ovis_gemm_nt_f32_w3 picks (names as rocprofv3 prints them): profiling labels of bench.py
+extern "C" const char* ovis_gemm_nt_f32_w3_kernel(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C,
+                                                  long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr, int act) {
+  if (g_f32_gemm_mode == 2 && g_f32a_pp && ovis::gemm_f32a_pp_eligible(A, lda, W3, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, act))
+    return residual ? (act == 1 ? "gemm_f16_pp_kernel<0,1,true,false,true>" : "gemm_f16_pp_kernel<0,0,true,false,true>")
+                    : (act == 1 ? "gemm_f16_pp_kernel<0,1,false,false,true>" : "gemm_f16_pp_kernel<0,0,false,false,true>");
+  return "";
+}
 
 extern "C" int ovis_set_f32_gemm_mode(int mode) {
   OVIS_REQUIRE(mode >= 0 && mode <= 2, "set_f32_gemm_mode: mode must be 0 (native f32 MFMA), 1 (bf16x3 split) or 2 (bf16x2: 3 products)");
@@ -246,6 +265,8 @@ extern "C" int ovis_gemm_nt_f32_w3(const float* A, long long lda, const float* B
     return ovis_gemm_nt_f32(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, stream);
   OVIS_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldb >= K && ldc >= N && act >= 0 && act <= 3 && (!residual || ldr >= N),
                "gemm_nt_f32_w3: bad sizes");
+  if (g_f32_gemm_mode == 2 && g_f32a_pp && ovis::gemm_f32a_pp_eligible(A, lda, W3, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, act))
+    return ovis::gemm_f32a_pp_launch(A, lda, W3, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream);
   ovis::launch_gemm_f32x3_w3(DenseA<true>{A, lda, M, K}, W3, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream);
   return ovis::check_launch("gemm_f32x3 (pre-split weights)");
 }
@@ -263,6 +284,9 @@ extern "C" int ovis_conv2d_nhwc_f32_w3(const float* x, const float* w, const voi
   if (!(ok && blocks128 >= 256 && g_f32_gemm_mode >= 1))
     return ovis_conv2d_nhwc_f32(x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act, stream);
   OVIS_REQUIRE(act >= 0 && act <= 3, "conv2d_nhwc_f32_w3: unknown activation %d", act);
+  if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && g_f32_gemm_mode == 2 && g_f32a_pp &&      // a 1x1 conv is the dense GEMM on [M, Cin]
+      ovis::gemm_f32a_pp_eligible(x, Cin, w3, K, plane, y, Cout, (int)M, Cout, K, bias, residual, Cout, act))
+    return ovis::gemm_f32a_pp_launch(x, Cin, w3, K, plane, y, Cout, (int)M, Cout, K, bias, residual, Cout, act, (hipStream_t)stream);
   ConvA la{x, ConvGeom{H, W, Cin, OH, OW, KH, KW, stride, pad}, (int)M, K};
   ovis::launch_gemm_f32x3_w3(la, w3, (long long)K, plane, y, (long long)Cout, (int)M, Cout, K, bias, residual, (long long)Cout, act,
                              (hipStream_t)stream);

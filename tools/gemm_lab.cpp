@@ -13,6 +13,8 @@
 #include <string>
 #include <vector>
 #include "../include/openvis_hip.h"
+extern "C" int ovis_set_f32a_pp(int on);
+extern "C" const char* ovis_gemm_nt_f32_w3_kernel(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C, long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr, int act);
 extern "C" int ovis_pp_debug(int flags, unsigned long long* stamps);   // lab-only entry of gemm_f16_pp.hip
 
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
@@ -108,6 +110,24 @@ static int run_x3(hipStream_t s, bool do_time) {
     x3_err_kernel<<<1024, 256, 0, s>>>(ref, sc, C, nullptr, 0, MN, d_max);
     float mx; HIP_OK(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
     printf("x3 check %-16s legacy gemm_f32x3_kernel: max err / sum|ab| = %.3g\n", c.name, mx);
+    if (!c.out_planes) {   // bf16x2 (three products): gemm_f32x3_kernel<.., 2> against the ping-pong kernel's f32-A mode, three runs each
+      OVIS_OKAY(ovis_set_f32_gemm_mode(2));
+      for (int pp = 0; pp < 2; ++pp) {
+        OVIS_OKAY(ovis_set_f32a_pp(pp));
+        const char* kn = ovis_gemm_nt_f32_w3_kernel(A, c.K, W3, c.K, NK, C, c.N, c.M, c.N, c.K, bias, R, c.N, c.act);
+        for (int rep = 0; rep < 3; ++rep) {
+          HIP_OK(hipMemsetAsync(C, 0xff, MN * 4, s));
+          OVIS_OKAY(ovis_gemm_nt_f32_w3(A, c.K, W, c.K, W3, NK, C, c.N, c.M, c.N, c.K, bias, R, c.N, c.act, s));
+          HIP_OK(hipMemsetAsync(d_max, 0, 4, s));
+          x3_err_kernel<<<1024, 256, 0, s>>>(ref, sc, C, nullptr, 0, MN, d_max);
+          float m2; HIP_OK(hipMemcpyAsync(&m2, d_max, 4, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
+          const bool ok = m2 < 3.1e-5f;                              // 2^-15: two operands of 16 significand bits
+          if (!ok) ++fails;
+          if (rep == 0 || !ok) printf("x2 check %-16s %s [%s]: max err / sum|ab| = %.3g %s\n", c.name, pp ? "ping-pong f32-A" : "gemm_f32x3_kernel<..,2>", kn, m2, ok ? "OK" : "FAIL");
+        }
+      }
+      OVIS_OKAY(ovis_set_f32a_pp(1)); OVIS_OKAY(ovis_set_f32_gemm_mode(1));
+    }
     HIP_OK(hipFree(A)); HIP_OK(hipFree(W)); HIP_OK(hipFree(bias)); HIP_OK(hipFree(C)); HIP_OK(hipFree(ref)); HIP_OK(hipFree(sc)); HIP_OK(hipFree(A3)); HIP_OK(hipFree(W3));
     if (R) HIP_OK(hipFree(R));
     if (C3) HIP_OK(hipFree(C3));
@@ -141,6 +161,21 @@ static int run_x3(hipStream_t s, bool do_time) {
           float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
           if (r > 0) t[v] = std::min(t[v], (double)ms / 10);
         }
+      double t2[2] = {1e30, 1e30};                                  // bf16x2: gemm_f32x3_kernel<..,2> | ping-pong f32-A
+      OVIS_OKAY(ovis_set_f32_gemm_mode(2));
+      for (int r = 0; r < 4; ++r)
+        for (int pp = 0; pp < 2; ++pp) {
+          OVIS_OKAY(ovis_set_f32a_pp(pp));
+          HIP_OK(hipEventRecord(e0, s));
+          for (int it = 0; it < 10; ++it) OVIS_OKAY(ovis_gemm_nt_f32_w3(A, sh.K, W, sh.K, W3, NK, C, sh.N, sh.M, sh.N, sh.K, bias, R, sh.N, sh.act, s));
+          HIP_OK(hipEventRecord(e1, s)); HIP_OK(hipEventSynchronize(e1));
+          float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+          if (r > 0) t2[pp] = std::min(t2[pp], (double)ms / 10);
+        }
+      OVIS_OKAY(ovis_set_f32a_pp(1)); OVIS_OKAY(ovis_set_f32_gemm_mode(1));
+      printf("x2 time %-10s M=%d N=%d K=%d: gemm_f32x3_kernel<..,2> %.4f ms (%.0f TF f32-eq) | ping-pong f32-A %.4f ms (%.0f TF) [%s]\n", sh.name, sh.M, sh.N, sh.K,
+             t2[0], 2.0 * sh.M * sh.N * sh.K / t2[0] / 1e9, t2[1], 2.0 * sh.M * sh.N * sh.K / t2[1] / 1e9,
+             ovis_gemm_nt_f32_w3_kernel(A, sh.K, W3, sh.K, NK, C, sh.N, sh.M, sh.N, sh.K, bias, R, sh.N, sh.act));
       const double fl = 2.0 * sh.M * sh.N * sh.K;
       printf("x3 time %-10s M=%d N=%d K=%d: legacy %.4f ms (%.0f TF f32-eq) | split A %.4f ms | pp f32-out %.4f ms (%.0f TF) | pp planes-out %.4f ms\n", sh.name,
              sh.M, sh.N, sh.K, t[0], fl / t[0] / 1e9, t[1], t[2], fl / t[2] / 1e9, sh.res ? 0.0 : t[3]);
