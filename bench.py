@@ -291,20 +291,26 @@ def main():
     # "The dominant kernel" = the kernel TEMPLATE with the largest summed launch time (rocprofv3 lists every instantiation as
     # its own row -- <out dtype, activation, residual> for the fp16 GEMM --, but it is one piece of code); the line carries
     # the aggregate over its instantiations and every instantiation's own row for the cross-check against rocprofv3.
+    def _family_of(k):
+        # the ping-pong kernel's f32-A instantiations (<.., X3=false, FA=true>: bf16x2, three bf16 products per f32 product) are a
+        # family of their own: their flops are f32-equivalent and their ceiling is the bf16 peak / 3, not the fp16 peak
+        base = k.split("<")[0]
+        return base + "[f32A]" if base == "gemm_f16_pp_kernel" and k.endswith(",true>") and k.count(",") == 4 else base
+
     def _families(a):
         fam = {}
         for k, v in a.items():
-            f = fam.setdefault(k.split("<")[0], [0, 0.0, 0.0, {}])
+            f = fam.setdefault(_family_of(k), [0, 0.0, 0.0, {}])
             f[0] += v[0]; f[1] += v[1]; f[2] += v[2]; f[3][k] = v
         return fam
 
     fam_situ, fam_iso = _families(agg_situ), _families(agg)
     kbase, (n_launch, flops, secs, members) = max(fam_situ.items(), key=lambda kv: kv[1][2])
-    dom = (kbase + "<*>" if len(members) > 1 else next(iter(members)), None)
+    dom = (kbase.replace("[f32A]", "") + ("<*,true>" if "[f32A]" in kbase else "<*>") if len(members) > 1 else next(iter(members)), None)
     achieved = flops / secs / 1e12
     iso = fam_iso.get(kbase, (n_launch, flops, secs))
-    if "f32x3" in kbase:      # one f32 product = 6 (bf16x3) or 3 (bf16x2) bf16 MFMA products: ceiling = bf16 peak / that
-        nprod = 3 if f32_split == "bf16x2" else 6
+    if "f32x3" in kbase or "[f32A]" in kbase:      # one f32 product = 6 (bf16x3) or 3 (bf16x2) bf16 MFMA products: ceiling = bf16 peak / that
+        nprod = 3 if (f32_split == "bf16x2" or "[f32A]" in kbase) else 6
         peak, peak_note = round(PEAK_F16_MFMA_TFLOPS / nprod, 1), f"bf16 dense MFMA peak / {nprod} ({f32_split}: {nprod} bf16 products per f32 product)"
     elif "f16" in kbase:
         peak, peak_note = PEAK_F16_MFMA_TFLOPS, "fp16 dense MFMA peak"

@@ -149,6 +149,13 @@ int ovis_set_f16_gemm_mode(int mode, int raster_group, int desync_ns);
 const char* ovis_gemm_nt_f16_kernel(const void* C, long long lda, long long ldb, long long ldc, int M, int N, int K,
                                     const float* bias, const float* residual, long long ldr, int act, int out_f16);
 
+/* Name of the kernel ovis_gemm_nt_f32_w3 (and the 1x1 / stride 1 / pad 0 case of ovis_conv2d_nhwc_f32_w3) launches when it is the
+ * ping-pong kernel's f32-A mode -- bf16x2 (mode 2) on shapes of >= 256 tiles of 256x256 with K % 32 == 0 and <= 15 % padded
+ * columns --, "" when it is gemm_f32x3_kernel / gemm_f32_kernel (static string; for profiles and bench.py's roofline). */
+const char* ovis_gemm_nt_f32_w3_kernel(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C,
+                                       long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr,
+                                       int act);
+
 /* ovis_gemm_nt_f16: same contract with fp16 A [M,K] / B [N,K] (K, lda, ldb multiples of 8), f32 accumulation,
  *   f32 bias / residual, C written as f32 (out_f16 == 0) or fp16.  Used for the CLIP ViT GEMMs only — the reference
  *   runs CLIP in fp16 on the GPU (adapter.py:108-111; clip.load on cuda).  On tiles with 16-byte aligned rows the f32

@@ -70,6 +70,14 @@ import weakref
 _W3_CACHE = {}      # id(constant f32 weight tensor) -> (weakref to it, its three bf16 planes); split once per tensor
 
 
+def _w3_kernel_name(a, lda, w3, ldb, plane, out, ldc, M, N, K, bias, residual, ldr, act):
+    """The kernel ovis_gemm_nt_f32_w3 / the 1x1 case of ovis_conv2d_nhwc_f32_w3 would launch ("" = gemm_f32x3_kernel)."""
+    fn = _lib.lib().ovis_gemm_nt_f32_w3_kernel
+    fn.restype = ctypes.c_char_p
+    return fn(_lib._conv(a), _ll(lda), _lib._conv(w3), _ll(ldb), _ll(plane), _lib._conv(out), _ll(ldc), M, N, K, _lib._conv(bias),
+              _lib._conv(residual), _ll(ldr), act).decode()
+
+
 def w3_of(w):
     """The exact 3-way bf16 split of a CONSTANT weight tensor, cached per tensor object (csrc/gemm_f32x3.h)."""
     key = id(w)
@@ -101,8 +109,12 @@ def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None, cw
             _lib.call("ovis_gemm_nt_f32a_f16w", a2, _ll(K), w16, _ll(K), out, _ll(N), M, N, K, bias, r2, _ll(N), act,
                       _lib.stream_ptr())
         return out.view(*a.shape[:-1], N)
-    with _Prof(_gemm_variant(M, N, "DenseA", K), 2.0 * M * N * K):
-        if cw and w.is_contiguous() and K % 8 == 0 and _F32_GEMM_MODE >= 1 and ((M + 127) // 128) * ((N + 127) // 128) >= 256:
+    use_w3 = cw and w.is_contiguous() and K % 8 == 0 and _F32_GEMM_MODE >= 1 and ((M + 127) // 128) * ((N + 127) // 128) >= 256
+    label = _gemm_variant(M, N, "DenseA", K)
+    if PROFILE is not None and use_w3 and _F32_GEMM_MODE == 2:      # bf16x2: the ping-pong kernel's f32-A mode takes the eligible shapes
+        label = _w3_kernel_name(a2, K, w3_of(w), K, w.numel(), out, N, M, N, K, bias, r2, N, act) or label
+    with _Prof(label, 2.0 * M * N * K):
+        if use_w3:
             _lib.call("ovis_gemm_nt_f32_w3", a2, _ll(K), w, _ll(K), w3_of(w), _ll(w.numel()), out, _ll(N), M, N, K, bias, r2,
                       _ll(N), act, _lib.stream_ptr())
         else:
@@ -241,7 +253,11 @@ def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE, w
             _lib.call("ovis_conv2d_nhwc_f32a_f16w", x, w16, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act,
                       _lib.stream_ptr())
         return y
-    with _Prof(_gemm_variant(N * OH * OW, Cout, "ConvA", KH * KW * Cin), 2.0 * N * OH * OW * Cout * KH * KW * Cin):
+    label = _gemm_variant(N * OH * OW, Cout, "ConvA", KH * KW * Cin)
+    if (PROFILE is not None and cw and _F32_GEMM_MODE == 2 and KH == 1 and KW == 1 and stride == 1 and pad == 0 and Cin % 8 == 0
+            and ((N * OH * OW + 127) // 128) * ((Cout + 127) // 128) >= 256):
+        label = _w3_kernel_name(x, Cin, w3_of(w), Cin, w.numel(), y, Cout, N * OH * OW, Cout, Cin, bias, residual, Cout, act) or label
+    with _Prof(label, 2.0 * N * OH * OW * Cout * KH * KW * Cin):
         if cw and (KH * KW * Cin) % 8 == 0 and _F32_GEMM_MODE >= 1:
             _lib.call("ovis_conv2d_nhwc_f32_w3", x, w, w3_of(w), _ll(w.numel()), y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias,
                       residual, act, _lib.stream_ptr())
