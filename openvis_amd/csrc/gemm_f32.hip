@@ -182,6 +182,11 @@ bool gemm_f32a_pp_eligible(const float* A, long long lda, const void* W3, long l
 int gemm_f32a_pp_launch(const float* A, long long lda, const void* W3, long long ldb, long long plane, float* C, long long ldc, int M, int N,
                         int K, const float* bias, const float* residual, long long ldr, int act, hipStream_t s);
 }
+namespace ovis {   // gemm_f32_skinny.hip
+bool gemm_f32_skinny_eligible(const float* A, long long lda, const float* B, long long ldb, int M, int N, int K);
+int gemm_f32_skinny_launch(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N, int K,
+                           const float* bias, const float* R, long long ldr, int act, hipStream_t stream);
+}
 static int g_f32a_pp = 1;      // lab switch (ovis_set_f32a_pp): 0 keeps bf16x2 on gemm_f32x3_kernel
 
 extern "C" int ovis_set_f32a_pp(int on) { g_f32a_pp = on ? 1 : 0; return OVIS_OK; }
@@ -209,6 +214,8 @@ extern "C" int ovis_gemm_nt_f32(const float* A, long long lda, const float* B, l
   OVIS_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm_nt_f32: leading dimension too small");
   OVIS_REQUIRE(act >= 0 && act <= 3, "gemm_nt_f32: unknown activation %d", act);
   OVIS_REQUIRE(!residual || ldr >= N, "gemm_nt_f32: residual leading dimension too small");
+  if (ovis::gemm_f32_skinny_eligible(A, lda, B, ldb, M, N, K))       // the decoders' 100-row GEMMs (gemm_f32_skinny.hip)
+    return ovis::gemm_f32_skinny_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream);
   const bool veca = (K % 4 == 0) && ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
   if (veca) return launch_gemm(DenseA<true>{A, lda, M, K}, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream);
   return launch_gemm(DenseA<false>{A, lda, M, K}, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream);

@@ -186,3 +186,38 @@ def test_gemm_on_presplit_bf16_planes_is_f32_grade(N, K, act, res, planes):
         ref = ref.relu()
     got = out.double().sum(0) if planes else out.double()
     assert ((got - ref).abs() / scale).max().item() < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K,act,bias,res", [(100, 256, 256, 0, True, False), (100, 2048, 256, 1, True, False), (100, 256, 2048, 0, True, True),
+                                                (100, 768, 256, 0, True, False), (7, 41, 256, 0, True, True), (128, 483, 512, 2, False, False),
+                                                (100, 1024, 4096, 0, True, True), (1, 256, 256, 0, False, False)])
+def test_skinny_f32_gemm_of_the_decoders(M, N, K, act, bias, res):
+    # gemm_f32_skinny.hip: M <= 128 rows, the K axis spread over the 8 wavefronts of a workgroup (and over workgroups + a fixed-order
+    # fix-up for K > 512); exact f32 MFMA -> f32 accuracy, deterministic run to run
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    a = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda() if bias else None
+    r = torch.randn(M, N, generator=g).cuda() if res else None
+    ref = a.double() @ w.double().T
+    if bias:
+        ref = ref + b.double()
+    if res:
+        ref = ref + r.double()
+    ref = {0: lambda x: x, 1: torch.relu, 2: lambda x: x * torch.sigmoid(1.702 * x)}[act](ref)
+    lib = ops._lib.lib()
+    lib.ovis_set_skinny_gemm(2)                             # every eligible shape (the default takes the long-K ones only)
+    try:
+        outs = [ops.gemm_nt(a, w, b, r, act) for _ in range(3)]
+    finally:
+        lib.ovis_set_skinny_gemm(1)
+    assert outs[0].shape == (M, N)
+    assert (outs[0].double() - ref).abs().max().item() < 2e-5
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    lib.ovis_set_skinny_gemm(0)                             # the general kernel on the same problem
+    try:
+        old = ops.gemm_nt(a, w, b, r, act)
+    finally:
+        lib.ovis_set_skinny_gemm(1)
+    assert (outs[0] - old).abs().max().item() < 2e-5
