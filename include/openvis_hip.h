@@ -156,6 +156,24 @@ const char* ovis_gemm_nt_f32_w3_kernel(const float* A, long long lda, const void
                                        long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr,
                                        int act);
 
+/* fp16 residual stream of the CLIP tower (what the reference's fp16 CLIP keeps between blocks, adapter.py:108-111):
+ *   ovis_gemm_nt_f16_res16: C (fp16) = fp16( A B^T + bias + f32(R_f16) ), f32 accumulation, one rounding; only for the shapes the
+ *     ping-pong kernel takes (ovis_gemm_nt_f16_res16_eligible != 0; callers route smaller problems through ovis_gemm_nt_f16);
+ *   ovis_layernorm_f16_to_f16 / _to_f32: LayerNorm of fp16 rows with f32 statistics (model.py:157-163);
+ *   ovis_vit_embed_ln_f16: ln_pre(cat(cls, fp16 patch embeddings) + pos) -> fp16 tokens (model.py:328-343);
+ *   ovis_cast_f16_to_f32_rows: y[r, 0:C] (f32, dense) = x[r * ldx + 0:C] (fp16), e.g. the class-token rows. */
+int ovis_gemm_nt_f16_res16_eligible(const void* C, const void* R16, long long lda, long long ldb, long long ldc, long long ldr,
+                                    int M, int N, int K, const float* bias);
+int ovis_gemm_nt_f16_res16(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int M, int N, int K,
+                           const float* bias, const void* R16, long long ldr, ovis_stream_t stream);
+int ovis_layernorm_f16_to_f16(const void* x_f16, const float* gamma, const float* beta, void* y_f16, long long rows, int C, float eps,
+                              ovis_stream_t stream);
+int ovis_layernorm_f16_to_f32(const void* x_f16, const float* gamma, const float* beta, float* y, long long rows, int C, float eps,
+                              ovis_stream_t stream);
+int ovis_vit_embed_ln_f16(const void* patch_f16, const float* cls, const float* pos, const float* gamma, const float* beta,
+                          void* out_f16, int M, int L1, int C, float eps, ovis_stream_t stream);
+int ovis_cast_f16_to_f32_rows(const void* x_f16, long long ldx, float* y, long long rows, int C, ovis_stream_t stream);
+
 /* ovis_gemm_nt_f16: same contract with fp16 A [M,K] / B [N,K] (K, lda, ldb multiples of 8), f32 accumulation,
  *   f32 bias / residual, C written as f32 (out_f16 == 0) or fp16.  Used for the CLIP ViT GEMMs only — the reference
  *   runs CLIP in fp16 on the GPU (adapter.py:108-111; clip.load on cuda).  On tiles with 16-byte aligned rows the f32

@@ -120,6 +120,11 @@ def get_cfg():
                              # not a reference key: GEMM operand dtype of the CLIP tower on MI355X ("fp16" as the
                              # reference's GPU CLIP, or "fp32")
                              "PRECISION": "fp16",
+                             # not a reference key: dtype of the ViT's residual stream under PRECISION "fp16" for plain crops:
+                             # "fp16" = what the reference's fp16 CLIP keeps between blocks (one rounding per sub-block; measured
+                             # max |cos error| 9.7e-5 against 5.2e-5 with "fp32", bound 1e-3; profiles/r02/logit_bound.txt),
+                             # half the residual / LayerNorm traffic of the tower
+                             "RESIDUAL_STREAM": "fp16",
                              # SideAdapter (SAN / SANOnline / BriVIS) tower: "auto" = fp32 (see BACKBONE_PRECISION)
                              "SIDE_PRECISION": "auto"},
         },

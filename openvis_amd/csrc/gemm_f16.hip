@@ -403,6 +403,18 @@ cast_f32_f16_kernel(const float4* __restrict__ x, uint2* __restrict__ y, long lo
   y[i] = o.u;
 }
 
+// y[r, :] (f32, dense) = x[r * ldx + :] (fp16): the class-token rows of an fp16 token tensor
+__global__ void __launch_bounds__(256)
+cast_f16_f32_rows_kernel(const _Float16* __restrict__ x, long long ldx, float* __restrict__ y, long long rows, int C4) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C4) return;
+  const long long r = i / C4;
+  const int c = (int)(i - r * C4);
+  union { uint2 u; _Float16 h[4]; } v;
+  v.u = *reinterpret_cast<const uint2*>(x + r * ldx + 4 * c);
+  reinterpret_cast<float4*>(y)[i] = make_float4((float)v.h[0], (float)v.h[1], (float)v.h[2], (float)v.h[3]);
+}
+
 }  // namespace
 
 namespace ovis {   // gemm_f16_pp.hip: the ping-pong 256x256 kernel for the big CLIP GEMMs
@@ -464,6 +476,14 @@ extern "C" const char* ovis_gemm_nt_f16_kernel(const void* C, long long lda, lon
   if (blocks128 >= 128 && K % BKH == 0) return out_f16 ? "gemm_f16_glds_kernel<true>" : "gemm_f16_glds_kernel<false>";
   if (blocks128 >= 128) return out_f16 ? "gemm_f16_kernel<128,128,true>" : "gemm_f16_kernel<128,128,false>";
   return out_f16 ? "gemm_f16_kernel<64,64,true>" : "gemm_f16_kernel<64,64,false>";
+}
+
+extern "C" int ovis_cast_f16_to_f32_rows(const void* x_f16, long long ldx, float* y, long long rows, int C, ovis_stream_t stream) {
+  OVIS_REQUIRE(x_f16 && y && rows > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldx >= C, "cast_f16_to_f32_rows: C and ldx must be multiples of 4");
+  OVIS_REQUIRE((reinterpret_cast<uintptr_t>(x_f16) & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "cast_f16_to_f32_rows: alignment");
+  hipLaunchKernelGGL(cast_f16_f32_rows_kernel, dim3(ovis::cdiv(rows * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const _Float16*>(x_f16), ldx, y, rows, C / 4);
+  return ovis::check_launch("cast_f16_to_f32_rows");
 }
 
 extern "C" int ovis_cast_f32_to_f16(const float* x, void* y, long long n, ovis_stream_t stream) {

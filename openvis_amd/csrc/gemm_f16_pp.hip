@@ -96,10 +96,13 @@ struct PPArgs {
 //      into hi / lo bf16 in registers (3 VALU per element) and issues the three products a1 b0, a0 b1, a0 b0 -- no split pass over
 //      A in memory, no plane stores to LDS, and the DMA pipeline / barrier protocol / vmcnt accounting of the fp16 kernel unchanged
 //      (every half-tile is still two DMA instructions per wavefront).
-template <int OUT, int ACT, bool HAS_R, bool X3, bool FA = false>
+// R16: the residual is fp16 (and the output too, OUT == 1): the fp16 residual stream of the CLIP tower -- what the reference's
+//      fp16 CLIP keeps between blocks (adapter.py:108-111); a lane's 8 consecutive columns of a row are ONE 16-byte load.
+template <int OUT, int ACT, bool HAS_R, bool X3, bool FA = false, bool R16 = false>
 __global__ void __launch_bounds__(512)
 gemm_f16_pp_kernel(const PPArgs p) {
   static_assert(!(FA && X3) && (!FA || OUT == 0), "f32-A mode: f32 output, no plane walking");
+  static_assert(!R16 || (HAS_R && OUT == 1 && !X3 && !FA), "fp16 residual: fp16 output of the fp16 GEMM");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[PP_LDS];   // ONE LDS object (a second one de-pipelines the DMA)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -383,6 +386,21 @@ gemm_f16_pp_kernel(const PPArgs p) {
       for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if constexpr (R16) {
+      const _Float16* rp = reinterpret_cast<const _Float16*>(p.R) + (long long)(bml + wr * 128 + l15) * p.ldr + bnl + wc * 64 + 8 * q;
+      const int col0 = bnl + wc * 64 + 8 * q;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x4 bv[2];
+        bias8(col0 + 32 * j, bv[0], bv[1]);
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) {
+          const f16x8 r = *reinterpret_cast<const f16x8*>(rp + (long long)mb * 16 * p.ldr + 32 * j);
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            acc[mb][2 * j + e] = f32x4{(float)r[4 * e], (float)r[4 * e + 1], (float)r[4 * e + 2], (float)r[4 * e + 3]} + bv[e];
+        }
+      }
     } else if constexpr (HAS_R) {
       const float* rp = p.R + (long long)(bml + wr * 128 + l15) * p.ldr + bnl + wc * 64 + 8 * q;
       const int col0 = bnl + wc * 64 + 8 * q;
@@ -424,7 +442,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
   asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                 // B1 of K step 0 (5 younger half-tiles)
   PP_BARRIER();
 
-  constexpr int NS = OUT == 1 ? 16 : OUT == 2 ? 48 : (HAS_R ? 53 : 32);   // vm ops of one epilogue (+ residual loads) per lane; 10 + NS <= 63
+  constexpr int NS = OUT == 1 ? (R16 ? 32 : 16) : OUT == 2 ? 48 : (HAS_R ? 53 : 32);   // vm ops of one epilogue (+ residual loads) per lane; 10 + NS <= 63
 #define PP_WAIT(n_first, n_later) do { if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_first) : "memory"); \
                                        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_later) : "memory"); } while (0)
 #define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
@@ -543,6 +561,32 @@ bool gemm_f16_pp_eligible(const void* C, long long lda, long long ldb, long long
   if (out_f16 ? (ldc % 8 != 0) : (ldc % 4 != 0)) return false;
   if (residual && ((ldr % 4 != 0) || (reinterpret_cast<uintptr_t>(residual) & 15))) return false;
   return true;   // (act, residual, out dtype) combinations without an instantiation are rejected by gemm_f16_pp_launch's caller check below
+}
+
+// fp16 residual + fp16 output (the tower's fp16 residual stream): same shape rules; R_f16 16-byte aligned, ldr % 8 == 0
+bool gemm_f16_pp_res16_eligible(const void* C, const void* R16, long long lda, long long ldb, long long ldc, long long ldr, int M, int N, int K,
+                                const float* bias) {
+  if (!gemm_f16_pp_eligible(C, lda, ldb, ldc, M, N, K, bias, nullptr, 0, 1, true)) return false;
+  return R16 && ldr % 8 == 0 && ldr >= N && (reinterpret_cast<uintptr_t>(R16) & 15) == 0;
+}
+
+int gemm_f16_pp_res16_launch(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int M, int N, int K,
+                             const float* bias, const void* R16, long long ldr, hipStream_t s) {
+  PPArgs p;
+  p.A = reinterpret_cast<const _Float16*>(A); p.B = reinterpret_cast<const _Float16*>(B); p.C = C; p.bias = bias;
+  p.R = reinterpret_cast<const float*>(R16);
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.M = M; p.N = N; p.K = K; p.act = 0;
+  p.tiles_m = (int)cdiv(M, 256); p.tiles_n = (int)cdiv(N, 256); p.n_tiles = p.tiles_m * p.tiles_n;
+  const int groups = (int)cdiv(p.tiles_n, g_pp_grp > 0 ? g_pp_grp : p.tiles_n);
+  p.grp_w = p.tiles_n / groups; p.grp_rem = p.tiles_n % groups;
+  p.desync_ns = g_pp_desync_ns >= 0 ? g_pp_desync_ns : 24000;        // residual GEMM: see gemm_f16_pp_launch
+  p.dbg = g_pp_dbg; p.stamps = g_pp_stamps;
+  p.dump = pp_dump_buffer();
+  if (!p.dump) return fail(OVIS_EINVAL, "gemm_nt_f16 (ping-pong): cannot allocate the 4 KB dump buffer");
+  p.planeA = p.planeB = p.planeC = 0;
+  const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
+  hipLaunchKernelGGL((gemm_f16_pp_kernel<1, 0, true, false, false, true>), dim3(grid), dim3(512), 0, s, p);
+  return check_launch("gemm_nt_f16 (ping-pong, fp16 residual)");
 }
 
 int gemm_f16_pp_launch(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int M, int N, int K,
@@ -675,6 +719,23 @@ extern "C" int ovis_gemm_nt_bf16x3_planes(const void* A3, long long lda, long lo
   else { if (act == 1) PP_LAUNCH(0, 1, false); else PP_LAUNCH(0, 0, false); }
 #undef PP_LAUNCH
   return ovis::check_launch("gemm_nt_bf16x3_planes");
+}
+
+// C (fp16) = A B^T + bias + R (fp16): out-proj / c_proj of a CLIP block on the fp16 residual stream.  Only the shapes the ping-pong kernel
+// takes (ovis_gemm_nt_f16_res16_eligible); smaller problems go through ovis_gemm_nt_f16 with an f32 residual (openvis_amd/ops.py).
+extern "C" int ovis_gemm_nt_f16_res16_eligible(const void* C, const void* R16, long long lda, long long ldb, long long ldc, long long ldr,
+                                               int M, int N, int K, const float* bias) {
+  return ovis::gemm_f16_pp_res16_eligible(C, R16, lda, ldb, ldc, ldr, M, N, K, bias) ? 1 : 0;
+}
+
+extern "C" int ovis_gemm_nt_f16_res16(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int M, int N, int K,
+                                      const float* bias, const void* R16, long long ldr, ovis_stream_t stream) {
+  OVIS_REQUIRE(A && B && C && R16, "gemm_nt_f16_res16: null pointer");
+  OVIS_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldb >= K && ldc >= N, "gemm_nt_f16_res16: bad sizes");
+  OVIS_REQUIRE(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm_nt_f16_res16: alignment");
+  OVIS_REQUIRE(ovis::gemm_f16_pp_res16_eligible(C, R16, lda, ldb, ldc, ldr, M, N, K, bias),
+               "gemm_nt_f16_res16: shape not taken by the ping-pong kernel (M=%d N=%d K=%d): use ovis_gemm_nt_f16 with an f32 residual", M, N, K);
+  return ovis::gemm_f16_pp_res16_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, R16, ldr, (hipStream_t)stream);
 }
 
 extern "C" int ovis_set_f16_gemm_mode(int mode, int raster_group, int desync_ns) {

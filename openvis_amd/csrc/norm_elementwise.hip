@@ -66,7 +66,9 @@ maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int N, i
 
 // ---- LayerNorm over the last dim (C % 4 == 0, C <= 4096): one wavefront per row -----------------
 // y = LN(x + residual) * gamma + beta ; torch.nn.LayerNorm eps inside the sqrt, biased variance.
-template <int MAXV, bool OUT16>
+// IN16: x is fp16 (the fp16 residual stream of the CLIP tower, the reference's GPU dtype; statistics in f32 as CLIP's LayerNorm
+// subclass computes them, model.py:157-163); no residual input in that mode.
+template <int MAXV, bool OUT16, bool IN16 = false>
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
                  const float* __restrict__ beta, void* __restrict__ yv, long long rows, int C, float eps) {
@@ -75,6 +77,7 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, con
   if (row >= rows) return;
   const int nv = C >> 2;
   const float4* xp = reinterpret_cast<const float4*>(x + row * C);
+  const uint2* xh = reinterpret_cast<const uint2*>(reinterpret_cast<const _Float16*>(x) + row * C);
   const float4* rp = res ? reinterpret_cast<const float4*>(res + row * C) : nullptr;
   float4 v[MAXV];
   float s = 0.f;
@@ -83,8 +86,14 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, con
     const int idx = lane + i * 64;
     v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (idx < nv) {
-      v[i] = xp[idx];
-      if (rp) { const float4 r = rp[idx]; v[i].x += r.x; v[i].y += r.y; v[i].z += r.z; v[i].w += r.w; }
+      if constexpr (IN16) {
+        union { uint2 u; _Float16 h[4]; } pk;
+        pk.u = xh[idx];
+        v[i] = make_float4((float)pk.h[0], (float)pk.h[1], (float)pk.h[2], (float)pk.h[3]);
+      } else {
+        v[i] = xp[idx];
+      }
+      if (!IN16 && rp) { const float4 r = rp[idx]; v[i].x += r.x; v[i].y += r.y; v[i].z += r.z; v[i].w += r.w; }
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
   }
@@ -305,6 +314,27 @@ static int layernorm_launch(const float* x, const float* residual, const float* 
 extern "C" int ovis_layernorm_f32(const float* x, const float* residual, const float* gamma, const float* beta,
                                   float* y, long long rows, int C, float eps, ovis_stream_t stream) {
   return layernorm_launch<false>(x, residual, gamma, beta, y, rows, C, eps, (hipStream_t)stream);
+}
+
+template <bool OUT16>
+static int layernorm_f16in_launch(const void* x, const float* gamma, const float* beta, void* y, long long rows, int C, float eps, hipStream_t s) {
+  OVIS_REQUIRE(x && gamma && beta && y, "layernorm (fp16 input): null pointer");
+  OVIS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 1024, "layernorm (fp16 input): C must be a multiple of 4 and <= 1024");
+  const unsigned grid = ovis::cdiv(rows, 4);
+  const float* xf = reinterpret_cast<const float*>(x);
+  if (C / 4 <= 64) hipLaunchKernelGGL((layernorm_kernel<1, OUT16, true>), dim3(grid), dim3(256), 0, s, xf, nullptr, gamma, beta, y, rows, C, eps);
+  else hipLaunchKernelGGL((layernorm_kernel<4, OUT16, true>), dim3(grid), dim3(256), 0, s, xf, nullptr, gamma, beta, y, rows, C, eps);
+  return ovis::check_launch("layernorm (fp16 input)");
+}
+
+extern "C" int ovis_layernorm_f16_to_f16(const void* x_f16, const float* gamma, const float* beta, void* y_f16, long long rows, int C,
+                                         float eps, ovis_stream_t stream) {
+  return layernorm_f16in_launch<true>(x_f16, gamma, beta, y_f16, rows, C, eps, (hipStream_t)stream);
+}
+
+extern "C" int ovis_layernorm_f16_to_f32(const void* x_f16, const float* gamma, const float* beta, float* y, long long rows, int C,
+                                         float eps, ovis_stream_t stream) {
+  return layernorm_f16in_launch<false>(x_f16, gamma, beta, y, rows, C, eps, (hipStream_t)stream);
 }
 
 extern "C" int ovis_layernorm_f32_to_f16(const float* x, const float* residual, const float* gamma, const float* beta,

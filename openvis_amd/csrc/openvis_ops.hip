@@ -651,7 +651,8 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
 
 // ViT token assembly + ln_pre (model.py:341-343): tok[m,0] = cls + pos[0]; tok[m,1+p] = patch[m,p] + pos[1+p]; LN.
 // one wavefront per token; C % 256 == 0 (C = 768 / 1024).
-template <int NV>
+// H16: patch embeddings arrive as fp16 and the tokens leave as fp16 (the fp16 residual stream of the tower); cls / pos / LN in f32.
+template <int NV, bool H16 = false>
 __global__ void __launch_bounds__(256)
 vit_embed_ln_kernel(const float* __restrict__ patch, const float* __restrict__ cls, const float* __restrict__ pos,
                     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out,
@@ -668,7 +669,15 @@ vit_embed_ln_kernel(const float* __restrict__ patch, const float* __restrict__ c
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const float4 a = src[lane + i * 64], b = pp[lane + i * 64];
+    float4 a;
+    if (H16 && p != 0) {
+      union { uint2 u; _Float16 h[4]; } pk;
+      pk.u = reinterpret_cast<const uint2*>(reinterpret_cast<const _Float16*>(patch) + (m * (L1 - 1) + (p - 1)) * C)[lane + i * 64];
+      a = make_float4((float)pk.h[0], (float)pk.h[1], (float)pk.h[2], (float)pk.h[3]);
+    } else {
+      a = src[lane + i * 64];
+    }
+    const float4 b = pp[lane + i * 64];
     v[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
@@ -688,8 +697,15 @@ vit_embed_ln_kernel(const float* __restrict__ patch, const float* __restrict__ c
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const float4 g = reinterpret_cast<const float4*>(gamma)[lane + i * 64], b = reinterpret_cast<const float4*>(beta)[lane + i * 64];
-    op[lane + i * 64] = make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
-                                    (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+    const float4 o = make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                                 (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+    if constexpr (H16) {
+      union { _Float16 h[4]; uint2 u; } pk;
+      pk.h[0] = (_Float16)o.x; pk.h[1] = (_Float16)o.y; pk.h[2] = (_Float16)o.z; pk.h[3] = (_Float16)o.w;
+      reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(out) + tok * C)[lane + i * 64] = pk.u;
+    } else {
+      op[lane + i * 64] = o;
+    }
   }
 }
 
@@ -1062,6 +1078,24 @@ extern "C" int ovis_vit_embed_ln_f32(const float* patch, const float* cls, const
     default: hipLaunchKernelGGL(vit_embed_ln_kernel<4>, dim3(grid), dim3(256), 0, s, patch, cls, pos, gamma, beta, out, n_tok, L1, C, eps); break;
   }
   return ovis::check_launch("vit_embed_ln");
+}
+
+extern "C" int ovis_vit_embed_ln_f16(const void* patch_f16, const float* cls, const float* pos, const float* gamma, const float* beta,
+                                     void* out_f16, int M, int L1, int C, float eps, ovis_stream_t stream) {
+  OVIS_REQUIRE(patch_f16 && cls && pos && gamma && beta && out_f16, "vit_embed_ln_f16: null pointer");
+  OVIS_REQUIRE(M > 0 && L1 > 1 && C > 0 && C % 256 == 0 && C <= 1024, "vit_embed_ln_f16: C must be a multiple of 256, <= 1024");
+  const long long n_tok = (long long)M * L1;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = ovis::cdiv(n_tok, 4);
+  const float* pf = reinterpret_cast<const float*>(patch_f16);
+  float* of = reinterpret_cast<float*>(out_f16);
+  switch (C / 256) {
+    case 1: hipLaunchKernelGGL((vit_embed_ln_kernel<1, true>), dim3(grid), dim3(256), 0, s, pf, cls, pos, gamma, beta, of, n_tok, L1, C, eps); break;
+    case 2: hipLaunchKernelGGL((vit_embed_ln_kernel<2, true>), dim3(grid), dim3(256), 0, s, pf, cls, pos, gamma, beta, of, n_tok, L1, C, eps); break;
+    case 3: hipLaunchKernelGGL((vit_embed_ln_kernel<3, true>), dim3(grid), dim3(256), 0, s, pf, cls, pos, gamma, beta, of, n_tok, L1, C, eps); break;
+    default: hipLaunchKernelGGL((vit_embed_ln_kernel<4, true>), dim3(grid), dim3(256), 0, s, pf, cls, pos, gamma, beta, of, n_tok, L1, C, eps); break;
+  }
+  return ovis::check_launch("vit_embed_ln_f16");
 }
 
 extern "C" int ovis_l2norm_rows_f32(const float* x, float* y, long long rows, int C, float scale, ovis_stream_t stream) {

@@ -7,10 +7,16 @@ def build_clip_adapter(cfg):
     """openvis/modeling/clip_adapter/__init__.py:9-15.  (SideAdapter is built by the SAN / BriVIS meta-architectures
     themselves: openvis_amd/modeling/clip_adapter/side_adapter.py.)"""
     precision = cfg.get("PRECISION", "fp16")
+    stream = cfg.get("RESIDUAL_STREAM", "fp16")
+    if stream not in ("fp16", "fp32"):
+        raise ValueError(f"MODEL.CLIP_ADAPTER.RESIDUAL_STREAM must be 'fp16' or 'fp32', got {stream!r}")
     if cfg.NAME in ("ClipAdapter", "BgClipAdapter"):
-        return ADAPTER_REGISTER[cfg.NAME](cfg.CLIP_MODEL_NAME, text_templates=cfg.PROMPT_NAME, precision=precision)
-    if cfg.NAME in ("AdaptedClipAdapter", "BgAdaptedClipAdapter"):
-        return ADAPTER_REGISTER[cfg.NAME](cfg.CLIP_MODEL_NAME, mask_prompt_depth=cfg.MASK_PROMPT_DEPTH,
-                                          mask_prompt_fwd=cfg.MASK_PROMPT_FWD, text_templates=cfg.PROMPT_NAME,
-                                          precision=precision)
-    raise NotImplementedError(f"clip adapter {cfg.NAME} is not in ADAPTER_REGISTER {sorted(ADAPTER_REGISTER)}")
+        ad = ADAPTER_REGISTER[cfg.NAME](cfg.CLIP_MODEL_NAME, text_templates=cfg.PROMPT_NAME, precision=precision)
+    elif cfg.NAME in ("AdaptedClipAdapter", "BgAdaptedClipAdapter"):
+        ad = ADAPTER_REGISTER[cfg.NAME](cfg.CLIP_MODEL_NAME, mask_prompt_depth=cfg.MASK_PROMPT_DEPTH,
+                                        mask_prompt_fwd=cfg.MASK_PROMPT_FWD, text_templates=cfg.PROMPT_NAME,
+                                        precision=precision)
+    else:
+        raise NotImplementedError(f"clip adapter {cfg.NAME} is not in ADAPTER_REGISTER {sorted(ADAPTER_REGISTER)}")
+    ad.visual.stream16 = precision == "fp16" and stream == "fp16"
+    return ad

@@ -33,6 +33,9 @@ class ClipVisual:
         if precision not in ("fp16", "fp32"):
             raise ValueError("precision must be 'fp16' (GEMM operands fp16 like the reference's GPU CLIP) or 'fp32'")
         self.precision = precision
+        # fp16 policy only: keep the residual stream of plain (no mask prompt, no attention bias) forward passes in fp16, as the
+        # reference's fp16 CLIP does (adapter.py:108-111); set by build_clip_adapter from MODEL.CLIP_ADAPTER.RESIDUAL_STREAM
+        self.stream16 = False
         self.w = {}
 
     def load_state_dict(self, sd, prefix, device):
@@ -60,18 +63,21 @@ class ClipVisual:
         return self
 
     def embed(self, A, M, patch_open=None):
-        """patch im2col matrix [M*G*G, 3*ps*ps] (f32 or fp16) -> ln_pre(tokens) f32 [M, G*G+1, C] (model.py:328-343)."""
+        """patch im2col matrix [M*G*G, 3*ps*ps] (f32 or fp16) -> ln_pre(tokens) [M, G*G+1, C] (model.py:328-343): f32, or fp16 when
+        the tower keeps an fp16 residual stream (stream16, plain crops only)."""
         w = self.w
         G = self.input_resolution // self.patch
-        x = ops.gemm_nt_f16(A, w["conv1.h"]) if self.precision == "fp16" else ops.gemm_nt(A, w["conv1"])   # conv1, no bias
+        s16 = self.stream16 and self.precision == "fp16" and patch_open is None
+        x = ops.gemm_nt_f16(A, w["conv1.h"], out_f16=s16) if self.precision == "fp16" else ops.gemm_nt(A, w["conv1"])   # conv1, no bias
         if patch_open is not None:                                  # model.py:334-338
             ops.mask_prompt_select(x, patch_open, w["mask_embedding"][0], 0)
         return ops.vit_embed_ln(x, w["cls"], w["pos"], w["ln_pre.w"], w["ln_pre.b"], M, G * G + 1)
 
     def run_blocks(self, x, i0, i1, attn_bias=None):
-        """resblocks[i0:i1] on x f32 [B, L, C] (model.py:238-268); attn_bias: additive f32 [B, heads, L, ld] (SideAdapter).
-        fp16 policy: GEMM operands rounded to fp16 (weights cast once), f32 accumulation / residual stream / LayerNorm /
-        softmax; fp32 policy: exact-f32 MFMA."""
+        """resblocks[i0:i1] on x [B, L, C] (model.py:238-268); attn_bias: additive f32 [B, heads, L, ld] (SideAdapter).
+        fp16 policy: GEMM operands rounded to fp16 (weights cast once), f32 accumulation / LayerNorm statistics / softmax; the
+        residual stream is whatever dtype x has: f32, or fp16 (stream16: x_new = fp16(f32(x) + bias + sum), one rounding per
+        sub-block -- what the reference's fp16 CLIP keeps between blocks).  fp32 policy: exact-f32 MFMA, f32 stream."""
         w = self.w
         B, L, C = x.shape
         Hh = self.heads
@@ -118,7 +124,8 @@ class ClipVisual:
         h = ops.layernorm(x, w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"], out_f16=f16)
         hq = h[:, 0, :].contiguous()
         bi = w[f"{i}.attn.in_proj_bias"]
-        xc = x[:, 0, :].contiguous()
+        # the class-token path is [B] rows: f32 from here on whatever the stream's dtype
+        xc = ops.cast_f16_to_f32_rows(x[:, 0, :]) if x.dtype == torch.float16 else x[:, 0, :].contiguous()
         if f16:
             wi = w[f"{i}.attn.in_proj_weight.h"]
             kv = ops.gemm_nt_f16(h.view(-1, C), wi[C:], bi[C:], out_f16=True)                   # [B*L, 2C]: keys | values

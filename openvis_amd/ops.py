@@ -132,8 +132,21 @@ def gemm_nt_f16(a, w, bias=None, residual=None, act=ACT_NONE, out_f16=False):
     if a2.dtype != torch.float16 or w.dtype != torch.float16:
         raise _lib.OvisError("gemm_nt_f16 needs fp16 operands")
     M = a2.shape[0]
-    out = torch.empty((M, N), dtype=torch.float16 if out_f16 else torch.float32, device=a.device)
     r2 = residual.reshape(-1, N) if residual is not None else None
+    if r2 is not None and r2.dtype == torch.float16:
+        # the tower's fp16 residual stream: C (fp16) = A B^T + bias + R (fp16), accumulated in f32
+        if act != ACT_NONE:
+            raise _lib.OvisError("gemm_nt_f16: an fp16 residual goes with act = none (out-proj / c_proj)")
+        out = torch.empty((M, N), dtype=torch.float16, device=a.device)
+        if _lib.lib().ovis_gemm_nt_f16_res16_eligible(_lib._conv(out), _lib._conv(r2), _ll(K), _ll(w.stride(0)), _ll(N), _ll(N), M, N, K,
+                                                      _lib._conv(bias)):
+            with _Prof("gemm_f16_pp_kernel<1,0,true,false,false,true>", 2.0 * M * N * K):
+                _lib.call("ovis_gemm_nt_f16_res16", a2, _ll(K), w, _ll(w.stride(0)), out, _ll(N), M, N, K, bias, r2, _ll(N), _lib.stream_ptr())
+            return out.view(*a.shape[:-1], N)
+        # small problems (few crops): the same arithmetic through the f32-residual kernels and one rounding at the end
+        o32 = gemm_nt_f16(a2, w, bias, cast_f16_to_f32_rows(r2, N), act, out_f16=False)
+        return cast_f16(o32).view(*a.shape[:-1], N)
+    out = torch.empty((M, N), dtype=torch.float16 if out_f16 else torch.float32, device=a.device)
     kname = ""
     if PROFILE is not None:                     # the kernel the library picks (name as rocprofv3 reports it)
         fn = _lib.lib().ovis_gemm_nt_f16_kernel
@@ -231,6 +244,16 @@ def batch_index_rows(src, idx, out, src_bs, src_rs, out_bs, out_rs, length):
     return out
 
 
+def cast_f16_to_f32_rows(x, C=None):
+    """fp16 rows -> dense f32 [rows, C]; x may be a strided row view (e.g. the class-token rows x[:, 0, :] of [B, L, C])."""
+    if not (x.is_cuda and x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1):
+        raise _lib.OvisError("cast_f16_to_f32_rows needs a 2-d fp16 HIP tensor with contiguous rows")
+    C = x.shape[1] if C is None else C
+    y = torch.empty((x.shape[0], C), dtype=torch.float32, device=x.device)
+    _lib.call("ovis_cast_f16_to_f32_rows", ctypes.c_void_p(x.data_ptr()), _ll(x.stride(0)), y, _ll(x.shape[0]), C, _lib.stream_ptr())
+    return y
+
+
 def cast_f16(x):
     _chk(x)
     y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
@@ -293,6 +316,12 @@ def layernorm(x, gamma, beta, residual=None, eps=1e-5, out_f16=False):
     _chk(x, gamma, beta, residual)
     C = x.shape[-1]
     y = torch.empty(x.shape, dtype=torch.float16 if out_f16 else torch.float32, device=x.device)
+    if x.dtype == torch.float16:             # fp16 residual stream: statistics in f32 (CLIP's LayerNorm subclass, model.py:157-163)
+        if residual is not None:
+            raise _lib.OvisError("layernorm: no residual input with an fp16 x")
+        _lib.call("ovis_layernorm_f16_to_f16" if out_f16 else "ovis_layernorm_f16_to_f32", x, gamma, beta, y, _ll(x.numel() // C), C,
+                  float(eps), _lib.stream_ptr())
+        return y
     _lib.call("ovis_layernorm_f32_to_f16" if out_f16 else "ovis_layernorm_f32", x, residual, gamma, beta, y,
               _ll(x.numel() // C), C, float(eps), _lib.stream_ptr())
     return y
@@ -462,6 +491,10 @@ def mask_prompt_select(x, patch_open, mask_embedding, first_token):
 def vit_embed_ln(patch, cls, pos, gamma, beta, M, L1, eps=1e-5):
     _chk(patch, cls, pos, gamma, beta)
     C = cls.numel()
+    if patch.dtype == torch.float16:         # fp16 patch embeddings in, fp16 tokens out (the tower's fp16 residual stream)
+        out = torch.empty((M, L1, C), dtype=torch.float16, device=patch.device)
+        _lib.call("ovis_vit_embed_ln_f16", patch, cls, pos, gamma, beta, out, M, L1, C, float(eps), _lib.stream_ptr())
+        return out
     out = torch.empty((M, L1, C), dtype=torch.float32, device=patch.device)
     _lib.call("ovis_vit_embed_ln_f32", patch, cls, pos, gamma, beta, out, M, L1, C, float(eps), _lib.stream_ptr())
     return out

@@ -221,3 +221,44 @@ def test_skinny_f32_gemm_of_the_decoders(M, N, K, act, bias, res):
     finally:
         lib.ovis_set_skinny_gemm(1)
     assert (outs[0] - old).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("M", [22000 + 37, 700])
+def test_fp16_gemm_on_the_fp16_residual_stream(M):
+    # out-proj / c_proj of a CLIP block with the residual stream in fp16: C = fp16(f32(R) + bias + A B^T), one rounding at the end.
+    # M = 22 037 rows is taken by the ping-pong kernel's fp16-residual instantiation, 700 rows by the fallback (f32-residual kernels + a cast)
+    from openvis_amd import ops
+    N, K = 768, 768
+    g = torch.Generator().manual_seed(M)
+    a = torch.randn(M, K, generator=g).half().cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).half().cuda()
+    b = torch.randn(N, generator=g).cuda()
+    r = (3 * torch.randn(M, N, generator=g)).half().cuda()
+    ref = (a.double() @ w.double().T + b.double() + r.double())
+    out = ops.gemm_nt_f16(a, w, b, r)
+    assert out.dtype == torch.float16 and out.shape == (M, N)
+    err = (out.double() - ref).abs()
+    assert (err <= 1e-3 + 2.0 ** -10 * ref.abs()).all(), err.max().item()       # fp16 rounding of the result (+ f32 accumulation noise)
+    assert torch.equal(out, ops.gemm_nt_f16(a, w, b, r))
+
+
+def test_layernorm_and_token_embedding_on_fp16_streams():
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = (2 * torch.randn(3001, 768, generator=g) + 0.5).half().cuda()
+    gamma, beta = torch.randn(768, generator=g).cuda(), torch.randn(768, generator=g).cuda()
+    ref = torch.nn.functional.layer_norm(x.double(), (768,), gamma.double(), beta.double(), 1e-5)
+    y32 = ops.layernorm(x, gamma, beta)
+    y16 = ops.layernorm(x, gamma, beta, out_f16=True)
+    assert y32.dtype == torch.float32 and (y32.double() - ref).abs().max().item() < 2e-5
+    assert y16.dtype == torch.float16 and (y16.double() - ref).abs().max().item() < 5e-3
+    # class-token rows of an fp16 token tensor -> dense f32
+    tok = x[:3000].view(100, 30, 768)
+    assert torch.equal(ops.cast_f16_to_f32_rows(tok[:, 0, :]), tok[:, 0, :].float())
+    # ln_pre(cat(cls, patches) + pos): fp16 patch embeddings in, fp16 tokens out == the f32 kernel on the same values, rounded
+    M, L1, C = 7, 197, 768
+    patch = torch.randn(M * (L1 - 1), C, generator=g).cuda()
+    cls, pos = torch.randn(C, generator=g).cuda(), torch.randn(L1, C, generator=g).cuda()
+    t32 = ops.vit_embed_ln(patch.half().float(), cls, pos, gamma, beta, M, L1)
+    t16 = ops.vit_embed_ln(patch.half(), cls, pos, gamma, beta, M, L1)
+    assert t16.dtype == torch.float16 and torch.equal(t16, t32.half())

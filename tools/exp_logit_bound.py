@@ -52,8 +52,9 @@ def run(Q=40, T=2, K=482, device="cuda"):
         ref = feat @ text.T                                                    # cosines [M,K]
     t_ref = time.time() - t0
     res = {}
-    for prec in ("fp16", "fp32"):
-        ad = ClipAdapter("ViT-B/16", precision=prec).load_state_dict(sd, "clip_adapter.", device)
+    for prec in ("fp16 + fp16 stream", "fp16", "fp32"):      # first = the bench policy (MODEL.CLIP_ADAPTER.RESIDUAL_STREAM fp16)
+        ad = ClipAdapter("ViT-B/16", precision=prec.split()[0]).load_state_dict(sd, "clip_adapter.", device)
+        ad.visual.stream16 = prec.endswith("stream")
         ad.set_text_features(names, text)
         logits, v, crops = ad(frames.to(device), names, masks.to(device), (Hp, Wp))
         assert (v == valid.numpy()).all() and logits.shape == ref.shape
