@@ -1,10 +1,17 @@
+"""fp16 storage of the backbone activations, emulated (OVIS_EXP_BB16=1): per-query mask IoU at 720p against the f32 oracle.
+Result: profiles/r02/negative_backbone_fp16_activations.txt"""
 import sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from openvis_amd import config, weights
 from openvis_amd.catalog import MetadataCatalog
 from oracle import torch_ref as TR
+if os.environ.get("OVIS_EXP_BB16"):          # emulate fp16 activation storage: round every conv output of the ResNet to fp16
+    from openvis_amd.modeling.backbone import resnet as _rn
+    _cls = next(v for v in vars(_rn).values() if isinstance(v, type) and hasattr(v, "_conv"))
+    _orig = _cls._conv
+    _cls._conv = lambda self, *a, **k: _orig(self, *a, **k).half().float()
 K, T = 40, 2
 sd = weights.random_init(weights.openvis_spec("r50", None, 100), seed=42)
 names = [f"class_{i}" for i in range(K)]
