@@ -1,5 +1,5 @@
-// Skinny f32 GEMM for the 100-row problems of the masked-attention decoders (queries x Linear; video / frame decoder layers,
-// mask-embed MLP, class heads: video_mask2former_transformer_decoder.py:413-452 and the nn.Linear modules it calls).
+// Skinny f32 GEMM for the 100-row problems of the masked-attention decoders (queries x Linear; FFNLayer.forward_post,
+// video_mask2former_transformer_decoder.py:175-179, and the other nn.Linear modules of the layer loop :413-452).
 //
 //   C[m,n] = act( sum_k A[m,k] * B[n,k] + bias[n] + R[m,n] ),  M <= 128, K % 256 == 0, f32 everywhere (exact f32 MFMA).
 //
