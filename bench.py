@@ -295,7 +295,8 @@ def main():
         # the ping-pong kernel's f32-A instantiations (<.., X3=false, FA=true>: bf16x2, three bf16 products per f32 product) are a
         # family of their own: their flops are f32-equivalent and their ceiling is the bf16 peak / 3, not the fp16 peak
         base = k.split("<")[0]
-        return base + "[f32A]" if base == "gemm_f16_pp_kernel" and k.endswith(",true>") and k.count(",") == 4 else base
+        targs = k[len(base) + 1:-1].split(",") if "<" in k else []          # <OUT, ACT, HAS_R, X3, FA, R16>
+        return base + "[f32A]" if base == "gemm_f16_pp_kernel" and len(targs) >= 5 and targs[4] == "true" else base
 
     def _families(a):
         fam = {}
@@ -306,7 +307,7 @@ def main():
 
     fam_situ, fam_iso = _families(agg_situ), _families(agg)
     kbase, (n_launch, flops, secs, members) = max(fam_situ.items(), key=lambda kv: kv[1][2])
-    dom = (kbase.replace("[f32A]", "") + ("<*,true>" if "[f32A]" in kbase else "<*>") if len(members) > 1 else next(iter(members)), None)
+    dom = (kbase.replace("[f32A]", "") + ("<*,FA=true>" if "[f32A]" in kbase else "<*>") if len(members) > 1 else next(iter(members)), None)
     achieved = flops / secs / 1e12
     iso = fam_iso.get(kbase, (n_launch, flops, secs))
     if "f32x3" in kbase or "[f32A]" in kbase:      # one f32 product = 6 (bf16x3) or 3 (bf16x2) bf16 MFMA products: ceiling = bf16 peak / that

@@ -466,10 +466,10 @@ extern "C" const char* ovis_gemm_nt_f16_kernel(const void* C, long long lda, lon
                                                const float* bias, const float* residual, long long ldr, int act, int out_f16) {
   // same decision tree as ovis_gemm_nt_f16 (names as rocprofv3 prints them, without the anonymous namespace)
   if (ovis::gemm_f16_pp_eligible(C, lda, ldb, ldc, M, N, K, bias, residual, ldr, out_f16, act == 0))
-    // <OUT, ACT, HAS_R, X3> as rocprofv3 prints the instantiation (bench.py joins the PMC summaries on this name)
-    return out_f16 ? (act == 0 ? "gemm_f16_pp_kernel<1,0,false,false>" : act == 1 ? "gemm_f16_pp_kernel<1,1,false,false>" :
-                      act == 2 ? "gemm_f16_pp_kernel<1,2,false,false>" : "gemm_f16_pp_kernel<1,3,false,false>")
-                   : (residual ? "gemm_f16_pp_kernel<0,0,true,false>" : "gemm_f16_pp_kernel<0,0,false,false>");
+    // <OUT, ACT, HAS_R, X3, FA, R16> as rocprofv3 prints the instantiation (bench.py joins the PMC summaries on this name)
+    return out_f16 ? (act == 0 ? "gemm_f16_pp_kernel<1,0,false,false,false,false>" : act == 1 ? "gemm_f16_pp_kernel<1,1,false,false,false,false>" :
+                      act == 2 ? "gemm_f16_pp_kernel<1,2,false,false,false,false>" : "gemm_f16_pp_kernel<1,3,false,false,false,false>")
+                   : (residual ? "gemm_f16_pp_kernel<0,0,true,false,false,false>" : "gemm_f16_pp_kernel<0,0,false,false,false,false>");
   const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128);
   const long long blocks256 = (long long)ovis::cdiv(M, 256) * ovis::cdiv(N, 256);
   if (blocks256 >= 256 && K % 64 == 0) return out_f16 ? "gemm_f16_256_kernel<true>" : "gemm_f16_256_kernel<false>";

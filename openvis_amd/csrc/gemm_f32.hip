@@ -195,8 +195,8 @@ extern "C" int ovis_set_f32a_pp(int on) { g_f32a_pp = on ? 1 : 0; return OVIS_OK
 extern "C" const char* ovis_gemm_nt_f32_w3_kernel(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C,
                                                   long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr, int act) {
   if (g_f32_gemm_mode == 2 && g_f32a_pp && ovis::gemm_f32a_pp_eligible(A, lda, W3, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, act))
-    return residual ? (act == 1 ? "gemm_f16_pp_kernel<0,1,true,false,true>" : "gemm_f16_pp_kernel<0,0,true,false,true>")
-                    : (act == 1 ? "gemm_f16_pp_kernel<0,1,false,false,true>" : "gemm_f16_pp_kernel<0,0,false,false,true>");
+    return residual ? (act == 1 ? "gemm_f16_pp_kernel<0,1,true,false,true,false>" : "gemm_f16_pp_kernel<0,0,true,false,true,false>")
+                    : (act == 1 ? "gemm_f16_pp_kernel<0,1,false,false,true,false>" : "gemm_f16_pp_kernel<0,0,false,false,true,false>");
   return "";
 }
 

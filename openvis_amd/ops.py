@@ -637,7 +637,7 @@ def gemm_nt_planes(a3, w3, bias=None, residual=None, act=ACT_NONE, out_planes=Fa
     N = w3.shape[1]
     out = torch.empty((3, M, N), dtype=torch.bfloat16, device=a3.device) if out_planes else \
         torch.empty((M, N), dtype=torch.float32, device=a3.device)
-    with _Prof(f"gemm_f16_pp_kernel<{2 if out_planes else 0},{act},{'true' if residual is not None else 'false'},true>", 2.0 * M * N * K):
+    with _Prof(f"gemm_f16_pp_kernel<{2 if out_planes else 0},{act},{'true' if residual is not None else 'false'},true,false,false>", 2.0 * M * N * K):
         _lib.call("ovis_gemm_nt_bf16x3_planes", a3, _ll(K), _ll(M * K), w3, _ll(K), _ll(N * K), out, _ll(N), _ll(M * N), M, N, K, bias,
                   residual, _ll(N), act, int(out_planes), _lib.stream_ptr())
     return out
