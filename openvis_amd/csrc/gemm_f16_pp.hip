@@ -60,8 +60,8 @@ constexpr int PP_HT = 128 * 128;           // bytes of a half-tile: 128 rows x 6
 constexpr int PP_BUF = 4 * PP_HT;          // one K step: A0 A1 B0 B1
 constexpr int PP_BIAS = 2 * PP_BUF;        // bias (f32) behind the two buffers
 constexpr int PP_LDS = 160 * 1024;
-constexpr int PP_TAB = PP_LDS - 4096;      // this workgroup's tile list: 128 entries of 32 bytes
-constexpr int PP_MAX_TILES = 128;
+constexpr int PP_TAB = PP_LDS - 8192;      // this workgroup's tile list: 256 entries of 32 bytes (1000 crops x ViT-L/14@336 fc1: 141 per workgroup)
+constexpr int PP_MAX_TILES = 256;
 constexpr int PP_MAX_BIAS_N = (PP_TAB - PP_BIAS) / 4;
 struct PPTile { long long a_off, b_off; int bm, bml, bn, bnl; };   // DMA bases (bytes) of the shifted tile; rows / columns owned and computed
 
@@ -621,9 +621,10 @@ int gemm_f16_pp_launch(const void* A, long long lda, const void* B, long long ld
 // ---- f32-A mode (bf16x2): A f32 [M,K], W as bf16 planes [>=2][N][ldb] (the first two of ovis_split_f32_to_bf16x3) ----
 bool gemm_f32a_pp_eligible(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C, long long ldc,
                            int M, int N, int K, const float* bias, const float* residual, long long ldr, int act) {
-  if (act != 0 && act != 1) return false;
+  if (act < 0 || act > 3 || (residual && act > 1)) return false;          // instantiated: none / ReLU (+ residual), QuickGELU, GELU
   const long long tiles_n = cdiv(N, 256), blocks256 = (long long)cdiv(M, 256) * tiles_n;
   if (blocks256 < 256 || blocks256 > 256ll * PP_MAX_TILES || M < 256 || N < 256) return false;
+  if (blocks256 * 10 < 256 * cdiv(blocks256, 256) * 7) return false;       // last round < 40 % full on top of one round (e.g. 288 tiles): 2 WGs / CU of gemm_f32x3_kernel win
   if (tiles_n * 256 * 100 > (long long)N * 115) return false;           // > 15 % of the columns computed for nothing (N = 288: 78 %)
   if (K % 32 != 0 || K < 64 || N % 8 != 0) return false;
   if (lda % 4 != 0 || ldb % 8 != 0 || plane % 8 != 0 || ldc % 4 != 0) return false;
@@ -649,7 +650,10 @@ int gemm_f32a_pp_launch(const float* A, long long lda, const void* W3, long long
   const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
 #define PP_LAUNCH(A_, R_) hipLaunchKernelGGL((gemm_f16_pp_kernel<0, A_, R_, false, true>), dim3(grid), dim3(512), 0, s, p)
   if (residual) { if (act == 1) PP_LAUNCH(1, true); else PP_LAUNCH(0, true); }
-  else { if (act == 1) PP_LAUNCH(1, false); else PP_LAUNCH(0, false); }
+  else if (act == 1) PP_LAUNCH(1, false);
+  else if (act == 2) PP_LAUNCH(2, false);
+  else if (act == 3) PP_LAUNCH(3, false);
+  else PP_LAUNCH(0, false);
 #undef PP_LAUNCH
   return check_launch("gemm_nt_f32 (ping-pong, f32 A, bf16x2)");
 }

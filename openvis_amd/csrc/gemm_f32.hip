@@ -196,7 +196,8 @@ extern "C" const char* ovis_gemm_nt_f32_w3_kernel(const float* A, long long lda,
                                                   long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr, int act) {
   if (g_f32_gemm_mode == 2 && g_f32a_pp && ovis::gemm_f32a_pp_eligible(A, lda, W3, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, act))
     return residual ? (act == 1 ? "gemm_f16_pp_kernel<0,1,true,false,true,false>" : "gemm_f16_pp_kernel<0,0,true,false,true,false>")
-                    : (act == 1 ? "gemm_f16_pp_kernel<0,1,false,false,true,false>" : "gemm_f16_pp_kernel<0,0,false,false,true,false>");
+                    : (act == 1 ? "gemm_f16_pp_kernel<0,1,false,false,true,false>" : act == 2 ? "gemm_f16_pp_kernel<0,2,false,false,true,false>" :
+                       act == 3 ? "gemm_f16_pp_kernel<0,3,false,false,true,false>" : "gemm_f16_pp_kernel<0,0,false,false,true,false>");
   return "";
 }
 

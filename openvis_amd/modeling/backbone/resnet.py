@@ -62,9 +62,9 @@ class ResNet:
             N, H, W, C = x.shape
             y = ops.gemm_nt(x.view(-1, C), w.view(w.shape[0], C), b,
                             residual.view(-1, w.shape[0]) if residual is not None else None, act,
-                            w16=w16.view(w.shape[0], C) if w16 is not None else None)
+                            w16=w16.view(w.shape[0], C) if w16 is not None else None, cw=True)
             return y.view(N, H, W, -1)
-        return ops.conv2d_nhwc(x, w, stride, pad, b, residual, act, w16=w16)
+        return ops.conv2d_nhwc(x, w, stride, pad, b, residual, act, w16=w16, cw=True)
 
     def forward(self, x):
         """x: f32 [T,Hp,Wp,4] (normalised, channel 3 zero) -> {res2..res5} NHWC."""

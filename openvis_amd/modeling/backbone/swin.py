@@ -83,7 +83,7 @@ class SwinTransformer:
         b = self.w.get(name + ".bias") if bias else None
         if x.dtype == torch.float16:
             return ops.gemm_nt_f16(x, self.w16[name + ".weight"], b, residual, act, out_f16=out_f16)
-        return ops.gemm_nt(x, self.w[name + ".weight"], b, residual, act)
+        return ops.gemm_nt(x, self.w[name + ".weight"], b, residual, act, cw=True)
 
     def _ape_table(self, H, W, device):
         """absolute_pos_embed bicubically interpolated to the patch grid (swin.py:706-712) as [H,W,E] NHWC, cached per size."""
@@ -136,7 +136,7 @@ class SwinTransformer:
     def forward(self, x):
         """x: f32 [T,Hp,Wp,4] (normalised, channel 3 zero; Hp, Wp multiples of 32) -> {res2..res5} NHWC."""
         w = self.w
-        x = ops.conv2d_nhwc(x, w["patch_embed.proj.weight"], self.patch_size, 0, w["patch_embed.proj.bias"])
+        x = ops.conv2d_nhwc(x, w["patch_embed.proj.weight"], self.patch_size, 0, w["patch_embed.proj.bias"], cw=True)
         if self.patch_norm:
             x = ops.layernorm(x, w["patch_embed.norm.weight"], w["patch_embed.norm.bias"])
         if self.ape:

@@ -68,7 +68,7 @@ class ClipVisual:
         w = self.w
         G = self.input_resolution // self.patch
         s16 = self.stream16 and self.precision == "fp16" and patch_open is None
-        x = ops.gemm_nt_f16(A, w["conv1.h"], out_f16=s16) if self.precision == "fp16" else ops.gemm_nt(A, w["conv1"])   # conv1, no bias
+        x = ops.gemm_nt_f16(A, w["conv1.h"], out_f16=s16) if self.precision == "fp16" else ops.gemm_nt(A, w["conv1"], cw=True)   # conv1, no bias
         if patch_open is not None:                                  # model.py:334-338
             ops.mask_prompt_select(x, patch_open, w["mask_embedding"][0], 0)
         return ops.vit_embed_ln(x, w["cls"], w["pos"], w["ln_pre.w"], w["ln_pre.b"], M, G * G + 1)
@@ -93,7 +93,7 @@ class ClipVisual:
                 if f16:
                     qkv = ops.gemm_nt_f16(h.view(-1, C), w[f"{i}.attn.in_proj_weight.h"], w[f"{i}.attn.in_proj_bias"])
                 else:
-                    qkv = ops.gemm_nt(h.view(-1, C), w[f"{i}.attn.in_proj_weight"], w[f"{i}.attn.in_proj_bias"])
+                    qkv = ops.gemm_nt(h.view(-1, C), w[f"{i}.attn.in_proj_weight"], w[f"{i}.attn.in_proj_bias"], cw=True)
                 att = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B, Hh, L, L, D, L * 3 * C, 3 * C, L * 3 * C, 3 * C,
                                     L * 3 * C, 3 * C, bias=attn_bias, out_f16=f16)
             if f16:
@@ -105,10 +105,10 @@ class ClipVisual:
                 x = ops.gemm_nt_f16(f, w[f"{i}.mlp.c_proj.weight.h"], w[f"{i}.mlp.c_proj.bias"], x.view(-1, C)).view(B, L, C)
             else:
                 x = ops.gemm_nt(att.view(-1, C), w[f"{i}.attn.out_proj.weight"], w[f"{i}.attn.out_proj.bias"],
-                                x.view(-1, C)).view(B, L, C)
+                                x.view(-1, C), cw=True).view(B, L, C)
                 h = ops.layernorm(x, w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"])
-                f = ops.gemm_nt(h.view(-1, C), w[f"{i}.mlp.c_fc.weight"], w[f"{i}.mlp.c_fc.bias"], None, ops.ACT_QUICKGELU)
-                x = ops.gemm_nt(f, w[f"{i}.mlp.c_proj.weight"], w[f"{i}.mlp.c_proj.bias"], x.view(-1, C)).view(B, L, C)
+                f = ops.gemm_nt(h.view(-1, C), w[f"{i}.mlp.c_fc.weight"], w[f"{i}.mlp.c_fc.bias"], None, ops.ACT_QUICKGELU, cw=True)
+                x = ops.gemm_nt(f, w[f"{i}.mlp.c_proj.weight"], w[f"{i}.mlp.c_proj.bias"], x.view(-1, C), cw=True).view(B, L, C)
         return x
 
     def last_block_cls(self, x, i):
@@ -136,7 +136,7 @@ class ClipVisual:
             f = ops.gemm_nt_f16(h2, w[f"{i}.mlp.c_fc.weight.h"], w[f"{i}.mlp.c_fc.bias"], None, ops.ACT_QUICKGELU, out_f16=True)
             return ops.gemm_nt_f16(f, w[f"{i}.mlp.c_proj.weight.h"], w[f"{i}.mlp.c_proj.bias"], xc)
         wi = w[f"{i}.attn.in_proj_weight"]
-        kv = ops.gemm_nt(h.view(-1, C), wi[C:], bi[C:])
+        kv = ops.gemm_nt(h.view(-1, C), wi[C:], bi[C:], cw=True)
         q = ops.gemm_nt(hq, wi[:C], bi[:C])
         att = ops.attention(q, kv, kv[:, C:], B, Hh, 1, L, D, C, C, L * 2 * C, 2 * C, L * 2 * C, 2 * C)
         xc = ops.gemm_nt(att.view(B, C), w[f"{i}.attn.out_proj.weight"], w[f"{i}.attn.out_proj.bias"], xc)

@@ -93,7 +93,7 @@ class SideAdapter:
                 x = self.visual.run_blocks(x, done, mid)
                 done = mid
             pix = x[:, 1:, :].contiguous().view(T * g * g, C)
-            mg.append(ops.gemm_nt(pix, self.w[f"attn_projs.{j}.w"], self.w[f"attn_projs.{j}.b"]).view(T, g, g, -1))
+            mg.append(ops.gemm_nt(pix, self.w[f"attn_projs.{j}.w"], self.w[f"attn_projs.{j}.b"], cw=True).view(T, g, g, -1))
         if done < self.broken_idx:
             x = self.visual.run_blocks(x, done, self.broken_idx)
         return mg, x

@@ -41,7 +41,7 @@ class TemporalInstanceResampler:
         return self
 
     def _mm(self, x, wk, bk=None, residual=None, act=ops.ACT_NONE):
-        return ops.gemm_nt(x, self.w[wk], self.w[bk] if bk else None, residual, act, w16=self.h.get(wk))
+        return ops.gemm_nt(x, self.w[wk], self.w[bk] if bk else None, residual, act, w16=self.h.get(wk), cw=True)
 
     @staticmethod
     def _temporal_taps(x, k):

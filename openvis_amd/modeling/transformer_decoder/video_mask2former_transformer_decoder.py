@@ -87,7 +87,7 @@ class VideoMultiScaleMaskedTransformerDecoder:
         return self
 
     def _mm(self, x, wk, bk=None, residual=None, act=ops.ACT_NONE):
-        return ops.gemm_nt(x, self.w[wk], self.w[bk] if bk else None, residual, act, w16=self.h.get(wk))
+        return ops.gemm_nt(x, self.w[wk], self.w[bk] if bk else None, residual, act, w16=self.h.get(wk), cw=True)
 
     def _pos(self, T, H, W):
         key = (T, H, W)

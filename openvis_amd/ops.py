@@ -79,15 +79,17 @@ def _w3_kernel_name(a, lda, w3, ldb, plane, out, ldc, M, N, K, bias, residual, l
 
 
 def w3_of(w):
-    """The exact 3-way bf16 split of a CONSTANT weight tensor, cached per tensor object (csrc/gemm_f32x3.h)."""
-    key = id(w)
+    """The exact 3-way bf16 split of a CONSTANT weight tensor (csrc/gemm_f32x3.h), cached per (base tensor, view geometry): a
+    `w.view(...)` or a row slice `w[C:]` made afresh at every call hits the same entry; entries die with the base tensor."""
+    base = w._base if w._base is not None else w
+    key = (id(base), w.storage_offset(), tuple(w.shape), tuple(w.stride()))
     hit = _W3_CACHE.get(key)
-    if hit is not None and hit[0]() is w:
+    if hit is not None and hit[0]() is base:
         return hit[1]
     _chk(w)
     p = torch.empty((3,) + tuple(w.shape), dtype=torch.bfloat16, device=w.device)
     _lib.call("ovis_split_f32_to_bf16x3", w, p, _ll(w.numel()), _lib.stream_ptr())
-    _W3_CACHE[key] = (weakref.ref(w, lambda _r, k=key: _W3_CACHE.pop(k, None)), p)
+    _W3_CACHE[key] = (weakref.ref(base, lambda _r, k=key: _W3_CACHE.pop(k, None)), p)
     return p
 
 

@@ -262,3 +262,34 @@ def test_layernorm_and_token_embedding_on_fp16_streams():
     t32 = ops.vit_embed_ln(patch.half().float(), cls, pos, gamma, beta, M, L1)
     t16 = ops.vit_embed_ln(patch.half(), cls, pos, gamma, beta, M, L1)
     assert t16.dtype == torch.float16 and torch.equal(t16, t32.half())
+
+
+@pytest.mark.parametrize("N,K,act,res", [(1024, 256, 1, False), (256, 256, 0, True), (768, 192, 3, False), (512, 1024, 2, False), (256, 2048, 1, True)])
+def test_bf16x2_on_the_ping_pong_schedule_matches_the_tiled_kernel(gemm_modes, N, K, act, res):
+    # MODEL.F32_GEMM_SPLIT bf16x2 with constant weights: eligible shapes run on the ping-pong kernel's f32-A mode (f32 A tiles by LDS-DMA,
+    # split into hi / lo bf16 in registers); same three products as gemm_f32x3_kernel<.., 2> -> same error class, every activation
+    ops = gemm_modes
+    M = 70000 + 13
+    g = torch.Generator().manual_seed(N + K + act)
+    a = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    r = torch.randn(M, N, generator=g).cuda() if res else None
+    pre = a.double() @ w.double().T + b.double() + (r.double() if res else 0)
+    ref = {0: lambda x: x, 1: torch.relu, 2: lambda x: x * torch.sigmoid(1.702 * x), 3: lambda x: torch.nn.functional.gelu(x)}[act](pre)
+    scale = a.double().abs() @ w.double().abs().T + b.double().abs() + (r.double().abs() if res else 0)
+    lib = ops._lib.lib()
+    ops.set_f32_gemm_mode(2)
+    lib.ovis_gemm_nt_f32_w3_kernel.restype = __import__("ctypes").c_char_p
+    outs = {}
+    for pp in (1, 0):
+        lib.ovis_set_f32a_pp(pp)
+        try:
+            outs[pp] = [ops.gemm_nt(a, w, b, r, act, cw=True) for _ in range(2)]
+        finally:
+            lib.ovis_set_f32a_pp(1)
+    for pp in (1, 0):
+        err = ((outs[pp][0].double() - ref).abs() / scale).max().item()
+        assert err < 2.0 ** -15, (pp, err)
+    assert torch.equal(outs[1][0], outs[1][1])                       # deterministic
+    assert ((outs[1][0] - outs[0][0]).abs().double() / scale).max().item() < 2.0 ** -15
