@@ -150,7 +150,7 @@ const char* ovis_gemm_nt_f16_kernel(const void* C, long long lda, long long ldb,
                                     const float* bias, const float* residual, long long ldr, int act, int out_f16);
 
 /* Name of the kernel ovis_gemm_nt_f32_w3 (and the 1x1 / stride 1 / pad 0 case of ovis_conv2d_nhwc_f32_w3) launches when it is the
- * ping-pong kernel's f32-A mode -- bf16x2 (mode 2) on shapes of >= 256 tiles of 256x256 with K % 32 == 0 and <= 15 % padded
+ * ping-pong kernel's f32-A mode -- bf16x2 (mode 2) on shapes of >= 256 tiles of 256x256 with K % 32 == 0 and <= 35 % padded
  * columns --, "" when it is gemm_f32x3_kernel / gemm_f32_kernel (static string; for profiles and bench.py's roofline). */
 const char* ovis_gemm_nt_f32_w3_kernel(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C,
                                        long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr,
