@@ -253,11 +253,19 @@ attn_mask_kernel(const float* __restrict__ logits, long long ld, uint8_t* __rest
   int open = 0;
   if (k0 < Nk) {
     unsigned bits = 0;
+    const float* row = logits + (long long)q * ld + k0;
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    if (k0 + 3 < Nk && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {   // one 16-byte load (was four scalar ones: 270 GB/s)
+      const float4 v = *reinterpret_cast<const float4*>(row);
+      x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (k0 + e < Nk) x[e] = row[e];
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (k0 + e < Nk) {
-        const float x = logits[(long long)q * ld + k0 + e];
-        const bool blocked = sigmoidf_(x) < 0.5f;
+        const bool blocked = sigmoidf_(x[e]) < 0.5f;
         bits |= (blocked ? 1u : 0u) << (8 * e);
         open += blocked ? 0 : 1;
       }
