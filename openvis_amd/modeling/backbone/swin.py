@@ -86,7 +86,7 @@ class SwinTransformer:
         return ops.gemm_nt(x, self.w[name + ".weight"], b, residual, act, cw=True)
 
     def _ape_table(self, H, W, device):
-        """absolute_pos_embed bicubically interpolated to the patch grid (swin.py:706-712) as [H,W,E] NHWC, cached per size."""
+        """absolute_pos_embed bicubically interpolated to the patch grid (swin.py:656-661) as [H,W,E] NHWC, cached per size."""
         k = ("ape", H, W)
         if k not in self._tables:
             t = torch.nn.functional.interpolate(self._ape, size=(H, W), mode="bicubic")        # constant preparation, once per size
