@@ -98,9 +98,19 @@ struct PPArgs {
 //      (every half-tile is still two DMA instructions per wavefront).
 // R16: the residual is fp16 (and the output too, OUT == 1): the fp16 residual stream of the CLIP tower -- what the reference's
 //      fp16 CLIP keeps between blocks (adapter.py:108-111); a lane's 8 consecutive columns of a row are ONE 16-byte load.
-template <int OUT, int ACT, bool HAS_R, bool X3, bool FA = false, bool R16 = false>
+// TM : rows of a tile, 256 or 192.  192 = the same schedule with 96 rows per wave group (row-block quadrant i = 1 has two 16-row
+//      blocks instead of four: 3/4 of the MFMAs and stores, the DMA volume of a 256-row tile); chosen per launch when it saves a
+//      whole round of tiles (e.g. N = K = 256 at M = 96 600: 378 tiles = 1.48 rounds of 256 workgroups -> 504 tiles = 1.97).
+template <int OUT, int ACT, bool HAS_R, bool X3, bool FA = false, bool R16 = false, int TM = 256>
 __global__ void __launch_bounds__(512)
 gemm_f16_pp_kernel(const PPArgs p) {
+  static_assert(TM == 256 || (TM == 192 && !X3), "tile heights: 256, or 192 for the fp16 / f32-A modes");
+  constexpr int GS = TM / 2;                                       // rows of a wave group
+  // TM = 192: the second half-tile of a group starts 32 rows into the group (rows GS wr + 32 .. + 95, overlapping the first by 32 rows)
+  // and only its upper two 16-row blocks are multiplied -- no load reaches beyond the tile's 192 rows
+  constexpr int A1_ROW = TM == 256 ? 64 : 32;                      // first row (inside the group) of half-tile i = 1
+  constexpr int MB1_LO = TM == 256 ? 0 : 2;                        // first 16-row block of half-tile i = 1 that is used
+  constexpr int MBT = 8 - MB1_LO;                                  // 16-row blocks of a wavefront (accumulator rows 0 .. MBT-1)
   static_assert(!(FA && X3) && (!FA || OUT == 0), "f32-A mode: f32 output, no plane walking");
   static_assert(!R16 || (HAS_R && OUT == 1 && !X3 && !FA), "fp16 residual: fp16 output of the fp16 GEMM");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[PP_LDS];   // ONE LDS object (a second one de-pipelines the DMA)
@@ -136,7 +146,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
     int tm, tn;
     tile_mn(first + i * nblk, tm, tn);
     PPTile t;
-    t.bm = tm * 256; t.bn = tn * 256; t.bml = min(t.bm, p.M - 256); t.bnl = min(t.bn, p.N - 256);
+    t.bm = tm * TM; t.bn = tn * 256; t.bml = min(t.bm, p.M - TM); t.bnl = min(t.bn, p.N - 256);
     t.a_off = (long long)t.bml * p.lda * (FA ? 4 : 2); t.b_off = (long long)t.bnl * p.ldb * 2;
     *reinterpret_cast<PPTile*>(lds + PP_TAB + i * 32) = t;
   }
@@ -174,7 +184,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
     const int i16 = 8 * g + dr;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      voA[h][g] = (unsigned)((long long)(wr * 128 + h * 64 + 16 * (wave & 3) + i16) * p.lda * (FA ? 4 : 2) + c * 16);   // half-tile row 64 wr + 16 (wave&3) + i16
+      voA[h][g] = (unsigned)((long long)(wr * GS + h * A1_ROW + 16 * (wave & 3) + i16) * p.lda * (FA ? 4 : 2) + c * 16);   // half-tile row 64 wr + 16 (wave&3) + i16
       if constexpr (FA) {     // instruction g = plane g; 16 rows x 64 B: lane -> (row lane>>2, 16-byte chunk lane&3)
         const int r16 = lane >> 2;
         voB[h][g] = (unsigned)(g * p.planeB + (long long)((wave >> 1) * 64 + 32 * h + 8 * (r16 >> 2) + 4 * (wave & 1) + (r16 & 3)) * p.ldb * 2 + (lane & 3) * 16);
@@ -205,6 +215,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
       using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
+        if (i == 1 && mb < MB1_LO) continue;                         // TM = 192: only the upper two row blocks of half-tile 1
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(lds + buf + i * PP_HT + mb * 2048 + a_rd);
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(lds + buf + i * PP_HT + mb * 2048 + (a_rd ^ 16));
         bf16x8 h0, h1;
@@ -219,6 +230,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
     } else {
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
+        if (i == 1 && mb < MB1_LO) continue;
         af[mb][0] = *reinterpret_cast<const f16x8*>(lds + buf + i * PP_HT + mb * 2048 + a_rd);
         af[mb][1] = *reinterpret_cast<const f16x8*>(lds + buf + i * PP_HT + mb * 2048 + (a_rd ^ 64));
       }
@@ -242,9 +254,12 @@ gemm_f16_pp_kernel(const PPArgs p) {
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-          for (int e = 0; e < 2; ++e)
-            acc[i * 4 + mb][j * 2 + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, bf[e][PB2[t]]), __builtin_bit_cast(bf16x8, af[mb][PA2[t]]), acc[i * 4 + mb][j * 2 + e], 0, 0, 0);
+          for (int e = 0; e < 2; ++e) {
+            if (i == 1 && mb < MB1_LO) continue;
+            const int ar = i * 4 + mb - (i == 1 ? MB1_LO : 0);       // accumulator row block
+            acc[ar][j * 2 + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, bf[e][PB2[t]]), __builtin_bit_cast(bf16x8, af[mb][PA2[t]]), acc[ar][j * 2 + e], 0, 0, 0);
+          }
     } else {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -252,13 +267,14 @@ gemm_f16_pp_kernel(const PPArgs p) {
       for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int e = 0; e < 2; ++e)
-          if constexpr (X3) {
+          if (i == 1 && mb < MB1_LO) {
+          } else if constexpr (X3) {
             using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
             acc[i * 4 + mb][j * 2 + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                 __builtin_bit_cast(bf16x8, bf[e][kb]), __builtin_bit_cast(bf16x8, af[mb][kb]), acc[i * 4 + mb][j * 2 + e], 0, 0, 0);
           } else {
-            acc[i * 4 + mb][j * 2 + e] =
-                __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[e][kb], af[mb][kb], acc[i * 4 + mb][j * 2 + e], 0, 0, 0);
+            const int ar = i * 4 + mb - (i == 1 ? MB1_LO : 0);
+            acc[ar][j * 2 + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[e][kb], af[mb][kb], acc[ar][j * 2 + e], 0, 0, 0);
           }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -302,12 +318,12 @@ gemm_f16_pp_kernel(const PPArgs p) {
 
   // ---- epilogue of one tile: a lane owns one output row per 16-row block and 8 consecutive columns per column pair ----
   constexpr int ESZ = OUT == 0 ? 4 : 2;
-  const unsigned lane_c = (unsigned)(((long long)(wr * 128 + l15) * p.ldc + wc * 64 + 8 * q) * ESZ);
+  const unsigned lane_c = (unsigned)(((long long)(wr * GS + l15) * p.ldc + wc * 64 + 8 * q) * ESZ);
   // Row block outer, column pair inner: the two 64-byte halves of a 128-byte line come from CONSECUTIVE store instructions.
   // (Column pair outer -- the halves 8 instructions apart -- measured 5-6 % slower on the whole GEMM: partial-line writes.)
   auto epilogue_rows = [&](auto pred_tag, int bm, int bml, int bn, int bnl) {
     constexpr bool PRED = decltype(pred_tag)::value;                 // edge tile: mask the rows / columns of the neighbour tile
-    const int row0 = bml + wr * 128 + l15, col0 = bnl + wc * 64 + 8 * q;
+    const int row0 = bml + wr * GS + l15, col0 = bnl + wc * 64 + 8 * q;
     // wave-uniform tile base + 32-bit lane offset (one VGPR live across the K loop; 256 rows of C stay far below 4 GB)
     char* cp = reinterpret_cast<char*>(p.C) + ((long long)bml * p.ldc + bnl) * ESZ;
     if (p.dbg & 32) cp = reinterpret_cast<char*>(p.C) + (long long)((blockIdx.x & 7) * 256) * p.ldc * ESZ;   // lab: every tile of a workgroup stores to the same 256 rows (L2-resident)
@@ -375,7 +391,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
       }
     };
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb)
+    for (int mb = 0; mb < MBT; ++mb)
 #pragma unroll
       for (int j = 0; j < 2; ++j) put(mb, j);
   };
@@ -383,18 +399,18 @@ gemm_f16_pp_kernel(const PPArgs p) {
   auto acc_init = [&](int bml, int bnl) {
     if constexpr (X3) {
 #pragma unroll
-      for (int mb = 0; mb < 8; ++mb)
+      for (int mb = 0; mb < MBT; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     } else if constexpr (R16) {
-      const _Float16* rp = reinterpret_cast<const _Float16*>(p.R) + (long long)(bml + wr * 128 + l15) * p.ldr + bnl + wc * 64 + 8 * q;
+      const _Float16* rp = reinterpret_cast<const _Float16*>(p.R) + (long long)(bml + wr * GS + l15) * p.ldr + bnl + wc * 64 + 8 * q;
       const int col0 = bnl + wc * 64 + 8 * q;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         f32x4 bv[2];
         bias8(col0 + 32 * j, bv[0], bv[1]);
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb) {
+        for (int mb = 0; mb < MBT; ++mb) {
           const f16x8 r = *reinterpret_cast<const f16x8*>(rp + (long long)mb * 16 * p.ldr + 32 * j);
 #pragma unroll
           for (int e = 0; e < 2; ++e)
@@ -402,7 +418,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
         }
       }
     } else if constexpr (HAS_R) {
-      const float* rp = p.R + (long long)(bml + wr * 128 + l15) * p.ldr + bnl + wc * 64 + 8 * q;
+      const float* rp = p.R + (long long)(bml + wr * GS + l15) * p.ldr + bnl + wc * 64 + 8 * q;
       const int col0 = bnl + wc * 64 + 8 * q;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -411,7 +427,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
-          for (int mb = 0; mb < 8; ++mb)
+          for (int mb = 0; mb < MBT; ++mb)
             acc[mb][2 * j + e] = *reinterpret_cast<const f32x4*>(rp + (long long)mb * 16 * p.ldr + 32 * j + 4 * e) + bv[e];
       }
     } else {                                                         // accumulators start at the bias: nothing to add in the epilogue
@@ -423,7 +439,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
-          for (int mb = 0; mb < 8; ++mb) acc[mb][2 * j + e] = bv[e];
+          for (int mb = 0; mb < MBT; ++mb) acc[mb][2 * j + e] = bv[e];
       }
     }
   };
@@ -442,7 +458,9 @@ gemm_f16_pp_kernel(const PPArgs p) {
   asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                 // B1 of K step 0 (5 younger half-tiles)
   PP_BARRIER();
 
-  constexpr int NS = OUT == 1 ? (R16 ? 32 : 16) : OUT == 2 ? 48 : (HAS_R ? 53 : 32);   // vm ops of one epilogue (+ residual loads) per lane; 10 + NS <= 63
+  // (MBT row blocks: 2 fp16 / 4 f32 / 6 plane stores each, + 2 fp16 / 4 f32 residual loads; the f32 residual case is clamped to 63 - 10)
+  constexpr int NS_ = OUT == 1 ? (R16 ? 4 : 2) * MBT : OUT == 2 ? 6 * MBT : (HAS_R ? 8 : 4) * MBT;
+  constexpr int NS = NS_ > 53 ? 53 : NS_;   // vm ops of one epilogue (+ residual loads) per lane; 10 + NS <= 63
 #define PP_WAIT(n_first, n_later) do { if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_first) : "memory"); \
                                        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_later) : "memory"); } while (0)
 #define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
@@ -538,6 +556,16 @@ void* pp_dump_buffer() {
   return buf[dev];
 }
 
+// Tile height of a launch: 192-row tiles cost ~0.8 of a 256-row tile (3/4 of the MFMAs and stores, the same DMA volume) -- worth it
+// when they save whole rounds of 256 workgroups.  g_pp_tm: 0 automatic, 256 / 192 forced (lab).
+int g_pp_tm = 0;
+int pp_pick_tm(int M, int tiles_n) {
+  if (g_pp_tm == 256 || g_pp_tm == 192) return g_pp_tm;
+  const double c256 = (double)ovis::cdiv((long long)ovis::cdiv(M, 256) * tiles_n, 256);
+  const double c192 = 0.8 * (double)ovis::cdiv((long long)ovis::cdiv(M, 192) * tiles_n, 256);
+  return c192 < 0.95 * c256 && (long long)ovis::cdiv(M, 192) * tiles_n <= 256ll * PP_MAX_TILES ? 192 : 256;
+}
+
 int g_f16_gemm_mode = 1;          // 1: ping-pong kernel for eligible problems, 0: gemm_f16_256_kernel (gemm_f16.hip)
 int g_pp_grp = 6;                 // raster: at most this many N tiles per column group
 int g_pp_desync_ns = -1;          // < 0: automatic
@@ -576,7 +604,9 @@ int gemm_f16_pp_res16_launch(const void* A, long long lda, const void* B, long l
   p.A = reinterpret_cast<const _Float16*>(A); p.B = reinterpret_cast<const _Float16*>(B); p.C = C; p.bias = bias;
   p.R = reinterpret_cast<const float*>(R16);
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.M = M; p.N = N; p.K = K; p.act = 0;
-  p.tiles_m = (int)cdiv(M, 256); p.tiles_n = (int)cdiv(N, 256); p.n_tiles = p.tiles_m * p.tiles_n;
+  p.tiles_n = (int)cdiv(N, 256);
+  const int tm = pp_pick_tm(M, p.tiles_n);
+  p.tiles_m = (int)cdiv(M, tm); p.n_tiles = p.tiles_m * p.tiles_n;
   const int groups = (int)cdiv(p.tiles_n, g_pp_grp > 0 ? g_pp_grp : p.tiles_n);
   p.grp_w = p.tiles_n / groups; p.grp_rem = p.tiles_n % groups;
   p.desync_ns = g_pp_desync_ns >= 0 ? g_pp_desync_ns : 24000;        // residual GEMM: see gemm_f16_pp_launch
@@ -585,7 +615,8 @@ int gemm_f16_pp_res16_launch(const void* A, long long lda, const void* B, long l
   if (!p.dump) return fail(OVIS_EINVAL, "gemm_nt_f16 (ping-pong): cannot allocate the 4 KB dump buffer");
   p.planeA = p.planeB = p.planeC = 0;
   const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
-  hipLaunchKernelGGL((gemm_f16_pp_kernel<1, 0, true, false, false, true>), dim3(grid), dim3(512), 0, s, p);
+  if (tm == 192) hipLaunchKernelGGL((gemm_f16_pp_kernel<1, 0, true, false, false, true, 192>), dim3(grid), dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((gemm_f16_pp_kernel<1, 0, true, false, false, true>), dim3(grid), dim3(512), 0, s, p);
   return check_launch("gemm_nt_f16 (ping-pong, fp16 residual)");
 }
 
@@ -641,14 +672,17 @@ int gemm_f32a_pp_launch(const float* A, long long lda, const void* W3, long long
   p.A = reinterpret_cast<const _Float16*>(A); p.B = reinterpret_cast<const _Float16*>(W3); p.C = C; p.bias = bias; p.R = residual;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.M = M; p.N = N; p.K = K; p.act = act;
   p.planeA = 0; p.planeB = plane * 2; p.planeC = 0;                  // bytes
-  p.tiles_m = (int)cdiv(M, 256); p.tiles_n = (int)cdiv(N, 256); p.n_tiles = p.tiles_m * p.tiles_n;
+  p.tiles_n = (int)cdiv(N, 256);
+  const int tm = pp_pick_tm(M, p.tiles_n);
+  p.tiles_m = (int)cdiv(M, tm); p.n_tiles = p.tiles_m * p.tiles_n;
   const int groups = (int)cdiv(p.tiles_n, g_pp_grp > 0 ? g_pp_grp : p.tiles_n);
   p.grp_w = p.tiles_n / groups; p.grp_rem = p.tiles_n % groups;
   p.desync_ns = g_pp_desync_ns > 0 ? g_pp_desync_ns : 0; p.dbg = g_pp_dbg; p.stamps = g_pp_stamps;
   p.dump = pp_dump_buffer();
   if (!p.dump) return fail(OVIS_EINVAL, "gemm_nt_f32 (ping-pong, f32 A): cannot allocate the 4 KB dump buffer");
   const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
-#define PP_LAUNCH(A_, R_) hipLaunchKernelGGL((gemm_f16_pp_kernel<0, A_, R_, false, true>), dim3(grid), dim3(512), 0, s, p)
+#define PP_LAUNCH(A_, R_) do { if (tm == 192) hipLaunchKernelGGL((gemm_f16_pp_kernel<0, A_, R_, false, true, false, 192>), dim3(grid), dim3(512), 0, s, p); \
+                               else hipLaunchKernelGGL((gemm_f16_pp_kernel<0, A_, R_, false, true>), dim3(grid), dim3(512), 0, s, p); } while (0)
   if (residual) { if (act == 1) PP_LAUNCH(1, true); else PP_LAUNCH(0, true); }
   else if (act == 1) PP_LAUNCH(1, false);
   else if (act == 2) PP_LAUNCH(2, false);
@@ -753,3 +787,4 @@ extern "C" int ovis_set_f16_gemm_mode(int mode, int raster_group, int desync_ns)
 
 // lab only (tools/gemm_lab.cpp; not part of include/openvis_hip.h): debug flags and the in-kernel time stamp buffer
 extern "C" int ovis_pp_debug(int flags, unsigned long long* stamps) { g_pp_dbg = flags; g_pp_stamps = stamps; return OVIS_OK; }
+extern "C" int ovis_pp_tile_rows(int tm) { g_pp_tm = tm; return OVIS_OK; }   // lab / tests: 0 automatic, 256, 192

@@ -223,8 +223,17 @@ def test_skinny_f32_gemm_of_the_decoders(M, N, K, act, bias, res):
     assert (outs[0] - old).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("M", [22000 + 37, 700])
-def test_fp16_gemm_on_the_fp16_residual_stream(M):
+@pytest.fixture
+def pp_tile_rows():
+    from openvis_amd import ops
+    lib = ops._lib.lib()
+    yield lib.ovis_pp_tile_rows
+    lib.ovis_pp_tile_rows(0)
+
+
+@pytest.mark.parametrize("M,tm", [(22000 + 37, 256), (22000 + 37, 192), (66000 + 5, 0), (700, 0)])
+def test_fp16_gemm_on_the_fp16_residual_stream(pp_tile_rows, M, tm):
+    pp_tile_rows(tm)                                        # 0 = the launch picks 256- or 192-row tiles
     # out-proj / c_proj of a CLIP block with the residual stream in fp16: C = fp16(f32(R) + bias + A B^T), one rounding at the end.
     # M = 22 037 rows is taken by the ping-pong kernel's fp16-residual instantiation, 700 rows by the fallback (f32-residual kernels + a cast)
     from openvis_amd import ops
@@ -264,8 +273,10 @@ def test_layernorm_and_token_embedding_on_fp16_streams():
     assert t16.dtype == torch.float16 and torch.equal(t16, t32.half())
 
 
+@pytest.mark.parametrize("tm", [256, 192])
 @pytest.mark.parametrize("N,K,act,res", [(1024, 256, 1, False), (256, 256, 0, True), (768, 192, 3, False), (512, 1024, 2, False), (256, 2048, 1, True)])
-def test_bf16x2_on_the_ping_pong_schedule_matches_the_tiled_kernel(gemm_modes, N, K, act, res):
+def test_bf16x2_on_the_ping_pong_schedule_matches_the_tiled_kernel(gemm_modes, pp_tile_rows, N, K, act, res, tm):
+    pp_tile_rows(tm)
     # MODEL.F32_GEMM_SPLIT bf16x2 with constant weights: eligible shapes run on the ping-pong kernel's f32-A mode (f32 A tiles by LDS-DMA,
     # split into hi / lo bf16 in registers); same three products as gemm_f32x3_kernel<.., 2> -> same error class, every activation
     ops = gemm_modes
