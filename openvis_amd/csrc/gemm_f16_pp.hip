@@ -73,7 +73,8 @@ struct PPArgs {
   int tiles_m, tiles_n, n_tiles;
   int grp_w, grp_rem;                       // raster: column groups of grp_w (+1 for the first grp_rem groups) N tiles
   int desync_ns;                            // start offset spread over the workgroups that own one tile fewer (ns)
-  int dbg;                                  // lab only: 1 = skip the epilogue stores, 2 = skip the epilogue arithmetic too, 4 = nt stores, 8 = per-workgroup desync
+  int dbg;                                  // lab only: 8 = start offsets per XCD instead of per workgroup, 16 = no s_setprio for G1's epilogue
+                                            // (the store-suppressing flags 1 / 2 / 32 of the round-2 experiments are gone: profiles/r02/lab_ub*.txt)
   unsigned long long* stamps;               // lab only: s_memrealtime stamps [workgroup][tile iteration < 16][2 groups][4]
   void* dump;                               // 2 KB scratch that the masked lanes of edge tiles store to (never read)
 };
@@ -326,7 +327,6 @@ gemm_f16_pp_kernel(const PPArgs p) {
     const int row0 = bml + wr * GS + l15, col0 = bnl + wc * 64 + 8 * q;
     // wave-uniform tile base + 32-bit lane offset (one VGPR live across the K loop; 256 rows of C stay far below 4 GB)
     char* cp = reinterpret_cast<char*>(p.C) + ((long long)bml * p.ldc + bnl) * ESZ;
-    if (p.dbg & 32) cp = reinterpret_cast<char*>(p.C) + (long long)((blockIdx.x & 7) * 256) * p.ldc * ESZ;   // lab: every tile of a workgroup stores to the same 256 rows (L2-resident)
     const unsigned row_step = (unsigned)(16 * p.ldc * ESZ);
     unsigned lane_off = lane_c;
     asm volatile("" : "+v"(lane_off));                               // opaque: the per-row offsets are not worth 16 registers across the K loop
@@ -365,11 +365,9 @@ gemm_f16_pp_kernel(const PPArgs p) {
       act4(x0); act4(x1);
       char* c = cp + (lane_off + (unsigned)mb * row_step + (unsigned)(j * 32 * ESZ));
       if constexpr (PRED) { if (!(col0 + 32 * j >= bn && row0 + mb * 16 >= bm)) c = dump; }
-      constexpr bool ok = true;
       if constexpr (OUT == 1) {
         const uint4 o = pack8(x0, x1);
-        if (p.dbg & 1) asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
-        else if (ok) *reinterpret_cast<uint4*>(c) = o;
+        *reinterpret_cast<uint4*>(c) = o;
       } else if constexpr (OUT == 2) {                               // exact 3-way bf16 split of the f32 result, one 16-byte store per plane
         using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
         bf16x8 h0, h1, h2;
@@ -386,8 +384,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
         *reinterpret_cast<bf16x8*>(c + pc) = h1;
         *reinterpret_cast<bf16x8*>(c + 2 * pc) = h2;
       } else {
-        if (p.dbg & 1) asm volatile("" :: "v"(x0[0]), "v"(x0[3]), "v"(x1[0]), "v"(x1[3]));
-        else if (ok) { *reinterpret_cast<f32x4*>(c) = x0; *reinterpret_cast<f32x4*>(c + 16) = x1; }
+        *reinterpret_cast<f32x4*>(c) = x0; *reinterpret_cast<f32x4*>(c + 16) = x1;
       }
     };
 #pragma unroll
@@ -526,10 +523,8 @@ gemm_f16_pp_kernel(const PPArgs p) {
     //         G1: [phase-4 reads] | last MFMAs | epilogue               | phase-1 reads   | MFMAs ...
     if (wr == 0) PP_BARRIER();
     if (wr == 1 && !(p.dbg & 16)) __builtin_amdgcn_s_setprio(1);     // the younger wavefronts 4-7 lose every arbitration against 0-3 otherwise
-    if ((p.dbg & 3) < 2) {
-      if (bm == bml && bn == bnl) epilogue_rows(std::false_type{}, bm, bml, bn, bnl);
-      else epilogue_rows(std::true_type{}, bm, bml, bn, bnl);
-    }
+    if (bm == bml && bn == bnl) epilogue_rows(std::false_type{}, bm, bml, bn, bnl);
+    else epilogue_rows(std::true_type{}, bm, bml, bn, bnl);
     if (has_next) acc_init(nbml, nbnl);
     if (st) st[2] = __builtin_amdgcn_s_memrealtime();
     if (wr == 1) { __builtin_amdgcn_s_setprio(0); PP_BARRIER(); }

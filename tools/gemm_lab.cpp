@@ -14,6 +14,7 @@
 #include <vector>
 #include "../include/openvis_hip.h"
 extern "C" int ovis_set_f32a_pp(int on);
+extern "C" int ovis_pp_tile_rows(int tm);
 extern "C" const char* ovis_gemm_nt_f32_w3_kernel(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C, long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr, int act);
 extern "C" int ovis_pp_debug(int flags, unsigned long long* stamps);   // lab-only entry of gemm_f16_pp.hip
 
@@ -190,7 +191,7 @@ static int run_x3(hipStream_t s, bool do_time) {
 struct Variant { int mode, grp, desync, dbg; std::string name; };
 
 int main(int argc, char** argv) {
-  bool do_check = false, do_time = false, do_trace = false, do_x3 = false;
+  bool do_check = false, do_time = false, do_trace = false, do_x3 = false, do_r16 = false;
   std::vector<Variant> variants;
   int iters = 10, rounds = 3;
   for (int i = 1; i < argc; ++i) {
@@ -200,6 +201,7 @@ int main(int argc, char** argv) {
     else if (!strncmp(argv[i], "rounds=", 7)) rounds = atoi(argv[i] + 7);
     else if (!strcmp(argv[i], "trace")) do_trace = true;
     else if (!strcmp(argv[i], "x3")) do_x3 = true;
+    else if (!strcmp(argv[i], "r16")) do_r16 = true;
     else { Variant v; v.dbg = 0; if (sscanf(argv[i], "%d,%d,%d,%d", &v.mode, &v.grp, &v.desync, &v.dbg) >= 3) { v.name = argv[i]; variants.push_back(v); } }
   }
   if (variants.empty()) { variants.push_back({0, 0, 0, 0, "0,0,0"}); variants.push_back({1, 6, 0, 0, "1,6,0"}); }
@@ -208,6 +210,35 @@ int main(int argc, char** argv) {
   HIP_OK(hipMalloc(&d_max, 4)); HIP_OK(hipMalloc(&d_bad, 8));
   int fails = 0;
   if (do_x3) fails += run_x3(s, true);
+  if (do_r16) {   // out-proj / c_proj on the fp16 residual stream: tile height 256 vs 192 vs automatic, interleaved
+    hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    struct Shape { int M, N, K; const char* name; };
+    const Shape shapes[] = {{94600, 768, 768, "outproj16"}, {94600, 768, 3072, "fc2_16"}, {98500, 768, 768, "outproj16b"}, {98500, 768, 3072, "fc2_16b"}};
+    for (const Shape& sh : shapes) {
+      _Float16 *A, *B, *R, *C; float* bias;
+      const long long MN = (long long)sh.M * sh.N;
+      HIP_OK(hipMalloc(&A, (size_t)sh.M * sh.K * 2)); HIP_OK(hipMalloc(&B, (size_t)sh.N * sh.K * 2)); HIP_OK(hipMalloc(&R, MN * 2));
+      HIP_OK(hipMalloc(&C, MN * 2)); HIP_OK(hipMalloc(&bias, sh.N * 4));
+      fill_f16<<<2048, 256, 0, s>>>(A, (long long)sh.M * sh.K, 11u, 0, 1.f); fill_f16<<<2048, 256, 0, s>>>(B, (long long)sh.N * sh.K, 23u, 0, 1.f / sqrtf((float)sh.K));
+      fill_f16<<<2048, 256, 0, s>>>(R, MN, 7u, 0, 1.f); fill_f32<<<64, 256, 0, s>>>(bias, sh.N, 5u, 0, 1.f);
+      const int tms[3] = {256, 192, 0};
+      double best[3] = {1e30, 1e30, 1e30};
+      for (int r = 0; r < rounds + 1; ++r)
+        for (int v = 0; v < 3; ++v) {
+          ovis_pp_tile_rows(tms[v]);
+          HIP_OK(hipEventRecord(e0, s));
+          for (int it = 0; it < iters; ++it) OVIS_OKAY(ovis_gemm_nt_f16_res16(A, sh.K, B, sh.K, C, sh.N, sh.M, sh.N, sh.K, bias, R, sh.N, s));
+          HIP_OK(hipEventRecord(e1, s)); HIP_OK(hipEventSynchronize(e1));
+          float t; HIP_OK(hipEventElapsedTime(&t, e0, e1));
+          if (r > 0) best[v] = std::min(best[v], (double)t / iters);
+        }
+      ovis_pp_tile_rows(0);
+      const double fl = 2.0 * sh.M * sh.N * sh.K;
+      printf("r16 time %-10s M=%d N=%d K=%d: TM 256 %.4f ms (%.0f TF) | TM 192 %.4f ms (%.0f TF) | auto %.4f ms\n", sh.name, sh.M, sh.N, sh.K, best[0],
+             fl / best[0] / 1e9, best[1], fl / best[1] / 1e9, best[2]);
+      HIP_OK(hipFree(A)); HIP_OK(hipFree(B)); HIP_OK(hipFree(R)); HIP_OK(hipFree(C)); HIP_OK(hipFree(bias));
+    }
+  }
 
   if (do_check) {
     struct Case { int M, N, K, act, out16, bias, res, kind; };
@@ -232,7 +263,7 @@ int main(int argc, char** argv) {
       ref_gemm<<<(unsigned)((MN + 255) / 256), 256, 0, s>>>(A, B, ref, c.M, c.N, c.K, bias, R, c.act);
       for (const Variant& v : variants) {
         OVIS_OKAY(ovis_set_f16_gemm_mode(v.mode, v.grp, v.desync));
-        if (v.dbg & 35) continue;                                 // variants that skip the stores cannot be checked
+        if (v.dbg & 35) { printf("dbg flags 1 / 2 / 32 were removed from the kernel (results: profiles/r02/lab_ub1.txt, lab_ub2.txt)\n"); continue; }
         ovis_pp_debug(v.dbg, nullptr);
         for (int rep = 0; rep < 3; ++rep) {                       // repeated: a race shows up as run-to-run differences
           HIP_OK(hipMemsetAsync(C, 0xff, MN * 4, s));
