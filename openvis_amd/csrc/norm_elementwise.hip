@@ -133,6 +133,59 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, con
   }
 }
 
+// fp16 rows in, fp16 rows out with 16-byte accesses (8 halves per lane and step): the LayerNorms of the CLIP tower's fp16 residual
+// stream.  One wavefront per row, C % 8 == 0, C <= 1024; statistics and affine in f32.  (The generic kernel above moves 8 bytes per
+// lane and instruction on this path: 4.0 TB/s against 5.5 for its f32-input form.)
+template <int NV8>
+__global__ void __launch_bounds__(256)
+layernorm_h16_kernel(const _Float16* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                     _Float16* __restrict__ y, long long rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int n8 = C >> 3;
+  const uint4* xp = reinterpret_cast<const uint4*>(x + row * C);
+  float v[NV8][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV8; ++i) {
+    const int idx = lane + i * 64;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    if (idx < n8) {
+      union { uint4 u; _Float16 h[8]; } pk;
+      pk.u = xp[idx];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = (float)pk.h[e]; }
+      s += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV8; ++i) {
+    if (lane + i * 64 < n8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
+  uint4* yp = reinterpret_cast<uint4*>(y + row * C);
+#pragma unroll
+  for (int i = 0; i < NV8; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < n8) {
+      const float4 g0 = reinterpret_cast<const float4*>(gamma)[2 * idx], g1 = reinterpret_cast<const float4*>(gamma)[2 * idx + 1];
+      const float4 b0 = reinterpret_cast<const float4*>(beta)[2 * idx], b1 = reinterpret_cast<const float4*>(beta)[2 * idx + 1];
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      union { _Float16 h[8]; uint4 u; } o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.h[e] = (_Float16)((v[i][e] - mean) * rstd * g[e] + b[e]);
+      yp[idx] = o.u;
+    }
+  }
+}
+
 // ---- GroupNorm on NHWC (C % 4 == 0, (C/G) % 4 == 0) -------------------------------------------
 // pass 1: per-(n,g) sum / sum of squares accumulated in f64 (block partials -> f64 atomics);
 // pass 2: normalise (+ optional bilinear x2-upsampled addend, + optional ReLU).
@@ -322,6 +375,13 @@ static int layernorm_f16in_launch(const void* x, const float* gamma, const float
   OVIS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 1024, "layernorm (fp16 input): C must be a multiple of 4 and <= 1024");
   const unsigned grid = ovis::cdiv(rows, 4);
   const float* xf = reinterpret_cast<const float*>(x);
+  if (OUT16 && C % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
+    const _Float16* xh = reinterpret_cast<const _Float16*>(x);
+    _Float16* yh = reinterpret_cast<_Float16*>(y);
+    if (C <= 512) hipLaunchKernelGGL(layernorm_h16_kernel<1>, dim3(grid), dim3(256), 0, s, xh, gamma, beta, yh, rows, C, eps);
+    else hipLaunchKernelGGL(layernorm_h16_kernel<2>, dim3(grid), dim3(256), 0, s, xh, gamma, beta, yh, rows, C, eps);
+    return ovis::check_launch("layernorm (fp16 rows)");
+  }
   if (C / 4 <= 64) hipLaunchKernelGGL((layernorm_kernel<1, OUT16, true>), dim3(grid), dim3(256), 0, s, xf, nullptr, gamma, beta, y, rows, C, eps);
   else hipLaunchKernelGGL((layernorm_kernel<4, OUT16, true>), dim3(grid), dim3(256), 0, s, xf, nullptr, gamma, beta, y, rows, C, eps);
   return ovis::check_launch("layernorm (fp16 input)");
