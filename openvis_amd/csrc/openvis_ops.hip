@@ -913,6 +913,12 @@ final_masks_kernel(const float* __restrict__ masks, const int* __restrict__ sel_
   const int j = (int)(r / T);
   const float* mp = masks + ((long long)sel_q[j] * T + t) * h * w;
   const float usy = (float)h / (float)Hp, usx = (float)w / (float)Wp;
+  if (OH == H && OW == W) {
+    // output size == image size (the usual case): the second resize is the identity (its taps are (oy, weight 1) and a weight-0
+    // neighbour), so one bilinear evaluation gives the same bits as the four below
+    out[i] = bilerp(mp, w, make_tap(oy, usy, h), make_tap(ox, usx, w)) > 0.f ? 1 : 0;
+    return;
+  }
   const Tap oyT = make_tap(oy, (float)H / (float)OH, H), oxT = make_tap(ox, (float)W / (float)OW, W);
   const Tap ty0 = make_tap(oyT.i0, usy, h), ty1 = make_tap(oyT.i1, usy, h);
   const Tap tx0 = make_tap(oxT.i0, usx, w), tx1 = make_tap(oxT.i1, usx, w);
