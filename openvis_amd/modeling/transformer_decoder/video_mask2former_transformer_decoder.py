@@ -104,7 +104,7 @@ class VideoMultiScaleMaskedTransformerDecoder:
 
     @staticmethod
     def _nsplit(nk):
-        return max(1, min(64, nk // 1024))
+        return max(1, min(64, nk // 256))        # x 8 heads: >= 128 workgroups from 4 600 keys on (nk // 1024 left the 18 400-key level on 136)
 
     def forward(self, x, mask_features, mask=None):
         """x: 3 maps [T,H_l,W_l,C] (res5,res4,res3 scale); mask_features [T,h,w,C] (NHWC).
