@@ -41,8 +41,10 @@ struct AttnArgs {
   float scale;
 };
 
-template <int D>
-__global__ void __launch_bounds__(256)
+// WAVES = 4: 128 queries per workgroup.  WAVES = 5 (160 queries): for 128 < Nq <= 160 -- Swin's 12x12 windows have 144 tokens, and a
+// second 128-query workgroup per (window, head) would stage every K / V tile again for 16 queries.  Threads 0-255 do the staging.
+template <int D, int WAVES = 4>
+__global__ void __launch_bounds__(WAVES * 64)
 flash_attn_f32_kernel(AttnArgs a) {
   constexpr int LDK = D + 4;
   constexpr int DT = D / 32;        // 32-wide output tiles
@@ -54,7 +56,7 @@ flash_attn_f32_kernel(AttnArgs a) {
   const int r32 = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
   const int split = blockIdx.z;
-  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const int q0 = (blockIdx.x * WAVES + wave) * 32;
   const int qi = q0 + r32;
   const bool wave_active = q0 < a.Nq;
   const bool q_ok = qi < a.Nq;
@@ -94,6 +96,7 @@ flash_attn_f32_kernel(AttnArgs a) {
   float4 pk[NLD], pv[NLD];
   bool okr[NLD];
   auto gload = [&](int kt) {
+    if (WAVES > 4 && tid >= 256) return;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = tid + i * 256;
@@ -106,6 +109,7 @@ flash_attn_f32_kernel(AttnArgs a) {
     }
   };
   auto lstore = [&]() {
+    if (WAVES > 4 && tid >= 256) return;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = tid + i * 256;
@@ -300,9 +304,13 @@ extern "C" int ovis_attention_f32(const float* q, long long q_bs, int q_ld, cons
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.nsplit = nsplit; a.keys_per_split = keys_per_split; a.scale = scale;
   a.part_o = workspace;
   a.part_ml = workspace ? workspace + (long long)nsplit * B * H * Nq * D : nullptr;
-  dim3 grid(ovis::cdiv(Nq, 128), B * H, nsplit);
+  const bool five = Nq > 128 && Nq <= 160;                          // one 160-query workgroup instead of 128 + a nearly empty one
+  dim3 grid(five ? 1 : ovis::cdiv(Nq, 128), B * H, nsplit);
   hipStream_t s = (hipStream_t)stream;
-  if (D == 32) hipLaunchKernelGGL(flash_attn_f32_kernel<32>, grid, dim3(256), 0, s, a);
+  if (five) {
+    if (D == 32) hipLaunchKernelGGL((flash_attn_f32_kernel<32, 5>), grid, dim3(320), 0, s, a);
+    else hipLaunchKernelGGL((flash_attn_f32_kernel<64, 5>), grid, dim3(320), 0, s, a);
+  } else if (D == 32) hipLaunchKernelGGL(flash_attn_f32_kernel<32>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(flash_attn_f32_kernel<64>, grid, dim3(256), 0, s, a);
   int rc = ovis::check_launch("attention");
   if (rc) return rc;

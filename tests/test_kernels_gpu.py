@@ -81,7 +81,8 @@ def _attn_ref(q, k, v, mask=None):
 
 @pytest.mark.parametrize("B,H,Nq,Nk,D,nsplit,masked", [
     (1, 8, 100, 4600, 32, 4, True), (1, 8, 100, 100, 32, 1, False), (3, 12, 197, 197, 64, 1, False),
-    (1, 8, 100, 1000, 32, 1, True), (2, 4, 37, 333, 64, 3, False), (1, 8, 100, 73600 // 8, 32, 8, True)])
+    (1, 8, 100, 1000, 32, 1, True), (2, 4, 37, 333, 64, 3, False), (1, 8, 100, 73600 // 8, 32, 8, True),
+    (7, 6, 144, 144, 32, 1, False), (2, 3, 160, 300, 64, 2, False), (1, 4, 129, 129, 32, 1, True)])   # 128 < Nq <= 160: the 5-wavefront variant
 def test_attention(B, H, Nq, Nk, D, nsplit, masked):
     from openvis_amd import ops
     g = torch.Generator().manual_seed(Nq * Nk)
