@@ -304,3 +304,32 @@ def test_bf16x2_on_the_ping_pong_schedule_matches_the_tiled_kernel(gemm_modes, p
         assert err < 2.0 ** -15, (pp, err)
     assert torch.equal(outs[1][0], outs[1][1])                       # deterministic
     assert ((outs[1][0] - outs[0][0]).abs().double() / scale).max().item() < 2.0 ** -15
+
+
+@pytest.mark.parametrize("M,N,K", [(96600 + 5, 256, 64), (98500 - 3, 392, 160), (70001, 776, 96), (131072 + 9, 512, 32 * 9)])
+def test_192_row_tiles_on_ragged_shapes(gemm_modes, pp_tile_rows, M, N, K):
+    # edge tiles of the 192-row variant are shifted inside the matrix and masked; ragged M (not a multiple of 192 or 256), ragged N
+    # (a shifted column tile), short K (two or three 32-float K steps)
+    ops = gemm_modes
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    r = torch.randn(M, N, generator=g).cuda()
+    ref = a.double() @ w.double().T + b.double() + r.double()
+    scale = a.double().abs() @ w.double().abs().T + b.double().abs() + r.double().abs()
+    ops.set_f32_gemm_mode(2)
+    import ctypes
+    fn = ops._lib.lib().ovis_gemm_nt_f32_w3_kernel
+    fn.restype = ctypes.c_char_p
+    name = fn(ctypes.c_void_p(a.data_ptr()), ctypes.c_longlong(K), ctypes.c_void_p(ops.w3_of(w).data_ptr()), ctypes.c_longlong(K),
+              ctypes.c_longlong(w.numel()), ctypes.c_void_p(a.data_ptr()), ctypes.c_longlong(N), M, N, K, ctypes.c_void_p(b.data_ptr()),
+              ctypes.c_void_p(r.data_ptr()), ctypes.c_longlong(N), 0).decode()
+    assert name.startswith("gemm_f16_pp_kernel<0,0,true,false,true"), name          # the shape IS taken by the f32-A kernel
+    outs = {}
+    for tm in (192, 256):
+        pp_tile_rows(tm)
+        outs[tm] = ops.gemm_nt(a, w, b, r, 0, cw=True)
+        assert ((outs[tm].double() - ref).abs() / scale).max().item() < 2.0 ** -15, tm
+    # the same products in the same order per output element: the two tile heights agree to the last bit
+    assert torch.equal(outs[192], outs[256])
