@@ -102,9 +102,13 @@ struct PPArgs {
 // TM : rows of a tile, 256 or 192.  192 = the same schedule with 96 rows per wave group (row-block quadrant i = 1 has two 16-row
 //      blocks instead of four: 3/4 of the MFMAs and stores, the DMA volume of a 256-row tile); chosen per launch when it saves a
 //      whole round of tiles (e.g. N = K = 256 at M = 96 600: 378 tiles = 1.48 rounds of 256 workgroups -> 504 tiles = 1.97).
-template <int OUT, int ACT, bool HAS_R, bool X3, bool FA = false, bool R16 = false, int TM = 256>
+// EPI (fp16 output only): bit 0 = full-line stores -- the lanes l and l ^ 8 of a 16-lane row exchange one 16-byte pack (DPP row_ror:8),
+//      so that a store instruction writes 8 rows x 128 B (whole cache lines) instead of 16 rows x 64 B; bits 1-2 = cache policy of the
+//      C stores: 0 default, 1 sc1 (write-through: the line is not kept in the XCD's L2, which the operand panels need), 2 nt.
+template <int OUT, int ACT, bool HAS_R, bool X3, bool FA = false, bool R16 = false, int TM = 256, int EPI = 0>
 __global__ void __launch_bounds__(512)
 gemm_f16_pp_kernel(const PPArgs p) {
+  static_assert(EPI == 0 || (OUT == 1 && !X3 && (!HAS_R || R16)), "EPI variants: fp16 output (fp16 residual or none)");
   static_assert(TM == 256 || (TM == 192 && !X3), "tile heights: 256, or 192 for the fp16 / f32-A modes");
   constexpr int GS = TM / 2;                                       // rows of a wave group
   // TM = 192: the second half-tile of a group starts 32 rows into the group (rows GS wr + 32 .. + 95, overlapping the first by 32 rows)
@@ -319,7 +323,8 @@ gemm_f16_pp_kernel(const PPArgs p) {
 
   // ---- epilogue of one tile: a lane owns one output row per 16-row block and 8 consecutive columns per column pair ----
   constexpr int ESZ = OUT == 0 ? 4 : 2;
-  const unsigned lane_c = (unsigned)(((long long)(wr * GS + l15) * p.ldc + wc * 64 + 8 * q) * ESZ);
+  const unsigned lane_c = (EPI & 1) ? (unsigned)(((long long)(wr * GS + (l15 & 7)) * p.ldc + wc * 64 + 32 * (l15 >> 3) + 8 * q) * ESZ)
+                                    : (unsigned)(((long long)(wr * GS + l15) * p.ldc + wc * 64 + 8 * q) * ESZ);
   // Row block outer, column pair inner: the two 64-byte halves of a 128-byte line come from CONSECUTIVE store instructions.
   // (Column pair outer -- the halves 8 instructions apart -- measured 5-6 % slower on the whole GEMM: partial-line writes.)
   auto epilogue_rows = [&](auto pred_tag, int bm, int bml, int bn, int bnl) {
@@ -349,8 +354,39 @@ gemm_f16_pp_kernel(const PPArgs p) {
       const f16x2 h2 = __builtin_convertvector(f32x2{x1[0], x1[1]}, f16x2), h3 = __builtin_convertvector(f32x2{x1[2], x1[3]}, f16x2);
       return make_uint4(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), __builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3));
     };
+    auto store16 = [&](char* c, const uint4& o) {
+      using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+      const u32x4 d = {o.x, o.y, o.z, o.w};
+      if constexpr (((EPI >> 1) & 3) == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(c), "v"(d) : "memory");
+      else if constexpr (((EPI >> 1) & 3) == 2) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(c), "v"(d) : "memory");
+      else *reinterpret_cast<uint4*>(c) = o;
+    };
     const float* rp = nullptr;
     if constexpr (X3 && HAS_R) rp = p.R + (long long)row0 * p.ldr + col0;
+    // EPI bit 0: one 16-row block as two full-line stores.  low = lanes whose row is 0-7 of the block.  A: rows 0-7 (low lanes their own
+    // columns 8q.., high lanes the low partner's columns 32 + 8q..), B: rows 8-15 (low lanes the high partner's columns 8q.., high lanes own).
+    auto put_lines = [&](int mb) {
+      f32x4 x0 = acc[mb][0], x1 = acc[mb][1], y0 = acc[mb][2], y1 = acc[mb][3];
+      act4(x0); act4(x1); act4(y0); act4(y1);
+      const uint4 P0 = pack8(x0, x1), P1 = pack8(y0, y1);
+      const bool low = l15 < 8;
+      uint4 snd = low ? P1 : P0, rcv;
+      rcv.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)snd.x, 0x128, 0xf, 0xf, false);
+      rcv.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)snd.y, 0x128, 0xf, 0xf, false);
+      rcv.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)snd.z, 0x128, 0xf, 0xf, false);
+      rcv.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)snd.w, 0x128, 0xf, 0xf, false);
+      const uint4 dA = low ? P0 : rcv, dB = low ? rcv : P1;
+      // lane_off of this variant: row wr GS + (l15 & 7), column wc 64 + 32 (l15 >> 3) + 8 q
+      char* cA = cp + (lane_off + (unsigned)mb * row_step);
+      char* cB = cA + 8 * p.ldc * ESZ;
+      if constexpr (PRED) {
+        const int colL = bnl + wc * 64 + 32 * (l15 >> 3) + 8 * q, rowL = bml + wr * GS + (l15 & 7) + mb * 16;
+        if (!(colL >= bn && rowL >= bm)) cA = dump;
+        if (!(colL >= bn && rowL + 8 >= bm)) cB = dump;
+      }
+      store16(cA, dA);
+      store16(cB, dB);
+    };
     auto put = [&](int mb, int j) {
       f32x4 x0 = acc[mb][2 * j], x1 = acc[mb][2 * j + 1];
       if constexpr (X3) {                                            // bias / residual enter here, not as the accumulators' start value
@@ -367,7 +403,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
       if constexpr (PRED) { if (!(col0 + 32 * j >= bn && row0 + mb * 16 >= bm)) c = dump; }
       if constexpr (OUT == 1) {
         const uint4 o = pack8(x0, x1);
-        *reinterpret_cast<uint4*>(c) = o;
+        store16(c, o);
       } else if constexpr (OUT == 2) {                               // exact 3-way bf16 split of the f32 result, one 16-byte store per plane
         using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
         bf16x8 h0, h1, h2;
@@ -388,9 +424,13 @@ gemm_f16_pp_kernel(const PPArgs p) {
       }
     };
 #pragma unroll
-    for (int mb = 0; mb < MBT; ++mb)
+    for (int mb = 0; mb < MBT; ++mb) {
+      if constexpr (EPI & 1) put_lines(mb);
+      else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) put(mb, j);
+        for (int j = 0; j < 2; ++j) put(mb, j);
+      }
+    }
   };
   // ... followed by the start value of the next tile's accumulators: bias + residual (gemm_epilogue.h) or zero
   auto acc_init = [&](int bml, int bnl) {
@@ -399,6 +439,37 @@ gemm_f16_pp_kernel(const PPArgs p) {
       for (int mb = 0; mb < MBT; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if constexpr (R16 && (EPI & 1)) {
+      // full-line residual loads (the mirror image of put_lines): A = rows 0-7 of a 16-row block, B = rows 8-15; the lanes l and l ^ 8
+      // then exchange the pack that belongs to the partner's accumulator row
+      using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+      const _Float16* rp = reinterpret_cast<const _Float16*>(p.R) + (long long)(bml + wr * GS + (l15 & 7)) * p.ldr + bnl + wc * 64 + 32 * (l15 >> 3) + 8 * q;
+      const int col0 = bnl + wc * 64 + 8 * q;
+      const bool low = l15 < 8;
+      f32x4 bv[2][2];
+      bias8(col0, bv[0][0], bv[0][1]);
+      bias8(col0 + 32, bv[1][0], bv[1][1]);
+#pragma unroll
+      for (int mb = 0; mb < MBT; ++mb) {
+        u32x4 LA, LB;
+        if constexpr (((EPI >> 1) & 3) != 0) {
+          LA = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rp + (long long)mb * 16 * p.ldr));
+          LB = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rp + (long long)(mb * 16 + 8) * p.ldr));
+        } else {
+          LA = *reinterpret_cast<const u32x4*>(rp + (long long)mb * 16 * p.ldr);
+          LB = *reinterpret_cast<const u32x4*>(rp + (long long)(mb * 16 + 8) * p.ldr);
+        }
+        const u32x4 snd = low ? LB : LA;
+        u32x4 rcv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rcv[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)snd[e], 0x128, 0xf, 0xf, false);
+        const f16x8 r0 = __builtin_bit_cast(f16x8, low ? LA : rcv), r1 = __builtin_bit_cast(f16x8, low ? rcv : LB);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          acc[mb][e] = f32x4{(float)r0[4 * e], (float)r0[4 * e + 1], (float)r0[4 * e + 2], (float)r0[4 * e + 3]} + bv[0][e];
+          acc[mb][2 + e] = f32x4{(float)r1[4 * e], (float)r1[4 * e + 1], (float)r1[4 * e + 2], (float)r1[4 * e + 3]} + bv[1][e];
+        }
+      }
     } else if constexpr (R16) {
       const _Float16* rp = reinterpret_cast<const _Float16*>(p.R) + (long long)(bml + wr * GS + l15) * p.ldr + bnl + wc * 64 + 8 * q;
       const int col0 = bnl + wc * 64 + 8 * q;
@@ -565,6 +636,8 @@ int g_f16_gemm_mode = 1;          // 1: ping-pong kernel for eligible problems, 
 int g_pp_grp = 6;                 // raster: at most this many N tiles per column group
 int g_pp_desync_ns = -1;          // < 0: automatic
 int g_pp_dbg = 0;
+int g_pp_epi = 5;              // epilogue variant of the fp16-output launches (template parameter EPI): full-line nt stores, measured
+                               // +7 % QKV, +6 % fc1, +5-9 % out-proj, +2 % fc2 against EPI 0 in one process (profiles/r03/lab_epi*.txt)
 unsigned long long* g_pp_stamps = nullptr;
 
 }  // namespace
@@ -579,7 +652,8 @@ bool gemm_f16_pp_eligible(const void* C, long long lda, long long ldb, long long
   if (blocks256 > 256ll * PP_MAX_TILES) return false;
   if (blocks256 < 256 || K % 64 != 0 || K < 128 || N % 8 != 0 || M < 256 || N < 256) return false;
   if (256 * lda * 2 >= (1ll << 31) || 256 * ldb * 2 >= (1ll << 31)) return false;                      // 32-bit DMA row offsets inside a tile
-  if (bias && (N > PP_MAX_BIAS_N || (reinterpret_cast<uintptr_t>(bias) & 15))) return false;
+  // the kernel fills the LDS bias region for every column of N (zeros when bias is NULL), so the limit holds with or without a bias
+  if (N > PP_MAX_BIAS_N || (bias && (reinterpret_cast<uintptr_t>(bias) & 15))) return false;
   if (reinterpret_cast<uintptr_t>(C) & 15) return false;
   if (out_f16 ? (ldc % 8 != 0) : (ldc % 4 != 0)) return false;
   if (residual && ((ldr % 4 != 0) || (reinterpret_cast<uintptr_t>(residual) & 15))) return false;
@@ -610,8 +684,13 @@ int gemm_f16_pp_res16_launch(const void* A, long long lda, const void* B, long l
   if (!p.dump) return fail(OVIS_EINVAL, "gemm_nt_f16 (ping-pong): cannot allocate the 4 KB dump buffer");
   p.planeA = p.planeB = p.planeC = 0;
   const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
-  if (tm == 192) hipLaunchKernelGGL((gemm_f16_pp_kernel<1, 0, true, false, false, true, 192>), dim3(grid), dim3(512), 0, s, p);
-  else hipLaunchKernelGGL((gemm_f16_pp_kernel<1, 0, true, false, false, true>), dim3(grid), dim3(512), 0, s, p);
+#define PP_R16(E_) do { if (tm == 192) hipLaunchKernelGGL((gemm_f16_pp_kernel<1, 0, true, false, false, true, 192, E_>), dim3(grid), dim3(512), 0, s, p); \
+                        else hipLaunchKernelGGL((gemm_f16_pp_kernel<1, 0, true, false, false, true, 256, E_>), dim3(grid), dim3(512), 0, s, p); } while (0)
+  switch (g_pp_epi) {
+    case 0: PP_R16(0); break; case 1: PP_R16(1); break; case 4: PP_R16(4); break; case 5: PP_R16(5); break;
+    default: return fail(OVIS_EINVAL, "gemm_nt_f16 (ping-pong, fp16 residual): bad epilogue variant %d", g_pp_epi);
+  }
+#undef PP_R16
   return check_launch("gemm_nt_f16 (ping-pong, fp16 residual)");
 }
 
@@ -632,7 +711,13 @@ int gemm_f16_pp_launch(const void* A, long long lda, const void* B, long long ld
   const int grid = p.n_tiles < 256 ? p.n_tiles : 256;              // one persistent workgroup per CU (MI355X: 256 CUs)
   p.planeA = p.planeB = p.planeC = 0;
 #define PP_LAUNCH(O, A_, R_) hipLaunchKernelGGL((gemm_f16_pp_kernel<O, A_, R_, false>), dim3(grid), dim3(512), 0, s, p)
-  if (out_f16 && !residual) {
+#define PP_LAUNCH_E(A_, E_) hipLaunchKernelGGL((gemm_f16_pp_kernel<1, A_, false, false, false, false, 256, E_>), dim3(grid), dim3(512), 0, s, p)
+  const int epi = g_pp_epi;
+  if (out_f16 && !residual && epi != 0 && (act == 0 || act == 2)) {
+#define PP_E(E_) case E_: if (act == 0) PP_LAUNCH_E(0, E_); else PP_LAUNCH_E(2, E_); break;
+    switch (epi) { PP_E(1) PP_E(2) PP_E(3) PP_E(4) PP_E(5) default: return fail(OVIS_EINVAL, "gemm_nt_f16 (ping-pong): bad epilogue variant %d", epi); }
+#undef PP_E
+  } else if (out_f16 && !residual) {
     if (act == 0) PP_LAUNCH(1, 0, false); else if (act == 1) PP_LAUNCH(1, 1, false);
     else if (act == 2) PP_LAUNCH(1, 2, false); else PP_LAUNCH(1, 3, false);
   } else if (!out_f16 && act == 0) {
@@ -641,6 +726,7 @@ int gemm_f16_pp_launch(const void* A, long long lda, const void* B, long long ld
     return fail(OVIS_EINVAL, "gemm_nt_f16 (ping-pong): no instantiation for out_f16=%d act=%d residual=%d", out_f16, act, residual != nullptr);
   }
 #undef PP_LAUNCH
+#undef PP_LAUNCH_E
   return check_launch("gemm_nt_f16 (ping-pong)");
 }
 
@@ -656,7 +742,8 @@ bool gemm_f32a_pp_eligible(const float* A, long long lda, const void* W3, long l
   if (lda % 4 != 0 || ldb % 8 != 0 || plane % 8 != 0 || ldc % 4 != 0) return false;
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W3) | reinterpret_cast<uintptr_t>(C)) & 15) return false;
   if (256 * lda * 4 >= (1ll << 31) || plane * 2 + 256 * ldb * 2 >= (1ll << 31)) return false;           // 32-bit DMA offsets inside a tile
-  if (bias && (N > PP_MAX_BIAS_N || (reinterpret_cast<uintptr_t>(bias) & 15))) return false;
+  // the kernel fills the LDS bias region for every column of N (zeros when bias is NULL), so the limit holds with or without a bias
+  if (N > PP_MAX_BIAS_N || (bias && (reinterpret_cast<uintptr_t>(bias) & 15))) return false;
   if (residual && ((ldr % 4 != 0) || (reinterpret_cast<uintptr_t>(residual) & 15))) return false;
   return true;
 }
@@ -710,7 +797,7 @@ x3_split8_kernel(const float4* __restrict__ x, uint4* __restrict__ p0, uint4* __
 extern "C" int ovis_gemm_x3pp_eligible(int M, int N, int K, int has_bias) {
   const long long blocks256 = (long long)ovis::cdiv(M, 256) * ovis::cdiv(N, 256);
   return blocks256 >= 256 && blocks256 <= 256ll * PP_MAX_TILES && K % 64 == 0 && K >= 64 && N % 8 == 0 && M >= 256 && N >= 256 &&
-         (!has_bias || N <= PP_MAX_BIAS_N) && 256ll * K * 2 < (1ll << 31);
+         N <= PP_MAX_BIAS_N && 256ll * K * 2 < (1ll << 31);   // the bias region is zero-filled for N columns when there is no bias
 }
 
 extern "C" int ovis_split_f32_to_bf16x3_v8(const float* x, void* planes, long long n, ovis_stream_t stream) {
@@ -782,4 +869,5 @@ extern "C" int ovis_set_f16_gemm_mode(int mode, int raster_group, int desync_ns)
 
 // lab only (tools/gemm_lab.cpp; not part of include/openvis_hip.h): debug flags and the in-kernel time stamp buffer
 extern "C" int ovis_pp_debug(int flags, unsigned long long* stamps) { g_pp_dbg = flags; g_pp_stamps = stamps; return OVIS_OK; }
+extern "C" int ovis_pp_epilogue(int epi) { g_pp_epi = epi; return OVIS_OK; }   // lab / tests: EPI variant 0-5
 extern "C" int ovis_pp_tile_rows(int tm) { g_pp_tm = tm; return OVIS_OK; }   // lab / tests: 0 automatic, 256, 192

@@ -181,7 +181,8 @@ SkWorkspace sk_workspace(hipStream_t stream) {
   auto it = table.find({dev, stream});
   if (it != table.end()) return it->second;
   void *a = nullptr, *c = nullptr;
-  if (hipMalloc(&a, SK_WS_BYTES) != hipSuccess || hipMalloc(&c, 4096) != hipSuccess || hipMemset(c, 0, 4096) != hipSuccess)
+  // the counters are zeroed ON THE LAUNCH STREAM: a memset on the null stream is not ordered against a non-blocking stream's first kernel
+  if (hipMalloc(&a, SK_WS_BYTES) != hipSuccess || hipMalloc(&c, 4096) != hipSuccess || hipMemsetAsync(c, 0, 4096, stream) != hipSuccess)
     return SkWorkspace{nullptr, nullptr};
   return table[{dev, stream}] = SkWorkspace{(float*)a, (unsigned*)c};
 }

@@ -305,6 +305,38 @@ def _c2_resnet_name(k):
     return None
 
 
+def migrate_legacy_keys(sd):
+    """The automatic conversions the reference applies to old checkpoints when a module's stored version is < 2, plus detectron2's
+    FrozenBatchNorm2d defaults:
+
+    * `MaskFormerHead._load_from_state_dict` (mask_former_head.py:23-45): `sem_seg_head.<x>` with <x> outside `predictor.` (and not
+      already under `pixel_decoder.`) is a pixel-decoder tensor of a Mask2Former v1 checkpoint -> `sem_seg_head.pixel_decoder.<x>`;
+    * `VideoMultiScaleMaskedTransformerDecoder._load_from_state_dict` (video_mask2former_transformer_decoder.py:224-245):
+      `static_query` -> `query_feat` (the README.md:5 Mask2Former `.pkl`);
+    * detectron2 `FrozenBatchNorm2d._load_from_state_dict` (version < 2): a norm that has `weight` but no `running_mean` /
+      `running_var` (the MSRA R-50.pkl carries only `*_bn_s` / `*_bn_b`) gets zeros / ones.
+
+    Returns (new dict, list of (old key, new key) renames); the input dict is not modified."""
+    out, renamed = {}, []
+    head = "sem_seg_head."
+    for k, v in sd.items():
+        nk = k
+        if nk.startswith(head) and not nk.startswith((head + "predictor.", head + "pixel_decoder.")):
+            nk = head + "pixel_decoder." + nk[len(head):]
+        if "static_query" in nk:
+            nk = nk.replace("static_query", "query_feat")
+        if nk != k:
+            renamed.append((k, nk))
+        out[nk] = v
+    for k in [k for k in out if k.startswith("backbone.") and k.endswith(".norm.weight")]:
+        base = k[:-len("weight")]
+        if base + "running_mean" not in out:
+            out[base + "running_mean"] = torch.zeros_like(out[k])
+        if base + "running_var" not in out:
+            out[base + "running_var"] = torch.ones_like(out[k])
+    return out, renamed
+
+
 def load_checkpoint(path):
     """State dict of a reference checkpoint: a torch `.pth` / `.pt` file ({"model": state_dict} as DetectionCheckpointer
     writes it, or a bare state dict; loaded with weights_only=True) or a detectron2 model-zoo `.pkl` (pickle of
@@ -332,6 +364,15 @@ def load_checkpoint(path):
                 else:
                     continue                      # fc1000 / optimizer blobs of a classification checkpoint
             out[k] = t
-        return out
+        return _migrated(out)
     ck = torch.load(path, map_location="cpu", weights_only=True)
-    return ck.get("model", ck) if isinstance(ck, dict) else ck
+    return _migrated(ck.get("model", ck) if isinstance(ck, dict) else ck)
+
+
+def _migrated(sd):
+    sd, renamed = migrate_legacy_keys(sd)
+    if renamed:                                   # the reference warns once per module (mask_former_head.py:41-45)
+        import logging
+        logging.getLogger(__name__).warning("old checkpoint format: %d keys converted automatically (e.g. %s -> %s)",
+                                            len(renamed), renamed[0][0], renamed[0][1])
+    return sd

@@ -57,7 +57,7 @@ def test_load_checkpoint_pth_and_pkl(tmp_path):
     import pickle
     import numpy as np
     import torch
-    sd = {"backbone.stem.conv1.weight": torch.randn(4, 3, 7, 7), "sem_seg_head.x.bias": torch.randn(5)}
+    sd = {"backbone.stem.conv1.weight": torch.randn(4, 3, 7, 7), "sem_seg_head.pixel_decoder.x.bias": torch.randn(5)}
     torch.save({"model": sd, "iteration": 3}, tmp_path / "m.pth")
     with open(tmp_path / "m.pkl", "wb") as f:
         pickle.dump({"model": {k: v.numpy() for k, v in sd.items()}, "__author__": "x", "matching_heuristics": True}, f)
@@ -82,13 +82,59 @@ def test_backbone_only_pickles_get_the_backbone_prefix(tmp_path):
     got = weights.load_checkpoint(str(tmp_path / "c2.pkl"))
     assert set(got) == {"backbone.stem.conv1.weight", "backbone.stem.conv1.norm.weight", "backbone.res2.0.conv1.weight",
                         "backbone.res2.0.conv1.norm.bias", "backbone.res3.0.shortcut.weight",
-                        "backbone.res3.0.shortcut.norm.running_mean", "backbone.res5.2.conv3.norm.running_var"}
+                        "backbone.res3.0.shortcut.norm.running_mean", "backbone.res5.2.conv3.norm.running_var",
+                        # FrozenBatchNorm2d defaults for a norm that arrives without statistics (below)
+                        "backbone.stem.conv1.norm.running_mean", "backbone.stem.conv1.norm.running_var"}
     d2 = {"stem.conv1.weight": np.zeros((64, 3, 7, 7), np.float32), "res4.5.conv2.norm.bias": np.zeros(256, np.float32)}
     with open(tmp_path / "d2.pkl", "wb") as f:
         pickle.dump({"model": d2, "matching_heuristics": True}, f)
     assert set(weights.load_checkpoint(str(tmp_path / "d2.pkl"))) == {"backbone." + k for k in d2}
     r50 = {k for k, _ in weights.openvis_spec("r50", dict(width=64, layers=1, heads=1, patch=16, resolution=32, embed_dim=16), 100)}
     assert {k for k in got} <= r50                             # every converted name is a key of the R50 models
+
+
+def test_msra_r50_pickle_without_bn_statistics_loads_like_detectron2(tmp_path):
+    """The real MSRA R-50.pkl carries only `*_bn_s` / `*_bn_b` per norm: detectron2's FrozenBatchNorm2d._load_from_state_dict
+    (version < 2) fills running_mean = 0 and running_var = 1.  The converted dict must feed the ResNet weight folding."""
+    import pickle
+    import numpy as np
+    import torch
+    from openvis_amd.modeling.backbone import resnet
+    rng = np.random.default_rng(0)
+    c2 = {"conv1_w": rng.standard_normal((64, 3, 7, 7)).astype(np.float32), "res_conv1_bn_s": rng.random(64).astype(np.float32) + 0.5,
+          "res_conv1_bn_b": rng.standard_normal(64).astype(np.float32)}
+    with open(tmp_path / "R-50.pkl", "wb") as f:
+        pickle.dump({"model": c2, "__author__": "MSRA", "matching_heuristics": True}, f)
+    got = weights.load_checkpoint(str(tmp_path / "R-50.pkl"))
+    assert torch.equal(got["backbone.stem.conv1.norm.running_mean"], torch.zeros(64))
+    assert torch.equal(got["backbone.stem.conv1.norm.running_var"], torch.ones(64))
+    w, b = resnet._fold(got, "backbone.stem.conv1")                       # KeyError before the defaults existed
+    scale = torch.from_numpy(c2["res_conv1_bn_s"]) * (1.0 + 1e-5) ** -0.5
+    assert torch.allclose(w, (torch.from_numpy(c2["conv1_w"]) * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1))
+    assert torch.allclose(b, torch.from_numpy(c2["res_conv1_bn_b"]))
+
+
+def test_legacy_checkpoint_keys_are_migrated(tmp_path):
+    """mask_former_head.py:23-45 (`sem_seg_head.* -> sem_seg_head.pixel_decoder.*` unless under `predictor.`) and
+    video_mask2former_transformer_decoder.py:224-245 (`static_query -> query_feat`): a Mask2Former v1 checkpoint (README.md:5)."""
+    import torch
+    old = {"sem_seg_head.adapter_1.weight": torch.randn(4, 4, 1, 1), "sem_seg_head.layer_1.norm.bias": torch.randn(4),
+           "sem_seg_head.predictor.static_query.weight": torch.randn(10, 4), "sem_seg_head.predictor.query_embed.weight": torch.randn(10, 4),
+           "sem_seg_head.pixel_decoder.mask_features.bias": torch.randn(4), "backbone.res2.0.conv1.weight": torch.randn(4, 4, 1, 1)}
+    new, renamed = weights.migrate_legacy_keys(old)
+    assert set(new) == {"sem_seg_head.pixel_decoder.adapter_1.weight", "sem_seg_head.pixel_decoder.layer_1.norm.bias",
+                        "sem_seg_head.predictor.query_feat.weight", "sem_seg_head.predictor.query_embed.weight",
+                        "sem_seg_head.pixel_decoder.mask_features.bias", "backbone.res2.0.conv1.weight"}
+    assert len(renamed) == 3 and torch.equal(new["sem_seg_head.predictor.query_feat.weight"], old["sem_seg_head.predictor.static_query.weight"])
+    assert set(old) != set(new) and "sem_seg_head.adapter_1.weight" in old               # the input dict is left alone
+    # idempotent, and a current-format dict passes through unchanged
+    again, renamed2 = weights.migrate_legacy_keys(new)
+    assert set(again) == set(new) and not renamed2
+    torch.save({"model": old}, tmp_path / "v1.pth")
+    assert set(weights.load_checkpoint(str(tmp_path / "v1.pth"))) == set(new)
+    # a migrated v1 dict has every key the current spec asks for under those names
+    spec = {k for k, _ in weights.openvis_spec("r50", dict(width=64, layers=1, heads=1, patch=16, resolution=32, embed_dim=16), 100)}
+    assert "sem_seg_head.predictor.query_feat.weight" in spec and "sem_seg_head.pixel_decoder.adapter_1.weight" in spec
 
 
 def test_checkpoint_files_cannot_execute_code(tmp_path):

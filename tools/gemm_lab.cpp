@@ -17,6 +17,7 @@ extern "C" int ovis_set_f32a_pp(int on);
 extern "C" int ovis_pp_tile_rows(int tm);
 extern "C" const char* ovis_gemm_nt_f32_w3_kernel(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C, long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr, int act);
 extern "C" int ovis_pp_debug(int flags, unsigned long long* stamps);   // lab-only entry of gemm_f16_pp.hip
+extern "C" int ovis_pp_epilogue(int epi);                               // epilogue variant (variant field 4, bits 8..)
 
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 #define OVIS_OKAY(x) do { int r_ = (x); if (r_ != 0) { printf("ovis error %d: %s at %s:%d\n", r_, ovis_last_error(), __FILE__, __LINE__); exit(3); } } while (0)
@@ -56,6 +57,12 @@ __global__ void diff_kernel(const float* ref, const void* out, int out_f16, long
     mx = fmaxf(mx, d == d ? d : 1e30f);
   }
   atomicMax((int*)maxabs, __float_as_int(mx));
+  if (bad) atomicAdd(nbad, bad);
+}
+
+__global__ void bitdiff_kernel(const unsigned short* a, const unsigned short* b, long long n, unsigned long long* nbad) {
+  unsigned long long bad = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) bad += a[i] != b[i];
   if (bad) atomicAdd(nbad, bad);
 }
 
@@ -221,21 +228,45 @@ int main(int argc, char** argv) {
       HIP_OK(hipMalloc(&C, MN * 2)); HIP_OK(hipMalloc(&bias, sh.N * 4));
       fill_f16<<<2048, 256, 0, s>>>(A, (long long)sh.M * sh.K, 11u, 0, 1.f); fill_f16<<<2048, 256, 0, s>>>(B, (long long)sh.N * sh.K, 23u, 0, 1.f / sqrtf((float)sh.K));
       fill_f16<<<2048, 256, 0, s>>>(R, MN, 7u, 0, 1.f); fill_f32<<<64, 256, 0, s>>>(bias, sh.N, 5u, 0, 1.f);
-      const int tms[3] = {256, 192, 0};
-      double best[3] = {1e30, 1e30, 1e30};
+      // epilogue variants (EPI): bit-identical outputs expected (same arithmetic, different store / residual-load shapes), then interleaved timing
+      const int epis[4] = {0, 1, 4, 5};
+      _Float16* C0; HIP_OK(hipMalloc(&C0, MN * 2));
+      for (int tmv = 0; tmv < 2; ++tmv) {
+        ovis_pp_tile_rows(tmv ? 192 : 256);
+        ovis_pp_epilogue(0);
+        HIP_OK(hipMemsetAsync(C0, 0xff, MN * 2, s));
+        OVIS_OKAY(ovis_gemm_nt_f16_res16(A, sh.K, B, sh.K, C0, sh.N, sh.M, sh.N, sh.K, bias, R, sh.N, s));
+        for (int v = 1; v < 4; ++v) {
+          ovis_pp_epilogue(epis[v]);
+          HIP_OK(hipMemsetAsync(C, 0xee, MN * 2, s));
+          OVIS_OKAY(ovis_gemm_nt_f16_res16(A, sh.K, B, sh.K, C, sh.N, sh.M, sh.N, sh.K, bias, R, sh.N, s));
+          HIP_OK(hipMemsetAsync(d_bad, 0, 8, s));
+          bitdiff_kernel<<<1024, 256, 0, s>>>(reinterpret_cast<const unsigned short*>(C0), reinterpret_cast<const unsigned short*>(C), MN, d_bad);
+          unsigned long long bad; HIP_OK(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
+          if (bad) ++fails;
+          printf("r16 check %-10s TM %d EPI %d vs EPI 0: %llu differing elements %s\n", sh.name, tmv ? 192 : 256, epis[v], bad, bad ? "FAIL" : "OK");
+        }
+      }
+      HIP_OK(hipFree(C0));
+      ovis_pp_tile_rows(0);
+      double best[4] = {1e30, 1e30, 1e30, 1e30};
+      std::vector<double> all[4];
       for (int r = 0; r < rounds + 1; ++r)
-        for (int v = 0; v < 3; ++v) {
-          ovis_pp_tile_rows(tms[v]);
+        for (int v = 0; v < 4; ++v) {
+          ovis_pp_epilogue(epis[v]);
           HIP_OK(hipEventRecord(e0, s));
           for (int it = 0; it < iters; ++it) OVIS_OKAY(ovis_gemm_nt_f16_res16(A, sh.K, B, sh.K, C, sh.N, sh.M, sh.N, sh.K, bias, R, sh.N, s));
           HIP_OK(hipEventRecord(e1, s)); HIP_OK(hipEventSynchronize(e1));
           float t; HIP_OK(hipEventElapsedTime(&t, e0, e1));
-          if (r > 0) best[v] = std::min(best[v], (double)t / iters);
+          if (r > 0) { best[v] = std::min(best[v], (double)t / iters); all[v].push_back((double)t / iters); }
         }
-      ovis_pp_tile_rows(0);
+      ovis_pp_epilogue(0);
       const double fl = 2.0 * sh.M * sh.N * sh.K;
-      printf("r16 time %-10s M=%d N=%d K=%d: TM 256 %.4f ms (%.0f TF) | TM 192 %.4f ms (%.0f TF) | auto %.4f ms\n", sh.name, sh.M, sh.N, sh.K, best[0],
-             fl / best[0] / 1e9, best[1], fl / best[1] / 1e9, best[2]);
+      for (int v = 0; v < 4; ++v) {
+        std::sort(all[v].begin(), all[v].end());
+        const double med = all[v][all[v].size() / 2];
+        printf("r16 time %-10s M=%d N=%d K=%d EPI %d (auto TM): median %.4f ms (%.0f TF)  min %.4f ms (%.0f TF)\n", sh.name, sh.M, sh.N, sh.K, epis[v], med, fl / med / 1e9, best[v], fl / best[v] / 1e9);
+      }
       HIP_OK(hipFree(A)); HIP_OK(hipFree(B)); HIP_OK(hipFree(R)); HIP_OK(hipFree(C)); HIP_OK(hipFree(bias));
     }
   }
@@ -264,7 +295,7 @@ int main(int argc, char** argv) {
       for (const Variant& v : variants) {
         OVIS_OKAY(ovis_set_f16_gemm_mode(v.mode, v.grp, v.desync));
         if (v.dbg & 35) { printf("dbg flags 1 / 2 / 32 were removed from the kernel (results: profiles/r02/lab_ub1.txt, lab_ub2.txt)\n"); continue; }
-        ovis_pp_debug(v.dbg, nullptr);
+        ovis_pp_debug(v.dbg & 255, nullptr); ovis_pp_epilogue(v.dbg >> 8);
         for (int rep = 0; rep < 3; ++rep) {                       // repeated: a race shows up as run-to-run differences
           HIP_OK(hipMemsetAsync(C, 0xff, MN * 4, s));
           OVIS_OKAY(ovis_gemm_nt_f16(A, c.K, B, c.K, C, c.N, c.M, c.N, c.K, bias, R, c.N, c.act, c.out16, s));
@@ -309,7 +340,7 @@ int main(int argc, char** argv) {
         for (size_t vi = 0; vi < variants.size(); ++vi) {
           const Variant& v = variants[vi];
           OVIS_OKAY(ovis_set_f16_gemm_mode(v.mode, v.grp, v.desync));
-          ovis_pp_debug(v.dbg, nullptr);
+          ovis_pp_debug(v.dbg & 255, nullptr); ovis_pp_epilogue(v.dbg >> 8);
           HIP_OK(hipEventRecord(e0, s));
           for (int it = 0; it < iters; ++it)
             OVIS_OKAY(ovis_gemm_nt_f16(A, sh.K, B, sh.K, C, sh.N, sh.M, sh.N, sh.K, bias, R, sh.N, sh.act, sh.out16, s));
@@ -331,7 +362,7 @@ int main(int argc, char** argv) {
           const size_t nst = 256 * 16 * 2 * 4 + 256 * 2 * 64;
           unsigned long long* d_st; HIP_OK(hipMalloc(&d_st, nst * 8)); HIP_OK(hipMemsetAsync(d_st, 0, nst * 8, s));
           OVIS_OKAY(ovis_set_f16_gemm_mode(v.mode, v.grp, v.desync));
-          ovis_pp_debug(v.dbg, d_st);
+          ovis_pp_debug(v.dbg & 255, d_st); ovis_pp_epilogue(v.dbg >> 8);
           OVIS_OKAY(ovis_gemm_nt_f16(A, sh.K, B, sh.K, C, sh.N, sh.M, sh.N, sh.K, bias, R, sh.N, sh.act, sh.out16, s));
           ovis_pp_debug(0, nullptr);
           std::vector<unsigned long long> st(nst);
