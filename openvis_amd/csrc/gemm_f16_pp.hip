@@ -153,6 +153,8 @@ gemm_f16_pp_kernel(const PPArgs p) {
     PPTile t;
     t.bm = tm * TM; t.bn = tn * 256; t.bml = min(t.bm, p.M - TM); t.bnl = min(t.bn, p.N - 256);
     t.a_off = (long long)t.bml * p.lda * (FA ? 4 : 2); t.b_off = (long long)t.bnl * p.ldb * 2;
+    if (p.dbg & 4) t.a_off = t.b_off = 0;           // lab: every tile loads tile (0, 0)'s operands (all L2 hits; wrong results)
+    if (p.dbg & 2) t.a_off = 0;                     // lab: every tile loads M tile 0's rows of A
     *reinterpret_cast<PPTile*>(lds + PP_TAB + i * 32) = t;
   }
   __syncthreads();

@@ -417,7 +417,93 @@ def gen_clip_text():
     print("wrote clip_text.npz", tokens.shape, ens.shape)
 
 
-GENERATORS = {"sidevideo": gen_side_video_decoder, "text": gen_clip_text, "swin": gen_swin, "swinape": gen_swin_ape, "msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "san": gen_side_adapter, "resampler": gen_resampler, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual, "clipmask": gen_clip_visual_mask_prompt,
+def gen_window_inference():
+    """Reference MinVIS.run_window_inference (minvis.py:340-362) + MinVIS.post_processing (:320-338) and SAN.run_window_inference
+    (SANOnline, san.py:285-307), called as UNBOUND methods on a stub `self` whose `backbone` is the oracle's ResNet-50 restatement (detectron2's
+    is not in /root/reference) and whose `sem_seg_head` is the reference's own pixel decoder + frame decoder (MinVIS) or pixel decoder
+    with extra features + side-adapter frame decoder (SAN).  5 frames of 64 x 96 in windows of 2 (2 + 2 + 1)."""
+    import types
+    from tests._synth import synth_inputs, synth_weights
+    from oracle import torch_ref as TR
+    from openvis_amd import weights as PW                                      # key / shape list of the R50 backbone only
+    mv = R.ref("openvis.modeling.minvis")
+    fd = R.ref("openvis.modeling.transformer_decoder.frame_mask2former_transformer_decoder")
+    sfd = R.ref("openvis.modeling.transformer_decoder.side_adapter_frame_mask2former_transformer_decoder")
+    sa = R.ref("openvis.modeling.clip_adapter.side_adapter")
+    sys.modules["openvis.modeling.clip_adapter"].SideAdapter = sa.SideAdapter
+    R.ref("openvis.modeling.clip_adapter.text_prompt")
+    san = R.ref("openvis.san")
+    T, H, Wd, WIN, Q = 5, 64, 96, 2, 100
+    tiny = dict(width=64, layers=1, heads=1, patch=16, resolution=32, embed_dim=16)
+    spec_bb = [(k[len("backbone."):], s) for k, s in PW.openvis_spec("r50", tiny, Q) if k.startswith("backbone.")]
+    Wbb = synth_weights(spec_bb, 171, "backbone.")
+    pd = _build_pixel_decoder()
+    spec_pd = _load_synth(pd, 172)
+    dec = fd.FrameMultiScaleMaskedTransformerDecoder(
+        256, True, num_classes=1, hidden_dim=256, num_queries=Q, nheads=8, dim_feedforward=2048, dec_layers=9,
+        pre_norm=False, mask_dim=256, enforce_input_project=False, num_frames=T).eval()
+    spec_dec = _load_synth(dec, 173)
+    sdec = sfd.SideAdapterFrameMultiScaleMaskedTransformerDecoder(
+        clip_heads=4, mask_classification=True, in_channels=256, num_classes=1, hidden_dim=256, num_queries=Q, nheads=8,
+        dim_feedforward=2048, dec_layers=9, pre_norm=False, mask_dim=256, enforce_input_project=False, num_frames=T).eval()
+    spec_sdec = _load_synth(sdec, 174)
+    Wall = dict(Wbb)
+    Wall.update(synth_weights(spec_pd, 172, "sem_seg_head.pixel_decoder."))
+    Wall.update(synth_weights(spec_dec, 173, "sem_seg_head.predictor."))
+    Wsan = synth_weights(spec_sdec, 174, "sem_seg_head.predictor.")
+
+    def backbone(x):
+        with torch.no_grad():
+            return TR.resnet50(x, Wbb)
+
+    def head(features, extra_feats=None):
+        with torch.no_grad():
+            mf, _, ms = pd.forward_features(features, extra_feats) if extra_feats is not None else pd.forward_features(features)
+            return (sdec if extra_feats is not None else dec)(ms, mf)
+
+    stub = types.SimpleNamespace(backbone=backbone, sem_seg_head=head)
+    for s_in in range(175, 275, 10):                                        # stable seed (see gen_frame_decoder_and_tracker)
+        frames = (synth_inputs([(T, 3, H, Wd)], s_in)[0].sigmoid() * 255).floor().to(torch.uint8)
+        images, _ = TR.preprocess([f for f in frames])
+        mg = synth_inputs([(T, 256, H // 32, Wd // 32), (T, 256, H // 16, Wd // 16), (T, 256, H // 8, Wd // 8)], s_in + 1, 0.5)
+        with torch.no_grad():
+            out = mv.MinVIS.run_window_inference(stub, images, window_size=WIN)
+            full = head(backbone(images))
+            mine = TR.run_window_inference(images, lambda x: TR.resnet50(x, Wall),
+                                           lambda f: TR.frame_decoder(TR.pixel_decoder(f, Wall)[2], TR.pixel_decoder(f, Wall)[0], Wall), WIN)
+            out_san = san.SANOnline.run_window_inference(stub, images, mg, window_size=WIN)
+            full_san = head(backbone(images), mg)
+        ok = all((out[k] - full[k]).abs().max() < 1e-3 for k in ("pred_masks", "pred_embeds")) and \
+            (out["pred_masks"] - mine["pred_masks"]).abs().max() < 1e-3 and \
+            all((out_san[k] - full_san[k]).abs().max() < 1e-3 for k in ("pred_masks", "pred_embeds", "class_attn_biases"))
+        if ok:                                                               # ... and a tracker assignment without near-ties
+            with torch.no_grad():
+                mine_san = TR.run_window_inference(
+                    images, lambda x: TR.resnet50(x, Wall),
+                    lambda f, ex: TR.side_frame_decoder(TR.pixel_decoder(f, Wall, extra_features=ex)[2],
+                                                        TR.pixel_decoder(f, Wall, extra_features=ex)[0], Wsan, clip_heads=4), WIN, clip_feats=mg)
+            ok = torch.equal(TR.video_match_via_embeds(mine["pred_embeds"][0])[0], mv.batch_video_match_via_embeds(out["pred_embeds"])[0][0]) and \
+                torch.equal(TR.video_match_via_embeds(mine_san["pred_embeds"][0])[0], mv.batch_video_match_via_embeds(out_san["pred_embeds"])[0][0])
+        if ok:
+            break
+    else:
+        raise RuntimeError("no stable seed found")
+    print("window fixture uses input seed", s_in)
+    with torch.no_grad():
+        post = mv.MinVIS.post_processing(stub, dict(out))
+        idx, _ = mv.batch_video_match_via_embeds(out["pred_embeds"])
+        post_san_idx, _ = mv.batch_video_match_via_embeds(out_san["pred_embeds"])
+    np.savez_compressed(os.path.join(GOLD, "window_inference.npz"), spec_bb=_spec_arrays(spec_bb), spec_pd=_spec_arrays(spec_pd),
+                        spec_dec=_spec_arrays(spec_dec), spec_sdec=_spec_arrays(spec_sdec),
+                        seeds=np.array([171, 172, 173, 174, s_in, s_in + 1]), thw_win=np.array([T, H, Wd, WIN]),
+                        pred_embeds=out["pred_embeds"].numpy(), indices=idx.numpy(),   # (un-tracked masks / logits = the tracked ones, un-permuted)
+                        post_pred_masks=post["pred_masks"].numpy(), post_pred_logits=post["pred_logits"].numpy(),
+                        san_pred_masks=out_san["pred_masks"].numpy(), san_pred_embeds=out_san["pred_embeds"].numpy(),
+                        san_class_attn_biases=out_san["class_attn_biases"].numpy(), san_indices=post_san_idx.numpy())
+    print("wrote window_inference.npz", out["pred_masks"].shape, out_san["class_attn_biases"].shape)
+
+
+GENERATORS = {"window": gen_window_inference, "sidevideo": gen_side_video_decoder, "text": gen_clip_text, "swin": gen_swin, "swinape": gen_swin_ape, "msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "san": gen_side_adapter, "resampler": gen_resampler, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual, "clipmask": gen_clip_visual_mask_prompt,
               "pe": gen_position_encodings}
 
 if __name__ == "__main__":

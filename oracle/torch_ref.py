@@ -764,6 +764,29 @@ def minvis_post_processing(outputs):
     return out
 
 
+def run_window_inference(images, backbone_fn, head_fn, window_size=30, clip_feats=None):
+    """MinVIS.run_window_inference (minvis.py:340-362) and, with `clip_feats`, SAN.run_window_inference (san.py:285-307):
+    ceil(T / window_size) windows of consecutive frames go through backbone + head one after the other (a ragged last
+    window is whatever the slice returns); the per-frame outputs are concatenated along their time axis -- pred_logits /
+    pred_embeds / class_attn_biases dim 1, pred_masks dim 2 (moved to the CPU as f32 by the reference, :358 / :305) --
+    and the auxiliary outputs are dropped.  BriVIS' own copy (brivis.py:267-316) is broken in the reference
+    and is not restated."""
+    T = len(images)
+    iters = T // window_size + (1 if T % window_size != 0 else 0)
+    out_list = []
+    for i in range(iters):
+        b0, b1 = i * window_size, (i + 1) * window_size
+        feats = backbone_fn(images[b0:b1])
+        out = head_fn(feats) if clip_feats is None else head_fn(feats, [x[b0:b1] for x in clip_feats])
+        out_list.append(out)
+    outputs = {}
+    for key, dim in (("pred_logits", 1), ("class_attn_biases", 1), ("pred_embeds", 1), ("pred_masks", 2)):
+        if key in out_list[0]:
+            outputs[key] = torch.cat([o[key] for o in out_list], dim=dim)
+    outputs["pred_masks"] = outputs["pred_masks"].to(torch.float32)
+    return outputs
+
+
 def openvis_online_forward(frames, W, text_features, out_hw=None, stages=None, clip_heads=12, clip_resolution=224):
     """OpenVISOnline.forward, eval (openvis/openvis.py:176-281); part_len = 10."""
     images, (H, Wd) = preprocess([f for f in frames])

@@ -1,5 +1,6 @@
-"""GPU: COCO RLE of the output masks -- kernel vs the numpy statement of the run-length semantics,
-string round trip, and the model's RLE output vs its dense masks."""
+"""GPU: COCO RLE of the output masks -- kernel vs the checker oracle/rle_ref.py (plain-loop restatement of
+pycocotools' rleEncode / rleToString, pinned by known answers in tests/test_oracle_rle.py), string round trip, and the model's
+RLE output vs its dense masks."""
 import numpy as np
 import pytest
 import torch
@@ -11,6 +12,7 @@ pytestmark = pytest.mark.gpu
                                      (1, 129, 127, 0.02)])
 def test_rle_kernel_vs_numpy(n, H, W, p):
     from openvis_amd import ops, rle
+    from oracle import rle_ref
     rng = np.random.default_rng(H * W + n)
     masks = rng.random((n, H, W)) < p
     if p == 0.3:                                          # blob-like masks (few long runs) next to the noisy ones
@@ -20,12 +22,13 @@ def test_rle_kernel_vs_numpy(n, H, W, p):
     counts, n_runs = ops.rle_encode(cm)
     counts, n_runs = counts.cpu().numpy(), n_runs.cpu().numpy()
     for i in range(n):
-        ref = rle.mask_to_counts(masks[i])
-        assert n_runs[i] == len(ref)
+        ref = rle_ref.rle_encode(masks[i].tolist()) if H * W <= 20000 else rle.mask_to_counts(masks[i])   # (the loop checker on the small cases;
+        assert n_runs[i] == len(ref)                                                                       #  tests/test_oracle_rle.py ties the two)
         got = counts[i, :n_runs[i]].tolist()
         assert got == ref
         assert (rle.counts_to_mask(got, H, W) == masks[i]).all()
-        assert rle.string_to_counts(rle.counts_to_string(got)) == got
+        assert rle.counts_to_string(got).decode("ascii") == rle_ref.rle_to_string(got)
+        assert rle_ref.rle_from_string(rle_ref.rle_to_string(got)) == got
 
 
 def test_rle_buffer_overflow_is_reported():

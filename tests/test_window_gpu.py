@@ -1,4 +1,5 @@
-"""GPU: window inference (minvis.py:340-362 / san.py:285-307 / openvis.py:283-305) of the online models equals the
+"""GPU: window inference (minvis.py:340-362 / san.py:285-307 / openvis.py:283-305) of the online models: (1) against the REFERENCE's
+own `run_window_inference` methods (tests/golden/window_inference.npz, oracle/make_golden.py `window`), (2) equal to the
 un-windowed run: per-frame stages are independent, windows only bound activation memory."""
 import numpy as np
 import pytest
@@ -54,3 +55,56 @@ def test_window_inference_equals_full_clip(arch, decoder):
     assert outs[0]["pred_labels"] == outs[1]["pred_labels"]
     for m0, m1 in zip(outs[0]["pred_masks"], outs[1]["pred_masks"]):
         assert (m0 != m1).float().mean().item() < 1e-4
+
+
+@pytest.mark.parametrize("arch", ["OpenVISOnline", "SANOnline"])
+def test_window_inference_matches_the_reference_golden(arch):
+    """The HIP path's backbone -> sem_seg_head windows (MODEL.MASK_FORMER.TEST.WINDOW_SIZE 2 on 5 frames: 2 + 2 + 1) and the tracker
+    against the outputs of the reference's MinVIS.run_window_inference + post_processing / SANOnline.run_window_inference."""
+    from openvis_amd import config
+    from tests.test_oracle_path import load_window_case
+
+    g, Wd, Ws, frames, mg, win = load_window_case()
+    san = arch == "SANOnline"
+    cfg = config.get_cfg()
+    cfg.MODEL.META_ARCHITECTURE = arch
+    cfg.MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME = ("SideAdapterFrameMultiScaleMaskedTransformerDecoder" if san
+                                                      else "FrameMultiScaleMaskedTransformerDecoder")
+    cfg.MODEL.MASK_FORMER.TEST.WINDOW_INFERENCE = True
+    cfg.MODEL.MASK_FORMER.TEST.WINDOW_SIZE = win
+    cfg.MODEL.CLIP_ADAPTER.CLIP_NUM_HEADS = 4
+    cfg.MODEL.PRECISION = "fp32"
+    model = config.build_model(cfg)
+    sd = Ws if san else Wd
+    model.backbone.load_state_dict(sd, "backbone.", model.device)                      # (no CLIP tower: the rows under test end at the tracker)
+    model.sem_seg_head.load_state_dict(sd, "sem_seg_head.", model.device)
+    assert model.window_inference and model.window_size == win
+    images, _, _ = model.preprocess(frames.to(model.device))
+    mg_d = [x.permute(0, 2, 3, 1).contiguous().to(model.device) for x in mg]            # channel-last, like the side adapter's features
+    calls = []
+
+    def per_window(b0, b1):
+        calls.append((b0, b1))
+        extra = [x[b0:b1] for x in mg_d] if san else None
+        return model.sem_seg_head(model.backbone(images[b0:b1]), extra_feats=extra)
+
+    run = model.run_window_inference if san else (lambda fn, T: model._windowed(model, fn, T))
+    out = run(per_window, images.shape[0])
+    assert calls == [(0, 2), (2, 4), (4, 5)]
+    torch.cuda.synchronize()
+    emb = out["pred_embeds"].cpu().numpy()
+    if san:
+        assert np.abs(emb - g["san_pred_embeds"]).max() < 2e-3
+        pm, ref = out["pred_masks"].cpu().numpy(), g["san_pred_masks"]
+        assert np.abs(pm - ref).max() < 5e-3 and ((pm > 0) == (ref > 0)).mean() > 0.9995
+        assert np.abs(out["class_attn_biases"].cpu().numpy() - g["san_class_attn_biases"]).max() < 5e-3
+        from openvis_amd.modeling.minvis import batch_video_match_via_embeds
+        idx, _ = batch_video_match_via_embeds(out["pred_embeds"])
+        assert np.array_equal(idx.cpu().numpy(), g["san_indices"])
+        return
+    assert np.abs(emb - g["pred_embeds"]).max() < 2e-3
+    post = model._post(model, out)
+    assert np.array_equal(post["indices"].cpu().numpy(), g["indices"])
+    pm, ref = post["pred_masks"].cpu().numpy(), g["post_pred_masks"]
+    assert np.abs(pm - ref).max() < 5e-3 and ((pm > 0) == (ref > 0)).mean() > 0.9995
+    assert np.abs(post["pred_logits"].cpu().numpy() - g["post_pred_logits"]).max() < 2e-3
