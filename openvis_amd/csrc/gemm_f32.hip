@@ -146,7 +146,9 @@ gemm_f32_kernel(LoaderA la, const float* __restrict__ B, long long ldb, float* _
 
 // 0: native f32 MFMA everywhere; 1 (default): large problems run on the bf16 matrix cores with the exact three-way
 // bf16 split of gemm_f32x3.h (same accuracy class, ~2.5x the throughput)
-int g_f32_gemm_mode = 1;
+// thread_local: the ClipPipeline slot threads (one model instance per slot is legal) and a caller using the ops directly each own their
+// setting; every model (re)applies its MODEL.F32_GEMM_SPLIT on the calling thread at the start of forward
+thread_local int g_f32_gemm_mode = 1;
 
 template <typename LoaderA>
 int launch_gemm(LoaderA la, const float* B, long long ldb, float* C, long long ldc, int M, int N, int K,

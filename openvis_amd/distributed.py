@@ -169,3 +169,24 @@ def all_reduce_sum(t):
         t = t.contiguous()
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+def warm_up(device):
+    """One small collective of every kind the frame-sharded path uses (all_gather_into_tensor on the side stream, all_reduce,
+    gather, and the scalar MAX of the timing), so that RCCL's communicator / channel set-up happens here and not inside a timed
+    step.  A no-op without a process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    world = dist.get_world_size()
+    dev = torch.device(device)
+    t_local = len(inference_shard(2 * world + 1, dist.get_rank(), world))          # ragged on purpose: exercises the padding
+    x = torch.full((t_local, 4, 8), float(dist.get_rank()), device=dev)
+    g = all_gather_frames(x, 2 * world + 1)
+    assert g.shape[0] == 2 * world + 1
+    all_reduce_sum(torch.ones(16, device=dev))
+    gather_frame_masks(torch.zeros((2, t_local, 4, 4), dtype=torch.uint8, device=dev), 2 * world + 1)
+    max_over_ranks(0.0, "cpu" if dist.get_backend() == "gloo" else dev)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    dist.barrier()

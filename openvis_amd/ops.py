@@ -16,12 +16,17 @@ ACT_NONE, ACT_RELU, ACT_QUICKGELU, ACT_GELU = 0, 1, 2, 3
 PROFILE = None
 
 
-_F32_GEMM_MODE = 1
+class _Mode(__import__("threading").local):
+    """the library keeps the f32-GEMM split per host thread (thread_local in csrc/gemm_f32.hip): so does this mirror of it"""
+    v = 1
+
+
+_MODE = _Mode()
 
 
 def _gemm_variant(M, N, loader, K=4, batch=1):
     big = ((M + 127) // 128) * ((N + 127) // 128) * batch >= 256       # mirrors launch_gemm() in csrc/gemm_f32.hip
-    if big and _F32_GEMM_MODE >= 1 and K % 4 == 0:
+    if big and _MODE.v >= 1 and K % 4 == 0:
         return f"gemm_f32x3_kernel<128,128,{loader}>"
     return f"gemm_f32_kernel<{'128,128' if big else '64,64'},{loader}>"
 
@@ -54,15 +59,15 @@ def _chk(*ts):
 
 
 def f32_gemm_mode():
-    return _F32_GEMM_MODE
+    return _MODE.v
 
 
 def set_f32_gemm_mode(mode):
     """0: native f32 MFMA for every f32 GEMM/conv; 1 (library default): large problems use the exact bf16x3 split (gemm_f32x3.h);
-    2: the same kernel with the two leading planes only (bf16x2, three products).  Process-wide (MODEL.F32_GEMM_SPLIT)."""
-    global _F32_GEMM_MODE
+    2: the same kernel with the two leading planes only (bf16x2, three products).  Per HOST THREAD (MODEL.F32_GEMM_SPLIT): two models
+    with different splits on different ClipPipeline threads do not see each other's setting."""
     _lib.call("ovis_set_f32_gemm_mode", int(mode))
-    _F32_GEMM_MODE = int(mode)
+    _MODE.v = int(mode)
 
 
 import weakref
@@ -111,9 +116,9 @@ def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None, cw
             _lib.call("ovis_gemm_nt_f32a_f16w", a2, _ll(K), w16, _ll(K), out, _ll(N), M, N, K, bias, r2, _ll(N), act,
                       _lib.stream_ptr())
         return out.view(*a.shape[:-1], N)
-    use_w3 = cw and w.is_contiguous() and K % 8 == 0 and _F32_GEMM_MODE >= 1 and ((M + 127) // 128) * ((N + 127) // 128) >= 256
+    use_w3 = cw and w.is_contiguous() and K % 8 == 0 and _MODE.v >= 1 and ((M + 127) // 128) * ((N + 127) // 128) >= 256
     label = _gemm_variant(M, N, "DenseA", K)
-    if PROFILE is not None and use_w3 and _F32_GEMM_MODE == 2:      # bf16x2: the ping-pong kernel's f32-A mode takes the eligible shapes
+    if PROFILE is not None and use_w3 and _MODE.v == 2:      # bf16x2: the ping-pong kernel's f32-A mode takes the eligible shapes
         label = _w3_kernel_name(a2, K, w3_of(w), K, w.numel(), out, N, M, N, K, bias, r2, N, act) or label
     with _Prof(label, 2.0 * M * N * K):
         if use_w3:
@@ -279,11 +284,11 @@ def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE, w
                       _lib.stream_ptr())
         return y
     label = _gemm_variant(N * OH * OW, Cout, "ConvA", KH * KW * Cin)
-    if (PROFILE is not None and cw and _F32_GEMM_MODE == 2 and KH == 1 and KW == 1 and stride == 1 and pad == 0 and Cin % 8 == 0
+    if (PROFILE is not None and cw and _MODE.v == 2 and KH == 1 and KW == 1 and stride == 1 and pad == 0 and Cin % 8 == 0
             and ((N * OH * OW + 127) // 128) * ((Cout + 127) // 128) >= 256):
         label = _w3_kernel_name(x, Cin, w3_of(w), Cin, w.numel(), y, Cout, N * OH * OW, Cout, Cin, bias, residual, Cout, act) or label
     with _Prof(label, 2.0 * N * OH * OW * Cout * KH * KW * Cin):
-        if cw and (KH * KW * Cin) % 8 == 0 and _F32_GEMM_MODE >= 1:
+        if cw and (KH * KW * Cin) % 8 == 0 and _MODE.v >= 1:
             _lib.call("ovis_conv2d_nhwc_f32_w3", x, w, w3_of(w), _ll(w.numel()), y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias,
                       residual, act, _lib.stream_ptr())
         else:

@@ -5,7 +5,7 @@ ONCE in the build container on seeded synthetic inputs, and what the GPU tests c
   tests/golden/c3_san_online_720p.npz    SANOnline R50 + SideAdapter ViT-B/16, 2 frames of 720x1280
   tests/golden/c4_brivis_720p_36f.npz    BriVIS R50, ONE 36-frame 720p clip (linker over all 36 frames, resampler, heads)
   tests/golden/c5_brivis_swinl_1080p.npz BriVIS Swin-L (embed 192, depths 2/2/18/2, window 12) + SideAdapter ViT-L/14@336,
-                                         1 frame of 1080x1920
+                                         3 frames of 1080x1920 (tracker + temporal resampler active)
 
 Inputs are NOT stored: frames = bench.synth_frames(T, H, W, seed), weights = weights.random_init(spec, seed 42), text =
 bench.synth_text(40, E) -- all seeded torch CPU generators, identical on the GPU box (same image).  Stored per case: tracker
@@ -119,10 +119,10 @@ def c5():
     arch = _CLIP_ARCH["ViT-L/14@336px"]
     a = weights.SWIN_ARCH["swin_l"]
     sd = weights.random_init(weights.brivis_spec("swin_l", arch, Q), seed=42)
-    frames = bench.synth_frames(1, 1080, 1920, 1000, "cpu")
+    frames = bench.synth_frames(3, 1080, 1920, 1000, "cpu")              # 3 frames: the linker and the resampler's temporal attention do real work
     text = bench.synth_text(K, arch["embed_dim"])
     bb = lambda images, W: TR.swin(images, W, a["embed_dim"], a["depths"], a["num_heads"], a["window"])
-    brivis_case("c5_brivis_swinl_1080p.npz", frames, sd, text, 1, [0], broken_idx=21, merge_ids=(6, 12, 18), resolution=336,
+    brivis_case("c5_brivis_swinl_1080p.npz", frames, sd, text, 1, [0, 2], broken_idx=21, merge_ids=(6, 12, 18), resolution=336,
                 clip_heads=arch["width"] // 64, num_queries=Q, backbone_fn=bb)
 
 

@@ -25,3 +25,31 @@ def logit_errors_by_box(st_gpu, st_ref):
         d = float(np.abs(lg[ig[k]] - lr[i]).max())
         (same if (b[0] == x0 and b[1] == y0 and b[2] == x0 + side and b[3] == y0 + side) else diff).append(d)
     return np.array(same), np.array(diff)
+
+
+def check_top10(out_gpu, ref, ref_probs, rows_ref=None, tol=1e-3):
+    """Top-10 of the flattened [Q_valid x K] scores (video_maskformer.py:267-278; `topk(sorted=False)`: compared as sets keyed by
+    (query, label)).  Exact, tie-aware statement: with d = `tol` the score tolerance,
+      * every GPU entry also found in the reference top-10 has |score - ref score| <= d;
+      * every reference entry whose score beats the reference's 11th score by more than 2 d must be in the GPU top-10 (the others can
+        legitimately swap with the 11th);
+      * every GPU entry must score >= the reference's 10th score - 2 d on the reference side.
+    Returns (n_common, margin = reference 10th - 11th score).  `rows_ref`: reference row -> query id (rows of valid queries)."""
+    p = np.asarray(ref_probs, dtype=np.float64)
+    flat = np.sort(p.reshape(-1))[::-1]
+    s10, s11 = float(flat[9]), float(flat[10]) if flat.size > 10 else 0.0
+    K = p.shape[1]
+    qid = (lambda r: rows_ref[r]) if rows_ref is not None else (lambda r: r)
+    row_of = {qid(r): r for r in range(p.shape[0])}
+    sg = {(q, l): s for q, l, s in zip(out_gpu["pred_queries"], out_gpu["pred_labels"], out_gpu["pred_scores"])}
+    sr = {(qid(r), l): s for r, l, s in zip(ref["rows"], ref["pred_labels"], ref["pred_scores"])}
+    assert len(sg) == len(sr) == 10
+    for k in set(sg) & set(sr):
+        assert abs(sg[k] - sr[k]) <= tol, (k, sg[k], sr[k])
+    for k, s in sr.items():
+        if s > s11 + 2 * tol:
+            assert k in sg, ("reference top-10 entry with a clear margin is missing", k, s, s11)
+    for (q, l), s in sg.items():
+        assert q in row_of and p[row_of[q], l] >= s10 - 2 * tol, ("GPU top-10 entry is not a reference top-10 candidate", q, l, s)
+        assert abs(p[row_of[q], l] - s) <= tol, ((q, l), s, p[row_of[q], l])
+    return len(set(sg) & set(sr)), s10 - s11

@@ -23,7 +23,7 @@ def test_c1_single_480p_frame_matches_oracle():
     model.load_state_dict(sd)
     names = [f"class_{i}" for i in range(K)]
     MetadataCatalog.get("synthetic_c1").set(thing_classes=names)
-    text = bench.synth_text(K, 512)
+    text = bench.synth_text(K, 512, spread=0.25)              # separated classes: a sharp top-10 (bench.synth_text)
     model.clip_adapter.set_text_features(names, text)
     frames = bench.synth_frames(1, 480, 854, 0, "cpu")
     st, ref_st = {}, {}
@@ -37,6 +37,15 @@ def test_c1_single_480p_frame_matches_oracle():
     agree = ((g > 0) == (r > 0)).float().mean().item()
     inter, union = ((g > 0) & (r > 0)).sum().item(), ((g > 0) | (r > 0)).sum().item()
     assert agree > 0.9995 and inter / max(union, 1) > 0.999, (agree, inter / max(union, 1))      # north star: mask IoU >= 0.999
+    # exact-f32 policy: the mask BITS themselves.  Both sides compute in f32 with different summation orders, so a logit within ~1e-5
+    # of zero can land on either side: the exact match rate is asserted (and printed), every query mask at IoU >= 0.9999
+    gb, rb = (g[0] > 0).flatten(1), (r[0] > 0).flatten(1)
+    iq = ((gb & rb).sum(1).double() / (gb | rb).sum(1).clamp(min=1).double())
+    iq[(gb | rb).sum(1) == 0] = 1.0
+    exact = (gb == rb).double().mean().item()
+    print("C1 masks under the f32 policy: exact bit match rate %.7f (%d of %d bits differ), per-query IoU min %.6f, queries "
+          "bit-identical: %d of 100" % (exact, int((gb != rb).sum()), gb.numel(), iq.min().item(), int((gb == rb).all(1).sum())))
+    assert exact >= 0.99999 and iq.min().item() >= 0.9999, (exact, iq.min().item())
     vg, vr = st["valid"], ref_st["valid"].numpy()
     assert (vg == vr).mean() > 0.99
     lg, lr = st["crop_logits"].cpu().numpy(), ref_st["crop_logits"].numpy()
@@ -50,12 +59,14 @@ def test_c1_single_480p_frame_matches_oracle():
     assert len(d_same) >= 0.97 * (len(d_same) + len(d_diff)) and d_same.max() <= 1e-1, (len(d_same), len(d_diff), d_same.max())
     # final output: 10 masks at 480x854, IoU per matched (query, label)
     assert len(out["pred_masks"]) == 10 and tuple(out["pred_masks"][0].shape) == (1, 480, 854)
+    from tests._logits import check_top10
+    n_common, margin = check_top10(out, ref, ref_st["probs"].numpy(), ref_st["valid"].any(0).nonzero()[:, 0].tolist(), tol=1e-3)
+    print("C1 top-10: %d of 10 (query, label) pairs in common, reference margin 10th - 11th score %.2e" % (n_common, margin))
+    assert n_common == 10 or margin <= 2e-3, (n_common, margin)
+    rows_ref = ref_st["valid"].any(0).nonzero()[:, 0].tolist()
     sg = {(q, l): i for i, (q, l) in enumerate(zip(out["pred_queries"], out["pred_labels"]))}
-    sr = {(q, l): i for i, (q, l) in enumerate(zip(ref["rows"], ref["pred_labels"]))}
-    both = set(sg) & set(sr)
-    assert len(both) >= 8, (sorted(sg), sorted(sr))
-    for k in both:
+    sr = {(rows_ref[q], l): i for i, (q, l) in enumerate(zip(ref["rows"], ref["pred_labels"]))}
+    for k in set(sg) & set(sr):
         a, b = out["pred_masks"][sg[k]].cpu().numpy().astype(bool), np.asarray(ref["pred_masks"][sr[k]]).astype(bool)
         u = (a | b).sum()
         assert u == 0 or (a & b).sum() / u > 0.999
-        assert abs(out["pred_scores"][sg[k]] - ref["pred_scores"][sr[k]]) < 1e-3

@@ -24,7 +24,7 @@ def test_c2_720p_clip_under_the_bench_policy_matches_oracle():
     model.load_state_dict(sd)
     names = [f"class_{i}" for i in range(K)]
     MetadataCatalog.get("synthetic_c2").set(thing_classes=names)
-    text = bench.synth_text(K, 512)
+    text = bench.synth_text(K, 512, spread=0.25)              # separated classes: a sharp top-10 (bench.synth_text)
     model.clip_adapter.set_text_features(names, text)
     frames = bench.synth_frames(T, 720, 1280, 3, "cpu")
     st, ref_st = {}, {}
@@ -39,6 +39,14 @@ def test_c2_720p_clip_under_the_bench_policy_matches_oracle():
     agree = ((g > 0) == (r > 0)).float().mean().item()
     inter, union = ((g > 0) & (r > 0)).sum().item(), ((g > 0) | (r > 0)).sum().item()
     assert agree > 0.999 and inter / max(union, 1) > 0.999, (agree, inter / max(union, 1))       # north star: mask IoU >= 0.999
+    gb, rb = (g[0] > 0).flatten(1), (r[0] > 0).flatten(1)                                             # [Q, T h w]
+    iq = ((gb & rb).sum(1).double() / (gb | rb).sum(1).clamp(min=1).double())
+    iq[(gb | rb).sum(1) == 0] = 1.0
+    exact = (gb == rb).double().mean().item()
+    print("C2 masks under the bench policy: exact bit match rate %.6f (%d of %d bits differ), per-query IoU min %.5f median %.5f, "
+          "queries bit-identical: %d of 100" % (exact, int((gb != rb).sum()), gb.numel(), iq.min().item(), iq.median().item(),
+                                                int((gb == rb).all(1).sum())))
+    assert iq.min().item() >= 0.999, (iq.min().item(), int((iq < 0.999).sum()))                   # EVERY query mask, not the aggregate
     vg, vr = st["valid"], ref_st["valid"].numpy()
     assert (vg == vr).mean() > 0.99
     lg, lr = st["crop_logits"].cpu().numpy(), ref_st["crop_logits"].numpy()
@@ -54,16 +62,17 @@ def test_c2_720p_clip_under_the_bench_policy_matches_oracle():
     assert len(d_same) >= 0.95 * (len(d_same) + len(d_diff)) and d_same.max() <= 1e-1, (len(d_same), len(d_diff), d_same.max())
     assert len(out["pred_masks"]) == 10 and tuple(out["pred_masks"][0].shape) == (T, 720, 1280)
     rows_ref = ref_st["valid"].any(0).nonzero()[:, 0].tolist()
+    from tests._logits import check_top10
+    n_common, margin = check_top10(out, ref, ref_st["probs"].numpy(), rows_ref, tol=1e-3)
+    print("C2 top-10: %d of 10 (query, label) pairs in common, reference margin 10th - 11th score %.2e" % (n_common, margin))
+    assert n_common == 10 or margin <= 2e-3, (n_common, margin)
     sg = {(q, l): i for i, (q, l) in enumerate(zip(out["pred_queries"], out["pred_labels"]))}
     sr = {(rows_ref[q], l): i for i, (q, l) in enumerate(zip(ref["rows"], ref["pred_labels"]))}
-    both = set(sg) & set(sr)
-    assert len(both) >= 7, (sorted(sg), sorted(sr))
     ious = []
-    for k in both:
+    for k in set(sg) & set(sr):
         a, b = out["pred_masks"][sg[k]].cpu().numpy().astype(bool), np.asarray(ref["pred_masks"][sr[k]]).astype(bool)
         u = (a | b).sum()
         ious.append(1.0 if u == 0 else (a & b).sum() / u)
-        assert abs(out["pred_scores"][sg[k]] - ref["pred_scores"][sr[k]]) < 2e-2
     # bench policy: backbone fp16 operands, decoder f32 (MODEL.MASK_FORMER.DECODER_PRECISION): every output mask holds the
     # north-star IoU; with an fp16-operand decoder two of the ten dip to 0.9984 (tools/exp_policy_mix.py)
     print("C2 per-mask IoU:", [round(float(v), 5) for v in ious])

@@ -127,3 +127,29 @@ def test_c4_layout_world_size_8_end_to_end():
     assert all(r[2] for r in res)
     assert all(r[3] < 1e-6 for r in res)
     assert all(r[4] for r in res)
+
+
+def _worker_warm_up(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from openvis_amd import distributed as D
+    D.init_from_env("gloo")
+    D.warm_up("cpu")                                   # every collective kind of the frame-sharded path, ragged shards
+    out.put((rank, D.world_size()))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_communicator_warm_up_runs_every_collective_kind():
+    """bench.py calls distributed.warm_up before the timed region for world > 1 (RCCL builds rings at the first collective)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_warm_up, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs) and res == [(0, 2), (1, 2)]
+    from openvis_amd import distributed as D
+    D.warm_up("cpu")                                   # no process group: a no-op

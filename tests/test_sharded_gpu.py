@@ -65,3 +65,20 @@ def test_bench_multi_rank_control_flow(model, scaling, tmp_path):
     d = json.loads(outs[0][0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == scaling and d["value"] > 0
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and "roofline" in d
+
+
+def test_rccl_collectives_of_the_frame_sharded_path():
+    """One rank per GPU over RCCL (backend "nccl"): the async all-gather on the side stream, the device all-reduce and the mask
+    gather -- the branches of openvis_amd/distributed.py that the gloo rigs never execute.  Needs >= 2 GPUs on the box (the
+    driver's 8-GPU node; a 1-GPU box skips: RCCL refuses two ranks on one device)."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("RCCL test needs >= 2 GPUs (this box has %d)" % n)
+    world = min(n, 8)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("OVIS_BENCH_TEST_RIG", None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+                        "127.0.0.1", "--master-port", "29671", os.path.join(ROOT, "tests", "_rccl_worker.py")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and f"RCCL_OK world={world}" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])

@@ -123,4 +123,4 @@ def test_c4_brivis_36_frames_720p_under_the_bench_policy():
 
 
 def test_c5_brivis_swinl_vitl14_336_1080p_under_the_bench_policy():
-    _brivis_case("c5_brivis_swinl_1080p.npz", "swin_l", "ViT-L/14@336px", 1, 1080, 1920, 1000)
+    _brivis_case("c5_brivis_swinl_1080p.npz", "swin_l", "ViT-L/14@336px", 3, 1080, 1920, 1000)
