@@ -59,12 +59,16 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, fl
   bool oka[A_LD][2];
   uint4 pb[B_LD];
   bool okb[B_LD];
+  typename LoaderA::RowCtx rca[A_LD];                     // the staged rows of this thread, decomposed once (gemm_loaders.h)
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) rca[i] = la.row(bm + srow + i * 32);
   auto gload = [&](int k0) {
     const int k = k0 + scol;
+    const auto kc0 = la.kctx(k), kc1 = la.kctx(k + 4);
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-      pa[i][0] = la.load(bm + srow + i * 32, k, oka[i][0]);
-      pa[i][1] = la.load(bm + srow + i * 32, k + 4, oka[i][1]);
+      pa[i][0] = la.load(rca[i], kc0, oka[i][0]);
+      pa[i][1] = la.load(rca[i], kc1, oka[i][1]);
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {

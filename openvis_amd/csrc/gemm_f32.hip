@@ -70,9 +70,13 @@ gemm_f32_kernel(LoaderA la, const float* __restrict__ B, long long ldb, float* _
   const DenseA<VECB> lb{B, ldb, N, K};
   float4 pa[A_LD], pb[B_LD];
   bool oka[A_LD], okb[B_LD];
-  auto gload = [&](int k0) {
+  typename LoaderA::RowCtx rca[A_LD];                     // the staged rows of this thread, decomposed once (gemm_loaders.h)
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) pa[i] = la.load(bm + srow + i * 32, k0 + scol, oka[i]);
+  for (int i = 0; i < A_LD; ++i) rca[i] = la.row(bm + srow + i * 32);
+  auto gload = [&](int k0) {
+    const auto kc = la.kctx(k0 + scol);
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) pa[i] = la.load(rca[i], kc, oka[i]);
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) pb[i] = lb.load(bn + srow + i * 32, k0 + scol, okb[i]);
   };

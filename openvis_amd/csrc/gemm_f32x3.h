@@ -82,12 +82,16 @@ gemm_f32x3_kernel(LoaderA la, LoaderB lb, float* __restrict__ C, long long ldc, 
   bool oka[A_IT][2], okb[B_IT][2];
   X3Planes sa[A_IT], sb[B_IT];           // split planes of the next tile, waiting for the LDS buffer to be free
   X3Planes qb[B_IT];                     // pre-split B: planes in flight
+  typename LoaderA::RowCtx rca[A_IT];                     // the staged rows of this thread, decomposed once (gemm_loaders.h)
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) rca[i] = la.row(bm + srow + i * 64);
   auto gload = [&](int k0) {
     const int k = k0 + scol;
+    const auto kc0 = la.kctx(k), kc1 = la.kctx(k + 4);
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      pa[i][0] = la.load(bm + srow + i * 64, k, oka[i][0]);
-      pa[i][1] = la.load(bm + srow + i * 64, k + 4, oka[i][1]);
+      pa[i][0] = la.load(rca[i], kc0, oka[i][0]);
+      pa[i][1] = la.load(rca[i], kc1, oka[i][1]);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {

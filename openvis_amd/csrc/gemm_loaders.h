@@ -22,6 +22,12 @@ struct DenseA {
   long long lda;
   int M, K;
   __device__ __forceinline__ void advance(long long elems) { A += elems; }   // batched GEMM: blockIdx.y * a_bs
+  // hoisted form (the kernels call row() once per staged row before the K loop and kctx() once per K step)
+  struct RowCtx { int m; };
+  struct KCtx { int k; };
+  __device__ __forceinline__ RowCtx row(int m) const { return RowCtx{m}; }
+  __device__ __forceinline__ KCtx kctx(int k) const { return KCtx{k}; }
+  __device__ __forceinline__ float4 load(const RowCtx& r, const KCtx& kc, bool& ok) const { return load(r.m, kc.k, ok); }
   // raw load from a clamped address; `ok` tells the caller whether to keep it (selected at LDS-store time so the
   // s_waitcnt for this load lands AFTER the current tile's MFMAs, not right behind the load)
   __device__ __forceinline__ float4 load(int m, int k, bool& ok) const {
@@ -49,6 +55,36 @@ struct ConvA {
   ConvGeom g;
   int M, K;
   __device__ __forceinline__ void advance(long long) {}
+  // Hoisted form: load(m, k) below costs five runtime integer divisions per 16-byte load (m -> n, oh, ow; k -> kh, kw, c) --
+  // 40 per thread and K step in the 128x128x64 kernels, several times the tile's MFMA time.  A staged row's pixel is fixed for the
+  // whole K loop and the 8 consecutive k of a thread are one tap (Cin % 4 == 0: a float4 never straddles a pixel), so the kernels
+  // decompose each row ONCE (row()) and each K step's two k offsets once (kctx()); a load is then adds and compares.
+  struct RowCtx { long long base; int ih0, iw0; bool okm; };        // element offset of input pixel (n, oh*stride - pad, ow*stride - pad)
+  struct KCtx { int off, kh, kw; bool okk; };                        // (kh*W + kw)*Cin + c
+  __device__ __forceinline__ RowCtx row(int m) const {
+    const int ow = m % g.OW;
+    const int t = m / g.OW;
+    const int oh = t % g.OH;
+    const int n = t / g.OH;
+    RowCtx r;
+    r.ih0 = oh * g.stride - g.pad; r.iw0 = ow * g.stride - g.pad; r.okm = m < M;
+    r.base = (((long long)n * g.H + r.ih0) * g.W + r.iw0) * g.Cin;
+    return r;
+  }
+  __device__ __forceinline__ KCtx kctx(int k) const {
+    const int c = k % g.Cin;
+    const int t2 = k / g.Cin;
+    KCtx kc;
+    kc.kw = t2 % g.KW; kc.kh = t2 / g.KW; kc.okk = k < K;
+    kc.off = (kc.kh * g.W + kc.kw) * g.Cin + c;
+    return kc;
+  }
+  __device__ __forceinline__ float4 load(const RowCtx& r, const KCtx& kc, bool& ok) const {
+    const int ih = r.ih0 + kc.kh, iw = r.iw0 + kc.kw;
+    ok = r.okm && kc.okk && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+    const float* p = X + (ok ? r.base + kc.off : 0);
+    return *reinterpret_cast<const float4*>(p);
+  }
   __device__ __forceinline__ float4 load(int m, int k, bool& ok) const {
     const int ow = m % g.OW;
     const int t = m / g.OW;

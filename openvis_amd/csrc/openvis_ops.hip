@@ -4,6 +4,7 @@
 // full-resolution intermediates the reference materialises ([Q,T,Hp,Wp] fp32 masks, x8-replicated
 // boolean masks, per-mask host loops).
 #include "common.h"
+#include <utility>
 #include <atomic>
 
 #pragma clang fp contract(off)
@@ -127,6 +128,141 @@ msda_encoder_fused_kernel(const float* __restrict__ value, const float* __restri
     }
   }
   *reinterpret_cast<float4*>(out + sidx * D + cv * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Lane-sharing variant (round 3), head_dim 32: the 8 lanes of a (query, head) -- one lane per 4 channels -- used to compute the
+// SAME 12 sampling points each (coordinates, bounds, 4 clamped tap offsets, 4 bilinear weights, softmax weight: ~55 VALU
+// instructions per point, ~1000 per thread for 48 gathers: the kernel was VALU-bound at 8x redundant arithmetic, not gather-bound).
+// Here lane c of the group computes point c (and point 8 + c for c < 4) ONCE, and every lane fetches a point's nine values (4 element
+// offsets, 4 tap weights, the attention weight) from its owner with ds_swizzle (a broadcast inside each group of 8 lanes: no LDS
+// memory, no address register).  Every value is produced by the same expressions in the same order as in msda_encoder_fused_kernel,
+// so the output is bit-identical to it and to oracle/msda_ref.c.
+// -------------------------------------------------------------------------------------------------
+template <int K8>
+__device__ __forceinline__ int bcast8_i(int v) {                      // value of lane (lane & ~7) | K8
+  return __builtin_amdgcn_ds_swizzle(v, (K8 << 5) | 0x18);            // bit mode: and_mask 0b11000, or_mask K8, xor_mask 0
+}
+template <int K8>
+__device__ __forceinline__ float bcast8_f(float v) { return __int_as_float(bcast8_i<K8>(__float_as_int(v))); }
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void msda_static_for(F& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); msda_static_for<I + 1, N>(f); }
+}
+
+struct MsdaPoint { unsigned o1, o2, o3, o4; float w1, w2, w3, w4, aw; };     // BYTE offsets of the 4 taps inside a frame's value tensor (level start included)
+
+template <int L, int P>
+__global__ void __launch_bounds__(256)
+msda_encoder_fused8_kernel(const float* __restrict__ value, const float* __restrict__ oa, int ld_oa,
+                           const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                           float* __restrict__ out, long long n_items, int S, int M) {
+  constexpr int D = 32, NPT = L * P;
+  static_assert(NPT <= 16, "two rounds of 8 owner lanes");
+  const unsigned blk = ovis::xcd_remap(blockIdx.x, gridDim.x);
+  long long item = (long long)blk * blockDim.x + threadIdx.x;
+  const bool live = item < n_items;                                    // (n_items is a multiple of 8: whole groups are live or not)
+  if (!live) item = n_items - 1;                                       // keep every lane in the swizzles; dead lanes do not store
+  const int cv = (int)(item & 7);
+  const long long qm = item >> 3;
+  const int m = (int)(qm % M);
+  const long long bs = qm / M;                                         // b*S + s
+  const int s = (int)(bs % S);
+  const long long b = bs / S;
+  const int qid_stride = M * D;
+
+  int Hs[L], Ws[L], starts[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) { Hs[l] = (int)shapes[2 * l]; Ws[l] = (int)shapes[2 * l + 1]; starts[l] = (int)lsi[l]; }
+  float refx = 0.f, refy = 0.f;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int e = starts[l] + Hs[l] * Ws[l];
+    if (s >= starts[l] && s < e) {
+      const int rr = s - starts[l];
+      refx = ((float)(rr % Ws[l]) + 0.5f) / (float)Ws[l];
+      refy = ((float)(rr / Ws[l]) + 0.5f) / (float)Hs[l];
+    }
+  }
+  const float* op = oa + bs * ld_oa + m * (NPT * 2);
+  const float* ap = oa + bs * ld_oa + M * NPT * 2 + m * NPT;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) mx = fmaxf(mx, ap[i]);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) sum += __builtin_amdgcn_exp2f((ap[i] - mx) * 1.4426950408889634f);
+  const float rsum = 1.f / sum;
+
+  // the point(s) this lane owns: pt = cv + 8 r
+  auto own = [&](int pt) {
+    MsdaPoint o;
+    const bool valid = pt < NPT;
+    const int ptc = valid ? pt : 0;
+    const int l = ptc / P;
+    int H = Hs[0], W = Ws[0], st = starts[0];
+#pragma unroll
+    for (int k = 1; k < L; ++k) if (l == k) { H = Hs[k]; W = Ws[k]; st = starts[k]; }
+    const float rW = 1.f / (float)W, rH = 1.f / (float)H;
+    const float loc_w = refx + op[ptc * 2] * rW;
+    const float loc_h = refy + op[ptc * 2 + 1] * rH;
+    o.aw = __builtin_amdgcn_exp2f((ap[ptc] - mx) * 1.4426950408889634f) * rsum;
+    const float h_im = loc_h * (float)H - 0.5f;
+    const float w_im = loc_w * (float)W - 0.5f;
+    const bool in = h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const int h_low = in ? (int)hf : 0, w_low = in ? (int)wf : 0;
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    const float lh = h_im - hf, lw = w_im - wf, hh = 1 - lh, hw = 1 - lw;
+    const bool t1 = in && h_low >= 0 && w_low >= 0, t2 = in && h_low >= 0 && w_high <= W - 1;
+    const bool t3 = in && h_high <= H - 1 && w_low >= 0, t4 = in && h_high <= H - 1 && w_high <= W - 1;
+    const int yl = max(h_low, 0), yh = min(h_high, H - 1), xl = max(w_low, 0), xh = min(w_high, W - 1);
+    const unsigned px = (unsigned)qid_stride * 4u;                       // bytes per token
+    o.o1 = (unsigned)(st + yl * W + xl) * px; o.o2 = (unsigned)(st + yl * W + xh) * px;
+    o.o3 = (unsigned)(st + yh * W + xl) * px; o.o4 = (unsigned)(st + yh * W + xh) * px;
+    o.w1 = t1 ? hh * hw : 0.f; o.w2 = t2 ? hh * lw : 0.f; o.w3 = t3 ? lh * hw : 0.f; o.w4 = t4 ? lh * lw : 0.f;
+    return o;
+  };
+  MsdaPoint own0 = own(cv);
+  MsdaPoint own1 = own0;
+  if constexpr (NPT > 8) own1 = own(cv + 8);
+
+  // a tap's address = the (wave-uniform) value pointer + a 32-bit byte offset: one VGPR and one add per tap (the host checks that
+  // the whole value tensor is below 2^32 bytes)
+  const char* vbytes = reinterpret_cast<const char*>(value);
+  const unsigned lane_base = (unsigned)((b * (long long)S * qid_stride + m * D + cv * 4) * 4);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  auto point = [&](auto tag) {
+    constexpr int pt = decltype(tag)::value, k = pt & 7;
+    MsdaPoint& o = pt < 8 ? own0 : own1;
+    const unsigned o1 = lane_base + (unsigned)bcast8_i<k>((int)o.o1), o2 = lane_base + (unsigned)bcast8_i<k>((int)o.o2);
+    const unsigned o3 = lane_base + (unsigned)bcast8_i<k>((int)o.o3), o4 = lane_base + (unsigned)bcast8_i<k>((int)o.o4);
+    const float w1 = bcast8_f<k>(o.w1), w2 = bcast8_f<k>(o.w2), w3 = bcast8_f<k>(o.w3), w4 = bcast8_f<k>(o.w4);
+    const float weight = bcast8_f<k>(o.aw);
+    const float4 v1 = *reinterpret_cast<const float4*>(vbytes + o1);
+    const float4 v2 = *reinterpret_cast<const float4*>(vbytes + o2);
+    const float4 v3 = *reinterpret_cast<const float4*>(vbytes + o3);
+    const float4 v4 = *reinterpret_cast<const float4*>(vbytes + o4);
+    acc[0] += (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) * weight;
+    acc[1] += (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) * weight;
+    acc[2] += (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) * weight;
+    acc[3] += (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w) * weight;
+    if constexpr ((pt + 1) % P == 0) {
+      // One level's 4 P taps in flight at a time (registers -> occupancy).  sched_barrier pins the machine scheduler; the empty asm
+      // (memory clobber, accumulators and owner values opaque) keeps the IR passes from hoisting the next levels' swizzles and
+      // loads above this point -- without it hipcc issues all 108 swizzles and all 48 gathers up front (250 VGPRs, one wavefront
+      // per SIMD).
+      asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) :: "memory");
+      asm volatile("" : "+v"(own0.o1), "+v"(own0.o2), "+v"(own0.o3), "+v"(own0.o4), "+v"(own0.w1), "+v"(own0.w2), "+v"(own0.w3),
+                        "+v"(own0.w4), "+v"(own0.aw));
+      asm volatile("" : "+v"(own1.o1), "+v"(own1.o2), "+v"(own1.o3), "+v"(own1.o4), "+v"(own1.w1), "+v"(own1.w2), "+v"(own1.w3),
+                        "+v"(own1.w4), "+v"(own1.aw));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  msda_static_for<0, NPT>(point);
+  if (live) *reinterpret_cast<float4*>(out + (bs * M + m) * D + cv * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -931,6 +1067,9 @@ final_masks_kernel(const float* __restrict__ masks, const int* __restrict__ sel_
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
+static int g_msda_share = 1;      // lab / tests: 0 = msda_encoder_fused_kernel (every lane computes every point)
+extern "C" int ovis_msda_set_share(int on) { g_msda_share = on ? 1 : 0; return OVIS_OK; }
+
 extern "C" int ovis_msda_encoder_fused_f32(const float* value, const float* offs_attn, int ld_oa,
                                            const int64_t* spatial_shapes, const int64_t* level_start_index, float* out,
                                            int batch, int spatial_size, int num_heads, int channels, int num_levels,
@@ -941,6 +1080,11 @@ extern "C" int ovis_msda_encoder_fused_f32(const float* value, const float* offs
   OVIS_REQUIRE(num_levels == 3 && num_point == 4, "msda_encoder_fused: built for L=3, P=4 (got L=%d P=%d)", num_levels, num_point);
   OVIS_REQUIRE(ld_oa >= num_heads * num_levels * num_point * 3, "msda_encoder_fused: ld_oa too small");
   const long long n_items = (long long)batch * spatial_size * num_heads * (channels / 4);
+  // head_dim 32 (every config of the path): the lane-sharing kernel; 32-bit byte offsets into the value tensor
+  if (channels == 32 && g_msda_share && (long long)batch * spatial_size * num_heads * channels * 4 < (1ll << 32))
+    hipLaunchKernelGGL((msda_encoder_fused8_kernel<3, 4>), dim3(ovis::cdiv(n_items, 256)), dim3(256), 0, (hipStream_t)stream,
+                       value, offs_attn, ld_oa, spatial_shapes, level_start_index, out, n_items, spatial_size, num_heads);
+  else
   hipLaunchKernelGGL((msda_encoder_fused_kernel<3, 4>), dim3(ovis::cdiv(n_items, 256)), dim3(256), 0, (hipStream_t)stream,
                      value, offs_attn, ld_oa, spatial_shapes, level_start_index, out, n_items, spatial_size, num_heads, channels,
                      0, spatial_size);

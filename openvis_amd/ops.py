@@ -409,6 +409,12 @@ def attention_f16(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld):
 MSDA_TILE_RADIUS = -1
 
 
+def msda_set_share(on):
+    """lab / tests: False = msda_encoder_fused_kernel (every lane computes every sampling point); True (default) = the lane-sharing
+    msda_encoder_fused8_kernel (bit-identical output)."""
+    _lib.call("ovis_msda_set_share", int(bool(on)))
+
+
 def msda_encoder_fused(value, oa, shapes, lsi, M=8, L=3, P=4, shapes_host=None):
     """value [B,S,C], oa [B,S,M*L*P*3] -> [B,S,C].  shapes_host: the level shapes as python ints [(H,W)] * L (coarse to
     fine) -> the LDS-staged tiled kernel handles the finest level's queries."""

@@ -195,6 +195,34 @@ def test_msda_encoder_fused_matches_unfused_oracle():
     assert _rel(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("sizes,B,scale", [([(4, 7), (8, 14), (15, 27)], 2, 3.0), ([(3, 5), (6, 10), (11, 19)], 3, 40.0),
+                                           ([(23, 40), (46, 80), (92, 160)], 5, 2.0), ([(1, 1), (2, 2), (3, 5)], 1, 1.0)])
+def test_msda_lane_sharing_kernel_is_bit_identical(sizes, B, scale):
+    """msda_encoder_fused8_kernel (one lane of a (query, head) group computes a sampling point, the other 7 fetch it with ds_swizzle)
+    against msda_encoder_fused_kernel (every lane computes every point): same expressions, same order -> identical bits.  Cases: ragged
+    item counts (not a multiple of the 256-thread block), offsets far outside the maps (scale 40: border rules), the full 720p x 5
+    shape of the bench, a 1x1 level."""
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(len(sizes) * 100 + B)
+    shapes = torch.tensor(sizes)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    value = torch.randn(B, S, 256, generator=g).cuda()
+    oa = torch.randn(B, S, 288, generator=g)
+    oa[..., :192] *= scale
+    oa = oa.cuda()
+    try:
+        ops.msda_set_share(False)
+        ref = ops.msda_encoder_fused(value, oa, shapes.cuda(), lsi.cuda())
+        ops.msda_set_share(True)
+        out = ops.msda_encoder_fused(value, oa, shapes.cuda(), lsi.cuda())
+    finally:
+        ops.msda_set_share(True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert out.abs().max().item() > 0
+
+
 def test_mask_bbox_crop_and_final_masks_vs_oracle():
     from openvis_amd import ops
     from oracle import torch_ref as TR
