@@ -9,6 +9,7 @@
 //     4 keys of its own d column — exactly the k-order in which the accumulator registers hold P
 //     (register r of lane-half h  <->  key (r&3) + 8(r>>2) + 4h), so P never leaves registers.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -232,40 +233,48 @@ flash_attn_f16_seq_kernel(AttnH a) {
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
   const int nkt = (a.Nk + 31) / 32;
+  // Key tiles are walked in PAIRS (64 keys per online-softmax step; a single tile closes an odd count): one running-max update, one
+  // alpha and one rescale of the 32 output registers per 64 keys instead of per 32 -- the loop is VALU-bound (softmax), not MFMA-bound.
+  auto step = [&](auto nt_tag, int kt0) {
+    constexpr int NT = decltype(nt_tag)::value;
+    f32x16 s[NT];
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) {
-    if (kt >= nkt) break;
-    f32x16 s;
+    for (int u = 0; u < NT; ++u) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
 #pragma unroll
-    for (int st = 0; st < D / 16; ++st) {
-      const f16x8 kk = *reinterpret_cast<const f16x8*>(&Ks[(kt * 32 + r32) * KROW + 16 * st + 8 * h]);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kk, qf[st], s, 0, 0, 0);
+      for (int st = 0; st < D / 16; ++st) {
+        const f16x8 kk = *reinterpret_cast<const f16x8*>(&Ks[((kt0 + u) * 32 + r32) * KROW + 16 * st + 8 * h]);
+        s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kk, qf[st], s[u], 0, 0, 0);
+      }
     }
     // scores stay unscaled: the running max is tracked on the raw dot products (scale > 0 keeps the order) and the scale
     // is folded into the exponent's fma; only the last key tile can hold keys >= Nk, so only it is masked
-    if (kt == nkt - 1) {
+    if (kt0 + NT == nkt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        s[r] = key < a.Nk ? s[r] : -INFINITY;
+        const int key = (kt0 + NT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        s[NT - 1][r] = key < a.Nk ? s[NT - 1][r] : -INFINITY;
       }
     }
     float mt = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[u][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m_run, mt);                        // finite: every key tile holds at least one valid key
     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
     const float moff = -m_new * sl2;
     float ps = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, moff));
-      s[r] = p;
-      ps += p;
-    }
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], sl2, moff));
+        s[u][r] = p;
+        ps += p;
+      }
     ps += __shfl_xor(ps, 32, 64);
     l_run = l_run * alpha + ps;
     m_run = m_new;
@@ -274,21 +283,34 @@ flash_attn_f16_seq_kernel(AttnH a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
 #pragma unroll
-    for (int sp = 0; sp < 2; ++sp) {
-      f16x8 pb;
+    for (int u = 0; u < NT; ++u)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pb[j] = (_Float16)s[8 * sp + j];
-      const int key0a = kt * 32 + 16 * sp + 4 * h, key0b = key0a + 8;
+      for (int sp = 0; sp < 2; ++sp) {
+        using f32x2 = __attribute__((ext_vector_type(2))) float;
+        using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+        f16x8 pb;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const f16x4 va = tr_read(&Vs[key0a * VROW + t * 32 + tr_off]);
-        const f16x4 vb = tr_read(&Vs[key0b * VROW + t * 32 + tr_off]);
-        f16x8 av;
-        av[0] = va[0]; av[1] = va[1]; av[2] = va[2]; av[3] = va[3];
-        av[4] = vb[0]; av[5] = vb[1]; av[6] = vb[2]; av[7] = vb[3];
-        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, pb, o[t], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {                              // packed conversion (v_cvt_pk_f16_f32), round to nearest even
+          const f16x2 hp = __builtin_convertvector(f32x2{s[u][8 * sp + 2 * j], s[u][8 * sp + 2 * j + 1]}, f16x2);
+          pb[2 * j] = hp[0]; pb[2 * j + 1] = hp[1];
+        }
+        const int key0a = (kt0 + u) * 32 + 16 * sp + 4 * h, key0b = key0a + 8;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f16x4 va = tr_read(&Vs[key0a * VROW + t * 32 + tr_off]);
+          const f16x4 vb = tr_read(&Vs[key0b * VROW + t * 32 + tr_off]);
+          f16x8 av;
+          av[0] = va[0]; av[1] = va[1]; av[2] = va[2]; av[3] = va[3];
+          av[4] = vb[0]; av[5] = vb[1]; av[6] = vb[2]; av[7] = vb[3];
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, pb, o[t], 0, 0, 0);
+        }
       }
-    }
+  };
+#pragma unroll
+  for (int kt = 0; kt < KT; kt += 2) {
+    if (kt >= nkt) break;
+    if (kt + 1 < KT && kt + 1 < nkt) step(std::integral_constant<int, 2>{}, kt);
+    else step(std::integral_constant<int, 1>{}, kt);
   }
   if (!q_ok) return;
   const float inv = l_run > 0.f ? 1.f / l_run : 0.f;

@@ -496,6 +496,82 @@ mask_bbox_kernel(const float* __restrict__ masks, int* __restrict__ boxes, int Q
   }
 }
 
+// Exact x4 form (Hp == 4 h, Wp == 4 w: mask logits at stride 4, every config of the path).  One thread = one LOW-RESOLUTION pixel
+// (cy, cx) and the 4 x 4 output pixels of its cell: their taps lie in the 3 x 3 neighbourhood of (cy, cx), which is loaded once
+// (9 loads per 16 output pixels; mask_bbox_kernel issues 64 and is bound by the load path).  Each output pixel is evaluated by
+// the SAME make_tap / bilerp expressions on those values (the neighbour is picked by the tap's own index), so the boxes are
+// identical.  A bilinear sample is a convex combination of its taps: a cell whose 9 values are all <= 0 has no pixel on (skipped),
+// one whose 9 values are all > 4e-6 has all 16 on (box extended by the cell) -- for trained checkpoints almost every cell.
+__global__ void __launch_bounds__(256)
+mask_bbox4_kernel(const float* __restrict__ masks, int* __restrict__ boxes, int Q, int T, int h, int w, int rows_per_blk) {
+  __shared__ int red[4][4];
+  const int tq = blockIdx.y;
+  const int t = tq / Q, q = tq % Q;
+  const float* mp = masks + ((long long)q * T + t) * h * w;
+  const int Hp = 4 * h, Wp = 4 * w;
+  const float sy = (float)h / (float)Hp, sx = (float)w / (float)Wp;
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const int cy_begin = blockIdx.x * rows_per_blk, cy_end = min(h, cy_begin + rows_per_blk);
+  int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
+  for (int cy = cy_begin + ly; cy < cy_end; cy += 4) {
+    const int ry[3] = {max(cy - 1, 0), cy, min(cy + 1, h - 1)};
+    for (int cx = lx; cx < w; cx += 64) {
+      const int rx[3] = {max(cx - 1, 0), cx, min(cx + 1, w - 1)};
+      float n[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) n[a][b] = mp[(long long)ry[a] * w + rx[b]];
+      float lo = n[0][0], hi = n[0][0];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { lo = fminf(lo, n[a][b]); hi = fmaxf(hi, n[a][b]); }
+      if (!(hi > 0.f)) continue;                                   // no tap positive: no pixel of the cell is on
+      if (lo > 4e-6f) {                                            // every tap clearly on (margin over mask_on's 1e-6 for the rounding of the blend)
+        x0 = min(x0, 4 * cx); x1 = max(x1, 4 * cx + 3); y0 = min(y0, 4 * cy); y1 = max(y1, 4 * cy + 3);
+        continue;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int y = 4 * cy + j;
+        const Tap ty = make_tap(y, sy, h);
+        const int k0 = ty.i0 - (cy - 1), k1 = ty.i1 - (cy - 1);      // 0 .. 2 (row index inside the neighbourhood)
+        float r0[3], r1[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          r0[b] = k0 == 0 ? n[0][b] : (k0 == 1 ? n[1][b] : n[2][b]);
+          r1[b] = k1 == 0 ? n[0][b] : (k1 == 1 ? n[1][b] : n[2][b]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int x = 4 * cx + i;
+          const Tap tx = make_tap(x, sx, w);
+          const int c0 = tx.i0 - (cx - 1), c1 = tx.i1 - (cx - 1);
+          const float a = c0 == 0 ? r0[0] : (c0 == 1 ? r0[1] : r0[2]), b = c1 == 0 ? r0[0] : (c1 == 1 ? r0[1] : r0[2]);
+          const float c = c0 == 0 ? r1[0] : (c0 == 1 ? r1[1] : r1[2]), d = c1 == 0 ? r1[0] : (c1 == 1 ? r1[1] : r1[2]);
+          const float v = ty.l0 * (tx.l0 * a + tx.l1 * b) + ty.l1 * (tx.l0 * c + tx.l1 * d);      // == bilerp()
+          if (mask_on(v)) { x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y); }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    x0 = min(x0, __shfl_xor(x0, o, 64)); y0 = min(y0, __shfl_xor(y0, o, 64));
+    x1 = max(x1, __shfl_xor(x1, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
+  }
+  if (lx == 0) { red[ly][0] = x0; red[ly][1] = y0; red[ly][2] = x1; red[ly][3] = y1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {                                           // one set of atomics per workgroup
+    for (int k = 1; k < 4; ++k) { x0 = min(x0, red[k][0]); y0 = min(y0, red[k][1]); x1 = max(x1, red[k][2]); y1 = max(y1, red[k][3]); }
+    if (x1 >= 0) {
+      atomicMin(&boxes[tq * 4 + 0], x0); atomicMin(&boxes[tq * 4 + 1], y0);
+      atomicMax(&boxes[tq * 4 + 2], x1); atomicMax(&boxes[tq * 4 + 3], y1);
+    }
+  }
+}
+
 // =================================================================================================
 // A10 (second half): CLIP input crops.  adapter.py:96-116 + 140-143:
 //   square box [x0,y0,x0+s,y0+s], s = max(x1+1-x0, y1+1-y0); roi_align(frame) and roi_align(sigmoid mask)
@@ -1163,11 +1239,19 @@ extern "C" int ovis_center_pool_nhwc_f32(const float* x, float* y, int N, int H,
   return ovis::check_launch("center_pool");
 }
 
+static int g_bbox4 = 1;           // lab / tests: 0 = mask_bbox_kernel for every size
+extern "C" int ovis_mask_bbox_set_cells(int on) { g_bbox4 = on ? 1 : 0; return OVIS_OK; }
+
 extern "C" int ovis_mask_bbox(const float* masks, int* boxes, int Q, int T, int h, int w, int Hp, int Wp, ovis_stream_t stream) {
   OVIS_REQUIRE(masks && boxes, "mask_bbox: null pointer");
   OVIS_REQUIRE(Q > 0 && T > 0 && h > 0 && w > 0 && Hp >= h && Wp >= w, "mask_bbox: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bbox_init_kernel, dim3(ovis::cdiv(T * Q * 4, 256)), dim3(256), 0, s, boxes, T * Q * 4);
+  if (Hp == 4 * h && Wp == 4 * w && g_bbox4) {                       // masks at stride 4: the cell kernel (identical boxes)
+    const int rows = 8;
+    hipLaunchKernelGGL(mask_bbox4_kernel, dim3(ovis::cdiv(h, rows), T * Q), dim3(256), 0, s, masks, boxes, Q, T, h, w, rows);
+    return ovis::check_launch("mask_bbox");
+  }
   const int rows_per_blk = 32;
   hipLaunchKernelGGL(mask_bbox_kernel, dim3(ovis::cdiv(Hp, rows_per_blk), T * Q), dim3(256), 0, s, masks, boxes, Q, T, h, w, Hp, Wp,
                      rows_per_blk);

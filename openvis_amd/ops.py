@@ -409,6 +409,11 @@ def attention_f16(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld):
 MSDA_TILE_RADIUS = -1
 
 
+def mask_bbox_set_cells(on):
+    """lab / tests: False = the per-pixel mask_bbox_kernel for every size; True (default) = mask_bbox4_kernel when the masks are at stride 4."""
+    _lib.call("ovis_mask_bbox_set_cells", int(bool(on)))
+
+
 def msda_set_share(on):
     """lab / tests: False = msda_encoder_fused_kernel (every lane computes every sampling point); True (default) = the lane-sharing
     msda_encoder_fused8_kernel (bit-identical output)."""

@@ -223,6 +223,37 @@ def test_msda_lane_sharing_kernel_is_bit_identical(sizes, B, scale):
     assert out.abs().max().item() > 0
 
 
+@pytest.mark.parametrize("Q,T,h,w,kind", [(7, 2, 12, 16, "noise"), (5, 3, 23, 40, "blobs"), (4, 1, 184, 320, "noise"), (6, 2, 46, 80, "tiny"),
+                                          (3, 2, 5, 3, "noise"), (4, 2, 1, 1, "noise")])
+def test_mask_bbox_cell_kernel_gives_identical_boxes(Q, T, h, w, kind):
+    """mask_bbox4_kernel (one thread per low-resolution pixel: 3x3 neighbourhood, 16 output pixels, whole-cell shortcuts) against the
+    per-pixel mask_bbox_kernel: identical boxes on noise around the threshold, smooth blobs, values within 1e-5 of zero, empty and
+    full masks, and maps narrower than the 3x3 neighbourhood."""
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(Q * 1000 + h)
+    if kind == "noise":
+        m = torch.randn(Q, T, h, w, generator=g)
+    elif kind == "tiny":
+        m = (torch.rand(Q, T, h, w, generator=g) - 0.5) * 2e-5                # |x| <= 1e-5: the sigmoid branch of mask_on
+    else:
+        yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+        c = torch.rand(Q, T, 2, generator=g)
+        m = 3.0 - ((yy[None, None] - c[..., 0, None, None] * h) ** 2 + (xx[None, None] - c[..., 1, None, None] * w) ** 2) / (0.02 * h * w + 1)
+    m[0] = -2.0                                                                # empty
+    m[-1, -1] = 5.0                                                            # full
+    m = m.contiguous().cuda()
+    try:
+        ops.mask_bbox_set_cells(False)
+        ref = ops.mask_bbox(m, 4 * h, 4 * w)
+        ops.mask_bbox_set_cells(True)
+        out = ops.mask_bbox(m, 4 * h, 4 * w)
+    finally:
+        ops.mask_bbox_set_cells(True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref), (out.cpu() - ref.cpu()).abs().max()
+    assert int(ref[:, 0, 2].max()) < 0 and ref[-1, -1].tolist() == [0, 0, 4 * w - 1, 4 * h - 1]
+
+
 def test_mask_bbox_crop_and_final_masks_vs_oracle():
     from openvis_amd import ops
     from oracle import torch_ref as TR
