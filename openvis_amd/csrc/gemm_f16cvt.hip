@@ -136,12 +136,16 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, fl
   }
 }
 
+int g_cvt_small_n = 1;             // lab: 0 = 128x128 tiles whatever N
+
 template <typename LoaderA>
 int launch(LoaderA la, const _Float16* B, long long ldb, float* C, long long ldc, int M, int N, int K, const float* bias,
            const float* R, long long ldr, int act, hipStream_t stream, int batch = 1, long long a_bs = 0, long long b_bs = 0,
            long long c_bs = 0) {
   const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128) * batch;
-  if (blocks128 >= 256) {
+  // N <= 64 (ResNet res2: 256 -> 64, 3x3 64 -> 64, stem): a 128-column tile would multiply half of its columns for nothing, and the
+  // 64x64 instantiation (92 VGPRs, five workgroups per CU instead of two) keeps more of the K loop's loads in flight
+  if (blocks128 >= 256 && (N > 64 || !g_cvt_small_n)) {
     const int tm = ovis::cdiv(M, 128), tn = ovis::cdiv(N, 128);
     hipLaunchKernelGGL((gemm_f16cvt_kernel<128, 128, LoaderA>), dim3(tm * tn, batch), dim3(256), 0, stream, la, B, ldb, C, ldc,
                        M, N, K, bias, R, ldr, act, tn, a_bs, b_bs, c_bs);
@@ -200,3 +204,5 @@ extern "C" int ovis_conv2d_nhwc_f32a_f16w(const float* x, const void* w16, float
   return launch(la, (const _Float16*)w16, (long long)K, y, (long long)Cout, (int)M, Cout, K, bias, residual, (long long)Cout,
                 act, (hipStream_t)stream);
 }
+
+extern "C" int ovis_f16cvt_small_n(int on) { g_cvt_small_n = on ? 1 : 0; return OVIS_OK; }   // lab / tests only

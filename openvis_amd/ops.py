@@ -11,6 +11,20 @@ from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_QUICKGELU, ACT_GELU = 0, 1, 2, 3
 
+_EXT = None
+
+
+def _mi():
+    """torch.ops.ovis_mi: the dispatcher ops of the hot stages (csrc/torch_ext/hot_ops.cpp + msda_module.cpp, registered when the
+    compiled extension `MultiScaleDeformableAttention` is imported).  A missing build fails loudly, with the build hint."""
+    global _EXT
+    if _EXT is None:
+        from .modeling.pixel_decoder.ops.functions import ms_deform_attn_func      # imports the extension (or raises the hint)
+        if not hasattr(torch.ops.ovis_mi, "gemm_nt_f16"):
+            raise _lib.OvisError("the compiled extension lacks the ovis_mi hot ops: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
+        _EXT = torch.ops.ovis_mi
+    return _EXT
+
 # bench.py sets this to a list to time every MFMA GEMM launch with HIP events on the launch stream:
 # entries are (kernel name, algorithmic flops, start event, end event).
 PROFILE = None
@@ -111,7 +125,7 @@ def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None, cw
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     r2 = residual.reshape(-1, N) if residual is not None else None
     if w16 is not None and K % 8 == 0:
-        big = ((M + 127) // 128) * ((N + 127) // 128) >= 256
+        big = ((M + 127) // 128) * ((N + 127) // 128) >= 256 and N > 64          # mirrors launch() in csrc/gemm_f16cvt.hip
         with _Prof(f"gemm_f16cvt_kernel<{'128,128' if big else '64,64'},DenseA>", 2.0 * M * N * K):
             _lib.call("ovis_gemm_nt_f32a_f16w", a2, _ll(K), w16, _ll(K), out, _ll(N), M, N, K, bias, r2, _ll(N), act,
                       _lib.stream_ptr())
@@ -144,25 +158,28 @@ def gemm_nt_f16(a, w, bias=None, residual=None, act=ACT_NONE, out_f16=False):
         # the tower's fp16 residual stream: C (fp16) = A B^T + bias + R (fp16), accumulated in f32
         if act != ACT_NONE:
             raise _lib.OvisError("gemm_nt_f16: an fp16 residual goes with act = none (out-proj / c_proj)")
-        out = torch.empty((M, N), dtype=torch.float16, device=a.device)
-        if _lib.lib().ovis_gemm_nt_f16_res16_eligible(_lib._conv(out), _lib._conv(r2), _ll(K), _ll(w.stride(0)), _ll(N), _ll(N), M, N, K,
-                                                      _lib._conv(bias)):
+        if w.is_contiguous() and _lib.lib().ovis_gemm_nt_f16_res16_eligible(_lib._conv(r2), _lib._conv(r2), _ll(K), _ll(K), _ll(N), _ll(N), M, N, K,
+                                                                              _lib._conv(bias)):
             with _Prof("gemm_f16_pp_kernel<1,0,true,false,false,true>", 2.0 * M * N * K):
-                _lib.call("ovis_gemm_nt_f16_res16", a2, _ll(K), w, _ll(w.stride(0)), out, _ll(N), M, N, K, bias, r2, _ll(N), _lib.stream_ptr())
+                out = _mi().gemm_nt_f16(a2, w, bias, r2, ACT_NONE, True)
             return out.view(*a.shape[:-1], N)
         # small problems (few crops): the same arithmetic through the f32-residual kernels and one rounding at the end
         o32 = gemm_nt_f16(a2, w, bias, cast_f16_to_f32_rows(r2, N), act, out_f16=False)
         return cast_f16(o32).view(*a.shape[:-1], N)
-    out = torch.empty((M, N), dtype=torch.float16 if out_f16 else torch.float32, device=a.device)
     kname = ""
     if PROFILE is not None:                     # the kernel the library picks (name as rocprofv3 reports it)
         fn = _lib.lib().ovis_gemm_nt_f16_kernel
         fn.restype = ctypes.c_char_p
-        kname = fn(_lib._conv(out), _ll(K), _ll(w.stride(0)), _ll(N), M, N, K, _lib._conv(bias), _lib._conv(r2), _ll(N), act,
+        probe = torch.empty((M, N), dtype=torch.float16 if out_f16 else torch.float32, device=a.device)
+        kname = fn(_lib._conv(probe), _ll(K), _ll(w.stride(0)), _ll(N), M, N, K, _lib._conv(bias), _lib._conv(r2), _ll(N), act,
                    int(out_f16)).decode()
     with _Prof(kname, 2.0 * M * N * K):
-        _lib.call("ovis_gemm_nt_f16", a2, _ll(K), w, _ll(w.stride(0)), out, _ll(N), M, N, K, bias, r2, _ll(N), act,
-                  int(out_f16), _lib.stream_ptr())
+        if w.is_contiguous():
+            out = _mi().gemm_nt_f16(a2, w, bias, r2, act, bool(out_f16))
+        else:                                   # row-strided weight view (e.g. the K / V rows of in_proj_weight): C ABI with ldb
+            out = torch.empty((M, N), dtype=torch.float16 if out_f16 else torch.float32, device=a.device)
+            _lib.call("ovis_gemm_nt_f16", a2, _ll(K), w, _ll(w.stride(0)), out, _ll(N), M, N, K, bias, r2, _ll(N), act,
+                      int(out_f16), _lib.stream_ptr())
     return out.view(*a.shape[:-1], N)
 
 
@@ -235,11 +252,7 @@ def bilinear_resize_add(dst, src):
 def hungarian_link(embeds):
     """embeds f32 [T,Q,C] -> int32 indices [T,Q] (minvis.py:28-72 chain)."""
     _chk(embeds)
-    T, Q, C = embeds.shape
-    idx = torch.empty((T, Q), dtype=torch.int32, device=embeds.device)
-    ws = torch.empty((_lib.lib().ovis_hungarian_link_workspace_bytes(T, Q, C) // 4,), dtype=torch.float32, device=embeds.device)
-    _lib.call("ovis_hungarian_link_f32", embeds, idx, ws, T, Q, C, _lib.stream_ptr())
-    return idx
+    return _mi().hungarian_link(embeds)
 
 
 def batch_index_rows(src, idx, out, src_bs, src_rs, out_bs, out_rs, length):
@@ -278,7 +291,7 @@ def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE, w
     OW = (W + 2 * pad - KW) // stride + 1
     y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device)
     if w16 is not None and (KH * KW * Cin) % 8 == 0:
-        big = ((N * OH * OW + 127) // 128) * ((Cout + 127) // 128) >= 256
+        big = ((N * OH * OW + 127) // 128) * ((Cout + 127) // 128) >= 256 and Cout > 64
         with _Prof(f"gemm_f16cvt_kernel<{'128,128' if big else '64,64'},ConvA>", 2.0 * N * OH * OW * Cout * KH * KW * Cin):
             _lib.call("ovis_conv2d_nhwc_f32a_f16w", x, w16, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act,
                       _lib.stream_ptr())
@@ -395,11 +408,7 @@ def attention_f16(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld):
     for t in (q, k, v):
         if not (t.is_cuda and t.dtype == torch.float16):
             raise _lib.OvisError("attention_f16 needs fp16 HIP tensors")
-    out = torch.empty((B, Nq, H * D), dtype=torch.float16, device=q.device)
-    vp = lambda t: ctypes.c_void_p(t.data_ptr())
-    _lib.call("ovis_attention_f16", vp(q), _ll(q_bs), q_ld, vp(k), _ll(k_bs), k_ld, vp(v), _ll(v_bs), v_ld, out,
-              _ll(Nq * H * D), H * D, B, H, Nq, Nk, D, float(D) ** -0.5, _lib.stream_ptr())
-    return out
+    return _mi().attention_f16(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld)
 
 
 # LDS-staged tiled K1 (csrc/openvis_ops.hip: msda_encoder_tiled_kernel): radius in pixels of the value window staged per
@@ -435,8 +444,7 @@ def msda_encoder_fused(value, oa, shapes, lsi, M=8, L=3, P=4, shapes_host=None):
                       MSDA_TILE_RADIUS, _lib.stream_ptr())
         return out
     with _Prof(f"msda_encoder_fused_kernel<{L},{P}>", nbytes, unit="byte"):
-        _lib.call("ovis_msda_encoder_fused_f32", value, oa, oa.shape[-1], shapes, lsi, out, B, S, M, C // M, L, P,
-                  _lib.stream_ptr())
+        out = _mi().msda_encoder_fused(value, oa, shapes, lsi, M, L, P)
     return out
 
 
@@ -462,22 +470,14 @@ def center_pool(x, s):
 def mask_bbox(masks, Hp, Wp):
     """masks [Q,T,h,w] logits -> int32 [T,Q,4] inclusive boxes at (Hp,Wp) resolution (x1 < 0: empty)."""
     _chk(masks)
-    Q, T, h, w = masks.shape
-    boxes = torch.empty((T, Q, 4), dtype=torch.int32, device=masks.device)
-    _lib.call("ovis_mask_bbox", masks, boxes, Q, T, h, w, Hp, Wp, _lib.stream_ptr())
+    boxes = _mi().mask_bbox(masks, int(Hp), int(Wp))
     return boxes
 
 
 def clip_crop_patches(frames, masks, crops, Hp, Wp, resolution, patch, mean, std, out_f16=False):
     _chk(frames, masks, crops)
-    T, _, H, W = frames.shape
-    Q, _, h, w = masks.shape
-    M = crops.shape[0]
-    G = resolution // patch
-    A = _patch_matrix(M * G * G, patch, out_f16, frames.device)
-    _lib.call("ovis_clip_crop_patches", frames, masks, crops, A, int(out_f16), M, Q, T, H, W, h, w, Hp, Wp, resolution,
-              patch, _ll(A.shape[1]), _f3(mean), _f3(std), _lib.stream_ptr())
-    return A
+    return _mi().clip_crop_patches(frames, masks, crops, int(Hp), int(Wp), int(resolution), int(patch), [float(v) for v in mean],
+                                   [float(v) for v in std], bool(out_f16))
 
 
 def clip_crop_patches_masked(frames, masks, crops, Hp, Wp, resolution, patch, mean, std, out_f16=False):
@@ -537,13 +537,7 @@ def openvis_aggregate(crop_logits, slot):
 
 def topk_entropy(probs, row_ids, topk):
     _chk(probs, row_ids)
-    K = probs.shape[1]
-    idx = torch.empty((topk,), dtype=torch.int32, device=probs.device)
-    score = torch.empty((topk,), dtype=torch.float32, device=probs.device)
-    ent = torch.empty((topk,), dtype=torch.float32, device=probs.device)
-    sel_q = torch.empty((topk,), dtype=torch.int32, device=probs.device)
-    _lib.call("ovis_topk_entropy_f32", probs, row_ids, row_ids.numel(), K, topk, idx, score, ent, sel_q, _lib.stream_ptr())
-    return idx, score, ent, sel_q
+    return _mi().topk_entropy(probs, row_ids, int(topk))
 
 
 def final_masks(masks, sel_q, Hp, Wp, H, W, OH, OW, column_major=False):
