@@ -55,36 +55,35 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, fl
   const int bm = (int)(bid / tiles_n) * BM;
   const int srow = tid >> 3, scol = (tid & 7) * 8;
 
-  float4 pa[A_LD][2];
-  bool oka[A_LD][2];
-  uint4 pb[B_LD];
-  bool okb[B_LD];
+  // staging registers of one K tile; the 64x64 instantiation (92 VGPRs) keeps TWO tiles in flight (set 0 / set 1 alternate), the
+  // 128x128 one (208+ VGPRs) one: with 64-column tiles the kernel is bound by the latency of these loads, not by the MFMAs
+  struct Stage { float4 pa[A_LD][2]; bool oka[A_LD][2]; uint4 pb[B_LD]; bool okb[B_LD]; };
   typename LoaderA::RowCtx rca[A_LD];                     // the staged rows of this thread, decomposed once (gemm_loaders.h)
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) rca[i] = la.row(bm + srow + i * 32);
-  auto gload = [&](int k0) {
+  auto gload = [&](Stage& st, int k0) {
     const int k = k0 + scol;
     const auto kc0 = la.kctx(k), kc1 = la.kctx(k + 4);
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-      pa[i][0] = la.load(rca[i], kc0, oka[i][0]);
-      pa[i][1] = la.load(rca[i], kc1, oka[i][1]);
+      st.pa[i][0] = la.load(rca[i], kc0, st.oka[i][0]);
+      st.pa[i][1] = la.load(rca[i], kc1, st.oka[i][1]);
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
       const int n = bn + srow + i * 32;
-      okb[i] = n < N && k < K;
-      pb[i] = *reinterpret_cast<const uint4*>(B + (okb[i] ? (long long)n * ldb + k : 0));
+      st.okb[i] = n < N && k < K;
+      st.pb[i] = *reinterpret_cast<const uint4*>(B + (st.okb[i] ? (long long)n * ldb + k : 0));
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](const Stage& st) {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i)
-      *reinterpret_cast<uint4*>(&As[(srow + i * 32) * LDS_ROW + scol]) = cvt8(oka[i][0], pa[i][0], oka[i][1], pa[i][1]);
+      *reinterpret_cast<uint4*>(&As[(srow + i * 32) * LDS_ROW + scol]) = cvt8(st.oka[i][0], st.pa[i][0], st.oka[i][1], st.pa[i][1]);
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)
       *reinterpret_cast<uint4*>(&Bs[(srow + i * 32) * LDS_ROW + scol]) =
-          make_uint4(okb[i] ? pb[i].x : 0u, okb[i] ? pb[i].y : 0u, okb[i] ? pb[i].z : 0u, okb[i] ? pb[i].w : 0u);
+          make_uint4(st.okb[i] ? st.pb[i].x : 0u, st.okb[i] ? st.pb[i].y : 0u, st.okb[i] ? st.pb[i].z : 0u, st.okb[i] ? st.pb[i].w : 0u);
   };
 
   const int r32 = lane & 31, h = lane >> 5;
@@ -105,12 +104,7 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, fl
     }
 
   const int nk = (K + BKH - 1) / BKH;
-  gload(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();
-    lstore();
-    __syncthreads();
-    if (kt + 1 < nk) gload((kt + 1) * BKH);
+  auto compute = [&]() {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       f16x8 af[TM], bf[TN];
@@ -123,6 +117,34 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, fl
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // roles swapped
+    }
+  };
+  Stage s0;
+  gload(s0, 0);
+  if constexpr (BM == 64) {
+    Stage s1;
+    gload(s1, BKH);                                        // (past K: clamped addresses, never stored)
+    for (int kt = 0; kt < nk; kt += 2) {
+      __syncthreads();
+      lstore(s0);
+      __syncthreads();
+      gload(s0, (kt + 2) * BKH);
+      compute();
+      if (kt + 1 < nk) {
+        __syncthreads();
+        lstore(s1);
+        __syncthreads();
+        gload(s1, (kt + 3) * BKH);
+        compute();
+      }
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();
+      lstore(s0);
+      __syncthreads();
+      if (kt + 1 < nk) gload(s0, (kt + 1) * BKH);
+      compute();
     }
   }
 
@@ -145,7 +167,7 @@ int launch(LoaderA la, const _Float16* B, long long ldb, float* C, long long ldc
   const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128) * batch;
   // N <= 64 (ResNet res2: 256 -> 64, 3x3 64 -> 64, stem): a 128-column tile would multiply half of its columns for nothing, and the
   // 64x64 instantiation (92 VGPRs, five workgroups per CU instead of two) keeps more of the K loop's loads in flight
-  if (blocks128 >= 256 && (N > 64 || !g_cvt_small_n)) {
+  if (blocks128 >= (g_cvt_small_n == 2 ? 1024 : 256) && (N > 64 || !g_cvt_small_n)) {
     const int tm = ovis::cdiv(M, 128), tn = ovis::cdiv(N, 128);
     hipLaunchKernelGGL((gemm_f16cvt_kernel<128, 128, LoaderA>), dim3(tm * tn, batch), dim3(256), 0, stream, la, B, ldb, C, ldc,
                        M, N, K, bias, R, ldr, act, tn, a_bs, b_bs, c_bs);
@@ -205,4 +227,4 @@ extern "C" int ovis_conv2d_nhwc_f32a_f16w(const float* x, const void* w16, float
                 act, (hipStream_t)stream);
 }
 
-extern "C" int ovis_f16cvt_small_n(int on) { g_cvt_small_n = on ? 1 : 0; return OVIS_OK; }   // lab / tests only
+extern "C" int ovis_f16cvt_small_n(int mode) { g_cvt_small_n = mode; return OVIS_OK; }   // 0 old rule, 1 N <= 64 -> 64x64, 2 also < 1024 tiles -> 64x64   // lab / tests only

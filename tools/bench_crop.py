@@ -17,5 +17,9 @@ for name, side in (("full-frame boxes", None), ("200px boxes", 200)):
                 crops.append([t, q, x0, y0, x0 + side - 1, y0 + side - 1])
     cr = torch.tensor(crops, dtype=torch.int32).cuda()
     mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
-    ms = timeit(lambda: ops.clip_crop_patches(frames, masks, cr, Hp, Wp, 224, 16, mean, std, out_f16=True), n=10)
-    print(name, len(crops), "crops", round(ms, 3), "ms")
+    from openvis_amd import _lib
+    for tile in (16, 8):
+        _lib.call("ovis_crop_tile", 8 if tile == 8 else 0)
+        ms = timeit(lambda: ops.clip_crop_patches(frames, masks, cr, Hp, Wp, 224, 16, mean, std, out_f16=True), n=10)
+        print(name, len(crops), "crops", f"{tile}x{tile}-bin tiles", round(ms, 3), "ms")
+    _lib.call("ovis_crop_tile", 0)
