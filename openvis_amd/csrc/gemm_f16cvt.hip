@@ -158,7 +158,8 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, fl
   }
 }
 
-int g_cvt_small_n = 1;             // lab: 0 = 128x128 tiles whatever N
+int g_cvt_small_n = 2;             // 0 = 128x128 tiles from 256 tiles on (round 2); 1 = 64x64 for N <= 64; 2 (default) = also below 1024 tiles of 128
+                                   // (ResNet-50 on 5 x 720p: 4.70 / 4.42 / 4.41 ms, tools/bench_backbone.py, profiles/r03/backbone_tiles.txt)
 
 template <typename LoaderA>
 int launch(LoaderA la, const _Float16* B, long long ldb, float* C, long long ldc, int M, int N, int K, const float* bias,

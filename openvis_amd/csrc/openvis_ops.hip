@@ -695,7 +695,7 @@ __global__ void __launch_bounds__(TY * TX)
 clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ masks, const int* __restrict__ crops,
                        void* __restrict__ Av, unsigned char* __restrict__ patch_open, int out_f16, int M, int Q, int T, int H,
                        int W, int h, int w, int Hp, int Wp, int R, int ps, long long lda, int PRmax, int PWmax, float m0,
-                       float m1, float m2, float s0, float s1, float s2, int x4) {
+                       float m1, float m2, float s0, float s1, float s2) {
   extern __shared__ uint2 patch[];                      // [PR][PW]: .x = r | g<<8 | b<<16, .y = bits of the soft mask
   __shared__ AxisW xtab[TX], ytab[TY];
   const int tiles_x = R / TX, tiles_y = R / TY;
@@ -731,66 +731,6 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
   // columns; with an even stride those rows alias to the same LDS banks (4-way conflicts on every tap read)
   const int PWs = PW | 1;
 
-  // Staging, x4 form (masks at stride 4 of the padded frame, frame width >= 4, patch <= 128 columns): a lane owns FOUR consecutive
-  // patch columns of one row and a wavefront two rows per pass.  The four pixels' mask taps lie in 3 low-resolution columns x 2 rows
-  // (6 loads instead of 16) and their frame bytes are one 4-byte load per colour plane (3 instead of 12): 9 gather instructions per
-  // 4 pixels instead of 28 -- the staging is bound by the NUMBER of gather instructions (texture-address path), not by bytes.  Every
-  // value is produced by the same expression as in the one-column form below.
-  if (Wp == 4 * w && Hp == 4 * h && W >= 4 && PW <= 128 && x4) {
-    constexpr int NW = TY * TX / 64;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int rsub = lane >> 5, c4 = 4 * (lane & 31);             // row inside the pass, first patch column of the lane
-    Tap tx4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) tx4[j] = make_tap(min(xlo + c4 + j, Wp - 1), usx, w);
-    const int cb = tx4[0].i0;
-    const int mc[3] = {cb, min(cb + 1, w - 1), min(cb + 2, w - 1)};
-    const int x0 = xlo + c4;                                      // frame column of the lane's first pixel
-    const int xa = min(x0, W - 4);                                // 4-byte window inside the row (x0 >= W: nothing of it is used)
-    const int sh = 8 * min(x0 - xa, 4);                           // pixel j = byte (x0 - xa + j) of the window
-    struct RowLoads4 { float m0[3], m1[3]; unsigned r, g, b; Tap ty; bool yin; };
-    auto load4 = [](const uint8_t* p) { unsigned v; __builtin_memcpy(&v, p, 4); return v; };
-    auto issue = [&](int rr, RowLoads4& L) {
-      const int y = min(ylo + rr, Hp - 1);
-      L.ty = make_tap(y, usy, h);
-      const float* r0 = mp + (long long)L.ty.i0 * w;
-      const float* r1 = mp + (long long)L.ty.i1 * w;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { L.m0[k] = r0[mc[k]]; L.m1[k] = r1[mc[k]]; }
-      L.yin = y < H;
-      const uint8_t* frow = fp + (long long)(L.yin ? y : 0) * W + max(xa, 0);
-      L.r = load4(frow); L.g = load4(frow + plane); L.b = load4(frow + 2 * plane);
-    };
-    auto pick = [](const float (&v)[3], int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); };
-    auto consume = [&](const RowLoads4& L, int rr) {
-      if (rr >= PR) return;
-      const unsigned long long rr64 = (unsigned long long)L.r >> 0, gg64 = L.g, bb64 = L.b;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (c4 + j < PW) {
-          const Tap& tx = tx4[j];
-          const float a = pick(L.m0, tx.i0 - cb), b = pick(L.m0, tx.i1 - cb), c = pick(L.m1, tx.i0 - cb), d = pick(L.m1, tx.i1 - cb);
-          const float u = L.ty.l0 * (tx.l0 * a + tx.l1 * b) + L.ty.l1 * (tx.l0 * c + tx.l1 * d);                // == bilerp()
-          const bool in = L.yin && x0 + j < W;
-          const int bs = sh + 8 * j;                              // < 32 whenever `in`
-          const unsigned v0 = in ? (unsigned)(rr64 >> bs) & 255u : 0u, v1 = in ? (unsigned)(gg64 >> bs) & 255u : 0u,
-                         v2 = in ? (unsigned)(bb64 >> bs) & 255u : 0u;
-          patch[rr * PWs + c4 + j] = make_uint2(v0 | (v1 << 8) | (v2 << 16), __float_as_uint(fast_sigmoid(u)));
-        }
-      }
-    };
-    // rows (2 p NW + 2 wv + rsub): four passes in flight per wavefront, register sets filled round-robin and never copied
-    RowLoads4 L0, L1, L2, L3;
-    const int r_first = 2 * wv + rsub, step_r = 2 * NW;
-    issue(r_first, L0); issue(r_first + step_r, L1); issue(r_first + 2 * step_r, L2); issue(r_first + 3 * step_r, L3);
-    for (int rb = 2 * wv; rb < PR; rb += 4 * step_r) {              // (loop bounds are wavefront-uniform: rb ignores rsub)
-      const int rr = rb + rsub;
-      consume(L0, rr);              issue(rr + 4 * step_r, L0);
-      consume(L1, rr + step_r);     issue(rr + 5 * step_r, L1);
-      consume(L2, rr + 2 * step_r); issue(rr + 6 * step_r, L2);
-      consume(L3, rr + 3 * step_r); issue(rr + 7 * step_r, L3);
-    }
-  } else
   // staging: wavefront -> patch rows, lane -> patch columns (no integer division; the column taps of a lane are hoisted
   // out of the row loop, the row taps are wavefront-uniform)
   {
@@ -1318,7 +1258,7 @@ extern "C" int ovis_mask_bbox(const float* masks, int* boxes, int Q, int T, int 
   return ovis::check_launch("mask_bbox");
 }
 
-static int g_crop_tile = 0;        // lab: 8 = the 8x8-bin tiles even where 16x16 fit; 1 = one-column staging (no x4 form)
+static int g_crop_tile = 0;        // lab: 8 = the 8x8-bin tiles even where 16x16 fit (measured 1.5x slower: profiles/r03/negative_crop.txt)
 extern "C" int ovis_crop_tile(int t) { g_crop_tile = t; return OVIS_OK; }
 
 static int clip_crop_impl(const uint8_t* frames, const float* masks, const int* crops, void* A, unsigned char* patch_open,
@@ -1346,13 +1286,11 @@ static int clip_crop_impl(const uint8_t* frames, const float* masks, const int* 
     }
     hipLaunchKernelGGL((clip_crop_tiled_kernel<16, 16>), dim3((unsigned)((long long)M * (resolution / 16) * (resolution / 16))), dim3(256),
                        (size_t)p16 * (p16 + 1) * 8, (hipStream_t)stream, frames, masks, crops, A, patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
-                       resolution, patch, lda, p16, p16, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2],
-                       g_crop_tile == 1 ? 0 : 1);
+                       resolution, patch, lda, p16, p16, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
   } else if (grid_ok && resolution % 8 == 0 && (size_t)p8 * (p8 + 1) * 8 <= 64 * 1024) {
     hipLaunchKernelGGL((clip_crop_tiled_kernel<8, 8>), dim3((unsigned)((long long)M * (resolution / 8) * (resolution / 8))), dim3(64),
                        (size_t)p8 * (p8 + 1) * 8, (hipStream_t)stream, frames, masks, crops, A, patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
-                       resolution, patch, lda, p8, p8, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2],
-                       g_crop_tile == 1 ? 0 : 1);
+                       resolution, patch, lda, p8, p8, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
   } else {
     const long long total = (long long)M * resolution * resolution;
     hipLaunchKernelGGL(clip_crop_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, frames, masks, crops, A,

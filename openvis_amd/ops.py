@@ -125,7 +125,7 @@ def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None, cw
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     r2 = residual.reshape(-1, N) if residual is not None else None
     if w16 is not None and K % 8 == 0:
-        big = ((M + 127) // 128) * ((N + 127) // 128) >= 256 and N > 64          # mirrors launch() in csrc/gemm_f16cvt.hip
+        big = ((M + 127) // 128) * ((N + 127) // 128) >= 1024 and N > 64         # mirrors launch() in csrc/gemm_f16cvt.hip
         with _Prof(f"gemm_f16cvt_kernel<{'128,128' if big else '64,64'},DenseA>", 2.0 * M * N * K):
             _lib.call("ovis_gemm_nt_f32a_f16w", a2, _ll(K), w16, _ll(K), out, _ll(N), M, N, K, bias, r2, _ll(N), act,
                       _lib.stream_ptr())
@@ -291,7 +291,7 @@ def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE, w
     OW = (W + 2 * pad - KW) // stride + 1
     y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device)
     if w16 is not None and (KH * KW * Cin) % 8 == 0:
-        big = ((N * OH * OW + 127) // 128) * ((Cout + 127) // 128) >= 256 and Cout > 64
+        big = ((N * OH * OW + 127) // 128) * ((Cout + 127) // 128) >= 1024 and Cout > 64
         with _Prof(f"gemm_f16cvt_kernel<{'128,128' if big else '64,64'},ConvA>", 2.0 * N * OH * OW * Cout * KH * KW * Cin):
             _lib.call("ovis_conv2d_nhwc_f32a_f16w", x, w16, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act,
                       _lib.stream_ptr())

@@ -254,33 +254,6 @@ def test_mask_bbox_cell_kernel_gives_identical_boxes(Q, T, h, w, kind):
     assert int(ref[:, 0, 2].max()) < 0 and ref[-1, -1].tolist() == [0, 0, 4 * w - 1, 4 * h - 1]
 
 
-@pytest.mark.parametrize("H,W,out_f16", [(720, 1280, True), (90, 120, False), (45, 60, False), (300, 500, True)])
-def test_crop_x4_staging_is_bit_identical(H, W, out_f16):
-    """clip_crop_tiled_kernel's x4 staging (a lane owns 4 patch columns: 6 mask loads + 3 four-byte frame loads per 4 pixels) against
-    the one-column staging: identical patch matrices for whole-frame boxes, small boxes at odd offsets, boxes that reach into the
-    padding (W < Wp, H < Hp) and both output dtypes."""
-    from openvis_amd import _lib, ops
-    Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
-    T, Q = 2, 6
-    g = torch.Generator().manual_seed(H + W)
-    frames = (torch.rand(T, 3, H, W, generator=g) * 255).to(torch.uint8).cuda()
-    masks = (torch.randn(Q, T, Hp // 4, Wp // 4, generator=g) * 3).cuda()
-    crops = [[0, 0, 0, 0, Wp - 1, Hp - 1], [1, 1, 3, 5, min(W - 2, 3 + Wp // 3), min(H - 3, 5 + Hp // 2)], [0, 2, 1, 0, 17, 40 % H],
-             [1, 3, max(W - 37, 0), max(H - 29, 0), Wp - 1, Hp - 1], [0, 4, 7, 9, 7 + 15, 9 + 15], [1, 5, 0, Hp // 2, Wp - 1, Hp // 2 + 5]]
-    cr = torch.tensor(crops, dtype=torch.int32).cuda()
-    mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
-    try:
-        _lib.call("ovis_crop_tile", 1)
-        ref = ops.clip_crop_patches(frames, masks, cr, Hp, Wp, 224, 16, mean, std, out_f16=out_f16)
-        _lib.call("ovis_crop_tile", 0)
-        out = ops.clip_crop_patches(frames, masks, cr, Hp, Wp, 224, 16, mean, std, out_f16=out_f16)
-    finally:
-        _lib.call("ovis_crop_tile", 0)
-    torch.cuda.synchronize()
-    assert torch.equal(out, ref), (out.float() - ref.float()).abs().max().item()
-    assert out.float().abs().max().item() > 0
-
-
 def test_mask_bbox_crop_and_final_masks_vs_oracle():
     from openvis_amd import ops
     from oracle import torch_ref as TR

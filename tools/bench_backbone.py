@@ -19,4 +19,4 @@ for rep in range(2):
             model.backbone(images)
         torch.cuda.synchronize()
         print(f"f16cvt tile mode {mode}: backbone {(time.perf_counter() - t) / 20 * 1e3:.3f} ms")
-_lib.call("ovis_f16cvt_small_n", 1)
+_lib.call("ovis_f16cvt_small_n", 2)
