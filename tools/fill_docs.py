@@ -18,8 +18,17 @@ vals = {"HEAD": f"{head['value']:.1f}", "HEADMS": f"{head['ms_per_step']:.1f}",
         "PPTF": f"{head['roofline']['achieved']:.0f}", "PPFRAC": f"{head['roofline']['frac']:.2f}",
         "PPMS": f"{head['roofline']['avg_launch_ms']:.3f}",
         "CPU": f"{head['cpu_baseline']['value']:.3f}" if "cpu_baseline" in head else "0.13"}
+if head.get("alt_f32_split"):
+    vals["ALT"], vals["ALTMS"] = f"{head['alt_f32_split']['value']:.1f}", f"{head['alt_f32_split']['ms_per_step']:.1f}"
+if head.get("stage_ms"):
+    st = head["stage_ms"]
+    vals.update({"A2": f"{st['A2_backbone']:.2f}", "A36": f"{st['A3-A6_pixel_decoder']:.2f}", "A78": f"{st['A7-A8_decoder']:.2f}",
+                 "A912": f"{st['A9-A12_boxes_crops_clip_logits']:.1f}"})
+if head.get("roofline_k1"):
+    k1 = head["roofline_k1"]
+    vals.update({"K1MS": f"{k1['avg_launch_ms']:.3f}", "K1GB": f"{k1['achieved'] / 1e3:.2f}", "K1FRAC": f"{k1['frac']:.3f}"})
 names = {"openvis_online": "ONLINE", "san_online": "SAN", "brivis R50": "BRIVIS", "brivis_swinl": "BSWIN", "openvis_swinl": "OSWIN"}
-for ln in open(os.path.join(d, "bench_all_models.jsonl")):
+for ln in (open(os.path.join(d, "bench_all_models.jsonl")) if os.path.exists(os.path.join(d, "bench_all_models.jsonl")) else []):
     l = json.loads(ln)
     for k, v in names.items():
         if l["config"]["workload"].startswith(k):
