@@ -242,9 +242,12 @@ def main():
     # frames every rank processes per step (frame-sharded: its block of the clip; clip replicas: whole clips)
     frames_per_rank = ([len(D.inference_shard(T, r, world)) for r in range(world)] if frame_sharded else [T] * world)
     if world > 1:
-        # RCCL builds its rings / channels at the first collective of every kind: one dummy all-gather, all-reduce and gather
-        # of the shapes the model uses, OUTSIDE the timed region (the warm-up steps repeat them through the model)
-        D.warm_up(device if not rig else "cpu")
+        # RCCL builds its rings / channels at the first collective of every kind, so the first ones run OUTSIDE the timed region:
+        # clip replicas only ever use the scalar all-reduce of the timing; the frame-sharded path also its all-gather / all-reduce /
+        # gather (distributed.warm_up; the warm-up steps then repeat them through the model)
+        D.max_over_ranks(0.0, "cpu" if rig else device)
+        if frame_sharded:
+            D.warm_up(device if not rig else "cpu")
 
     out = None
     if args.streams > 1 and not frame_sharded:

@@ -25,6 +25,7 @@ struct AttnH {
   _Float16* out; long long o_bs; int o_ld;
   int B, H, Nq, Nk;
   float scale;
+  int dbg;            // lab only (ovis_attention_f16_debug): 1 = stop after the K/V staging, 2 = skip the K/V loads (compute on whatever LDS holds)
 };
 
 __device__ __forceinline__ f16x4 tr_read(const _Float16* lds_ptr) {
@@ -207,6 +208,7 @@ flash_attn_f16_seq_kernel(AttnH a) {
     const int c = tid + it * 64 * KT;
     const int row = c >> 3, ch = c & 7;
     const int rc = row < a.Nk ? row : 0;
+    if (a.dbg == 2) { kk[it] = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u); vv[it] = kk[it]; continue; }
     kk[it] = *reinterpret_cast<const uint4*>(kp + (long long)rc * a.k_ld + ch * 8);
     vv[it] = *reinterpret_cast<const uint4*>(vp + (long long)rc * a.v_ld + ch * 8);
   }
@@ -222,6 +224,7 @@ flash_attn_f16_seq_kernel(AttnH a) {
   }
   __syncthreads();
   if (wave * 32 >= a.Nq) return;
+  if (a.dbg == 1) { if (q_ok && lane == 0) a.out[b * a.o_bs + (long long)qi * a.o_ld + head * D] = Ks[lane]; return; }
 
   const int g16 = lane >> 4, li = lane & 15;
   const int tr_off = (li >> 2) * VROW + 16 * (g16 & 1) + 4 * (li & 3);
@@ -343,6 +346,9 @@ int launch_seq(const AttnH& a, hipStream_t stream) {
 
 }  // namespace
 
+static int g_attn_dbg = 0;
+extern "C" int ovis_attention_f16_debug(int m) { g_attn_dbg = m; return OVIS_OK; }   // lab only
+
 extern "C" int ovis_attention_f16(const void* q, long long q_bs, int q_ld, const void* k, long long k_bs, int k_ld,
                                   const void* v, long long v_bs, int v_ld, void* out, long long o_bs, int o_ld, int B,
                                   int H, int Nq, int Nk, int D, float scale, ovis_stream_t stream) {
@@ -357,7 +363,7 @@ extern "C" int ovis_attention_f16(const void* q, long long q_bs, int q_ld, const
   AttnH a;
   a.q = (const _Float16*)q; a.q_bs = q_bs; a.q_ld = q_ld; a.k = (const _Float16*)k; a.k_bs = k_bs; a.k_ld = k_ld;
   a.v = (const _Float16*)v; a.v_bs = v_bs; a.v_ld = v_ld; a.out = (_Float16*)out; a.o_bs = o_bs; a.o_ld = o_ld;
-  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale; a.dbg = g_attn_dbg;
   // short sequences: whole K/V of a head in LDS, one wavefront per query tile
   const int kt = ovis::cdiv(Nk, 32);
   if (kt <= 7 && ovis::cdiv(Nq, 32) <= kt) {
