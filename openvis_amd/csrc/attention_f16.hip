@@ -11,6 +11,9 @@
 #include "common.h"
 #include <type_traits>
 
+#ifndef ATT_PAIR
+#define ATT_PAIR 0
+#endif
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -27,6 +30,16 @@ struct AttnH {
   float scale;
   int dbg;            // lab only (ovis_attention_f16_debug): 1 = stop after the K/V staging, 2 = skip the K/V loads (compute on whatever LDS holds)
 };
+
+// value of the lane 32 away, by v_permlane32_swap (VALU: no LDS round trip in the softmax's dependent chain, unlike ds_bpermute)
+__device__ __forceinline__ float max_xor32(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float sum_xor32(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 __device__ __forceinline__ f16x4 tr_read(const _Float16* lds_ptr) {
   const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -177,7 +190,7 @@ flash_attn_f16_kernel(AttnH a) {
 // above re-stages them for every group of 4 query tiles and synchronises twice per key tile), then every wavefront
 // walks the key tiles on its own with the online-softmax recurrence -- no barrier inside the loop.
 template <int KT>
-__global__ void __launch_bounds__(64 * KT)
+__global__ void __launch_bounds__(64 * KT, 4)          // <= 128 VGPRs: two 7-wavefront workgroups per CU (their LDS: 2 x 75 KB)
 flash_attn_f16_seq_kernel(AttnH a) {
   constexpr int D = 64;
   constexpr int KROW = D + 8;    // halfs -> 144 B rows (ds_read_b128, conflict-free)
@@ -243,13 +256,19 @@ flash_attn_f16_seq_kernel(AttnH a) {
     f32x16 s[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
+      // two independent accumulation chains of two MFMAs each (a chain of four waits out the 16-pass latency three times)
+      f32x16 s2;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { s[u][r] = 0.f; s2[r] = 0.f; }
+      f16x8 kk[D / 16];
 #pragma unroll
-      for (int st = 0; st < D / 16; ++st) {
-        const f16x8 kk = *reinterpret_cast<const f16x8*>(&Ks[((kt0 + u) * 32 + r32) * KROW + 16 * st + 8 * h]);
-        s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kk, qf[st], s[u], 0, 0, 0);
-      }
+      for (int st = 0; st < D / 16; ++st) kk[st] = *reinterpret_cast<const f16x8*>(&Ks[((kt0 + u) * 32 + r32) * KROW + 16 * st + 8 * h]);
+      s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kk[0], qf[0], s[u], 0, 0, 0);
+      s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kk[2], qf[2], s2, 0, 0, 0);
+      s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kk[1], qf[1], s[u], 0, 0, 0);
+      s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kk[3], qf[3], s2, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[u][r] += s2[r];
     }
     // scores stay unscaled: the running max is tracked on the raw dot products (scale > 0 keeps the order) and the scale
     // is folded into the exponent's fma; only the last key tile can hold keys >= Nk, so only it is masked
@@ -265,7 +284,7 @@ flash_attn_f16_seq_kernel(AttnH a) {
     for (int u = 0; u < NT; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[u][r]);
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    mt = max_xor32(mt);
     const float m_new = fmaxf(m_run, mt);                        // finite: every key tile holds at least one valid key
     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
     const float moff = -m_new * sl2;
@@ -278,7 +297,7 @@ flash_attn_f16_seq_kernel(AttnH a) {
         s[u][r] = p;
         ps += p;
       }
-    ps += __shfl_xor(ps, 32, 64);
+    ps = sum_xor32(ps);
     l_run = l_run * alpha + ps;
     m_run = m_new;
 #pragma unroll
@@ -312,8 +331,8 @@ flash_attn_f16_seq_kernel(AttnH a) {
 #pragma unroll
   for (int kt = 0; kt < KT; kt += 2) {
     if (kt >= nkt) break;
-    if (kt + 1 < KT && kt + 1 < nkt) step(std::integral_constant<int, 2>{}, kt);
-    else step(std::integral_constant<int, 1>{}, kt);
+    if (ATT_PAIR && kt + 1 < KT && kt + 1 < nkt) step(std::integral_constant<int, 2>{}, kt);
+    else { step(std::integral_constant<int, 1>{}, kt); if (!ATT_PAIR && kt + 1 < KT && kt + 1 < nkt) step(std::integral_constant<int, 1>{}, kt + 1); }
   }
   if (!q_ok) return;
   const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
