@@ -75,7 +75,11 @@ gemm_f32x3_kernel(LoaderA la, LoaderB lb, float* __restrict__ C, long long ldc, 
   const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
   const int bn = (int)(bid % tiles_n) * BN;
   const int bm = (int)(bid / tiles_n) * BM;
-  const int srow = tid >> 2, scol = (tid & 3) * 8;
+  // staging row of this thread.  ds_write_b128 is served 8 lanes at a time on 32 banks: lanes 4g .. 4g+3 write the four 16-byte chunks
+  // of one 80-byte row, so an octet covers two rows; with CONSECUTIVE rows their bank ranges overlap (20 banks apart: 2-way conflict on
+  // every store, SQ_LDS_BANK_CONFLICT = 63 % of the kernel's busy cycles).  Rows 4 apart start 16 banks apart mod 32: conflict-free.
+  const int g4 = tid >> 2;
+  const int srow = (g4 & ~7) | ((g4 & 1) << 2) | ((g4 >> 1) & 3), scol = (tid & 3) * 8;
 
   constexpr bool BSPLIT = !std::is_same<LoaderB, PlanesB>::value;   // false: B arrives already split
   float4 pa[A_IT][2], pb[B_IT][2];       // raw prefetch of the tile after next
