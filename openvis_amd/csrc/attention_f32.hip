@@ -242,30 +242,44 @@ flash_attn_f32_kernel(AttnArgs a) {
   }
 }
 
-// merge split-KV partials: one thread per (bh, q, d)
+// merge split-KV partials.  One workgroup of 256 threads per (bh, q): thread = (d = tid % D, split group = tid / D); a group walks
+// every G-th split (G = 256 / D groups), the groups' (max, sum, weighted V) are merged through LDS.  (Round 2 ran the nsplit
+// -- up to 250 for the 73 600-key level -- partials of a row as ONE serial loop per (bh, q, d) thread: 30 us of dependent loads
+// per launch, 9 launches per clip.)
+template <int D>
 __global__ void __launch_bounds__(256)
 attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, float* __restrict__ out,
-                    long long o_bs, int o_ld, int B, int H, int Nq, int D, int nsplit) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = (long long)B * H * Nq * D;
-  if (i >= total) return;
-  const int d = (int)(i % D);
-  long long r = i / D;
-  const int q = (int)(r % Nq);
-  const int bh = (int)(r / Nq);
+                    long long o_bs, int o_ld, int B, int H, int Nq, int nsplit) {
+  constexpr int G = 256 / D;
+  __shared__ float gm[G], gl[G][D], ga[G][D];
+  const int d = threadIdx.x % D, grp = threadIdx.x / D;
+  const long long row = blockIdx.x;                       // bh * Nq + q
+  const int q = (int)(row % Nq);
+  const int bh = (int)(row / Nq);
   const int b = bh / H, head = bh % H;
+  const long long BHQ = (long long)B * H * Nq;
   float m = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) m = fmaxf(m, part_ml[(((long long)s * B * H + bh) * Nq + q) * 2]);
+  for (int s = grp; s < nsplit; s += G) m = fmaxf(m, part_ml[((long long)s * BHQ + row) * 2]);
+  if (d == 0) gm[grp] = m;
+  __syncthreads();
+  float mall = gm[0];
+#pragma unroll
+  for (int g = 1; g < G; ++g) mall = fmaxf(mall, gm[g]);
   float l = 0.f, acc = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const long long slot = ((long long)s * B * H + bh) * Nq + q;
+  for (int s = grp; s < nsplit; s += G) {
+    const long long slot = (long long)s * BHQ + row;
     const float ms = part_ml[slot * 2];
-    if (ms == -INFINITY) continue;
-    const float w = exp2f(ms - m);
+    const float w = ms == -INFINITY ? 0.f : exp2f(ms - mall);
     l += part_ml[slot * 2 + 1] * w;
     acc += part_o[slot * D + d] * w;
   }
-  out[b * o_bs + (long long)q * o_ld + head * D + d] = l > 0.f ? acc / l : 0.f;
+  gl[grp][d] = l; ga[grp][d] = acc;
+  __syncthreads();
+  if (grp == 0) {
+#pragma unroll
+    for (int g = 1; g < G; ++g) { l += gl[g][d]; acc += ga[g][d]; }
+    out[b * o_bs + (long long)q * o_ld + head * D + d] = l > 0.f ? acc / l : 0.f;
+  }
 }
 
 }  // namespace
@@ -315,9 +329,9 @@ extern "C" int ovis_attention_f32(const float* q, long long q_bs, int q_ld, cons
   int rc = ovis::check_launch("attention");
   if (rc) return rc;
   if (nsplit > 1) {
-    const long long total = (long long)B * H * Nq * D;
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, s, a.part_o, a.part_ml, (float*)out, o_bs,
-                       o_ld, B, H, Nq, D, nsplit);
+    const unsigned rows = (unsigned)((long long)B * H * Nq);
+    if (D == 32) hipLaunchKernelGGL(attn_combine_kernel<32>, dim3(rows), dim3(256), 0, s, a.part_o, a.part_ml, (float*)out, o_bs, o_ld, B, H, Nq, nsplit);
+    else hipLaunchKernelGGL(attn_combine_kernel<64>, dim3(rows), dim3(256), 0, s, a.part_o, a.part_ml, (float*)out, o_bs, o_ld, B, H, Nq, nsplit);
     rc = ovis::check_launch("attention combine");
   }
   return rc;

@@ -443,7 +443,8 @@ def msda_encoder_fused(value, oa, shapes, lsi, M=8, L=3, P=4, shapes_host=None):
             _lib.call("ovis_msda_encoder_fused_tiled_f32", value, oa, oa.shape[-1], shapes, lsi, sh, out, B, S, M, C // M, L, P,
                       MSDA_TILE_RADIUS, _lib.stream_ptr())
         return out
-    with _Prof(f"msda_encoder_fused_kernel<{L},{P}>", nbytes, unit="byte"):
+    kname = "msda_encoder_fused8_kernel" if C // M == 32 else "msda_encoder_fused_kernel"      # head_dim 32: the lane-sharing kernel
+    with _Prof(f"{kname}<{L},{P}>", nbytes, unit="byte"):
         out = _mi().msda_encoder_fused(value, oa, shapes, lsi, M, L, P)
     return out
 
