@@ -31,6 +31,20 @@ normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long l
 // G_t = En_{t-1} En_t^T (G_0 = En_0 En_0^T) comes from one batched MFMA GEMM (stage 2).  A single 64-lane wavefront
 // owns the whole chain: lane l owns columns l, l+64, ...; the arg-min over columns is 6 cross-lane shuffles, and the
 // only synchronisation is the (single-wave, i.e. free) workgroup barrier that orders LDS traffic.
+// minimum of an unsigned over the 64 lanes, the same value in every lane: quad / half-row / row mirrors make every lane of a
+// 16-lane row hold its row's minimum, two row broadcasts bring it to lane 63, which is read back as a scalar (DPP: VALU only)
+__device__ __forceinline__ unsigned lnk_wave_min(unsigned v) {
+  int x = (int)v;
+  auto umin = [](int a, int b) { return (int)min((unsigned)a, (unsigned)b); };
+  x = umin(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
+  x = umin(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
+  x = umin(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false));    // row_half_mirror
+  x = umin(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false));    // row_mirror
+  x = umin(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xa, 0xf, false));    // row_bcast:15 -> rows 1, 3
+  x = umin(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xc, 0xf, false));    // row_bcast:31 -> rows 2, 3
+  return (unsigned)__builtin_amdgcn_readlane(x, 63);
+}
+
 __device__ __forceinline__ bool lnk_better(double v, int j, int fr, double bv, int bj, int bfr) {
   // smaller value; ties: a still-unassigned column first (scipy's rule), then the lower column index
   if (v < bv) return true;
@@ -70,6 +84,18 @@ hungarian_chain_kernel(const float* __restrict__ G, int ldg, int* __restrict__ i
       prev[q] = (t == 0 || parallel) ? q : indices[(t - 1) * Q + q];
     }
     __syncthreads();
+    // register mirrors of prev[] (constant for the frame) and row4col[] (changes only in the augment step): the tree walk reads them
+    // with v_readlane (the row / column index is wave-uniform) instead of two more dependent LDS round trips per step
+    int prev_r[NC], r4c_r[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { const int j = lane + 64 * c; prev_r[c] = j < Q ? prev[j] : 0; r4c_r[c] = -1; }
+    auto lane_read = [&](const int (&reg)[NC], int idx) {   // reg[idx >> 6] of lane idx & 63, idx wave-uniform
+      const int l = idx & 63, c = idx >> 6;
+      int r = __builtin_amdgcn_readlane(reg[0], l);
+#pragma unroll
+      for (int k = 1; k < NC; ++k) { const int rk = __builtin_amdgcn_readlane(reg[k], l); r = c == k ? rk : r; }
+      return r;
+    };
     for (int cur_row = 0; cur_row < Q; ++cur_row) {
       unsigned in_sc = 0;                               // bit c: column lane + 64c is in the tree
       double spc[NC];
@@ -78,8 +104,9 @@ hungarian_chain_kernel(const float* __restrict__ G, int ldg, int* __restrict__ i
       int i = cur_row, sink = -1;
       double min_val = 0.0;
       while (sink < 0) {
+        i = __builtin_amdgcn_readfirstlane(i);
         const double ui = u[i];
-        const float* crow = Gc + prev[i] * ldg;
+        const float* crow = Gc + lane_read(prev_r, i) * ldg;
         double bv = INFINITY; int bj = -1, bf = 0;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -87,19 +114,30 @@ hungarian_chain_kernel(const float* __restrict__ G, int ldg, int* __restrict__ i
           if (j < Q && !((in_sc >> c) & 1u)) {
             const double r = min_val + (double)(1.0f - crow[j]) - ui - v[c];
             if (r < spc[c]) { spc[c] = r; path[j] = i; }
-            const int fr = row4col[j] < 0;
+            const int fr = r4c_r[c] < 0;
             if (bj < 0 || lnk_better(spc[c], j, fr, bv, bj, bf)) { bv = spc[c]; bj = j; bf = fr; }
           }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const double ov = __shfl_xor(bv, o, 64);
-          const int oj = __shfl_xor(bj, o, 64), of = __shfl_xor(bf, o, 64);
-          if (oj >= 0 && (bj < 0 || lnk_better(ov, oj, of, bv, bj, bf))) { bv = ov; bj = oj; bf = of; }
+        // wave-wide arg-min of (value, unassigned-first, lower column) WITHOUT LDS shuffles (round 2: a 6-step butterfly of
+        // ds_bpermute on {f64, int, int} -- 24 LDS round trips in the dependent chain of every tree step, ~3 ms per 36-frame
+        // clip).  The value goes through an order-preserving map to a 64-bit unsigned key; three 32-bit DPP min-reductions give
+        // the minimal high word, the minimal low word among those lanes, and the minimal tie key (assigned bit, column)
+        // among the lanes that hold the minimal value -- the same total order as lnk_better.
+        {
+          const unsigned long long kb = (unsigned long long)__double_as_longlong(bv + 0.0);             // (-0 -> +0)
+          const unsigned long long key = bj < 0 ? ~0ull : (kb ^ ((kb >> 63) ? ~0ull : 0x8000000000000000ull));
+          const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
+          const unsigned mhi = lnk_wave_min(hi);
+          const unsigned mlo = lnk_wave_min(hi == mhi ? lo : 0xffffffffu);
+          const bool cand = bj >= 0 && hi == mhi && lo == mlo;
+          const unsigned mtk = lnk_wave_min(cand ? ((bf ? 0u : 1u) << 16) | (unsigned)bj : 0xffffffffu);
+          const unsigned long long mkey = ((unsigned long long)mhi << 32) | mlo;
+          bv = __longlong_as_double((long long)(mkey ^ ((mkey >> 63) ? 0x8000000000000000ull : ~0ull)));
+          bj = (int)(mtk & 0xffffu); bf = (mtk >> 16) ? 0 : 1;
         }
         min_val = bv;
         if ((bj & 63) == lane) in_sc |= 1u << (bj >> 6);
-        const int r4c = row4col[bj];
+        const int r4c = lane_read(r4c_r, __builtin_amdgcn_readfirstlane(bj));
         if (r4c < 0) sink = bj; else i = r4c;
       }
       // dual update, column-wise: the rows of the tree are cur_row and row4col[j] of every scanned column j, so
@@ -110,7 +148,7 @@ hungarian_chain_kernel(const float* __restrict__ G, int ldg, int* __restrict__ i
         if (j < Q && ((in_sc >> c) & 1u)) {
           const double d = min_val - spc[c];
           v[c] -= d;
-          const int r4c = row4col[j];
+          const int r4c = r4c_r[c];
           if (r4c >= 0 && j != sink) u[r4c] += d;
         }
       }
@@ -128,6 +166,8 @@ hungarian_chain_kernel(const float* __restrict__ G, int ldg, int* __restrict__ i
         }
       }
       __syncthreads();
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { const int j = lane + 64 * c; if (j < Q) r4c_r[c] = row4col[j]; }
     }
     for (int q = lane; q < Q; q += 64) indices[t * Q + q] = col4row[q];
     __threadfence();
