@@ -10,7 +10,6 @@ def _sources():
         for f in files:
             if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
                 yield os.path.join(d, f)
-    yield os.path.join(ROOT, "MultiScaleDeformableAttention.py")
     yield os.path.join(ROOT, "openvis_amd", "csrc", "torch_ext", "msda_module.cpp")
     yield os.path.join(ROOT, "train_net.py")
 
