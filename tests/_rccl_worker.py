@@ -11,11 +11,15 @@ from openvis_amd import distributed as D
 
 
 def main():
-    torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))        # before any other HIP call
-    rank, world, local_rank = D.init_from_env("nccl")
+    # OVIS_RCCL_TEST_BACKEND=gloo (tests/test_distributed_cpu.py): the same script on CPU tensors, to check its own logic where no
+    # second GPU exists; the GPU test runs it with nccl
+    backend = os.environ.get("OVIS_RCCL_TEST_BACKEND", "nccl")
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))    # before any other HIP call
+    rank, world, local_rank = D.init_from_env(backend)
     import torch.distributed as dist
-    assert dist.get_backend() == "nccl" and world >= 2
-    dev = torch.device("cuda", local_rank)
+    assert dist.get_backend() == backend and world >= 2
+    dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     D.warm_up(dev)
     T, Q, C = 4 * world + 3, 100, 256                            # ragged shards (the C4 layout: 36 frames over 8 ranks -> 5,5,5,5,4,4,4,4)
     full = torch.arange(T * Q * C, dtype=torch.float32).view(T, Q, C) * 1e-3
@@ -24,7 +28,7 @@ def main():
     h = D.all_gather_frames_async(local, T)                      # side stream; compute continues on the current stream meanwhile
     busy = torch.ones(1024, 1024, device=dev) @ torch.ones(1024, 1024, device=dev)
     got = h.wait()
-    assert got.is_cuda and torch.equal(got.cpu(), full), "async all-gather of query embeddings"
+    assert got.device.type == dev.type and torch.equal(got.cpu(), full), "async all-gather of query embeddings"
     assert float(busy[0, 0]) == 1024.0
     logits = torch.full((Q, 483), float(rank + 1), device=dev)
     s = D.all_reduce_sum(logits)

@@ -153,3 +153,16 @@ def test_communicator_warm_up_runs_every_collective_kind():
     assert all(p.exitcode == 0 for p in procs) and res == [(0, 2), (1, 2)]
     from openvis_amd import distributed as D
     D.warm_up("cpu")                                   # no process group: a no-op
+
+
+def test_rccl_worker_logic_on_gloo(tmp_path):
+    """tests/_rccl_worker.py (the script the >= 2-GPU RCCL test launches, one rank per GPU) run here with gloo on CPU tensors, 3 ranks:
+    ragged shards, gather order, all-reduce value and the mask gather are what the script asserts."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OVIS_RCCL_TEST_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "tests", "_rccl_worker.py")], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0 and "RCCL_OK world=3" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
