@@ -251,6 +251,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
     }
   };
   auto mma = [&](int i, int j, const f16x8 (&bf)[2][2]) {
+    if (p.dbg & 32) return;                                        // lab: no MFMAs (wrong results): what the DMA / LDS-read / barrier skeleton costs alone
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
     if constexpr (FA) {
