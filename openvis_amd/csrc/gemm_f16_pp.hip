@@ -74,6 +74,7 @@ struct PPArgs {
   int grp_w, grp_rem;                       // raster: column groups of grp_w (+1 for the first grp_rem groups) N tiles
   int desync_ns;                            // start offset spread over the workgroups that own one tile fewer (ns)
   int dbg;                                  // lab only: 8 = start offsets per XCD instead of per workgroup, 16 = no s_setprio for G1's epilogue
+                                            // (round 3's flags 2 / 4 = operands of tile (0,0) and 32 = no MFMAs are gone: profiles/r03/lab_l2_locality.txt, lab_skeleton.txt)
                                             // (the store-suppressing flags 1 / 2 / 32 of the round-2 experiments are gone: profiles/r02/lab_ub*.txt)
   unsigned long long* stamps;               // lab only: s_memrealtime stamps [workgroup][tile iteration < 16][2 groups][4]
   void* dump;                               // 2 KB scratch that the masked lanes of edge tiles store to (never read)
@@ -153,8 +154,6 @@ gemm_f16_pp_kernel(const PPArgs p) {
     PPTile t;
     t.bm = tm * TM; t.bn = tn * 256; t.bml = min(t.bm, p.M - TM); t.bnl = min(t.bn, p.N - 256);
     t.a_off = (long long)t.bml * p.lda * (FA ? 4 : 2); t.b_off = (long long)t.bnl * p.ldb * 2;
-    if (p.dbg & 4) t.a_off = t.b_off = 0;           // lab: every tile loads tile (0, 0)'s operands (all L2 hits; wrong results)
-    if (p.dbg & 2) t.a_off = 0;                     // lab: every tile loads M tile 0's rows of A
     *reinterpret_cast<PPTile*>(lds + PP_TAB + i * 32) = t;
   }
   __syncthreads();
@@ -251,7 +250,6 @@ gemm_f16_pp_kernel(const PPArgs p) {
     }
   };
   auto mma = [&](int i, int j, const f16x8 (&bf)[2][2]) {
-    if (p.dbg & 32) return;                                        // lab: no MFMAs (wrong results): what the DMA / LDS-read / barrier skeleton costs alone
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
     if constexpr (FA) {
