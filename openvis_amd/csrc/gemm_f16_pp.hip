@@ -542,7 +542,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
   { const PPTile t = tile_entry(0); acc_init(t.bml, t.bnl); }
   for (int it = 0; it < n_my; ++it) {
     unsigned long long* st = (p.stamps && it < 16 && (wave & 3) == 0 && lane == 0) ? p.stamps + ((blockIdx.x * 16 + it) * 2 + wr) * 4 : nullptr;
-    if (st) st[0] = __builtin_amdgcn_s_memrealtime();
+    if (st) { st[0] = __builtin_amdgcn_s_memrealtime(); st[3] = __builtin_amdgcn_s_memtime(); }   // [3]: shader clock, for the in-kernel clock
     unsigned long long* ks = (st && it >= 2 && it < 6) ? p.stamps + 256 * 16 * 2 * 4 + (blockIdx.x * 2 + wr) * 64 + (it - 2) * 16 : nullptr;
     for (int kt = 0; kt < nk; ++kt, ++s) {
       const unsigned cur = (s & 1) * PP_BUF, oth = PP_BUF - cur;

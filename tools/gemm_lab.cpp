@@ -199,6 +199,7 @@ struct Variant { int mode, grp, desync, dbg; std::string name; };
 
 int main(int argc, char** argv) {
   bool do_check = false, do_time = false, do_trace = false, do_x3 = false, do_r16 = false;
+  float time_scale = 1.f;   // `zeros`: zero-filled operands in the timing runs (data-dependent power -> clocks)
   std::vector<Variant> variants;
   int iters = 10, rounds = 3;
   for (int i = 1; i < argc; ++i) {
@@ -209,6 +210,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "trace")) do_trace = true;
     else if (!strcmp(argv[i], "x3")) do_x3 = true;
     else if (!strcmp(argv[i], "r16")) do_r16 = true;
+    else if (!strcmp(argv[i], "zeros")) time_scale = 0.f;
     else { Variant v; v.dbg = 0; if (sscanf(argv[i], "%d,%d,%d,%d", &v.mode, &v.grp, &v.desync, &v.dbg) >= 3) { v.name = argv[i]; variants.push_back(v); } }
   }
   if (variants.empty()) { variants.push_back({0, 0, 0, 0, "0,0,0"}); variants.push_back({1, 6, 0, 0, "1,6,0"}); }
@@ -331,9 +333,9 @@ int main(int argc, char** argv) {
       const long long MN = (long long)sh.M * sh.N;
       HIP_OK(hipMalloc(&A, (size_t)sh.M * sh.K * 2)); HIP_OK(hipMalloc(&B, (size_t)sh.N * sh.K * 2));
       HIP_OK(hipMalloc(&C, MN * (sh.out16 ? 2 : 4))); HIP_OK(hipMalloc(&bias, sh.N * 4));
-      fill_f16<<<2048, 256, 0, s>>>(A, (long long)sh.M * sh.K, 11u, 0, 1.f);
-      fill_f16<<<2048, 256, 0, s>>>(B, (long long)sh.N * sh.K, 23u, 0, 1.f / sqrtf((float)sh.K));
-      fill_f32<<<64, 256, 0, s>>>(bias, sh.N, 5u, 0, 1.f);
+      fill_f16<<<2048, 256, 0, s>>>(A, (long long)sh.M * sh.K, 11u, 0, time_scale);
+      fill_f16<<<2048, 256, 0, s>>>(B, (long long)sh.N * sh.K, 23u, 0, time_scale / sqrtf((float)sh.K));
+      fill_f32<<<64, 256, 0, s>>>(bias, sh.N, 5u, 0, time_scale);
       if (sh.res) { HIP_OK(hipMalloc(&R, MN * 4)); fill_f32<<<2048, 256, 0, s>>>(R, MN, 7u, 0, 1.f); }
       std::vector<std::vector<double>> ms(variants.size());
       for (int r = 0; r < rounds + 1; ++r)
@@ -370,6 +372,17 @@ int main(int argc, char** argv) {
           unsigned long long t0 = ~0ull, t1 = 0;
           for (size_t i = 0; i < 256 * 16 * 2 * 4; i += 4) if (st[i]) { t0 = std::min(t0, st[i]); t1 = std::max(t1, st[i + 2]); }
           printf("trace %s variant=%s: first tile begin -> last epilogue end %.2f us (100 MHz ticks)\n", sh.name, v.name.c_str(), (t1 - t0) * 0.01);
+          {   // in-kernel clock: shader-clock ticks / 100 MHz ticks between the first and the last stamped tile begin of a workgroup (median)
+            std::vector<double> ghz;
+            for (int b = 0; b < 256; ++b) {
+              const unsigned long long* x0 = &st[((size_t)(b * 16 + 0) * 2 + 0) * 4];
+              int last = 0;
+              for (int it = 1; it < 16; ++it) if (st[((size_t)(b * 16 + it) * 2 + 0) * 4]) last = it;
+              const unsigned long long* x1 = &st[((size_t)(b * 16 + last) * 2 + 0) * 4];
+              if (last > 0 && x1[0] > x0[0]) ghz.push_back((double)(x1[3] - x0[3]) / (double)(x1[0] - x0[0]) * 0.1);
+            }
+            if (!ghz.empty()) { std::sort(ghz.begin(), ghz.end()); printf("trace %s variant=%s: in-kernel clock %.3f GHz (median of %zu workgroups; min %.3f max %.3f)\n", sh.name, v.name.c_str(), ghz[ghz.size() / 2], ghz.size(), ghz[0], ghz.back()); }
+          }
           for (int it = 0; it < 16; ++it) {
             double kl[2] = {0, 0}, ep[2] = {0, 0}, gap[2] = {0, 0}, beg[2] = {0, 0}; int n[2] = {0, 0}; double bmin = 1e30, bmax = 0;
             for (int b = 0; b < 256; ++b) for (int g = 0; g < 2; ++g) {
