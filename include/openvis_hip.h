@@ -174,6 +174,26 @@ int ovis_vit_embed_ln_f16(const void* patch_f16, const float* cls, const float* 
                           void* out_f16, int M, int L1, int C, float eps, ovis_stream_t stream);
 int ovis_cast_f16_to_f32_rows(const void* x_f16, long long ldx, float* y, long long rows, int C, ovis_stream_t stream);
 
+/* LayerNorm folded into the GEMM that consumes it (ln_1 -> in_proj, ln_2 -> c_fc of a ResidualAttentionBlock, model.py:262-267, on
+ * the fp16 residual stream): the normalised rows are never written.  With Wg = fp16(gamma * W) (folded once at load),
+ * s[n] = sum_k f32(Wg[n,k]) and c[n] = b[n] + sum_k beta[k] W[n,k]:
+ *   LayerNorm(x) W^T + b  =  rstd[m] * (x Wg^T - mean[m] s[n]) + c[n]
+ *   ovis_row_stats_f16: stats[m] = (mean, 1/sqrt(var + eps)) of the fp16 row m, f32, the two-pass arithmetic of ovis_layernorm_f16_*;
+ *   ovis_gemm_nt_f16_ln: C (fp16) = act(...) with f32 accumulation starting at -mean[m] s[n]; act 0 (none) or 2 (QuickGELU); only
+ *     the shapes the ping-pong kernel takes (ovis_gemm_nt_f16_ln_eligible != 0: those of ovis_gemm_nt_f16's fp16-output path with
+ *     2 N <= 6144 and <= 128 tiles per workgroup); otherwise callers run ovis_layernorm_f16_to_f16 + ovis_gemm_nt_f16. */
+int ovis_row_stats_f16(const void* x_f16, float* stats, long long rows, int C, float eps, ovis_stream_t stream);
+/*   ovis_gemm_nt_f16_res16_stats: ovis_gemm_nt_f16_res16 whose epilogue also writes part [M][4 N/256][2] = (sum, sum of squares) of
+ *     every 64-column piece of the fp16 rows it stores (N % 256 == 0); ovis_row_stats_finalize: stats[m] = (mean, rstd) from those
+ *     partial sums in a fixed order (var = E[x^2] - mean^2 in f32, clamped at 0) -- the residual stream is not read again. */
+int ovis_gemm_nt_f16_res16_stats(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int M, int N, int K,
+                                 const float* bias, const void* R16, long long ldr, float* part, ovis_stream_t stream);
+int ovis_row_stats_finalize(const float* part, int slots, float* stats, long long rows, int C, float eps, ovis_stream_t stream);
+int ovis_gemm_nt_f16_ln_eligible(const void* C, long long lda, long long ldb, long long ldc, int M, int N, int K, const float* c,
+                                 const float* s_rows, const float* stats, int act);
+int ovis_gemm_nt_f16_ln(const void* A, long long lda, const void* Wg, long long ldb, void* C, long long ldc, int M, int N, int K,
+                        const float* c, const float* s_rows, const float* stats, int act, ovis_stream_t stream);
+
 /* ovis_gemm_nt_f16: same contract with fp16 A [M,K] / B [N,K] (K, lda, ldb multiples of 8), f32 accumulation,
  *   f32 bias / residual, C written as f32 (out_f16 == 0) or fp16.  Used for the CLIP ViT GEMMs only — the reference
  *   runs CLIP in fp16 on the GPU (adapter.py:108-111; clip.load on cuda).  On tiles with 16-byte aligned rows the f32

@@ -63,6 +63,10 @@ constexpr int PP_LDS = 160 * 1024;
 constexpr int PP_TAB = PP_LDS - 8192;      // this workgroup's tile list: 256 entries of 32 bytes (1000 crops x ViT-L/14@336 fc1: 141 per workgroup)
 constexpr int PP_MAX_TILES = 256;
 constexpr int PP_MAX_BIAS_N = (PP_TAB - PP_BIAS) / 4;
+// LNF (LayerNorm folded into the GEMM): the tile list is capped at 128 entries (4 KB) and the upper 4 KB of the list region hold two
+// 2 KB slots of per-row statistics (mean, rstd of the tile's 256 rows), filled by LDS-DMA one tile ahead
+constexpr int PP_STATS = PP_LDS - 4096;
+constexpr int PP_MAX_TILES_LNF = 128;
 struct PPTile { long long a_off, b_off; int bm, bml, bn, bnl; };   // DMA bases (bytes) of the shifted tile; rows / columns owned and computed
 
 struct PPArgs {
@@ -78,6 +82,10 @@ struct PPArgs {
                                             // (the store-suppressing flags 1 / 2 / 32 of the round-2 experiments are gone: profiles/r02/lab_ub*.txt)
   unsigned long long* stamps;               // lab only: s_memrealtime stamps [workgroup][tile iteration < 16][2 groups][4]
   void* dump;                               // 2 KB scratch that the masked lanes of edge tiles store to (never read)
+  const float* ln_stats = nullptr;          // LNF: [M][2] (mean, rstd) of the rows of A
+  const float* ln_s = nullptr;              // LNF: [N] row sums of the gamma-folded weight (f32)
+  float* ln_part = nullptr;                 // PSTAT: [M][ln_pslots][2] partial (sum, sum of squares) of the fp16 output rows, one slot per
+  int ln_pslots = 0;                        //        (N tile, wavefront column): slot = 4 * (N tile) + wc
 };
 
 #define PP_GLDS(src, dst) \
@@ -106,9 +114,19 @@ struct PPArgs {
 // EPI (fp16 output only): bit 0 = full-line stores -- the lanes l and l ^ 8 of a 16-lane row exchange one 16-byte pack (DPP row_ror:8),
 //      so that a store instruction writes 8 rows x 128 B (whole cache lines) instead of 16 rows x 64 B; bits 1-2 = cache policy of the
 //      C stores: 0 default, 1 sc1 (write-through: the line is not kept in the XCD's L2, which the operand panels need), 2 nt.
-template <int OUT, int ACT, bool HAS_R, bool X3, bool FA = false, bool R16 = false, int TM = 256, int EPI = 0>
+// LNF: C = act(LayerNorm(A) W^T + b) computed from the raw rows of A: with W' = gamma * W (folded once), s[n] = sum_k W'[n,k] and
+//      c[n] = b[n] + sum_k beta[k] W[n,k] it is rstd[m] * (A W'^T - mean[m] s[n]) + c[n].  The accumulators start at -mean[m] s[n], the
+//      epilogue applies rstd[m] and c[n] (`bias` = c).  mean / rstd of a tile's 256 rows come from LDS: every wavefront fetches 32 rows
+//      of the NEXT-BUT-ONE tile's statistics with one 4-byte-per-lane LDS-DMA right after the tile transition -- one more operation in
+//      the in-order vmcnt queue exactly where the epilogue's stores sit, so the counted waits of the K loop only grow by one.
+// PSTAT (fp16 residual GEMMs): the epilogue also emits, per output row and per (N tile, wavefront column), the sum and the sum of squares
+//      of the 64 fp16 values it stores -- the LayerNorm statistics of the NEXT block's ln are then a 12-term sum per row
+//      (row_stats_finalize_kernel) instead of a pass over the 151 MB residual stream.  Deterministic: fixed slots, fixed order.
+template <int OUT, int ACT, bool HAS_R, bool X3, bool FA = false, bool R16 = false, int TM = 256, int EPI = 0, bool LNF = false, bool PSTAT = false>
 __global__ void __launch_bounds__(512)
 gemm_f16_pp_kernel(const PPArgs p) {
+  static_assert(!PSTAT || (R16 && (EPI & 1)), "PSTAT: fp16 residual GEMM with the full-line epilogue");
+  static_assert(!LNF || (OUT == 1 && !HAS_R && !X3 && !FA && TM == 256 && (EPI & 1)), "LNF: fp16 output, full-line epilogue, 256-row tiles");
   static_assert(EPI == 0 || (OUT == 1 && !X3 && (!HAS_R || R16)), "EPI variants: fp16 output (fp16 residual or none)");
   static_assert(TM == 256 || (TM == 192 && !X3), "tile heights: 256, or 192 for the fp16 / f32-A modes");
   constexpr int GS = TM / 2;                                       // rows of a wave group
@@ -148,6 +166,9 @@ gemm_f16_pp_kernel(const PPArgs p) {
   for (int i = tid * 4; i < p.N; i += 512 * 4)
     *reinterpret_cast<float4*>(lds + PP_BIAS + i * 4) =
         p.bias ? *reinterpret_cast<const float4*>(p.bias + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (LNF)
+    for (int i = tid * 4; i < p.N; i += 512 * 4)
+      *reinterpret_cast<float4*>(lds + PP_BIAS + (p.N + i) * 4) = *reinterpret_cast<const float4*>(p.ln_s + i);
   for (int i = tid; i < n_my; i += 512) {
     int tm, tn;
     tile_mn(first + i * nblk, tm, tn);
@@ -179,6 +200,17 @@ gemm_f16_pp_kernel(const PPArgs p) {
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b0), "=&v"(b1) : "v"(addr) : "memory");
   };
 
+  // LNF: (mean, rstd) of this lane's row in each of the 8 row blocks of its wave group, from statistics slot `slot` (one asm block:
+  // eight reads in flight, one wait); and the LDS-DMA that fills a slot with the statistics of tile `i` (32 rows per wavefront)
+  using f32x2 = __attribute__((ext_vector_type(2))) float;
+  auto stats8 = [&](int slot, f32x2 (&st)[8]) {
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(lds + PP_STATS) + slot * 2048 + (wr * GS + l15) * 8;
+    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:128\n\tds_read_b64 %2, %8 offset:256\n\tds_read_b64 %3, %8 offset:384\n\t"
+                 "ds_read_b64 %4, %8 offset:512\n\tds_read_b64 %5, %8 offset:640\n\tds_read_b64 %6, %8 offset:768\n\tds_read_b64 %7, %8 offset:896\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(st[0]), "=&v"(st[1]), "=&v"(st[2]), "=&v"(st[3]), "=&v"(st[4]), "=&v"(st[5]), "=&v"(st[6]), "=&v"(st[7]) : "v"(addr) : "memory");
+  };
+
   // ---- DMA sources: a lane-constant byte offset per (half-tile, 8-row group) + a wave-uniform tile base ----
   // Edge tiles are SHIFTED inside the matrix for the loads (rows min(256 t, M - 256) ...) and their stores are masked to
   // the rows / columns that belong to the tile: no per-lane clamping, so a tile change costs scalar arithmetic only.
@@ -206,6 +238,13 @@ gemm_f16_pp_kernel(const PPArgs p) {
   auto issue = [&](const char* base, const unsigned (&off)[2], int kbytes, int dst_off) {
     PP_GLDS(base + off[0] + kbytes, dma_dst + dst_off);
     PP_GLDS(base + off[1] + kbytes, dma_dst + dst_off + 1024);
+  };
+  // LNF: statistics of tile i (clamped to this workgroup's last tile) -> slot; wavefront w moves rows 32 w .. 32 w + 31 (64 floats)
+  auto issue_stats = [&](int i, int slot) {
+    const PPTile t = tile_entry(i < n_my ? i : n_my - 1);
+    const float* src = p.ln_stats + ((long long)t.bml + 32 * wave) * 2 + lane;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + PP_STATS + slot * 2048 + wave * 256), 4, 0, 0);
   };
   // ---- fragment read addresses -----------------------------------------------------------------------------
   const unsigned rd0 = FA ? (unsigned)(l15 * 128 + (((2 * q) ^ sw) << 4))      // floats 8q .. 8q+3 of the row; 8q+4 .. 8q+7 = ^ 16
@@ -328,7 +367,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
                                     : (unsigned)(((long long)(wr * GS + l15) * p.ldc + wc * 64 + 8 * q) * ESZ);
   // Row block outer, column pair inner: the two 64-byte halves of a 128-byte line come from CONSECUTIVE store instructions.
   // (Column pair outer -- the halves 8 instructions apart -- measured 5-6 % slower on the whole GEMM: partial-line writes.)
-  auto epilogue_rows = [&](auto pred_tag, int bm, int bml, int bn, int bnl) {
+  auto epilogue_rows = [&](auto pred_tag, int bm, int bml, int bn, int bnl, int stats_slot) {
     constexpr bool PRED = decltype(pred_tag)::value;                 // edge tile: mask the rows / columns of the neighbour tile
     const int row0 = bml + wr * GS + l15, col0 = bnl + wc * 64 + 8 * q;
     // wave-uniform tile base + 32-bit lane offset (one VGPR live across the K loop; 256 rows of C stay far below 4 GB)
@@ -366,10 +405,45 @@ gemm_f16_pp_kernel(const PPArgs p) {
     if constexpr (X3 && HAS_R) rp = p.R + (long long)row0 * p.ldr + col0;
     // EPI bit 0: one 16-row block as two full-line stores.  low = lanes whose row is 0-7 of the block.  A: rows 0-7 (low lanes their own
     // columns 8q.., high lanes the low partner's columns 32 + 8q..), B: rows 8-15 (low lanes the high partner's columns 8q.., high lanes own).
+    f32x2 lst[8];                                                    // LNF: (mean, rstd) of this lane's eight rows; c of its 16 columns
+    f32x4 lc[4];
+    if constexpr (LNF) {
+      stats8(stats_slot, lst);
+      bias8(bnl + wc * 64 + 8 * q, lc[0], lc[1]);
+      bias8(bnl + wc * 64 + 8 * q + 32, lc[2], lc[3]);
+    }
     auto put_lines = [&](int mb) {
       f32x4 x0 = acc[mb][0], x1 = acc[mb][1], y0 = acc[mb][2], y1 = acc[mb][3];
+      if constexpr (LNF) {
+        const float rs = lst[mb][1];
+        x0 = x0 * rs + lc[0]; x1 = x1 * rs + lc[1]; y0 = y0 * rs + lc[2]; y1 = y1 * rs + lc[3];
+      }
       act4(x0); act4(x1); act4(y0); act4(y1);
       const uint4 P0 = pack8(x0, x1), P1 = pack8(y0, y1);
+      if constexpr (PSTAT) {                                         // this lane: row l15 of block mb, 16 of the wavefront's 64 columns
+        using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+        const f16x2 one2 = {(_Float16)1.f, (_Float16)1.f};
+        const unsigned pk[8] = {P0.x, P0.y, P0.z, P0.w, P1.x, P1.y, P1.z, P1.w};
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const f16x2 v = __builtin_bit_cast(f16x2, pk[e]);
+          sm = __builtin_amdgcn_fdot2(v, one2, sm, false);
+          sq = __builtin_amdgcn_fdot2(v, v, sq, false);
+        }
+        // the row's other 48 columns sit in the lanes 16 and 32 away (q): v_permlane16_swap / v_permlane32_swap, own + partner
+        auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(sm), __float_as_uint(sm), false, false);
+        sm = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+        r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
+        sq = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+        auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(sm), __float_as_uint(sm), false, false);
+        sm = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+        r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
+        sq = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+        // rows that two (shifted) tiles compute get the same value twice; one store instruction per row block from every wavefront
+        float* pp = p.ln_part + (((long long)(bml + wr * GS + mb * 16 + l15)) * p.ln_pslots + (bnl >> 6) + wc) * 2;
+        if (q == 0) *reinterpret_cast<float2*>(pp) = make_float2(sm, sq);
+      }
       const bool low = l15 < 8;
       uint4 snd = low ? P1 : P0, rcv;
       rcv.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)snd.x, 0x128, 0xf, 0xf, false);
@@ -434,8 +508,21 @@ gemm_f16_pp_kernel(const PPArgs p) {
     }
   };
   // ... followed by the start value of the next tile's accumulators: bias + residual (gemm_epilogue.h) or zero
-  auto acc_init = [&](int bml, int bnl) {
-    if constexpr (X3) {
+  auto acc_init = [&](int bml, int bnl, int stats_slot) {
+    if constexpr (LNF) {                                             // accumulators start at -mean[m] s[n]
+      f32x2 st[8];
+      stats8(stats_slot, st);
+      const int col0 = bnl + wc * 64 + 8 * q;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x4 sv[2];
+        bias8(p.N + col0 + 32 * j, sv[0], sv[1]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int mb = 0; mb < MBT; ++mb) acc[mb][2 * j + e] = sv[e] * (-st[mb][0]);
+      }
+    } else if constexpr (X3) {
 #pragma unroll
       for (int mb = 0; mb < MBT; ++mb)
 #pragma unroll
@@ -516,6 +603,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
   // prologue: K steps 0 and 1 completely (both buffers).  Every tile starts in this state: the DMA of the first two K
   // steps of the NEXT tile is issued before the epilogue's stores (the in-order vmcnt queue then lets the stores drain
   // under two K steps of compute: no load that is waited for before the end of K step 1 is younger than a store).
+  if constexpr (LNF) { issue_stats(0, 0); issue_stats(1, 1); }      // oldest in the queue: retired by the first counted wait below
   issue_a0(0); issue_b0(0); advance2(); issue_b1(0); issue_a1(0); advance1();
   issue_a0(PP_BUF); issue_b0(PP_BUF); advance2(); issue_b1(PP_BUF); issue_a1(PP_BUF); advance1();
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                 // A0, B0 of K step 0
@@ -528,7 +616,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
   PP_BARRIER();
 
   // (MBT row blocks: 2 fp16 / 4 f32 / 6 plane stores each, + 2 fp16 / 4 f32 residual loads; the f32 residual case is clamped to 63 - 10)
-  constexpr int NS_ = OUT == 1 ? (R16 ? 4 : 2) * MBT : OUT == 2 ? 6 * MBT : (HAS_R ? 8 : 4) * MBT;
+  constexpr int NS_ = OUT == 1 ? ((R16 ? 4 : 2) + (PSTAT ? 1 : 0)) * MBT : OUT == 2 ? 6 * MBT : (HAS_R ? 8 : 4) * MBT;
   constexpr int NS = NS_ > 53 ? 53 : NS_;   // vm ops of one epilogue (+ residual loads) per lane; 10 + NS <= 63
 #define PP_WAIT(n_first, n_later) do { if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_first) : "memory"); \
                                        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_later) : "memory"); } while (0)
@@ -537,9 +625,10 @@ gemm_f16_pp_kernel(const PPArgs p) {
   // epilogue's stores, which sit behind the early-issued B1/A1 of K step 1:
   //   kt = 0: (phase 1: in the tile transition below), 8 + NS, 8 + NS;   kt = 1: 8 + NS, 8 + NS, 8;   kt >= 2: 8
   // (the first tile of a workgroup has no stores in front of it: PP_WAIT's first argument)
-  static_assert(10 + NS <= 63, "vmcnt is a 6-bit field");
+  constexpr int NS1 = NS + (LNF ? 1 : 0);                            // + the statistics DMA issued right behind the epilogue
+  static_assert(10 + NS1 <= 63, "vmcnt is a 6-bit field");
   unsigned s = 0;                                                    // global K step counter (buffer = s & 1)
-  { const PPTile t = tile_entry(0); acc_init(t.bml, t.bnl); }
+  { const PPTile t = tile_entry(0); acc_init(t.bml, t.bnl, 0); }
   for (int it = 0; it < n_my; ++it) {
     unsigned long long* st = (p.stamps && it < 16 && (wave & 3) == 0 && lane == 0) ? p.stamps + ((blockIdx.x * 16 + it) * 2 + wr) * 4 : nullptr;
     if (st) { st[0] = __builtin_amdgcn_s_memrealtime(); st[3] = __builtin_amdgcn_s_memtime(); }   // [3]: shader clock, for the in-kernel clock
@@ -551,7 +640,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
         read_b(cur + 2 * PP_HT, 0, bf0);
         read_a(cur, 0);
         issue_b1(oth);
-        if (kt == 1) PP_WAIT(8, 8 + NS); else PP_VMCNT(8);
+        if (kt == 1) PP_WAIT(8, 8 + NS1); else PP_VMCNT(8);
         PP_BARRIER();
       }
       mma(0, 0, bf0);
@@ -559,7 +648,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
       // ---- phase 2: quadrant (0,1) ----
       read_b(cur + 2 * PP_HT, 1, bf1);
       if (kt) issue_a1(oth);
-      if (kt < 2) PP_WAIT(8, 8 + NS); else PP_VMCNT(8);
+      if (kt < 2) PP_WAIT(8, 8 + NS1); else PP_VMCNT(8);
       PP_BARRIER();
       mma(0, 1, bf1);
       if (kt) advance1();
@@ -572,7 +661,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
       PP_BARRIER();
       // ---- phase 4: quadrant (1,0), no LDS reads ----
       issue_b0(cur);
-      if (kt == 0) PP_WAIT(8, 8 + NS); else PP_VMCNT(8);
+      if (kt == 0) PP_WAIT(8, 8 + NS1); else PP_VMCNT(8);
       PP_BARRIER();
       mma(1, 0, bf0);
       advance2();
@@ -595,9 +684,9 @@ gemm_f16_pp_kernel(const PPArgs p) {
     //         G1: [phase-4 reads] | last MFMAs | epilogue               | phase-1 reads   | MFMAs ...
     if (wr == 0) PP_BARRIER();
     if (wr == 1 && !(p.dbg & 16)) __builtin_amdgcn_s_setprio(1);     // the younger wavefronts 4-7 lose every arbitration against 0-3 otherwise
-    if (bm == bml && bn == bnl) epilogue_rows(std::false_type{}, bm, bml, bn, bnl);
-    else epilogue_rows(std::true_type{}, bm, bml, bn, bnl);
-    if (has_next) acc_init(nbml, nbnl);
+    if (bm == bml && bn == bnl) epilogue_rows(std::false_type{}, bm, bml, bn, bnl, it & 1);
+    else epilogue_rows(std::true_type{}, bm, bml, bn, bnl, it & 1);
+    if (has_next) acc_init(nbml, nbnl, (it + 1) & 1);
     if (st) st[2] = __builtin_amdgcn_s_memrealtime();
     if (wr == 1) { __builtin_amdgcn_s_setprio(0); PP_BARRIER(); }
     {                                                                // read segment of the next tile's phase 1 (fragment registers are free again)
@@ -607,6 +696,9 @@ gemm_f16_pp_kernel(const PPArgs p) {
       PP_VMCNT(10 + NS);                                             // B1 of the next tile's K step 0: 5 younger half-tiles + the epilogue
     }
     PP_BARRIER();
+    // LNF: every wavefront has read slot it & 1 (its epilogue) before the barrier above: refill it with the statistics of tile it + 2.
+    // Issued by every wavefront for every tile (past the last one: a reload of the last tile's rows), so the counts stay uniform.
+    if constexpr (LNF) issue_stats(it + 2, it & 1);
   }
   if (wr == 0) PP_BARRIER();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -669,8 +761,9 @@ bool gemm_f16_pp_res16_eligible(const void* C, const void* R16, long long lda, l
 }
 
 int gemm_f16_pp_res16_launch(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int M, int N, int K,
-                             const float* bias, const void* R16, long long ldr, hipStream_t s) {
+                             const float* bias, const void* R16, long long ldr, hipStream_t s, float* part = nullptr) {
   PPArgs p;
+  p.ln_part = part; p.ln_pslots = 4 * (int)cdiv(N, 256);
   p.A = reinterpret_cast<const _Float16*>(A); p.B = reinterpret_cast<const _Float16*>(B); p.C = C; p.bias = bias;
   p.R = reinterpret_cast<const float*>(R16);
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.M = M; p.N = N; p.K = K; p.act = 0;
@@ -687,6 +780,12 @@ int gemm_f16_pp_res16_launch(const void* A, long long lda, const void* B, long l
   const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
 #define PP_R16(E_) do { if (tm == 192) hipLaunchKernelGGL((gemm_f16_pp_kernel<1, 0, true, false, false, true, 192, E_>), dim3(grid), dim3(512), 0, s, p); \
                         else hipLaunchKernelGGL((gemm_f16_pp_kernel<1, 0, true, false, false, true, 256, E_>), dim3(grid), dim3(512), 0, s, p); } while (0)
+  if (part) {
+    if (g_pp_epi != 5 || N % 256 != 0) return fail(OVIS_EINVAL, "gemm_nt_f16_res16_stats: needs the full-line epilogue and N %% 256 == 0");
+    if (tm == 192) hipLaunchKernelGGL((gemm_f16_pp_kernel<1, 0, true, false, false, true, 192, 5, false, true>), dim3(grid), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((gemm_f16_pp_kernel<1, 0, true, false, false, true, 256, 5, false, true>), dim3(grid), dim3(512), 0, s, p);
+    return check_launch("gemm_nt_f16 (ping-pong, fp16 residual, row statistics)");
+  }
   switch (g_pp_epi) {
     case 0: PP_R16(0); break; case 1: PP_R16(1); break; case 4: PP_R16(4); break; case 5: PP_R16(5); break;
     default: return fail(OVIS_EINVAL, "gemm_nt_f16 (ping-pong, fp16 residual): bad epilogue variant %d", g_pp_epi);
@@ -729,6 +828,36 @@ int gemm_f16_pp_launch(const void* A, long long lda, const void* B, long long ld
 #undef PP_LAUNCH
 #undef PP_LAUNCH_E
   return check_launch("gemm_nt_f16 (ping-pong)");
+}
+
+// ---- LayerNorm folded into the GEMM (LNF): A = the raw fp16 rows, Wg = gamma-folded fp16 weight, c / s f32 [N], stats f32 [M][2] ----
+bool gemm_f16_pp_ln_eligible(const void* C, long long lda, long long ldb, long long ldc, int M, int N, int K, const float* c, const float* s,
+                             const float* stats, int act) {
+  if (g_pp_epi != 5 || !(act == 0 || act == 2) || !c || !s || !stats) return false;
+  if (!gemm_f16_pp_eligible(C, lda, ldb, ldc, M, N, K, c, nullptr, 0, 1, act == 0)) return false;
+  if (2 * N > PP_MAX_BIAS_N || (reinterpret_cast<uintptr_t>(s) & 15) || (reinterpret_cast<uintptr_t>(stats) & 3)) return false;
+  const long long tiles = (long long)cdiv(M, 256) * cdiv(N, 256);
+  return cdiv(tiles, 256) <= PP_MAX_TILES_LNF && K >= 128;
+}
+
+int gemm_f16_pp_ln_launch(const void* A, long long lda, const void* Wg, long long ldb, void* C, long long ldc, int M, int N, int K,
+                          const float* c, const float* s_rows, const float* stats, int act, hipStream_t s) {
+  PPArgs p;
+  p.A = reinterpret_cast<const _Float16*>(A); p.B = reinterpret_cast<const _Float16*>(Wg); p.C = C; p.bias = c; p.R = nullptr;
+  p.ln_s = s_rows; p.ln_stats = stats;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = 0; p.M = M; p.N = N; p.K = K; p.act = act;
+  p.tiles_m = (int)cdiv(M, 256); p.tiles_n = (int)cdiv(N, 256); p.n_tiles = p.tiles_m * p.tiles_n;
+  const int groups = (int)cdiv(p.tiles_n, g_pp_grp > 0 ? g_pp_grp : p.tiles_n);
+  p.grp_w = p.tiles_n / groups; p.grp_rem = p.tiles_n % groups;
+  p.desync_ns = g_pp_desync_ns >= 0 ? g_pp_desync_ns : 0;
+  p.dbg = g_pp_dbg; p.stamps = g_pp_stamps;
+  p.dump = pp_dump_buffer();
+  if (!p.dump) return fail(OVIS_EINVAL, "gemm_nt_f16_ln (ping-pong): cannot allocate the 4 KB dump buffer");
+  p.planeA = p.planeB = p.planeC = 0;
+  const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
+  if (act == 0) hipLaunchKernelGGL((gemm_f16_pp_kernel<1, 0, false, false, false, false, 256, 5, true>), dim3(grid), dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((gemm_f16_pp_kernel<1, 2, false, false, false, false, 256, 5, true>), dim3(grid), dim3(512), 0, s, p);
+  return check_launch("gemm_nt_f16_ln (ping-pong, LayerNorm folded)");
 }
 
 // ---- f32-A mode (bf16x2): A f32 [M,K], W as bf16 planes [>=2][N][ldb] (the first two of ovis_split_f32_to_bf16x3) ----
@@ -857,6 +986,34 @@ extern "C" int ovis_gemm_nt_f16_res16(const void* A, long long lda, const void* 
   OVIS_REQUIRE(ovis::gemm_f16_pp_res16_eligible(C, R16, lda, ldb, ldc, ldr, M, N, K, bias),
                "gemm_nt_f16_res16: shape not taken by the ping-pong kernel (M=%d N=%d K=%d): use ovis_gemm_nt_f16 with an f32 residual", M, N, K);
   return ovis::gemm_f16_pp_res16_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, R16, ldr, (hipStream_t)stream);
+}
+
+// ovis_gemm_nt_f16_res16 that also writes part [M][4 * N/256][2] = (sum, sum of squares) of every 64-column piece of the fp16 output rows
+extern "C" int ovis_gemm_nt_f16_res16_stats(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int M, int N, int K,
+                                            const float* bias, const void* R16, long long ldr, float* part, ovis_stream_t stream) {
+  OVIS_REQUIRE(A && B && C && R16 && part, "gemm_nt_f16_res16_stats: null pointer");
+  OVIS_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldb >= K && ldc >= N && N % 256 == 0, "gemm_nt_f16_res16_stats: bad sizes (N %% 256 == 0)");
+  OVIS_REQUIRE(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+               (reinterpret_cast<uintptr_t>(part) & 7) == 0, "gemm_nt_f16_res16_stats: alignment");
+  OVIS_REQUIRE(ovis::gemm_f16_pp_res16_eligible(C, R16, lda, ldb, ldc, ldr, M, N, K, bias),
+               "gemm_nt_f16_res16_stats: shape not taken by the ping-pong kernel (M=%d N=%d K=%d)", M, N, K);
+  return ovis::gemm_f16_pp_res16_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, R16, ldr, (hipStream_t)stream, part);
+}
+
+// C (fp16) = act( LayerNorm(A) W^T + b ) from the raw fp16 rows A (LayerNorm folded into the GEMM; include/openvis_hip.h).
+extern "C" int ovis_gemm_nt_f16_ln_eligible(const void* C, long long lda, long long ldb, long long ldc, int M, int N, int K, const float* c,
+                                            const float* s_rows, const float* stats, int act) {
+  return ovis::gemm_f16_pp_ln_eligible(C, lda, ldb, ldc, M, N, K, c, s_rows, stats, act) ? 1 : 0;
+}
+
+extern "C" int ovis_gemm_nt_f16_ln(const void* A, long long lda, const void* Wg, long long ldb, void* C, long long ldc, int M, int N, int K,
+                                   const float* c, const float* s_rows, const float* stats, int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(A && Wg && C && c && s_rows && stats, "gemm_nt_f16_ln: null pointer");
+  OVIS_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldb >= K && ldc >= N, "gemm_nt_f16_ln: bad sizes");
+  OVIS_REQUIRE(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Wg)) & 15) == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm_nt_f16_ln: alignment");
+  OVIS_REQUIRE(ovis::gemm_f16_pp_ln_eligible(C, lda, ldb, ldc, M, N, K, c, s_rows, stats, act),
+               "gemm_nt_f16_ln: shape not taken by the ping-pong kernel (M=%d N=%d K=%d act=%d): use ovis_layernorm_f16_to_f16 + ovis_gemm_nt_f16", M, N, K, act);
+  return ovis::gemm_f16_pp_ln_launch(A, lda, Wg, ldb, C, ldc, M, N, K, c, s_rows, stats, act, (hipStream_t)stream);
 }
 
 extern "C" int ovis_set_f16_gemm_mode(int mode, int raster_group, int desync_ns) {

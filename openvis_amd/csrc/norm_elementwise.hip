@@ -185,6 +185,58 @@ layernorm_h16_kernel(const _Float16* __restrict__ x, const float* __restrict__ g
   }
 }
 
+// (mean, rstd) of fp16 rows, the statistics half of layernorm_h16_kernel (same loads, same two-pass arithmetic, 8 bytes written per
+// row instead of the normalised row): input of the LayerNorm-folded GEMM (gemm_f16_pp.hip, LNF).
+template <int NV8>
+__global__ void __launch_bounds__(256)
+row_stats_h16_kernel(const _Float16* __restrict__ x, float2* __restrict__ stats, long long rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int n8 = C >> 3;
+  const uint4* xp = reinterpret_cast<const uint4*>(x + row * C);
+  float v[NV8][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV8; ++i) {
+    const int idx = lane + i * 64;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    if (idx < n8) {
+      using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+      union { u32x4 u; _Float16 h[8]; } pk;
+      pk.u = *reinterpret_cast<const u32x4*>(xp + idx);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = (float)pk.h[e]; }
+      s += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV8; ++i) {
+    if (lane + i * 64 < n8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) stats[row] = make_float2(mean, rstd);
+}
+
+// (mean, rstd) from the partial (sum, sum of squares) pairs the fp16-residual GEMM's epilogue wrote (gemm_f16_pp.hip, PSTAT): one
+// thread per row, slots summed in index order.
+__global__ void __launch_bounds__(256)
+row_stats_finalize_kernel(const float2* __restrict__ part, int slots, float2* __restrict__ stats, long long rows, float inv_c, float eps) {
+  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  float s = 0.f, q = 0.f;
+  for (int i = 0; i < slots; ++i) { const float2 v = part[row * slots + i]; s += v.x; q += v.y; }
+  const float mean = s * inv_c;
+  const float var = fmaxf(q * inv_c - mean * mean, 0.f);
+  stats[row] = make_float2(mean, 1.f / sqrtf(var + eps));
+}
+
 // ---- GroupNorm on NHWC (C % 4 == 0, (C/G) % 4 == 0) -------------------------------------------
 // pass 1: per-(n,g) sum / sum of squares accumulated in f64 (block partials -> f64 atomics);
 // pass 2: normalise (+ optional bilinear x2-upsampled addend, + optional ReLU).
@@ -384,6 +436,26 @@ static int layernorm_f16in_launch(const void* x, const float* gamma, const float
   if (C / 4 <= 64) hipLaunchKernelGGL((layernorm_kernel<1, OUT16, true>), dim3(grid), dim3(256), 0, s, xf, nullptr, gamma, beta, y, rows, C, eps);
   else hipLaunchKernelGGL((layernorm_kernel<4, OUT16, true>), dim3(grid), dim3(256), 0, s, xf, nullptr, gamma, beta, y, rows, C, eps);
   return ovis::check_launch("layernorm (fp16 input)");
+}
+
+extern "C" int ovis_row_stats_f16(const void* x_f16, float* stats, long long rows, int C, float eps, ovis_stream_t stream) {
+  OVIS_REQUIRE(x_f16 && stats, "row_stats_f16: null pointer");
+  OVIS_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 1024, "row_stats_f16: C must be a multiple of 8, <= 1024");
+  OVIS_REQUIRE((reinterpret_cast<uintptr_t>(x_f16) & 15) == 0 && (reinterpret_cast<uintptr_t>(stats) & 7) == 0, "row_stats_f16: alignment");
+  const unsigned grid = (unsigned)ovis::cdiv(rows, 4);
+  const _Float16* xh = reinterpret_cast<const _Float16*>(x_f16);
+  hipStream_t s = (hipStream_t)stream;
+  if (C <= 512) hipLaunchKernelGGL(row_stats_h16_kernel<1>, dim3(grid), dim3(256), 0, s, xh, reinterpret_cast<float2*>(stats), rows, C, eps);
+  else hipLaunchKernelGGL(row_stats_h16_kernel<2>, dim3(grid), dim3(256), 0, s, xh, reinterpret_cast<float2*>(stats), rows, C, eps);
+  return ovis::check_launch("row_stats (fp16 rows)");
+}
+
+extern "C" int ovis_row_stats_finalize(const float* part, int slots, float* stats, long long rows, int C, float eps, ovis_stream_t stream) {
+  OVIS_REQUIRE(part && stats && rows > 0 && slots > 0 && C > 0, "row_stats_finalize: bad arguments");
+  OVIS_REQUIRE(((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(stats)) & 7) == 0, "row_stats_finalize: alignment");
+  hipLaunchKernelGGL(row_stats_finalize_kernel, dim3((unsigned)ovis::cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float2*>(part), slots, reinterpret_cast<float2*>(stats), rows, 1.f / (float)C, eps);
+  return ovis::check_launch("row_stats_finalize");
 }
 
 extern "C" int ovis_layernorm_f16_to_f16(const void* x_f16, const float* gamma, const float* beta, void* y_f16, long long rows, int C,

@@ -6,6 +6,9 @@
 // openvis_amd/ops.py calls THESE (torch.ops.ovis_mi.<name>) -- one path; the ctypes binding stays for the long tail of small kernels.
 //
 //   gemm_nt_f16        the CLIP ViT GEMMs (mask_adapted_clip/model.py:238-268; fp16 on the reference's GPU path, adapter.py:108-111)
+//   gemm_nt_f16_ln     ln_1 -> in_proj / ln_2 -> c_fc with the LayerNorm folded into the GEMM (model.py:262-267)
+//   gemm_nt_f16_res16_stats  out_proj / c_proj on the fp16 stream + partial LayerNorm statistics of the rows it writes (row_stats_finalize)
+//   row_stats_f16      (mean, rstd) of fp16 rows (the statistics half of model.py:157-163)
 //   msda_encoder_fused softmax + sampling locations + K1 (ms_deform_attn.py:102-118 + ms_deform_im2col_cuda.cuh:242-304)
 //   attention_f16      nn.MultiheadAttention core of the CLIP blocks (model.py:254-263)
 //   mask_bbox          boxes of {sigmoid(x4 upsample) > .5} (openvis.py:87-96, adapter.py:88-94)
@@ -64,6 +67,70 @@ at::Tensor gemm_nt_f16_meta(const at::Tensor& a, const at::Tensor& w, const c10:
   const bool r16 = residual.has_value() && residual->defined() && residual->scalar_type() == at::kHalf;
   return at::empty_symint({a.sym_size(0), w.sym_size(0)}, a.options().dtype(out_f16 || r16 ? at::kHalf : at::kFloat));
 }
+
+// ---- LayerNorm folded into the GEMM (include/openvis_hip.h: ovis_gemm_nt_f16_ln, ovis_row_stats_f16, ovis_gemm_nt_f16_res16_stats) ----
+at::Tensor row_stats_f16(const at::Tensor& x) {
+  need(x, "x");
+  TORCH_CHECK(x.dim() == 2 && x.scalar_type() == at::kHalf, "row_stats_f16: x fp16 [rows, C]");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+  at::Tensor st = at::empty({x.size(0), 2}, x.options().dtype(at::kFloat));
+  const int rc = ovis_row_stats_f16(x.data_ptr(), st.data_ptr<float>(), x.size(0), (int)x.size(1), 1e-5f, cur_stream());
+  TORCH_CHECK(rc == OVIS_OK, "row_stats_f16: ", ovis_last_error());
+  return st;
+}
+at::Tensor row_stats_f16_meta(const at::Tensor& x) { return at::empty_symint({x.sym_size(0), 2}, x.options().dtype(at::kFloat)); }
+
+at::Tensor gemm_nt_f16_ln(const at::Tensor& x, const at::Tensor& wg, const at::Tensor& s, const at::Tensor& c, const at::Tensor& stats, int64_t act) {
+  need(x, "x"); need(wg, "wg"); need(s, "s"); need(c, "c"); need(stats, "stats");
+  TORCH_CHECK(x.dim() == 2 && wg.dim() == 2 && x.size(1) == wg.size(1) && x.scalar_type() == at::kHalf && wg.scalar_type() == at::kHalf,
+              "gemm_nt_f16_ln: x fp16 [M,K], wg fp16 [N,K]");
+  const int M = (int)x.size(0), K = (int)x.size(1), N = (int)wg.size(0);
+  TORCH_CHECK(s.scalar_type() == at::kFloat && c.scalar_type() == at::kFloat && stats.scalar_type() == at::kFloat && s.numel() == N &&
+              c.numel() == N && stats.numel() == 2ll * M, "gemm_nt_f16_ln: s, c f32 [N]; stats f32 [M,2]");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+  at::Tensor out = at::empty({M, N}, x.options());
+  const int rc = ovis_gemm_nt_f16_ln(x.data_ptr(), K, wg.data_ptr(), K, out.data_ptr(), N, M, N, K, c.data_ptr<float>(), s.data_ptr<float>(),
+                                     stats.data_ptr<float>(), (int)act, cur_stream());
+  TORCH_CHECK(rc == OVIS_OK, "gemm_nt_f16_ln: ", ovis_last_error());
+  return out;
+}
+at::Tensor gemm_nt_f16_ln_meta(const at::Tensor& x, const at::Tensor& wg, const at::Tensor&, const at::Tensor&, const at::Tensor&, int64_t) {
+  return at::empty_symint({x.sym_size(0), wg.sym_size(0)}, x.options());
+}
+
+std::tuple<at::Tensor, at::Tensor> gemm_nt_f16_res16_stats(const at::Tensor& a, const at::Tensor& w, const c10::optional<at::Tensor>& bias,
+                                                           const at::Tensor& residual) {
+  need(a, "a"); need(w, "w"); need(residual, "residual");
+  TORCH_CHECK(a.dim() == 2 && w.dim() == 2 && a.size(1) == w.size(1) && a.scalar_type() == at::kHalf && w.scalar_type() == at::kHalf &&
+              residual.scalar_type() == at::kHalf, "gemm_nt_f16_res16_stats: fp16 a [M,K], w [N,K], residual [M,N]");
+  const int M = (int)a.size(0), K = (int)a.size(1), N = (int)w.size(0);
+  TORCH_CHECK(residual.dim() == 2 && residual.size(0) == M && residual.size(1) == N && N % 256 == 0, "gemm_nt_f16_res16_stats: residual [M,N], N % 256 == 0");
+  if (bias.has_value() && bias->defined()) { need(*bias, "bias"); TORCH_CHECK(bias->scalar_type() == at::kFloat && bias->numel() == N, "gemm_nt_f16_res16_stats: bias f32 [N]"); }
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(a.device());
+  const int slots = 4 * (N / 256);
+  at::Tensor out = at::empty({M, N}, a.options());
+  at::Tensor part = at::empty({M, slots, 2}, a.options().dtype(at::kFloat));
+  const int rc = ovis_gemm_nt_f16_res16_stats(a.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N, M, N, K, fptr(bias), residual.data_ptr(), N,
+                                              part.data_ptr<float>(), cur_stream());
+  TORCH_CHECK(rc == OVIS_OK, "gemm_nt_f16_res16_stats: ", ovis_last_error());
+  return {out, part};
+}
+std::tuple<at::Tensor, at::Tensor> gemm_nt_f16_res16_stats_meta(const at::Tensor& a, const at::Tensor& w, const c10::optional<at::Tensor>&,
+                                                                const at::Tensor&) {
+  return {at::empty_symint({a.sym_size(0), w.sym_size(0)}, a.options()),
+          at::empty_symint({a.sym_size(0), c10::SymInt(4) * (w.sym_size(0) / 256), c10::SymInt(2)}, a.options().dtype(at::kFloat))};
+}
+// partial (sum, sum of squares) pairs [M, slots, 2] of rows of C values -> (mean, rstd) [M, 2]
+at::Tensor row_stats_finalize(const at::Tensor& part, int64_t C) {
+  need(part, "part");
+  TORCH_CHECK(part.dim() == 3 && part.size(2) == 2 && part.scalar_type() == at::kFloat, "row_stats_finalize: part f32 [M, slots, 2]");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(part.device());
+  at::Tensor stats = at::empty({part.size(0), 2}, part.options());
+  const int rc = ovis_row_stats_finalize(part.data_ptr<float>(), (int)part.size(1), stats.data_ptr<float>(), part.size(0), (int)C, 1e-5f, cur_stream());
+  TORCH_CHECK(rc == OVIS_OK, "row_stats_finalize: ", ovis_last_error());
+  return stats;
+}
+at::Tensor row_stats_finalize_meta(const at::Tensor& part, int64_t) { return at::empty_symint({part.sym_size(0), 2}, part.options()); }
 
 // ---- msda_encoder_fused --------------------------------------------------------------------------------------------
 at::Tensor msda_encoder_fused(const at::Tensor& value, const at::Tensor& oa, const at::Tensor& shapes, const at::Tensor& lsi,
@@ -179,6 +246,10 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> topk_entropy_meta(con
 
 TORCH_LIBRARY_FRAGMENT(ovis_mi, m) {
   m.def("gemm_nt_f16(Tensor a, Tensor w, Tensor? bias, Tensor? residual, int act, bool out_f16) -> Tensor");
+  m.def("gemm_nt_f16_ln(Tensor x, Tensor wg, Tensor s, Tensor c, Tensor stats, int act) -> Tensor");
+  m.def("gemm_nt_f16_res16_stats(Tensor a, Tensor w, Tensor? bias, Tensor residual) -> (Tensor, Tensor)");
+  m.def("row_stats_f16(Tensor x) -> Tensor");
+  m.def("row_stats_finalize(Tensor part, int C) -> Tensor");
   m.def("msda_encoder_fused(Tensor value, Tensor offs_attn, Tensor spatial_shapes, Tensor level_start_index, int num_heads, int num_levels, "
         "int num_points) -> Tensor");
   m.def("attention_f16(Tensor q, Tensor k, Tensor v, int B, int H, int Nq, int Nk, int D, int q_bs, int q_ld, int k_bs, int k_ld, int v_bs, "
@@ -191,6 +262,10 @@ TORCH_LIBRARY_FRAGMENT(ovis_mi, m) {
 }
 TORCH_LIBRARY_IMPL(ovis_mi, CUDA, m) {       // "CUDA" is the HIP device's dispatch key on ROCm builds of torch
   m.impl("gemm_nt_f16", &gemm_nt_f16);
+  m.impl("gemm_nt_f16_ln", &gemm_nt_f16_ln);
+  m.impl("gemm_nt_f16_res16_stats", &gemm_nt_f16_res16_stats);
+  m.impl("row_stats_f16", &row_stats_f16);
+  m.impl("row_stats_finalize", &row_stats_finalize);
   m.impl("msda_encoder_fused", &msda_encoder_fused);
   m.impl("attention_f16", &attention_f16);
   m.impl("mask_bbox", &mask_bbox);
@@ -200,6 +275,10 @@ TORCH_LIBRARY_IMPL(ovis_mi, CUDA, m) {       // "CUDA" is the HIP device's dispa
 }
 TORCH_LIBRARY_IMPL(ovis_mi, Meta, m) {
   m.impl("gemm_nt_f16", &gemm_nt_f16_meta);
+  m.impl("gemm_nt_f16_ln", &gemm_nt_f16_ln_meta);
+  m.impl("gemm_nt_f16_res16_stats", &gemm_nt_f16_res16_stats_meta);
+  m.impl("row_stats_f16", &row_stats_f16_meta);
+  m.impl("row_stats_finalize", &row_stats_finalize_meta);
   m.impl("msda_encoder_fused", &msda_encoder_fused_meta);
   m.impl("attention_f16", &attention_f16_meta);
   m.impl("mask_bbox", &mask_bbox_meta);

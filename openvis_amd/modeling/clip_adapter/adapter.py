@@ -36,6 +36,9 @@ class ClipVisual:
         # fp16 policy only: keep the residual stream of plain (no mask prompt, no attention bias) forward passes in fp16, as the
         # reference's fp16 CLIP does (adapter.py:108-111); set by build_clip_adapter from MODEL.CLIP_ADAPTER.RESIDUAL_STREAM
         self.stream16 = False
+        # fp16 residual stream only: ln_1 / ln_2 folded into in_proj / c_fc (ops.fold_layernorm; the normalised rows are never
+        # written, include/openvis_hip.h ovis_gemm_nt_f16_ln).  False: LayerNorm kernel + plain GEMM (the round-2 path).
+        self.fold_ln = True
         self.w = {}
 
     def load_state_dict(self, sd, prefix, device):
@@ -60,6 +63,13 @@ class ClipVisual:
             for k in ["conv1"] + [f"{i}.{n}" for i in range(self.layers)
                                   for n in ("attn.in_proj_weight", "attn.out_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight")]:
                 w[k + ".h"] = ops.cast_f16(w[k])
+            C = self.width
+            for i in range(self.layers):                              # LayerNorm-folded operands (wg fp16, s, c) of in_proj / c_fc
+                g1, b1 = w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"]
+                w[f"{i}.qkv.fold"] = ops.fold_layernorm(w[f"{i}.attn.in_proj_weight"], w[f"{i}.attn.in_proj_bias"], g1, b1)
+                w[f"{i}.fc.fold"] = ops.fold_layernorm(w[f"{i}.mlp.c_fc.weight"], w[f"{i}.mlp.c_fc.bias"], w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"])
+                if i == self.layers - 1:                              # last_block_cls: keys | values of every token only
+                    w[f"{i}.kv.fold"] = ops.fold_layernorm(w[f"{i}.attn.in_proj_weight"][C:].contiguous(), w[f"{i}.attn.in_proj_bias"][C:].contiguous(), g1, b1)
         return self
 
     def embed(self, A, M, patch_open=None):
@@ -83,6 +93,8 @@ class ClipVisual:
         Hh = self.heads
         D = C // Hh
         f16 = self.precision == "fp16"
+        if f16 and attn_bias is None and x.dtype == torch.float16:
+            return self._run_blocks_stream16(x, i0, i1)
         for i in range(i0, i1):
             h = ops.layernorm(x, w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"], out_f16=f16)
             if f16 and attn_bias is None:
@@ -111,6 +123,52 @@ class ClipVisual:
                 x = ops.gemm_nt(f, w[f"{i}.mlp.c_proj.weight"], w[f"{i}.mlp.c_proj.bias"], x.view(-1, C), cw=True).view(B, L, C)
         return x
 
+    def _run_blocks_stream16(self, x, i0, i1):
+        """run_blocks on the fp16 residual stream (plain blocks).  Where the ping-pong kernel takes the problem, ln_1 / ln_2 are folded
+        into in_proj / c_fc (ops.gemm_nt_f16_ln: the normalised rows are never written) and the row statistics come out of the epilogue
+        of the GEMM that wrote the stream (ops.gemm_nt_f16_res16_stats); otherwise LayerNorm kernel + plain GEMM, per GEMM."""
+        w = self.w
+        B, L, C = x.shape
+        Hh = self.heads
+        D = C // Hh
+        M = B * L
+        Q = ops.ACT_QUICKGELU
+        can = self.fold_ln and f"{i0}.qkv.fold" in w
+        fold_qkv = can and ops.gemm_nt_f16_ln_eligible(M, 3 * C, C)
+        fold_fc = can and ops.gemm_nt_f16_ln_eligible(M, w[f"{i0}.mlp.c_fc.weight"].shape[0], C, Q)
+        st = self._stats_for(x) if fold_qkv else None                 # (mean, rstd) of the rows of x, if the GEMM that wrote x left them
+        x = x.view(M, C)
+        for i in range(i0, i1):
+            if fold_qkv:
+                qkv = ops.gemm_nt_f16_ln(x, *w[f"{i}.qkv.fold"], st if st is not None else ops.row_stats_f16(x))
+            else:
+                h = ops.layernorm(x, w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"], out_f16=True)
+                qkv = ops.gemm_nt_f16(h, w[f"{i}.attn.in_proj_weight.h"], w[f"{i}.attn.in_proj_bias"], out_f16=True)
+            att = ops.attention_f16(qkv, qkv[:, C:], qkv[:, 2 * C:], B, Hh, L, L, D, L * 3 * C, 3 * C, L * 3 * C, 3 * C, L * 3 * C, 3 * C)
+            wo, bo = w[f"{i}.attn.out_proj.weight.h"], w[f"{i}.attn.out_proj.bias"]
+            if fold_fc:
+                x, st = ops.gemm_nt_f16_res16_stats(att.view(M, C), wo, bo, x)
+                f = ops.gemm_nt_f16_ln(x, *w[f"{i}.fc.fold"], st if st is not None else ops.row_stats_f16(x), Q)
+            else:
+                x = ops.gemm_nt_f16(att.view(M, C), wo, bo, x)
+                h = ops.layernorm(x, w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"], out_f16=True)
+                f = ops.gemm_nt_f16(h, w[f"{i}.mlp.c_fc.weight.h"], w[f"{i}.mlp.c_fc.bias"], None, Q, out_f16=True)
+            wp, bp = w[f"{i}.mlp.c_proj.weight.h"], w[f"{i}.mlp.c_proj.bias"]
+            if fold_qkv:                                              # the next block's ln_1 (or last_block_cls) reads these statistics
+                x, st = ops.gemm_nt_f16_res16_stats(f, wp, bp, x)
+            else:
+                x = ops.gemm_nt_f16(f, wp, bp, x)
+        x = x.view(B, L, C)
+        self._row_stats = (x, st) if fold_qkv else (None, None)
+        return x
+
+    _row_stats = (None, None)
+
+    def _stats_for(self, x):
+        """statistics handed over by the GEMM that produced x (run_blocks), or None"""
+        t, st = self._row_stats
+        return st if t is x else None
+
     def last_block_cls(self, x, i):
         """resblock i evaluated for the CLASS TOKEN only -> f32 [B, C].  ln_post reads x[:, 0] alone (model.py:356-358), so in
         the last block every token still contributes its key / value, but the query projection, the attention rows, the
@@ -121,14 +179,23 @@ class ClipVisual:
         Hh = self.heads
         D = C // Hh
         f16 = self.precision == "fp16"
-        h = ops.layernorm(x, w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"], out_f16=f16)
-        hq = h[:, 0, :].contiguous()
+        fold = (f16 and self.fold_ln and x.dtype == torch.float16 and f"{i}.kv.fold" in w and ops.gemm_nt_f16_ln_eligible(B * L, 2 * C, C))
+        if fold:                                                     # keys | values from the raw rows; ln_1 itself only for the class rows
+            h = None
+            hq = ops.layernorm(x[:, 0, :].contiguous(), w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"], out_f16=True)
+        else:
+            h = ops.layernorm(x, w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"], out_f16=f16)
+            hq = h[:, 0, :].contiguous()
         bi = w[f"{i}.attn.in_proj_bias"]
         # the class-token path is [B] rows: f32 from here on whatever the stream's dtype
         xc = ops.cast_f16_to_f32_rows(x[:, 0, :]) if x.dtype == torch.float16 else x[:, 0, :].contiguous()
         if f16:
             wi = w[f"{i}.attn.in_proj_weight.h"]
-            kv = ops.gemm_nt_f16(h.view(-1, C), wi[C:], bi[C:], out_f16=True)                   # [B*L, 2C]: keys | values
+            if fold:
+                st = self._stats_for(x)
+                kv = ops.gemm_nt_f16_ln(x.view(-1, C), *w[f"{i}.kv.fold"], st if st is not None else ops.row_stats_f16(x))
+            else:
+                kv = ops.gemm_nt_f16(h.view(-1, C), wi[C:], bi[C:], out_f16=True)               # [B*L, 2C]: keys | values
             q = ops.gemm_nt_f16(hq, wi[:C], bi[:C], out_f16=True)                               # [B, C]
             att = ops.attention_f16(q, kv, kv[:, C:], B, Hh, 1, L, D, C, C, L * 2 * C, 2 * C, L * 2 * C, 2 * C)
             xc = ops.gemm_nt_f16(att.view(B, C), w[f"{i}.attn.out_proj.weight.h"], w[f"{i}.attn.out_proj.bias"], xc)

@@ -183,6 +183,64 @@ def gemm_nt_f16(a, w, bias=None, residual=None, act=ACT_NONE, out_f16=False):
     return out.view(*a.shape[:-1], N)
 
 
+def fold_layernorm(w, bias, gamma, beta):
+    """LayerNorm folded into the Linear that consumes it (include/openvis_hip.h, ovis_gemm_nt_f16_ln): f32 w [N,K], bias [N] or None,
+    gamma / beta [K] -> (wg fp16 [N,K] = fp16(gamma * w), s f32 [N] = row sums of wg, c f32 [N] = bias + w beta).  Once per weight."""
+    wg = cast_f16((w * gamma[None, :]).contiguous())
+    s = wg.float().sum(dim=1).contiguous()
+    c = (w.double() @ beta.double()).float()
+    if bias is not None:
+        c = c + bias
+    return wg, s, c.contiguous()
+
+
+def row_stats_f16(x):
+    """fp16 rows [..., C] -> f32 [rows, 2] = (mean, 1/sqrt(var + 1e-5)): the statistics of layernorm() without the normalised rows."""
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    _chk(x2)
+    with _Prof("row_stats_h16_kernel", 0.0):
+        return _mi().row_stats_f16(x2)
+
+
+def gemm_nt_f16_res16_stats(a, w, bias, residual):
+    """gemm_nt_f16 with an fp16 residual (out-proj / c_proj on the fp16 stream) that also returns the LayerNorm statistics of the rows
+    it wrote: (out fp16 [M,N], stats f32 [M,2] = (mean, rstd)) -- partial sums from the GEMM's epilogue, finished by a 12-term sum per
+    row; None instead of stats when the ping-pong kernel does not take the problem (callers then use row_stats_f16)."""
+    K = a.shape[-1]
+    N = w.shape[0]
+    a2 = a.reshape(-1, K)
+    r2 = residual.reshape(-1, N)
+    _chk(a2, w, bias, r2)
+    M = a2.shape[0]
+    if not (N % 256 == 0 and w.is_contiguous() and r2.dtype == torch.float16 and _lib.lib().ovis_gemm_nt_f16_res16_eligible(
+            _lib._conv(r2), _lib._conv(r2), _ll(K), _ll(K), _ll(N), _ll(N), M, N, K, _lib._conv(bias))):
+        return gemm_nt_f16(a, w, bias, residual), None
+    with _Prof("gemm_f16_pp_kernel<1,0,true,false,false,true>", 2.0 * M * N * K):
+        out, part = _mi().gemm_nt_f16_res16_stats(a2, w, bias, r2)
+    return out.view(*a.shape[:-1], N), _mi().row_stats_finalize(part, N)
+
+
+def gemm_nt_f16_ln_eligible(M, N, K, act=ACT_NONE):
+    """whether gemm_nt_f16_ln takes this problem (otherwise: layernorm(out_f16=True) + gemm_nt_f16)."""
+    big = 16 * 1024 * 1024          # alignment-only probes: the library checks pointers for 16-byte alignment, never reads them
+    return bool(_lib.lib().ovis_gemm_nt_f16_ln_eligible(ctypes.c_void_p(big), _ll(K), _ll(K), _ll(N), int(M), int(N), int(K), ctypes.c_void_p(big),
+                                                        ctypes.c_void_p(big), ctypes.c_void_p(big), int(act)))
+
+
+def gemm_nt_f16_ln(x, wg, s, c, stats, act=ACT_NONE):
+    """fp16( act( LayerNorm(x) w^T + b ) ) from the raw fp16 rows x [..., K], the folded weight (fold_layernorm) and the row statistics
+    (row_stats_f16): rstd * (x wg^T - mean s) + c with f32 accumulation -- the normalised rows never exist in memory."""
+    K = x.shape[-1]
+    N = wg.shape[0]
+    x2 = x.reshape(-1, K)
+    _chk(x2, wg, s, c, stats)
+    M = x2.shape[0]
+    with _Prof("gemm_f16_pp_kernel<1,%d,false,false,false,false,256,5,true>" % act, 2.0 * M * N * K):
+        out = _mi().gemm_nt_f16_ln(x2, wg, s, c, stats, int(act))
+    return out.view(*x.shape[:-1], N)
+
+
 def gemm_nt_batched(a, b, out, batch, M, N, K, lda, a_bs, ldb, b_bs, ldc, c_bs, bias=None, act=ACT_NONE, b16=None):
     """batch independent problems out_z = a_z b_z^T (pointer + z*stride, strides in elements); b16: fp16 copy of b
     (same strides) selects the autocast arithmetic.  Tensors give the base pointers only."""

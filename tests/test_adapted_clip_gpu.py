@@ -230,3 +230,48 @@ def test_last_block_for_the_class_token_equals_the_full_block(precision, tol, B)
     cls = vis.last_block_cls(x.clone(), 2)
     assert cls.shape == (B, 256)
     assert (cls - full).abs().max().item() / full.abs().max().item() < tol
+
+
+@pytest.mark.parametrize("arch", [dict(width=768, layers=3, heads=12, patch=16, resolution=224, embed_dim=512),
+                                  dict(width=1024, layers=2, heads=16, patch=14, resolution=336, embed_dim=768)])
+def test_layernorm_folded_tower_agrees_with_the_layernorm_kernels(arch):
+    """fp16 residual stream at production width: ln_1 / ln_2 folded into in_proj / c_fc (ViT-B: both; ViT-L: in_proj only, c_fc's 4096 columns
+    do not fit) and the statistics taken from the epilogue of out_proj / c_proj, against LayerNorm kernel + plain GEMM on the same weights
+    with non-trivial gamma / beta; and both against the f32-policy tower."""
+    from openvis_amd import ops, weights
+    from openvis_amd.modeling.clip_adapter.adapter import ClipVisual
+    prefix = "clip_adapter.clip_model.visual."
+    sd = weights.random_init(weights.clip_visual_spec(**arch), seed=43)
+    g = torch.Generator().manual_seed(1)
+    for k in list(sd):
+        if ".ln_1." in k or ".ln_2." in k:
+            sd[k] = sd[k] + (0.3 if k.endswith("weight") else 0.2) * torch.randn(sd[k].shape, generator=g)
+    vis = ClipVisual(**arch, precision="fp16").load_state_dict(sd, prefix, "cuda")
+    vis32 = ClipVisual(**arch, precision="fp32").load_state_dict(sd, prefix, "cuda")
+    L = (arch["resolution"] // arch["patch"]) ** 2 + 1
+    B = 360 if arch["width"] == 768 else 120                       # >= 256 tiles of 256 x 256 for every GEMM of the block
+    x = torch.randn(B, L, arch["width"], generator=g).cuda()
+    x16 = ops.cast_f16(x)
+    n = arch["layers"]
+    vis.fold_ln = True
+    calls = []
+    real_ln = ops.gemm_nt_f16_ln
+    ops.gemm_nt_f16_ln = lambda *a, **k: (calls.append(a[1].shape[0]), real_ln(*a, **k))[1]
+    try:
+        y_fold = vis.run_blocks(x16.clone(), 0, n - 1)
+        c_fold = vis.last_block_cls(y_fold, n - 1)
+    finally:
+        ops.gemm_nt_f16_ln = real_ln
+    C = arch["width"]
+    assert calls.count(3 * C) == n - 1 and calls.count(2 * C) == 1                  # in_proj of every block, keys | values of the last
+    assert calls.count(4 * C) == (n - 1 if C == 768 else 0)                        # c_fc: ViT-B only
+    vis.fold_ln = False
+    y_plain = vis.run_blocks(x16.clone(), 0, n - 1)
+    c_plain = vis.last_block_cls(y_plain, n - 1)
+    y32 = vis32.run_blocks(x16.float(), 0, n - 1)
+    c32 = vis32.last_block_cls(y32, n - 1)
+    scale = c32.abs().max().item()
+    d_fold, d_plain = (c_fold - c32).abs().max().item() / scale, (c_plain - c32).abs().max().item() / scale
+    assert d_fold < 4e-3 and d_plain < 4e-3, (d_fold, d_plain)
+    assert (c_fold - c32).abs().mean().item() <= 1.1 * (c_plain - c32).abs().mean().item()      # the fold skips one fp16 rounding: not worse
+    assert (y_fold.float() - y_plain.float()).abs().max().item() / y32.abs().max().item() < 4e-3

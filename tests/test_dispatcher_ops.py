@@ -7,7 +7,7 @@ import pytest
 import torch
 
 OPS = ["ms_deform_attn_forward", "gemm_nt_f16", "msda_encoder_fused", "attention_f16", "mask_bbox", "clip_crop_patches", "hungarian_link",
-       "topk_entropy"]
+       "topk_entropy", "gemm_nt_f16_ln", "gemm_nt_f16_res16_stats", "row_stats_f16", "row_stats_finalize"]
 
 
 def _mi():
@@ -51,6 +51,16 @@ def test_ops_are_registered_with_schemas_and_meta_kernels():
         outs = out if isinstance(out, (tuple, list)) else (out,)
         assert all(o.device.type == "meta" for o in outs), name
     assert mi.gemm_nt_f16(*_args("meta")["gemm_nt_f16"]).dtype == torch.float16
+    # the LayerNorm-folded CLIP GEMMs (shapes only: the real kernels take >= 256 tiles of 256 x 256, tests/test_gemm_gpu.py)
+    h = lambda *sh: torch.empty(*sh, dtype=torch.float16, device="meta")
+    f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device="meta")
+    st = mi.row_stats_f16(h(1970, 768))
+    assert tuple(st.shape) == (1970, 2) and st.dtype == torch.float32
+    o = mi.gemm_nt_f16_ln(h(1970, 768), h(2304, 768), f(2304), f(2304), st, 0)
+    assert tuple(o.shape) == (1970, 2304) and o.dtype == torch.float16
+    o, part = mi.gemm_nt_f16_res16_stats(h(1970, 768), h(768, 768), f(768), h(1970, 768))
+    assert tuple(o.shape) == (1970, 768) and o.dtype == torch.float16 and tuple(part.shape) == (1970, 12, 2) and part.dtype == torch.float32
+    assert tuple(mi.row_stats_finalize(part, 768).shape) == (1970, 2)
     assert tuple(mi.mask_bbox(*_args("meta")["mask_bbox"]).shape) == (2, 6, 4)
     assert tuple(mi.clip_crop_patches(*_args("meta")["clip_crop_patches"]).shape) == (3 * 4, 768)
     with pytest.raises((RuntimeError, NotImplementedError)):   # no CPU kernels: the product path has no CPU fallback

@@ -333,3 +333,76 @@ def test_192_row_tiles_on_ragged_shapes(gemm_modes, pp_tile_rows, M, N, K):
         assert ((outs[tm].double() - ref).abs() / scale).max().item() < 2.0 ** -15, tm
     # the same products in the same order per output element: the two tile heights agree to the last bit
     assert torch.equal(outs[192], outs[256])
+
+
+def _ln_problem(M, N, K, seed, big_mean):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, K, generator=g) * 1.5
+    if big_mean:                                            # rows with a large mean and one outlier channel: the cancellation case of the fold
+        x = x + torch.randn(M, 1, generator=g) * 4.0
+        x[:, 7] += 40.0
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    gamma = 1.0 + 0.3 * torch.randn(K, generator=g)
+    beta = 0.2 * torch.randn(K, generator=g)
+    return x.half().cuda(), w.cuda(), b.cuda(), gamma.cuda(), beta.cuda()
+
+
+@pytest.mark.parametrize("big_mean", [False, True])
+@pytest.mark.parametrize("M,N,K,act", [(8229, 2304, 768, 0), (7000, 3072, 768, 2), (70001, 1536, 768, 0), (20000, 3072, 1024, 2)])
+def test_layernorm_folded_into_the_fp16_gemm(M, N, K, act, big_mean):
+    """ln_1 -> in_proj / ln_2 -> c_fc (mask_adapted_clip/model.py:262-267) with the LayerNorm folded into the GEMM: from the raw fp16 rows,
+    rstd (x Wg^T - mean s) + c.  Checked against f64 on the same fp16 rows, against the LayerNorm kernel + plain GEMM (which rounds the
+    normalised rows to fp16 first: the fold must not be worse), and for run-to-run identity (the statistics travel by LDS-DMA)."""
+    from openvis_amd import ops
+    x, w, b, gamma, beta = _ln_problem(M, N, K, M + act, big_mean)
+    assert ops.gemm_nt_f16_ln_eligible(M, N, K, act)
+    wg, s, c = ops.fold_layernorm(w, b, gamma, beta)
+    st = ops.row_stats_f16(x)
+    outs = [ops.gemm_nt_f16_ln(x, wg, s, c, st, act) for _ in range(3)]
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    xd = x.double()
+    mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    assert (st[:, 0].double() - mu[:, 0]).abs().max().item() < 5e-6 and (st[:, 1].double() * torch.sqrt(var[:, 0] + 1e-5) - 1).abs().max().item() < 2e-6
+    ref = ((xd - mu) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()) @ w.double().T + b.double()
+    if act == 2:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    unfused = ops.gemm_nt_f16(ops.layernorm(x, gamma, beta, out_f16=True), ops.cast_f16(w), b, None, act, out_f16=True)
+    e_fold, e_unf = (outs[0].double() - ref).abs(), (unfused.double() - ref).abs()
+    assert (e_fold <= 2e-3 + 2.0 ** -9 * ref.abs()).all(), e_fold.max().item()
+    assert e_fold.mean().item() <= 1.05 * e_unf.mean().item(), (e_fold.mean().item(), e_unf.mean().item())
+
+
+def test_layernorm_fold_is_offered_only_where_the_ping_pong_kernel_runs():
+    from openvis_amd import ops
+    assert ops.gemm_nt_f16_ln_eligible(98500, 2304, 768) and ops.gemm_nt_f16_ln_eligible(98500, 3072, 768, ops.ACT_QUICKGELU)
+    assert not ops.gemm_nt_f16_ln_eligible(98500, 4096, 1024, ops.ACT_QUICKGELU)      # c and s of 4096 columns do not fit the LDS bias region
+    assert not ops.gemm_nt_f16_ln_eligible(700, 2304, 768)                            # fewer than 256 tiles: the small kernels
+    assert not ops.gemm_nt_f16_ln_eligible(98500, 2304, 768, ops.ACT_RELU)            # instantiated: none, QuickGELU
+    x, w, b, gamma, beta = _ln_problem(700, 2304, 768, 1, False)
+    wg, s, c = ops.fold_layernorm(w, b, gamma, beta)
+    with pytest.raises(ops._lib.OvisError if hasattr(ops._lib, "OvisError") else RuntimeError):
+        ops._lib.call("ovis_gemm_nt_f16_ln", x, ops._ll(768), wg, ops._ll(768), torch.empty(700, 2304, dtype=torch.float16, device="cuda"), ops._ll(2304),
+                      700, 2304, 768, c, s, ops.row_stats_f16(x), 0, ops._lib.stream_ptr())
+
+
+@pytest.mark.parametrize("M,N,K,tm", [(22000 + 37, 768, 768, 256), (22000 + 37, 768, 3072, 192), (66000 + 5, 768, 768, 0), (30000, 1024, 4096, 0)])
+def test_fp16_residual_gemm_also_emits_the_row_statistics(pp_tile_rows, M, N, K, tm):
+    """out_proj / c_proj on the fp16 stream: the epilogue's partial (sum, sum of squares) per 64-column piece give the next LayerNorm's
+    statistics without another pass over the stream; the output itself is bit-identical to the plain fp16-residual GEMM."""
+    from openvis_amd import ops
+    pp_tile_rows(tm)
+    g = torch.Generator().manual_seed(M)
+    a = torch.randn(M, K, generator=g).half().cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).half().cuda()
+    b = (torch.randn(N, generator=g) * 0.1).cuda()
+    r = (2 * torch.randn(M, N, generator=g) + 3 * torch.randn(M, 1, generator=g)).half().cuda()
+    ref = ops.gemm_nt_f16(a, w, b, r)
+    runs = [ops.gemm_nt_f16_res16_stats(a, w, b, r) for _ in range(3)]
+    assert all(st is not None and torch.equal(o, ref) and torch.equal(st, runs[0][1]) for o, st in runs)
+    two_pass = ops.row_stats_f16(ref)
+    st = runs[0][1]
+    assert (st[:, 0] - two_pass[:, 0]).abs().max().item() < 1e-5 and (st[:, 1] / two_pass[:, 1] - 1).abs().max().item() < 2e-5
+    # a problem the ping-pong kernel does not take: plain result, no statistics (callers fall back to row_stats_f16)
+    o2, s2 = ops.gemm_nt_f16_res16_stats(a[:700], w, b, r[:700].contiguous())
+    assert s2 is None and torch.equal(o2, ops.gemm_nt_f16(a[:700], w, b, r[:700].contiguous()))
