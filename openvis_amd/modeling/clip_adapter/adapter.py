@@ -159,15 +159,14 @@ class ClipVisual:
             else:
                 x = ops.gemm_nt_f16(f, wp, bp, x)
         x = x.view(B, L, C)
-        self._row_stats = (x, st) if fold_qkv else (None, None)
+        if fold_qkv and st is not None:
+            x._ovis_row_stats = st            # travels with THIS tensor object (no state on the model: clips in flight share the tower)
         return x
 
-    _row_stats = (None, None)
-
-    def _stats_for(self, x):
-        """statistics handed over by the GEMM that produced x (run_blocks), or None"""
-        t, st = self._row_stats
-        return st if t is x else None
+    @staticmethod
+    def _stats_for(x):
+        """statistics handed over by the GEMM that produced x (attached to the tensor by _run_blocks_stream16), or None"""
+        return getattr(x, "_ovis_row_stats", None)
 
     def last_block_cls(self, x, i):
         """resblock i evaluated for the CLASS TOKEN only -> f32 [B, C].  ln_post reads x[:, 0] alone (model.py:356-358), so in
