@@ -695,7 +695,7 @@ __global__ void __launch_bounds__(TY * TX)
 clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ masks, const int* __restrict__ crops,
                        void* __restrict__ Av, unsigned char* __restrict__ patch_open, int out_f16, int M, int Q, int T, int H,
                        int W, int h, int w, int Hp, int Wp, int R, int ps, long long lda, int PRmax, int PWmax, float m0,
-                       float m1, float m2, float s0, float s1, float s2) {
+                       float m1, float m2, float s0, float s1, float s2, int split_taps) {
   extern __shared__ uint2 patch[];                      // [PR][PW]: .x = r | g<<8 | b<<16, .y = bits of the soft mask
   __shared__ AxisW xtab[TX], ytab[TY];
   const int tiles_x = R / TX, tiles_y = R / TY;
@@ -726,6 +726,23 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
   const int xlo = min(max((int)floorf(fmaxf(x_first, 0.f)) - 1, 0), Wp - 1);
   const int yhi = min((int)floorf(fmaxf(y_last, 0.f)) + 1, Hp - 1);
   const int xhi = min((int)floorf(fmaxf(x_last, 0.f)) + 1, Wp - 1);
+  // a tile whose first sample already lies beyond the frame AND the padded mask (the square roi of a wide box reaches below the frame;
+  // of a tall box, right of it) has no valid sample (ra_prep rejects all of them): every bin is 0 * 0 -> the normalised zero pixel.
+  // Written here, before any staging, weight table or barrier (43 % of the tiles when every box is the whole 1280 x 736 frame).
+  if ((y_first > (float)max(H, Hp)) || (x_first > (float)max(W, Wp))) {
+    const int G = R / ps;
+    const long long row = (long long)m * G * G + (py / ps) * G + (px / ps);
+    const int col = (py % ps) * ps + (px % ps);
+    const float r0 = (0.f - m0) / s0, r1 = (0.f - m1) / s1, r2 = (0.f - m2) / s2;
+    if (out_f16) {
+      _Float16* ap = reinterpret_cast<_Float16*>(Av) + row * lda + col;
+      ap[0] = (_Float16)r0; ap[ps * ps] = (_Float16)r1; ap[2 * ps * ps] = (_Float16)r2;
+    } else {
+      float* ap = reinterpret_cast<float*>(Av) + row * lda + col;
+      ap[0] = r0; ap[ps * ps] = r1; ap[2 * ps * ps] = r2;
+    }
+    return;
+  }
   const int PR = min(max(yhi - ylo + 1, 1), PRmax), PW = min(max(xhi - xlo + 1, 1), PWmax);
   // odd row stride (in 8-byte elements): the 4 bin rows a wavefront covers read 4 different patch rows at similar
   // columns; with an even stride those rows alias to the same LDS banks (4-way conflicts on every tap read)
@@ -841,6 +858,23 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
     const AxisW& ey = ytab[tid / TX];
     const int fnx = ex.fn, fny = ey.fn, mnx = ex.mn, mny = ey.mn;
     const uint2* fbase = patch + ey.fbase * PWs + ex.fbase;
+    if (!split_taps && ex.fbase == ex.mbase && ey.fbase == ey.mbase && fnx == mnx && fny == mny) {
+      // interior bins: frame and mask taps are the same source pixels -- one LDS read per tap instead of two (each accumulator
+      // sees the same sequence of operations as in the two loops below: bit-identical)
+      for (int r = 0; r < fny; ++r) {
+        const uint2* row = fbase + r * PWs;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a = 0.f;
+        for (int c = 0; c < fnx; ++c) {
+          const uint2 pv = row[c];
+          const float wx = ex.fw[c];
+          a0 += wx * (float)(pv.x & 255u); a1 += wx * (float)((pv.x >> 8) & 255u); a2 += wx * (float)(pv.x >> 16);
+          a += ex.mw[c] * __uint_as_float(pv.y);
+        }
+        const float wy = ey.fw[r];
+        f0 += wy * a0; f1 += wy * a1; f2 += wy * a2;
+        mk += ey.mw[r] * a;
+      }
+    } else {
     for (int r = 0; r < fny; ++r) {
       const uint2* row = fbase + r * PWs;
       float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -858,6 +892,7 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
       float a = 0.f;
       for (int c = 0; c < mnx; ++c) a += ex.mw[c] * __uint_as_float(row[c].y);
       mk += ey.mw[r] * a;
+    }
     }
   }
   f0 /= count; f1 /= count; f2 /= count; mk /= count;
@@ -1272,7 +1307,7 @@ static int clip_crop_impl(const uint8_t* frames, const float* masks, const int* 
   auto args = [&](int ty) { return (int)ceilf((float)ty * bin_max) + 4; };
   const int p16 = args(16), p8 = args(8);
   const bool grid_ok = bin_max <= (float)CROP_GMAX;
-  if (g_crop_tile != 8 && grid_ok && resolution % 16 == 0 && (size_t)p16 * (p16 + 1) * 8 <= 76 * 1024) {
+  if ((g_crop_tile & 15) != 8 && grid_ok && resolution % 16 == 0 && (size_t)p16 * (p16 + 1) * 8 <= 76 * 1024) {
     // the attribute is per DEVICE (a process may drive several GPUs) and the ClipPipeline slot threads call this concurrently:
     // one atomic flag per device ordinal; setting it twice is harmless
     static std::atomic<bool> attr_set[64];
@@ -1286,11 +1321,11 @@ static int clip_crop_impl(const uint8_t* frames, const float* masks, const int* 
     }
     hipLaunchKernelGGL((clip_crop_tiled_kernel<16, 16>), dim3((unsigned)((long long)M * (resolution / 16) * (resolution / 16))), dim3(256),
                        (size_t)p16 * (p16 + 1) * 8, (hipStream_t)stream, frames, masks, crops, A, patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
-                       resolution, patch, lda, p16, p16, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
+                       resolution, patch, lda, p16, p16, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2], (g_crop_tile >> 4) & 1);
   } else if (grid_ok && resolution % 8 == 0 && (size_t)p8 * (p8 + 1) * 8 <= 64 * 1024) {
     hipLaunchKernelGGL((clip_crop_tiled_kernel<8, 8>), dim3((unsigned)((long long)M * (resolution / 8) * (resolution / 8))), dim3(64),
                        (size_t)p8 * (p8 + 1) * 8, (hipStream_t)stream, frames, masks, crops, A, patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
-                       resolution, patch, lda, p8, p8, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
+                       resolution, patch, lda, p8, p8, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2], (g_crop_tile >> 4) & 1);
   } else {
     const long long total = (long long)M * resolution * resolution;
     hipLaunchKernelGGL(clip_crop_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, frames, masks, crops, A,

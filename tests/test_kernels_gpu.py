@@ -420,3 +420,33 @@ def test_clip_patch14_tower_and_crops_vs_oracle(precision, tol):
         ref = 100.0 * feat @ text.T
     assert (valid == v2.numpy()).all()
     assert (logits.cpu() - ref).abs().max().item() < tol * 100, (logits.cpu() - ref).abs().max().item()
+
+
+def test_crop_kernel_merged_taps_and_out_of_frame_tiles():
+    """clip_crop_tiled_kernel: (a) interior bins read a source pixel once for the frame AND the mask tap -- bit-identical to the two
+    separate loops (lab switch ovis_crop_tile(16)); (b) tiles of a square roi that lie wholly below / right of the frame are written
+    without staging -- the same values as the untiled kernel gives (0 * 0 -> the normalised zero pixel), on wide, tall and small boxes."""
+    from openvis_amd import ops
+    from openvis_amd import _lib
+    T, Q, H, W, Hp, Wp = 2, 6, 360, 640, 384, 640
+    g = torch.Generator().manual_seed(11)
+    frames = (torch.rand(T, 3, H, W, generator=g) * 255).to(torch.uint8).cuda()
+    masks = (torch.randn(Q, T, Hp // 4, Wp // 4, generator=g) * 2).cuda()
+    boxes = [[0, 0, 0, 0, Wp - 1, Hp - 1], [1, 1, 0, 0, W - 1, H - 1], [0, 2, 5, 7, 604, 100], [1, 3, 560, 3, 600, 350], [0, 4, 50, 60, 90, 95],
+             [1, 5, 600, 300, 639, 359]]
+    cr = torch.tensor(boxes, dtype=torch.int32).cuda()
+    mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+    try:
+        merged = ops.clip_crop_patches(frames, masks, cr, Hp, Wp, 224, 16, mean, std, out_f16=False)
+        _lib.call("ovis_crop_tile", 16)
+        split = ops.clip_crop_patches(frames, masks, cr, Hp, Wp, 224, 16, mean, std, out_f16=False)
+    finally:
+        _lib.call("ovis_crop_tile", 0)
+    assert torch.equal(merged, split)
+    # wide box 0: the roi is 640 x 640 on a 384-row mask / 360-row frame -> bin rows >= 224 * 384 / 640 = 134.4 see no sample at all
+    P = merged.view(len(boxes), 14, 14, 3, 16, 16)
+    zero = ((torch.zeros(3) - torch.tensor(mean)) / torch.tensor(std)).cuda().view(1, 3, 1, 1)          # f32 arithmetic, as in the kernel
+    assert torch.equal(P[0, 9:], zero.expand(5, 14, 3, 16, 16))
+    assert not torch.equal(P[0, 7], P[0, 13])
+    # tall box 3 (41 x 348 -> roi 348 wide from x = 560): bins from (640 - 560) / (348 / 224) = 51.5 on lie right of the frame
+    assert torch.equal(P[3, :, 4:], zero.expand(14, 10, 3, 16, 16)) and not torch.equal(P[3, :, 3], P[3, :, 4])
