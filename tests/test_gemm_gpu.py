@@ -406,3 +406,24 @@ def test_fp16_residual_gemm_also_emits_the_row_statistics(pp_tile_rows, M, N, K,
     # a problem the ping-pong kernel does not take: plain result, no statistics (callers fall back to row_stats_f16)
     o2, s2 = ops.gemm_nt_f16_res16_stats(a[:700], w, b, r[:700].contiguous())
     assert s2 is None and torch.equal(o2, ops.gemm_nt_f16(a[:700], w, b, r[:700].contiguous()))
+
+
+def test_folded_gemm_race_screen_under_memory_traffic():
+    """The statistics of the LayerNorm-folded GEMM reach LDS by LDS-DMA behind counted vmcnt waits: a misplaced wait would show as rare
+    run-to-run differences that depend on memory latency.  Repeat the launch while a side stream streams 512 MB copies through HBM."""
+    from openvis_amd import ops
+    big_a = torch.empty(512 * 1024 * 1024, dtype=torch.uint8, device="cuda")
+    big_b = torch.empty_like(big_a)
+    side = torch.cuda.Stream()
+    for (M, N, K, act) in [(98500, 2304, 768, 0), (33333, 3072, 768, 2)]:
+        x, w, b, gamma, beta = _ln_problem(M, N, K, 7, True)
+        wg, s, c = ops.fold_layernorm(w, b, gamma, beta)
+        st = ops.row_stats_f16(x)
+        ref = ops.gemm_nt_f16_ln(x, wg, s, c, st, act).clone()
+        torch.cuda.synchronize()
+        for it in range(40):
+            if it % 2 == 0:
+                with torch.cuda.stream(side):
+                    big_b.copy_(big_a, non_blocking=True)
+            assert torch.equal(ops.gemm_nt_f16_ln(x, wg, s, c, st, act), ref), (M, N, K, it)
+        torch.cuda.synchronize()
