@@ -125,6 +125,10 @@ def get_cfg():
                              # max |cos error| 9.7e-5 against 5.2e-5 with "fp32", bound 1e-3; profiles/r02/logit_bound.txt),
                              # half the residual / LayerNorm traffic of the tower
                              "RESIDUAL_STREAM": "fp16",
+                             # not a reference key: with the fp16 stream, ln_1 / ln_2 are folded into in_proj / c_fc and their statistics
+                             # come out of the epilogue of out_proj / c_proj (one fp16 rounding LESS than LayerNorm kernel + GEMM; -1.0 ms
+                             # per 720p clip); False = LayerNorm kernels (the round-2 arithmetic)
+                             "FOLD_LAYERNORM": True,
                              # SideAdapter (SAN / SANOnline / BriVIS) tower: "auto" = fp32 (see BACKBONE_PRECISION)
                              "SIDE_PRECISION": "auto"},
         },

@@ -19,4 +19,5 @@ def build_clip_adapter(cfg):
     else:
         raise NotImplementedError(f"clip adapter {cfg.NAME} is not in ADAPTER_REGISTER {sorted(ADAPTER_REGISTER)}")
     ad.visual.stream16 = precision == "fp16" and stream == "fp16"
+    ad.visual.fold_ln = bool(cfg.get("FOLD_LAYERNORM", True))
     return ad

@@ -23,6 +23,10 @@ def test_yaml_base_inheritance_and_overrides(tmp_path):
     assert cfg.MODEL.META_ARCHITECTURE == "BriVIS" and cfg.MODEL.RESNETS.DEPTH == 50
     assert cfg.INPUT.MIN_SIZE_TEST == 480 and cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES == 200
     assert cfg.MODEL.CLIP_ADAPTER.MERGE_IDS == [6, 12, 18]
+    # extension keys of the CLIP tower: defaults and override syntax
+    assert cfg.MODEL.CLIP_ADAPTER.RESIDUAL_STREAM == "fp16" and cfg.MODEL.CLIP_ADAPTER.FOLD_LAYERNORM is True
+    cfg.merge_from_list(["MODEL.CLIP_ADAPTER.FOLD_LAYERNORM", "False"])
+    assert cfg.MODEL.CLIP_ADAPTER.FOLD_LAYERNORM is False
 
 
 def test_registry_names_of_the_reference_surface():
