@@ -499,8 +499,10 @@ def main():
                        "precision": (f"backbone GEMM operands {bb_prec}" + (" / f32 accumulate (the reference's autocast)" if bb_prec == "fp16" else
                                      " (exact 3-way bf16 split on the bf16 MFMA)") + "; pixel decoder, masked-attention decoder, masks and "
                                      "logits f32; CLIP ViT GEMM operands " +
-                                     ("fp16 with f32 accumulation (the reference's GPU CLIP dtype)" if _model.clip_adapter.precision == "fp16"
-                                      else "f32") + (f"; resampler {_model.resampler.precision}" if hasattr(_model, "resampler") else "")
+                                     ("fp16 with f32 accumulation (the reference's GPU CLIP dtype)"
+                                      + (", ln_1 / ln_2 folded into in_proj / c_fc with f32 statistics" if getattr(getattr(_model.clip_adapter, "visual", None), "fold_ln", False)
+                                         and getattr(_model.clip_adapter.visual, "stream16", False) else "")
+                                      if _model.clip_adapter.precision == "fp16" else "f32") + (f"; resampler {_model.resampler.precision}" if hasattr(_model, "resampler") else "")
                                      + f"; large f32 GEMMs/convs as {f32_split} on the bf16 MFMA (MODEL.F32_GEMM_SPLIT)"),
                        "valid_crops_per_clip": n_valid,
                        "parallelism": (f"frame-sharded x{world} + RCCL all-gather" if frame_sharded else f"clip-replicas x{world}")
