@@ -149,6 +149,17 @@ int ovis_set_f16_gemm_mode(int mode, int raster_group, int desync_ns);
 const char* ovis_gemm_nt_f16_kernel(const void* C, long long lda, long long ldb, long long ldc, int M, int N, int K,
                                     const float* bias, const float* residual, long long ldr, int act, int out_f16);
 
+/* ovis_gemm_nt_f32_w3 followed by LayerNorm over the N == 256 columns, in ONE kernel: C = LayerNorm(A W^T + b + R) * gamma + beta -- the
+ * post-norm of the pixel decoder's encoder layers (msdeformattn.py:139-146: norm1 after output_proj + residual, norm2 after linear2 +
+ * residual).  A 256-column tile of the ping-pong f32-A kernel holds whole rows, so its epilogue normalises them before they are stored
+ * (statistics in f32, single pass, clamped variance).  Only where ovis_gemm_nt_f32_w3_ln_eligible != 0 (f32-GEMM mode 2 = bf16x2, a shape
+ * the ping-pong kernel takes, N == 256, a residual); otherwise callers run ovis_gemm_nt_f32_w3 and ovis_layernorm_f32. */
+int ovis_gemm_nt_f32_w3_ln_eligible(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C, long long ldc,
+                                    int M, int N, int K, const float* bias, const float* residual, long long ldr);
+int ovis_gemm_nt_f32_w3_ln(const float* A, long long lda, const void* W3, long long ldb, long long plane, float* C, long long ldc, int M, int N,
+                           int K, const float* bias, const float* residual, long long ldr, const float* gamma, const float* beta, float eps,
+                           ovis_stream_t stream);
+
 /* Name of the kernel ovis_gemm_nt_f32_w3 (and the 1x1 / stride 1 / pad 0 case of ovis_conv2d_nhwc_f32_w3) launches when it is the
  * ping-pong kernel's f32-A mode -- bf16x2 (mode 2) on shapes of >= 256 tiles of 256x256 with K % 32 == 0 and <= 35 % padded
  * columns --, "" when it is gemm_f32x3_kernel / gemm_f32_kernel (static string; for profiles and bench.py's roofline). */

@@ -86,6 +86,9 @@ struct PPArgs {
   const float* ln_s = nullptr;              // LNF: [N] row sums of the gamma-folded weight (f32)
   float* ln_part = nullptr;                 // PSTAT: [M][ln_pslots][2] partial (sum, sum of squares) of the fp16 output rows, one slot per
   int ln_pslots = 0;                        //        (N tile, wavefront column): slot = 4 * (N tile) + wc
+  const float* lno_gamma = nullptr;         // LNO: LayerNorm weight / bias [N] applied to the output rows (N == 256: a tile holds whole rows)
+  const float* lno_beta = nullptr;
+  float lno_eps = 0.f;
 };
 
 #define PP_GLDS(src, dst) \
@@ -122,9 +125,16 @@ struct PPArgs {
 // PSTAT (fp16 residual GEMMs): the epilogue also emits, per output row and per (N tile, wavefront column), the sum and the sum of squares
 //      of the 64 fp16 values it stores -- the LayerNorm statistics of the NEXT block's ln are then a 12-term sum per row
 //      (row_stats_finalize_kernel) instead of a pass over the 151 MB residual stream.  Deterministic: fixed slots, fixed order.
-template <int OUT, int ACT, bool HAS_R, bool X3, bool FA = false, bool R16 = false, int TM = 256, int EPI = 0, bool LNF = false, bool PSTAT = false>
+// LNO (f32 output, N == 256): C = LayerNorm(A W^T + b + R) -- the post-norm of the pixel decoder's encoder layers (msdeformattn.py:139-146
+//      after output_proj / linear2): a 256-column tile holds whole rows, so the epilogue normalises them before they are stored and
+//      the LayerNorm kernel's pass over the [M, 256] tensor (99 MB in, 99 MB out per launch at 720p) disappears.  Row sums of the four
+//      wavefront columns meet in LDS (8 KB of the bias region) across one extra workgroup barrier inside the epilogue -- both wave groups
+//      run their epilogue in the same slot, so the barrier counts of the two groups stay equal.  Single pass (E[x^2] - mean^2) in f32.
+template <int OUT, int ACT, bool HAS_R, bool X3, bool FA = false, bool R16 = false, int TM = 256, int EPI = 0, bool LNF = false, bool PSTAT = false,
+          bool LNO = false>
 __global__ void __launch_bounds__(512)
 gemm_f16_pp_kernel(const PPArgs p) {
+  static_assert(!LNO || (OUT == 0 && !X3 && ACT == 0 && EPI == 0), "LNO: f32 output, no activation");
   static_assert(!PSTAT || (R16 && (EPI & 1)), "PSTAT: fp16 residual GEMM with the full-line epilogue");
   static_assert(!LNF || (OUT == 1 && !HAS_R && !X3 && !FA && TM == 256 && (EPI & 1)), "LNF: fp16 output, full-line epilogue, 256-row tiles");
   static_assert(EPI == 0 || (OUT == 1 && !X3 && (!HAS_R || R16)), "EPI variants: fp16 output (fp16 residual or none)");
@@ -169,6 +179,11 @@ gemm_f16_pp_kernel(const PPArgs p) {
   if constexpr (LNF)
     for (int i = tid * 4; i < p.N; i += 512 * 4)
       *reinterpret_cast<float4*>(lds + PP_BIAS + (p.N + i) * 4) = *reinterpret_cast<const float4*>(p.ln_s + i);
+  if constexpr (LNO)                                               // N == 256: bias [0,1 KB), gamma [1,2 KB), beta [2,3 KB), row partials [4,12 KB)
+    for (int i = tid * 4; i < p.N; i += 512 * 4) {
+      *reinterpret_cast<float4*>(lds + PP_BIAS + (p.N + i) * 4) = *reinterpret_cast<const float4*>(p.lno_gamma + i);
+      *reinterpret_cast<float4*>(lds + PP_BIAS + (2 * p.N + i) * 4) = *reinterpret_cast<const float4*>(p.lno_beta + i);
+    }
   for (int i = tid; i < n_my; i += 512) {
     int tm, tn;
     tile_mn(first + i * nblk, tm, tn);
@@ -498,6 +513,54 @@ gemm_f16_pp_kernel(const PPArgs p) {
         *reinterpret_cast<f32x4*>(c) = x0; *reinterpret_cast<f32x4*>(c + 16) = x1;
       }
     };
+    if constexpr (LNO) {
+      // phase 1: this wavefront's share (64 columns) of every row's sum and sum of squares -> LDS [row][wc]
+      const unsigned pbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(lds + PP_BIAS + 4096) + (unsigned)((wr * GS + l15) * 32 + wc * 8);
+#pragma unroll
+      for (int mb = 0; mb < MBT; ++mb) {
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float v = acc[mb][nb][e]; sm += v; sq = __builtin_fmaf(v, v, sq); }
+        auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(sm), __float_as_uint(sm), false, false);
+        sm = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+        r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
+        sq = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+        auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(sm), __float_as_uint(sm), false, false);
+        sm = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+        r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
+        sq = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+        const f32x2 pr = {sm, sq};
+        const unsigned addr = pbase + (unsigned)mb * 512u;              // 16 rows x 32 bytes per row block
+        if (q == 0) asm volatile("ds_write_b64 %0, %1" :: "v"(addr), "v"(pr) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PP_BARRIER();
+      // phase 2: totals of the lane's rows, normalise, store
+      const unsigned gaddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(lds + PP_BIAS) + (unsigned)((p.N + col0) * 4);
+      const unsigned rbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(lds + PP_BIAS + 4096) + (unsigned)((wr * GS + l15) * 32);
+#pragma unroll
+      for (int mb = 0; mb < MBT; ++mb) {
+        f32x4 t0, t1;                                                 // (sum, sq) of wavefront columns 0, 1 | 2, 3
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t0), "=&v"(t1) : "v"(rbase + (unsigned)mb * 512u) : "memory");
+        const float S1 = (t0[0] + t0[2]) + (t1[0] + t1[2]), S2 = (t0[1] + t0[3]) + (t1[1] + t1[3]);
+        const float mean = S1 * (1.f / 256.f);
+        const float var = fmaxf(S2 * (1.f / 256.f) - mean * mean, 0.f);
+        const float rstd = 1.f / sqrtf(var + p.lno_eps);
+        // gamma / beta of the lane's 16 columns, re-read per row block (eight LDS reads in flight, one wait): held across the whole
+        // epilogue they cost 32 registers on top of the accumulators and spill
+        f32x4 gm[4], bt[4];
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:128\n\tds_read_b128 %3, %8 offset:144\n\t"
+                     "ds_read_b128 %4, %8 offset:1024\n\tds_read_b128 %5, %8 offset:1040\n\tds_read_b128 %6, %8 offset:1152\n\tds_read_b128 %7, %8 offset:1168\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(gm[0]), "=&v"(gm[1]), "=&v"(gm[2]), "=&v"(gm[3]), "=&v"(bt[0]), "=&v"(bt[1]), "=&v"(bt[2]), "=&v"(bt[3]) : "v"(gaddr) : "memory");
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (acc[mb][nb] - mean) * rstd * gm[nb] + bt[nb];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) put(mb, j);
+      }
+    } else {
 #pragma unroll
     for (int mb = 0; mb < MBT; ++mb) {
       if constexpr (EPI & 1) put_lines(mb);
@@ -505,6 +568,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) put(mb, j);
       }
+    }
     }
   };
   // ... followed by the start value of the next tile's accumulators: bias + residual (gemm_epilogue.h) or zero
@@ -879,13 +943,18 @@ bool gemm_f32a_pp_eligible(const float* A, long long lda, const void* W3, long l
 }
 
 int gemm_f32a_pp_launch(const float* A, long long lda, const void* W3, long long ldb, long long plane, float* C, long long ldc, int M, int N,
-                        int K, const float* bias, const float* residual, long long ldr, int act, hipStream_t s) {
+                        int K, const float* bias, const float* residual, long long ldr, int act, hipStream_t s,
+                        const float* ln_gamma = nullptr, const float* ln_beta = nullptr, float ln_eps = 0.f) {
   PPArgs p;
+  p.lno_gamma = ln_gamma; p.lno_beta = ln_beta; p.lno_eps = ln_eps;
   p.A = reinterpret_cast<const _Float16*>(A); p.B = reinterpret_cast<const _Float16*>(W3); p.C = C; p.bias = bias; p.R = residual;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.M = M; p.N = N; p.K = K; p.act = act;
   p.planeA = 0; p.planeB = plane * 2; p.planeC = 0;                  // bytes
   p.tiles_n = (int)cdiv(N, 256);
-  const int tm = pp_pick_tm(M, p.tiles_n);
+  // LNO runs on 192-row tiles only: with 128 accumulator registers (256-row tiles) the LayerNorm epilogue spills ~80 registers per tile,
+  // which costs what the fused LayerNorm saves (BriVIS, M = 695 520: no gain); 192-row tiles cost <= 9 % more GEMM time there and spill 9
+  const int tm = ln_gamma ? ((long long)cdiv(M, 192) * p.tiles_n <= 256ll * PP_MAX_TILES ? 192 : 0) : pp_pick_tm(M, p.tiles_n);
+  if (tm == 0) return fail(OVIS_EINVAL, "gemm_nt_f32_w3_ln: too many tiles (M=%d)", M);
   p.tiles_m = (int)cdiv(M, tm); p.n_tiles = p.tiles_m * p.tiles_n;
   const int groups = (int)cdiv(p.tiles_n, g_pp_grp > 0 ? g_pp_grp : p.tiles_n);
   p.grp_w = p.tiles_n / groups; p.grp_rem = p.tiles_n % groups;
@@ -895,6 +964,11 @@ int gemm_f32a_pp_launch(const float* A, long long lda, const void* W3, long long
   const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
 #define PP_LAUNCH(A_, R_) do { if (tm == 192) hipLaunchKernelGGL((gemm_f16_pp_kernel<0, A_, R_, false, true, false, 192>), dim3(grid), dim3(512), 0, s, p); \
                                else hipLaunchKernelGGL((gemm_f16_pp_kernel<0, A_, R_, false, true>), dim3(grid), dim3(512), 0, s, p); } while (0)
+  if (ln_gamma) {                                                   // LayerNorm of the output rows in the epilogue (LNO): N == 256, residual, no activation
+    if (N != 256 || !residual || act != 0 || !ln_beta) return fail(OVIS_EINVAL, "gemm_nt_f32_w3_ln: needs N == 256, a residual and act == 0");
+    hipLaunchKernelGGL((gemm_f16_pp_kernel<0, 0, true, false, true, false, 192, 0, false, false, true>), dim3(grid), dim3(512), 0, s, p);
+    return check_launch("gemm_nt_f32 (ping-pong, f32 A, bf16x2, LayerNorm epilogue)");
+  }
   if (residual) { if (act == 1) PP_LAUNCH(1, true); else PP_LAUNCH(0, true); }
   else if (act == 1) PP_LAUNCH(1, false);
   else if (act == 2) PP_LAUNCH(2, false);

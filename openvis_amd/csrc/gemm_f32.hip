@@ -186,7 +186,7 @@ int x3_planes() { return g_f32_gemm_mode == 2 ? 2 : 3; }
 bool gemm_f32a_pp_eligible(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C, long long ldc,
                            int M, int N, int K, const float* bias, const float* residual, long long ldr, int act);
 int gemm_f32a_pp_launch(const float* A, long long lda, const void* W3, long long ldb, long long plane, float* C, long long ldc, int M, int N,
-                        int K, const float* bias, const float* residual, long long ldr, int act, hipStream_t s);
+                        int K, const float* bias, const float* residual, long long ldr, int act, hipStream_t s, const float* ln_gamma = nullptr, const float* ln_beta = nullptr, float ln_eps = 0.f);
 }
 namespace ovis {   // gemm_f32_skinny.hip
 bool gemm_f32_skinny_eligible(const float* A, long long lda, const float* B, long long ldb, int M, int N, int K);
@@ -283,6 +283,25 @@ extern "C" int ovis_gemm_nt_f32_w3(const float* A, long long lda, const float* B
     return ovis::gemm_f32a_pp_launch(A, lda, W3, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream);
   ovis::launch_gemm_f32x3_w3(DenseA<true>{A, lda, M, K}, W3, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream);
   return ovis::check_launch("gemm_f32x3 (pre-split weights)");
+}
+
+// C = LayerNorm(A W^T + b + R) over the N == 256 columns of every row, the LayerNorm inside the GEMM's epilogue (gemm_f16_pp.hip, LNO): the
+// bf16x2 policy's ping-pong f32-A kernel only; ovis_gemm_nt_f32_w3_ln_eligible says whether this problem takes it (else: GEMM + LayerNorm)
+extern "C" int ovis_gemm_nt_f32_w3_ln_eligible(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C,
+                                               long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr) {
+  const bool veca = (K % 8 == 0) && ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0) && ldb % 8 == 0 && (((uintptr_t)W3 & 15) == 0) && plane % 8 == 0;
+  return (veca && N == 256 && residual && g_f32_gemm_mode == 2 && g_f32a_pp &&
+          ovis::gemm_f32a_pp_eligible(A, lda, W3, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, 0)) ? 1 : 0;
+}
+
+extern "C" int ovis_gemm_nt_f32_w3_ln(const float* A, long long lda, const void* W3, long long ldb, long long plane, float* C, long long ldc, int M,
+                                      int N, int K, const float* bias, const float* residual, long long ldr, const float* gamma,
+                                      const float* beta, float eps, ovis_stream_t stream) {
+  OVIS_REQUIRE(A && W3 && C && residual && gamma && beta, "gemm_nt_f32_w3_ln: null pointer");
+  OVIS_REQUIRE(((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0, "gemm_nt_f32_w3_ln: gamma / beta must be 16-byte aligned");
+  OVIS_REQUIRE(ovis_gemm_nt_f32_w3_ln_eligible(A, lda, W3, ldb, plane, C, ldc, M, N, K, bias, residual, ldr),
+               "gemm_nt_f32_w3_ln: not a problem of the bf16x2 ping-pong kernel with N == 256 (M=%d N=%d K=%d): run the GEMM and the LayerNorm separately", M, N, K);
+  return ovis::gemm_f32a_pp_launch(A, lda, W3, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, 0, (hipStream_t)stream, gamma, beta, eps);
 }
 
 extern "C" int ovis_conv2d_nhwc_f32_w3(const float* x, const float* w, const void* w3, long long plane, float* y, int N, int H, int W,

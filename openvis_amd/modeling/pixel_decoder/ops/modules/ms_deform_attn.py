@@ -55,13 +55,16 @@ class MSDeformAttn:
                                          loc.contiguous(), aw.contiguous(), self.im2col_step)
         return ops.gemm_nt(out, self.w["output_proj.weight"], self.w["output_proj.bias"], cw=True)
 
-    def forward_encoder_fused(self, query, src, spatial_shapes, level_start_index, residual, shapes_host=None):
+    def forward_encoder_fused(self, query, src, spatial_shapes, level_start_index, residual, shapes_host=None, norm=None):
         """Encoder fast path: value_proj + fused [offsets|weights] GEMM + fused softmax/location/sampling kernel +
-        output_proj with the residual add fused.  Reference points are the encoder's (msdeformattn.py:155-168)."""
+        output_proj with the residual add fused.  Reference points are the encoder's (msdeformattn.py:155-168).
+        norm = (gamma, beta): also the layer's norm1 over the result (ops.gemm_nt_layernorm)."""
         value = ops.gemm_nt(src, self.w["value_proj.weight"], self.w["value_proj.bias"], cw=True)
         oa = ops.gemm_nt(query, self.w["oa.weight"], self.w["oa.bias"], cw=True)
         samp = ops.msda_encoder_fused(value, oa, spatial_shapes, level_start_index, self.n_heads, self.n_levels,
                                       self.n_points, shapes_host=shapes_host)
+        if norm is not None:
+            return ops.gemm_nt_layernorm(samp, self.w["output_proj.weight"], self.w["output_proj.bias"], residual, norm[0], norm[1])
         return ops.gemm_nt(samp, self.w["output_proj.weight"], self.w["output_proj.bias"], residual, cw=True)
 
     __call__ = forward

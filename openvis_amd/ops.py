@@ -144,6 +144,29 @@ def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None, cw
     return out.view(*a.shape[:-1], N)
 
 
+def gemm_nt_layernorm(a, w, bias, residual, gamma, beta, eps=1e-5):
+    """LayerNorm(a w^T + bias + residual) over the last dimension (post-norm of the pixel decoder's encoder layers, msdeformattn.py:139-146).
+    Where the bf16x2 ping-pong kernel takes the GEMM and N == 256, the LayerNorm runs in that kernel's epilogue (ovis_gemm_nt_f32_w3_ln:
+    the [M, N] tensor makes one trip to memory instead of three); otherwise gemm_nt + layernorm -- the same arithmetic up to the order
+    of the f32 row sums."""
+    K = a.shape[-1]
+    N = w.shape[0]
+    a2 = a.reshape(-1, K)
+    r2 = residual.reshape(-1, N)
+    _chk(a2, w, bias, r2, gamma, beta)
+    M = a2.shape[0]
+    if w.is_contiguous() and N == 256 and _MODE.v == 2 and K % 8 == 0 and ((M + 127) // 128) * ((N + 127) // 128) >= 256:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        w3 = w3_of(w)
+        if _lib.lib().ovis_gemm_nt_f32_w3_ln_eligible(_lib._conv(a2), _ll(K), _lib._conv(w3), _ll(K), _ll(w.numel()), _lib._conv(out), _ll(N), M, N, K,
+                                                      _lib._conv(bias), _lib._conv(r2), _ll(N)):
+            with _Prof("gemm_f16_pp_kernel<0,0,true,false,true,false>", 2.0 * M * N * K):
+                _lib.call("ovis_gemm_nt_f32_w3_ln", a2, _ll(K), w3, _ll(K), _ll(w.numel()), out, _ll(N), M, N, K, bias, r2, _ll(N), gamma, beta,
+                          ctypes.c_float(eps), _lib.stream_ptr())
+            return out.view(*a.shape[:-1], N)
+    return layernorm(gemm_nt(a, w, bias, residual, cw=True), gamma, beta, eps=eps)
+
+
 def gemm_nt_f16(a, w, bias=None, residual=None, act=ACT_NONE, out_f16=False):
     """fp16 a [...,K] x fp16 w [N,K] -> f32 (or fp16) [...,N]; f32 accumulation / bias / residual."""
     K = a.shape[-1]

@@ -427,3 +427,34 @@ def test_folded_gemm_race_screen_under_memory_traffic():
                     big_b.copy_(big_a, non_blocking=True)
             assert torch.equal(ops.gemm_nt_f16_ln(x, wg, s, c, st, act), ref), (M, N, K, it)
         torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,K", [(96600, 256), (96600, 1024), (100000 + 3, 256), (695520, 512)])
+def test_layernorm_in_the_epilogue_of_the_bf16x2_gemm(gemm_modes, M, K):
+    """Post-norm of the pixel decoder's encoder layers (msdeformattn.py:139-146): LayerNorm(a W^T + b + residual) with the LayerNorm in the
+    epilogue of the ping-pong f32-A kernel (N = 256: a tile holds whole rows) against the same GEMM followed by the LayerNorm kernel, and
+    against f64; run-to-run identical (the row sums of the four wavefront columns meet in LDS across a barrier)."""
+    from openvis_amd import ops
+    gemm_modes.set_f32_gemm_mode(2)
+    N = 256
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = (0.1 * torch.randn(N, generator=g)).cuda()
+    r = (2 * torch.randn(M, N, generator=g) + torch.randn(M, 1, generator=g)).cuda()
+    gamma, beta = (1 + 0.3 * torch.randn(N, generator=g)).cuda(), (0.2 * torch.randn(N, generator=g)).cuda()
+    w3 = ops.w3_of(w)
+    ll = ops._ll
+    assert ops._lib.lib().ovis_gemm_nt_f32_w3_ln_eligible(ops._lib._conv(a), ll(K), ops._lib._conv(w3), ll(K), ll(w.numel()), ops._lib._conv(r), ll(N),
+                                                          M, N, K, ops._lib._conv(b), ops._lib._conv(r), ll(N)) == 1
+    outs = [ops.gemm_nt_layernorm(a, w, b, r, gamma, beta) for _ in range(3)]
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    two = ops.layernorm(ops.gemm_nt(a, w, b, r, cw=True), gamma, beta)
+    ref = torch.nn.functional.layer_norm(a.double() @ w.double().T + b.double() + r.double(), (N,), gamma.double(), beta.double(), 1e-5)
+    e_fused, e_two = (outs[0].double() - ref).abs().max().item(), (two.double() - ref).abs().max().item()
+    assert (outs[0] - two).abs().max().item() < 2e-5                    # same GEMM values, statistics in a different f32 order
+    assert e_fused < 1.2 * e_two + 1e-5, (e_fused, e_two)
+    # exact-f32 policy: no ping-pong kernel -> the two-kernel form, transparently
+    gemm_modes.set_f32_gemm_mode(1)
+    assert torch.equal(ops.gemm_nt_layernorm(a[:3000], w, b, r[:3000].contiguous(), gamma, beta),
+                       ops.layernorm(ops.gemm_nt(a[:3000], w, b, r[:3000].contiguous(), cw=True), gamma, beta))
