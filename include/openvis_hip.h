@@ -130,6 +130,10 @@ int ovis_layernorm_f32_to_f16(const float* x, const float* residual, const float
 int ovis_groupnorm_nhwc_f32(const float* x, float* y, const float* gamma, const float* beta, double* stats_ws,
                             int N, int H, int W, int C, int G, float eps, int relu, const float* up_add, int UH,
                             int UW, ovis_stream_t stream);
+/* ... written into a zero-padded map y_padded [N][H+2][W+2][C] (ring of zeros stored by the same kernel): the input of ovis_conv3x3_padded_f32_w3 */
+int ovis_groupnorm_nhwc_f32_padded(const float* x, float* y_padded, const float* gamma, const float* beta, double* stats_ws,
+                                   int N, int H, int W, int C, int G, float eps, int relu, const float* up_add, int UH,
+                                   int UW, ovis_stream_t stream);
 /* out[i] = a[i] + b[i % nb]  (src + pos with pos shared by all frames; msdeformattn.py:138 with_pos_embed). */
 int ovis_add_bcast_f32(const float* a, const float* b, float* out, long long n, long long nb, ovis_stream_t stream);
 /* Sine position encodings, channel-last: 2-D (pixel_decoder/position_encoding.py:29-53) -> out [H,W,2*npf] with T=1,
@@ -159,6 +163,16 @@ int ovis_gemm_nt_f32_w3_ln_eligible(const float* A, long long lda, const void* W
 int ovis_gemm_nt_f32_w3_ln(const float* A, long long lda, const void* W3, long long ldb, long long plane, float* C, long long ldc, int M, int N,
                            int K, const float* bias, const float* residual, long long ldr, const float* gamma, const float* beta, float eps,
                            ovis_stream_t stream);
+
+/* 3x3 / stride 1 / pad 1 convolution (the FPN output convolutions, msdeformattn.py:287-296, 372) over an input that is ALREADY zero-padded:
+ * xpad f32 [T][H+2][W+2][Cin] (ovis_groupnorm_nhwc_f32_padded writes it), w3 = the bf16 planes of w [Cout][3][3][Cin], y f32 [T][H][W][Cout].
+ * The ping-pong f32-A kernel walks the padded image as a dense GEMM (M = T H W, K = 9 Cin): per-lane row bases, a wave-uniform tap offset per
+ * K step, the LDS-DMA pipeline of the GEMM -- instead of the gathering im2col loader.  bf16x2 policy, Cin % 32 == 0, shapes the ping-pong
+ * kernel takes (ovis_conv3x3_padded_f32_w3_eligible != 0); act 0 / 1 (ReLU); otherwise callers use ovis_conv2d_nhwc_f32_w3. */
+int ovis_conv3x3_padded_f32_w3_eligible(const float* xpad, const void* w3, long long plane, const float* y, int T, int H, int W, int Cin,
+                                        int Cout, const float* bias, int act);
+int ovis_conv3x3_padded_f32_w3(const float* xpad, const void* w3, long long plane, float* y, int T, int H, int W, int Cin, int Cout,
+                               const float* bias, int act, ovis_stream_t stream);
 
 /* Name of the kernel ovis_gemm_nt_f32_w3 (and the 1x1 / stride 1 / pad 0 case of ovis_conv2d_nhwc_f32_w3) launches when it is the
  * ping-pong kernel's f32-A mode -- bf16x2 (mode 2) on shapes of >= 256 tiles of 256x256 with K % 32 == 0 and <= 35 % padded

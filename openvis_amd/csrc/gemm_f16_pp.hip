@@ -89,7 +89,8 @@ struct PPArgs {
   const float* lno_gamma = nullptr;         // LNO: LayerNorm weight / bias [N] applied to the output rows (N == 256: a tile holds whole rows)
   const float* lno_beta = nullptr;
   float lno_eps = 0.f;
-};
+  int cv_H = 0, cv_W = 0, cv_C = 0;         // CV: 3x3 / stride 1 / pad 1 convolution; A = the ZERO-PADDED input [T][cv_H + 2][cv_W + 2][cv_C] (f32),
+};                                          //     M = T cv_H cv_W output pixels, K = 9 cv_C
 
 #define PP_GLDS(src, dst) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
@@ -131,9 +132,15 @@ struct PPArgs {
 //      wavefront columns meet in LDS (8 KB of the bias region) across one extra workgroup barrier inside the epilogue -- both wave groups
 //      run their epilogue in the same slot, so the barrier counts of the two groups stay equal.  Single pass (E[x^2] - mean^2) in f32.
 template <int OUT, int ACT, bool HAS_R, bool X3, bool FA = false, bool R16 = false, int TM = 256, int EPI = 0, bool LNF = false, bool PSTAT = false,
-          bool LNO = false>
+          bool LNO = false, bool CV = false>
 __global__ void __launch_bounds__(512)
 gemm_f16_pp_kernel(const PPArgs p) {
+  // CV (f32-A mode): implicit GEMM of a 3x3 / stride 1 / pad 1 convolution over a zero-padded NHWC input.  Row m of the GEMM is output
+  // pixel (t, y, x); K step k covers 32 channels of tap (kh, kw) = k / (C / 32): the row's 128 bytes sit at
+  //   rowbase(m) + ((kh (W + 2) + kw) C + 32 (k % (C / 32))) 4,     rowbase(m) = ((t (H + 2) + y) (W + 2) + x) C 4
+  // -- a per-lane row base (recomputed when a DMA cursor enters a new tile: two integer divisions per row, after a phase's MFMAs) plus a
+  // wave-uniform offset per K step.  Nothing else changes: same DMA count, same waits, same epilogue (C is [M, N], rows = pixels).
+  static_assert(!CV || (FA && !X3), "CV: the f32-A (bf16x2) mode");
   static_assert(!LNO || (OUT == 0 && !X3 && ACT == 0 && EPI == 0), "LNO: f32 output, no activation");
   static_assert(!PSTAT || (R16 && (EPI & 1)), "PSTAT: fp16 residual GEMM with the full-line epilogue");
   static_assert(!LNF || (OUT == 1 && !HAS_R && !X3 && !FA && TM == 256 && (EPI & 1)), "LNF: fp16 output, full-line epilogue, 256-row tiles");
@@ -246,6 +253,21 @@ gemm_f16_pp_kernel(const PPArgs p) {
       }
     }
   }
+  // CV: the two rows (g = 0, 1) of half-tile h this lane moves, for the tile whose first computed row is bml: byte offsets of their
+  // padded-input pixels (+ the lane's 16-byte chunk, as above).  The padded input stays below 4 GB (host check).
+  auto conv_rows = [&](int h, int bml) {
+    if constexpr (CV) {
+      const int HW = p.cv_H * p.cv_W;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int c = (lane & 7) ^ ((q + 4 * g) & 7);
+        const int m = bml + wr * GS + h * A1_ROW + 16 * (wave & 3) + 8 * g + dr;
+        const int t = m / HW, rem = m - t * HW;
+        const int y = rem / p.cv_W, x = rem - y * p.cv_W;
+        voA[h][g] = (unsigned)((((long long)t * (p.cv_H + 2) + y) * (p.cv_W + 2) + x) * p.cv_C * 4 + c * 16);
+      }
+    }
+  };
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Bb = reinterpret_cast<const char*>(p.B);
   unsigned char* dma_dst = lds + wave * 2048;                      // + buffer + half-tile + g * 1024
@@ -343,29 +365,40 @@ gemm_f16_pp_kernel(const PPArgs p) {
 
   // ---- the two DMA cursors: c1 = next K step of the half-tiles B1, A1; c2 = next K step of A0, B0 (one step further ahead) ----
   // (X3: a cursor also walks the six plane pairs; pair t reads plane PA[t] of A and PB[t] of B, 2 bits each in the codes below)
-  struct Cur { int i, kt, k, t; const char *ta, *tb, *a, *b; };     // tile ordinal, K step of the tile, K step of the pair, pair
+  struct Cur { int i, kt, k, t; const char *ta, *tb, *a, *b; int kin, tap; unsigned koff; };   // tile ordinal, K step of the tile, K step of the pair, pair
+  // (CV: kin = K step inside the tap, tap = 3 kh + kw, koff = byte offset of this K step inside a padded-input pixel row walk)
   auto planes = [&](Cur& c) {
     if constexpr (X3) { c.a = c.ta + ((82 >> (2 * c.t)) & 3) * p.planeA; c.b = c.tb + ((280 >> (2 * c.t)) & 3) * p.planeB; }
     else { c.a = c.ta; c.b = c.tb; }
   };
   Cur c1, c2;
-  { const PPTile t = tile_entry(0); c1.i = c1.kt = c1.k = c1.t = 0; c1.ta = Ab + t.a_off; c1.tb = Bb + t.b_off; planes(c1); c2 = c1; }
+  { const PPTile t = tile_entry(0); c1.i = c1.kt = c1.k = c1.t = 0; c1.kin = c1.tap = 0; c1.koff = 0; c1.ta = CV ? Ab : Ab + t.a_off; c1.tb = Bb + t.b_off;
+    planes(c1); c2 = c1; conv_rows(0, t.bml); conv_rows(1, t.bml); }
   // (tile change: called AFTER a phase's MFMAs were issued, where the wavefront has nothing else to do)
-  auto advance = [&](Cur& c) {
+  auto advance = [&](Cur& c, int h) {                                 // h: the A half-tile this cursor feeds (c2: 0, c1: 1)
     ++c.k;
     if (X3 && c.k == nk1) { c.k = 0; ++c.t; if (c.t < 6) planes(c); }
+    if constexpr (CV) {
+      c.koff += 128;
+      if (++c.kin == (p.cv_C >> 5)) { c.kin = 0; ++c.tap; c.koff = (unsigned)(((c.tap / 3) * (p.cv_W + 2) + c.tap % 3) * p.cv_C * 4); }
+    }
     if (++c.kt == nk) {
       c.kt = c.k = c.t = 0;
-      if (++c.i < n_my) { const PPTile t = tile_entry(c.i); c.ta = Ab + t.a_off; c.tb = Bb + t.b_off; }
+      if constexpr (CV) { c.kin = c.tap = 0; c.koff = 0; }
+      if (++c.i < n_my) {
+        const PPTile t = tile_entry(c.i);
+        c.ta = CV ? Ab : Ab + t.a_off; c.tb = Bb + t.b_off;
+        conv_rows(h, t.bml);
+      }
       planes(c);
     }
   };
-  auto advance1 = [&]() { advance(c1); };
-  auto advance2 = [&]() { advance(c2); };
+  auto advance1 = [&]() { advance(c1, 1); };
+  auto advance2 = [&]() { advance(c2, 0); };
   // (past the last tile the cursors keep re-loading the last tile's rows into slots nobody reads: the vmcnt counts stay uniform)
   auto issue_b1 = [&](unsigned buf) { issue(c1.b, voB[1], c1.k * B_STEP, buf + 3 * PP_HT); };
-  auto issue_a1 = [&](unsigned buf) { issue(c1.a, voA[1], c1.k * 128, buf + 1 * PP_HT); };
-  auto issue_a0 = [&](unsigned buf) { issue(c2.a, voA[0], c2.k * 128, buf + 0 * PP_HT); };
+  auto issue_a1 = [&](unsigned buf) { issue(c1.a, voA[1], CV ? (int)c1.koff : c1.k * 128, buf + 1 * PP_HT); };
+  auto issue_a0 = [&](unsigned buf) { issue(c2.a, voA[0], CV ? (int)c2.koff : c2.k * 128, buf + 0 * PP_HT); };
   auto issue_b0 = [&](unsigned buf) { issue(c2.b, voB[0], c2.k * B_STEP, buf + 2 * PP_HT); };
 
   if (p.desync_ns > 0) {
@@ -976,6 +1009,39 @@ int gemm_f32a_pp_launch(const float* A, long long lda, const void* W3, long long
   else PP_LAUNCH(0, false);
 #undef PP_LAUNCH
   return check_launch("gemm_nt_f32 (ping-pong, f32 A, bf16x2)");
+}
+
+// ---- CV: 3x3 / stride 1 / pad 1 convolution on the f32-A schedule, input already zero-padded ([T][H+2][W+2][Cin] f32) ----
+bool conv3x3_pp_eligible(const float* xpad, const void* W3, long long plane, const float* y, int T, int H, int W, int Cin, int Cout,
+                         const float* bias, int act) {
+  if (!(act == 0 || act == 1) || Cin % 32 != 0 || Cin < 32 || T < 1 || H < 1 || W < 1) return false;
+  const long long M = (long long)T * H * W, K = 9ll * Cin;
+  if (M >= (1ll << 31) || (long long)T * (H + 2) * (W + 2) * Cin * 4 + (2ll * (W + 2) + 2) * Cin * 4 + 128 >= (1ll << 32)) return false;   // 32-bit row bases
+  return gemm_f32a_pp_eligible(xpad, K, W3, K, plane, y, Cout, (int)M, Cout, (int)K, bias, nullptr, 0, act);
+}
+
+int conv3x3_pp_launch(const float* xpad, const void* W3, long long plane, float* y, int T, int H, int W, int Cin, int Cout, const float* bias,
+                      int act, hipStream_t s) {
+  const int M = T * H * W, N = Cout, K = 9 * Cin;
+  PPArgs p;
+  p.A = reinterpret_cast<const _Float16*>(xpad); p.B = reinterpret_cast<const _Float16*>(W3); p.C = y; p.bias = bias; p.R = nullptr;
+  p.lda = K; p.ldb = K; p.ldc = N; p.ldr = 0; p.M = M; p.N = N; p.K = K; p.act = act;
+  p.planeA = 0; p.planeB = plane * 2; p.planeC = 0;
+  p.cv_H = H; p.cv_W = W; p.cv_C = Cin;
+  p.tiles_n = (int)cdiv(N, 256);
+  const int tm = pp_pick_tm(M, p.tiles_n);
+  p.tiles_m = (int)cdiv(M, tm); p.n_tiles = p.tiles_m * p.tiles_n;
+  const int groups = (int)cdiv(p.tiles_n, g_pp_grp > 0 ? g_pp_grp : p.tiles_n);
+  p.grp_w = p.tiles_n / groups; p.grp_rem = p.tiles_n % groups;
+  p.desync_ns = g_pp_desync_ns > 0 ? g_pp_desync_ns : 0; p.dbg = g_pp_dbg; p.stamps = g_pp_stamps;
+  p.dump = pp_dump_buffer();
+  if (!p.dump) return fail(OVIS_EINVAL, "conv3x3 (ping-pong, f32 A): cannot allocate the 4 KB dump buffer");
+  const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
+#define PP_CV(A_) do { if (tm == 192) hipLaunchKernelGGL((gemm_f16_pp_kernel<0, A_, false, false, true, false, 192, 0, false, false, false, true>), dim3(grid), dim3(512), 0, s, p); \
+                       else hipLaunchKernelGGL((gemm_f16_pp_kernel<0, A_, false, false, true, false, 256, 0, false, false, false, true>), dim3(grid), dim3(512), 0, s, p); } while (0)
+  if (act == 1) PP_CV(1); else PP_CV(0);
+#undef PP_CV
+  return check_launch("conv3x3 (ping-pong, f32 A, bf16x2, padded input)");
 }
 
 // x [n] f32 -> planes [3][n] bf16 with x == p0 + p1 + p2 exactly, 8 elements per thread (16-byte stores)

@@ -197,6 +197,30 @@ static int g_f32a_pp = 1;      // lab switch (ovis_set_f32a_pp): 0 keeps bf16x2 
 
 extern "C" int ovis_set_f32a_pp(int on) { g_f32a_pp = on ? 1 : 0; return OVIS_OK; }
 
+namespace ovis {
+bool conv3x3_pp_eligible(const float* xpad, const void* W3, long long plane, const float* y, int T, int H, int W, int Cin, int Cout,
+                         const float* bias, int act);
+int conv3x3_pp_launch(const float* xpad, const void* W3, long long plane, float* y, int T, int H, int W, int Cin, int Cout, const float* bias,
+                      int act, hipStream_t s);
+}  // namespace ovis
+
+// 3x3 / stride 1 / pad 1 convolution whose input arrives ZERO-PADDED ([T][H+2][W+2][Cin], e.g. from ovis_groupnorm_nhwc_f32 with pad = 1):
+// the bf16x2 policy's ping-pong kernel walks it as a dense GEMM (gemm_f16_pp.hip, CV) -- no im2col gather, no border test
+extern "C" int ovis_conv3x3_padded_f32_w3_eligible(const float* xpad, const void* w3, long long plane, const float* y, int T, int H, int W,
+                                                   int Cin, int Cout, const float* bias, int act) {
+  return (g_f32_gemm_mode == 2 && g_f32a_pp && (((uintptr_t)xpad | (uintptr_t)w3 | (uintptr_t)y) & 15) == 0 && plane % 8 == 0 &&
+          ovis::conv3x3_pp_eligible(xpad, w3, plane, y, T, H, W, Cin, Cout, bias, act)) ? 1 : 0;
+}
+
+extern "C" int ovis_conv3x3_padded_f32_w3(const float* xpad, const void* w3, long long plane, float* y, int T, int H, int W, int Cin, int Cout,
+                                          const float* bias, int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(xpad && w3 && y, "conv3x3_padded_f32_w3: null pointer");
+  OVIS_REQUIRE(ovis_conv3x3_padded_f32_w3_eligible(xpad, w3, plane, y, T, H, W, Cin, Cout, bias, act),
+               "conv3x3_padded_f32_w3: not a problem of the bf16x2 ping-pong kernel (T=%d H=%d W=%d Cin=%d Cout=%d): use ovis_conv2d_nhwc_f32_w3 on the unpadded input",
+               T, H, W, Cin, Cout);
+  return ovis::conv3x3_pp_launch(xpad, w3, plane, y, T, H, W, Cin, Cout, bias, act, (hipStream_t)stream);
+}
+
 // the kernel ovis_gemm_nt_f32_w3 picks (names as rocprofv3 prints them): profiling labels of bench.py
 extern "C" const char* ovis_gemm_nt_f32_w3_kernel(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C,
                                                   long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr, int act) {

@@ -268,9 +268,23 @@ gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int HW,
 __global__ void __launch_bounds__(256)
 gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats, const float* __restrict__ gamma,
                 const float* __restrict__ beta, float* __restrict__ y, int N, int H, int W, int C, int G,
-                float eps, int relu, const float* __restrict__ up, int UH, int UW) {
+                float eps, int relu, const float* __restrict__ up, int UH, int UW, int pad) {
+  // pad = 1: y is [N][H+2][W+2][C] with a ring of zeros (the input layout of ovis_conv3x3_padded_f32_w3): one thread per channel quad of
+  // the PADDED map, the ring threads store zeros -- no memset pass, no state between calls
   const int c4n = C >> 2;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long oidx = i;
+  if (pad) {
+    const long long totalp = (long long)N * (H + 2) * (W + 2) * c4n;
+    if (i >= totalp) return;
+    const int cqp = (int)(i % c4n);
+    const long long pp = i / c4n;
+    const int xx = (int)(pp % (W + 2));
+    const long long rr = pp / (W + 2);
+    const int yy = (int)(rr % (H + 2)), nn = (int)(rr / (H + 2));
+    if (xx == 0 || yy == 0 || xx == W + 1 || yy == H + 1) { reinterpret_cast<float4*>(y)[i] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    i = (((long long)nn * H + (yy - 1)) * W + (xx - 1)) * c4n + cqp;
+  }
   const long long total = (long long)N * H * W * c4n;
   if (i >= total) return;
   const int cq = (int)(i % c4n);
@@ -307,7 +321,7 @@ gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats, c
     o.w += hy * (hx * a.w + lx * b.w) + ly * (hx * c.w + lx * d.w);
   }
   if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-  reinterpret_cast<float4*>(y)[i] = o;
+  reinterpret_cast<float4*>(y)[oidx] = o;
 }
 
 // out[i] = a[i] + b[i % nb]   (float4 granularity)
@@ -473,7 +487,7 @@ extern "C" int ovis_layernorm_f32_to_f16(const float* x, const float* residual, 
   return layernorm_launch<true>(x, residual, gamma, beta, y_f16, rows, C, eps, (hipStream_t)stream);
 }
 
-extern "C" int ovis_groupnorm_nhwc_f32(const float* x, float* y, const float* gamma, const float* beta,
+static int groupnorm_impl(int pad, const float* x, float* y, const float* gamma, const float* beta,
                                        double* stats_ws, int N, int H, int W, int C, int G, float eps, int relu,
                                        const float* up_add, int UH, int UW, ovis_stream_t stream) {
   OVIS_REQUIRE(x && y && gamma && beta && stats_ws, "groupnorm: null pointer");
@@ -489,10 +503,23 @@ extern "C" int ovis_groupnorm_nhwc_f32(const float* x, float* y, const float* ga
   const int pix_per_blk = 128;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(ovis::cdiv(HW, pix_per_blk), N), dim3(threads), sizeof(double) * 2 * G, s, x,
                      stats_ws, HW, C, G, pix_per_blk);
-  const long long total = (long long)N * HW * c4n;
+  const long long total = pad ? (long long)N * (H + 2) * (W + 2) * c4n : (long long)N * HW * c4n;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, s, x, stats_ws, gamma, beta, y, N, H,
-                     W, C, G, eps, relu, up_add, UH, UW);
+                     W, C, G, eps, relu, up_add, UH, UW, pad);
   return ovis::check_launch("groupnorm");
+}
+
+extern "C" int ovis_groupnorm_nhwc_f32(const float* x, float* y, const float* gamma, const float* beta,
+                                       double* stats_ws, int N, int H, int W, int C, int G, float eps, int relu,
+                                       const float* up_add, int UH, int UW, ovis_stream_t stream) {
+  return groupnorm_impl(0, x, y, gamma, beta, stats_ws, N, H, W, C, G, eps, relu, up_add, UH, UW, stream);
+}
+
+// the same GroupNorm written into a zero-padded map: y [N][H+2][W+2][C], ring = 0 (input of ovis_conv3x3_padded_f32_w3)
+extern "C" int ovis_groupnorm_nhwc_f32_padded(const float* x, float* y_padded, const float* gamma, const float* beta,
+                                              double* stats_ws, int N, int H, int W, int C, int G, float eps, int relu,
+                                              const float* up_add, int UH, int UW, ovis_stream_t stream) {
+  return groupnorm_impl(1, x, y_padded, gamma, beta, stats_ws, N, H, W, C, G, eps, relu, up_add, UH, UW, stream);
 }
 
 extern "C" int ovis_add_bcast_f32(const float* a, const float* b, float* out, long long n, long long nb,

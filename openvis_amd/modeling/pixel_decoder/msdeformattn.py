@@ -136,8 +136,12 @@ class MSDeformAttnPixelDecoder:
             x = features[f]
             T, H, W, C = x.shape
             cur = ops.gemm_nt(x.view(-1, C), w[f"adapter_{k}.w"], cw=True).view(T, H, W, -1)
-            y = ops.groupnorm_nhwc(cur, w[f"adapter_{k}.gn_w"], w[f"adapter_{k}.gn_b"], up_add=outs[-1])   # :369-371
-            y = ops.conv2d_nhwc(y, w[f"layer_{k}.w"], 1, 1, cw=True)
+            # lateral + upsampled top-down map (:369-371), then the 3x3 output convolution (:372): where the ping-pong kernel takes the
+            # convolution, the GroupNorm writes its result zero-padded and the convolution walks it as a dense GEMM
+            lw = w[f"layer_{k}.w"]
+            padded = ops.conv3x3_padded_eligible(T, H, W, cur.shape[-1], lw.shape[0])
+            y = ops.groupnorm_nhwc(cur, w[f"adapter_{k}.gn_w"], w[f"adapter_{k}.gn_b"], up_add=outs[-1], pad=padded)
+            y = ops.conv3x3_padded(y, lw) if padded else ops.conv2d_nhwc(y, lw, 1, 1, cw=True)
             y = ops.groupnorm_nhwc(y, w[f"layer_{k}.gn_w"], w[f"layer_{k}.gn_b"], relu=True)
             outs.append(y)
         top = outs[-1]

@@ -428,15 +428,43 @@ def layernorm(x, gamma, beta, residual=None, eps=1e-5, out_f16=False):
     return y
 
 
-def groupnorm_nhwc(x, gamma, beta, groups=32, eps=1e-5, relu=False, up_add=None):
+def groupnorm_nhwc(x, gamma, beta, groups=32, eps=1e-5, relu=False, up_add=None, pad=False):
+    """GroupNorm of an NHWC map (+ bilinear-upsampled addend, + ReLU).  pad=True: the result is written into a zero-padded map
+    [N, H+2, W+2, C] (ring of zeros stored by the same kernel) -- the input layout of conv3x3_padded."""
     _chk(x, gamma, beta, up_add)
     N, H, W, C = x.shape
-    y = torch.empty_like(x)
+    y = torch.empty((N, H + 2, W + 2, C), dtype=torch.float32, device=x.device) if pad else torch.empty_like(x)
     ws = torch.empty((N * groups * 2,), dtype=torch.float64, device=x.device)
     UH, UW = (up_add.shape[1], up_add.shape[2]) if up_add is not None else (0, 0)
-    _lib.call("ovis_groupnorm_nhwc_f32", x, y, gamma, beta, ws, N, H, W, C, groups, float(eps), int(relu), up_add, UH, UW,
-              _lib.stream_ptr())
+    _lib.call("ovis_groupnorm_nhwc_f32_padded" if pad else "ovis_groupnorm_nhwc_f32", x, y, gamma, beta, ws, N, H, W, C, groups, float(eps),
+              int(relu), up_add, UH, UW, _lib.stream_ptr())
     return y
+
+
+def conv3x3_padded_eligible(N, H, W, Cin, Cout, act=ACT_NONE):
+    """whether conv3x3_padded takes this problem on the ping-pong kernel (bf16x2 policy, Cin % 32 == 0, enough tiles); alignment-only
+    probe pointers (the library checks 16-byte alignment, it does not read them)"""
+    big = ctypes.c_void_p(16 * 1024 * 1024)
+    return _MODE.v == 2 and bool(_lib.lib().ovis_conv3x3_padded_f32_w3_eligible(big, big, _ll(Cout * 9 * Cin), big, int(N), int(H), int(W), int(Cin),
+                                                                                  int(Cout), None, int(act)))
+
+
+def conv3x3_padded(xpad, w, bias=None, act=ACT_NONE):
+    """3x3 / stride 1 / pad 1 convolution of an NHWC map given ZERO-PADDED: xpad [N, H+2, W+2, Cin] (groupnorm_nhwc(pad=True)), constant
+    weight w [Cout, 3, 3, Cin] -> [N, H, W, Cout].  The ping-pong kernel walks the padded map as a dense GEMM (no im2col gather); where it
+    does not take the problem, the ordinary convolution runs on the interior."""
+    _chk(xpad, w, bias)
+    N, Hp2, Wp2, Cin = xpad.shape
+    H, W = Hp2 - 2, Wp2 - 2
+    Cout = w.shape[0]
+    if tuple(w.shape[1:]) != (3, 3, Cin):
+        raise _lib.OvisError("conv3x3_padded: w must be [Cout, 3, 3, Cin]")
+    if conv3x3_padded_eligible(N, H, W, Cin, Cout, act):
+        y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=xpad.device)
+        with _Prof("gemm_f16_pp_kernel<0,%d,false,false,true,false>" % act, 2.0 * N * H * W * Cout * 9 * Cin):
+            _lib.call("ovis_conv3x3_padded_f32_w3", xpad, w3_of(w), _ll(w.numel()), y, N, H, W, Cin, Cout, bias, int(act), _lib.stream_ptr())
+        return y
+    return conv2d_nhwc(xpad[:, 1:-1, 1:-1, :].contiguous(), w, 1, 1, bias=bias, act=act, cw=True)
 
 
 def add_bcast(a, b):

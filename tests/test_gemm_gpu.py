@@ -458,3 +458,33 @@ def test_layernorm_in_the_epilogue_of_the_bf16x2_gemm(gemm_modes, M, K):
     gemm_modes.set_f32_gemm_mode(1)
     assert torch.equal(ops.gemm_nt_layernorm(a[:3000], w, b, r[:3000].contiguous(), gamma, beta),
                        ops.layernorm(ops.gemm_nt(a[:3000], w, b, r[:3000].contiguous(), cw=True), gamma, beta))
+
+
+@pytest.mark.parametrize("T,H,W,Cin,Cout,act", [(5, 184, 320, 256, 256, 0), (2, 92, 160, 256, 256, 1), (3, 67, 131, 128, 256, 0), (36, 46, 80, 256, 256, 0), (7, 131, 167, 128, 512, 1)])
+def test_conv3x3_on_a_zero_padded_map_matches_the_gathering_convolution(gemm_modes, T, H, W, Cin, Cout, act):
+    """The FPN output convolutions (msdeformattn.py:287-296, 372) on the ping-pong kernel: GroupNorm writes its result zero-padded, the
+    convolution walks the padded map as a dense GEMM (per-lane row bases, one tap offset per K step).  Against the im2col-loader
+    convolution of the same bf16x2 policy (same products, different summation blocking) and against f64."""
+    from openvis_amd import ops
+    gemm_modes.set_f32_gemm_mode(2)
+    g = torch.Generator().manual_seed(T * H + W)
+    x = torch.randn(T, H, W, Cin, generator=g).cuda()
+    gamma, beta = (1 + 0.2 * torch.randn(Cin, generator=g)).cuda(), (0.1 * torch.randn(Cin, generator=g)).cuda()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5).cuda()
+    dense = ops.groupnorm_nhwc(x, gamma, beta, relu=False)
+    padded = ops.groupnorm_nhwc(x, gamma, beta, relu=False, pad=True)
+    assert padded.shape == (T, H + 2, W + 2, Cin) and torch.equal(padded[:, 1:-1, 1:-1], dense)
+    ring = padded.clone(); ring[:, 1:-1, 1:-1] = 0
+    assert ring.abs().max().item() == 0.0
+    ref_lib = ops.conv2d_nhwc(dense, w, 1, 1, act=act, cw=True)
+    if not ops.conv3x3_padded_eligible(T, H, W, Cin, Cout, act):
+        assert torch.equal(ops.conv3x3_padded(padded, w, act=act), ref_lib)         # falls back to the gathering convolution
+        return
+    outs = [ops.conv3x3_padded(padded, w, act=act) for _ in range(3)]
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    ref = torch.nn.functional.conv2d(dense.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), padding=1).permute(0, 2, 3, 1)
+    if act == 1:
+        ref = ref.relu()
+    e_new, e_old = (outs[0].double() - ref).abs().max().item(), (ref_lib.double() - ref).abs().max().item()
+    assert e_new < 2.0 * e_old + 1e-5, (e_new, e_old)
+    assert (outs[0] - ref_lib).abs().max().item() < 5e-4 * ref.abs().max().item()
