@@ -959,11 +959,13 @@ int gemm_f16_pp_ln_launch(const void* A, long long lda, const void* Wg, long lon
 
 // ---- f32-A mode (bf16x2): A f32 [M,K], W as bf16 planes [>=2][N][ldb] (the first two of ovis_split_f32_to_bf16x3) ----
 bool gemm_f32a_pp_eligible(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C, long long ldc,
-                           int M, int N, int K, const float* bias, const float* residual, long long ldr, int act) {
+                           int M, int N, int K, const float* bias, const float* residual, long long ldr, int act, bool long_k = false) {
   if (act < 0 || act > 3 || (residual && act > 1)) return false;          // instantiated: none / ReLU (+ residual), QuickGELU, GELU
   const long long tiles_n = cdiv(N, 256), blocks256 = (long long)cdiv(M, 256) * tiles_n;
-  if (blocks256 < 256 || blocks256 > 256ll * PP_MAX_TILES || M < 256 || N < 256) return false;
-  if (blocks256 * 10 < 256 * cdiv(blocks256, 256) * 7) return false;       // last round < 40 % full on top of one round (e.g. 288 tiles): 2 WGs / CU of gemm_f32x3_kernel win
+  // long_k (the 3x3 convolutions, K = 9 Cin): 72 K steps per tile amortise the tile transition and the schedule's edge over the tiled kernel is
+  // 1.3-1.4x, so a launch of 0.8 rounds or of 1.1 still wins (5 x 92 x 160 x 256: 0.27 ms against 0.39)
+  if (blocks256 < (long_k ? 200 : 256) || blocks256 > 256ll * PP_MAX_TILES || M < 256 || N < 256) return false;
+  if (!long_k && blocks256 * 10 < 256 * cdiv(blocks256, 256) * 7) return false;       // last round < 40 % full on top of one round (e.g. 288 tiles): 2 WGs / CU of gemm_f32x3_kernel win
   if (tiles_n * 256 * 100 > (long long)N * 135) return false;           // > 35 % of the columns computed for nothing (N = 288: 78 %); at 33 % (N = 384, 576) the 1.5x faster loop still wins
   if (K % 32 != 0 || K < 64 || N % 8 != 0) return false;
   if (lda % 4 != 0 || ldb % 8 != 0 || plane % 8 != 0 || ldc % 4 != 0) return false;
@@ -1017,7 +1019,7 @@ bool conv3x3_pp_eligible(const float* xpad, const void* W3, long long plane, con
   if (!(act == 0 || act == 1) || Cin % 32 != 0 || Cin < 32 || T < 1 || H < 1 || W < 1) return false;
   const long long M = (long long)T * H * W, K = 9ll * Cin;
   if (M >= (1ll << 31) || (long long)T * (H + 2) * (W + 2) * Cin * 4 + (2ll * (W + 2) + 2) * Cin * 4 + 128 >= (1ll << 32)) return false;   // 32-bit row bases
-  return gemm_f32a_pp_eligible(xpad, K, W3, K, plane, y, Cout, (int)M, Cout, (int)K, bias, nullptr, 0, act);
+  return gemm_f32a_pp_eligible(xpad, K, W3, K, plane, y, Cout, (int)M, Cout, (int)K, bias, nullptr, 0, act, true);
 }
 
 int conv3x3_pp_launch(const float* xpad, const void* W3, long long plane, float* y, int T, int H, int W, int Cin, int Cout, const float* bias,

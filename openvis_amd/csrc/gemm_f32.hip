@@ -184,7 +184,7 @@ namespace ovis {
 int x3_planes() { return g_f32_gemm_mode == 2 ? 2 : 3; }
 // gemm_f16_pp.hip: the ping-pong kernel's f32-A mode (bf16x2 only)
 bool gemm_f32a_pp_eligible(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C, long long ldc,
-                           int M, int N, int K, const float* bias, const float* residual, long long ldr, int act);
+                           int M, int N, int K, const float* bias, const float* residual, long long ldr, int act, bool long_k = false);
 int gemm_f32a_pp_launch(const float* A, long long lda, const void* W3, long long ldb, long long plane, float* C, long long ldc, int M, int N,
                         int K, const float* bias, const float* residual, long long ldr, int act, hipStream_t s, const float* ln_gamma = nullptr, const float* ln_beta = nullptr, float ln_eps = 0.f);
 }
