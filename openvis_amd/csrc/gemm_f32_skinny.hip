@@ -36,9 +36,12 @@ struct SkArgs {
   float* ws; unsigned* counters;                 // split-K only
 };
 
+// RT = 32-row tiles per workgroup: 4 (all <= 128 rows; the split-K form of the long-K problems) or 1 (K <= 512: blockIdx.z picks the
+// 32-row tile, so a 100 x 256 x 256 problem runs on 32 workgroups instead of 8 and a wavefront issues 16 MFMAs instead of 64)
+template <int RT>
 __global__ void __launch_bounds__(512)
 gemm_f32_skinny_kernel(const SkArgs p) {
-  __shared__ __attribute__((aligned(16))) float part[SK_WAVES][128 * SK_BN];      // 128 KB
+  __shared__ __attribute__((aligned(16))) float part[SK_WAVES][RT * 32 * SK_BN];      // RT = 4: 128 KB
   __shared__ unsigned s_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, h = lane >> 5;
@@ -46,24 +49,25 @@ gemm_f32_skinny_kernel(const SkArgs p) {
   const int split = gridDim.y, ks = blockIdx.y;
   const int k0 = (ks * SK_WAVES + wave) * p.kw;
 
-  f32x16 acc[4];
+  const int m0 = RT == 4 ? 0 : blockIdx.z * RT * 32;                 // first row of this workgroup
+  f32x16 acc[RT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < RT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
   const int nb = min(n0 + r32, p.N - 1);                                   // clamped: columns >= N are computed and dropped
   const float* bp = p.B + (long long)nb * p.ldb + k0 + 16 * h;
-  const float* ap[4];
+  const float* ap[RT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) ap[t] = p.A + (long long)min(t * 32 + r32, p.M - 1) * p.lda + k0 + 16 * h;
+  for (int t = 0; t < RT; ++t) ap[t] = p.A + (long long)min(m0 + t * 32 + r32, p.M - 1) * p.lda + k0 + 16 * h;
 
   for (int kk = 0; kk < p.kw; kk += 32) {
-    float4 a[4][4], b[4];
+    float4 a[RT][4], b[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const float4*>(bp + kk + 4 * j);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
       for (int j = 0; j < 4; ++j) a[t][j] = *reinterpret_cast<const float4*>(ap[t] + kk + 4 * j);
 #pragma unroll
@@ -72,7 +76,7 @@ gemm_f32_skinny_kernel(const SkArgs p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < RT; ++t) {
           const float av = e == 0 ? a[t][j].x : e == 1 ? a[t][j].y : e == 2 ? a[t][j].z : a[t][j].w;
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[e], acc[t], 0, 0, 0);
         }
@@ -81,21 +85,23 @@ gemm_f32_skinny_kernel(const SkArgs p) {
 
   // partial tiles -> LDS: D[i] of lane l = row 8 (i / 4) + 4 (l / 32) + i % 4, column l % 32
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < RT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i)
       part[wave][(t * 32 + 8 * (i >> 2) + 4 * h + (i & 3)) * SK_BN + r32] = acc[t][i];
   __syncthreads();
+  if (RT != 4 && tid >= RT * 32 * 4) return;                         // (RT = 1 runs without split-K: no barrier behind this point)
 
-  // thread -> row m, 8 consecutive columns
-  const int m = tid >> 2, c8 = (tid & 3) * 8;
+  // thread -> row ml of the workgroup's rows (m globally), 8 consecutive columns
+  const int ml = tid >> 2, c8 = (tid & 3) * 8;
+  const int m = m0 + ml;
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = 0.f;
 #pragma unroll
   for (int w = 0; w < SK_WAVES; ++w) {
-    const float4 x0 = *reinterpret_cast<const float4*>(&part[w][m * SK_BN + c8]);
-    const float4 x1 = *reinterpret_cast<const float4*>(&part[w][m * SK_BN + c8 + 4]);
+    const float4 x0 = *reinterpret_cast<const float4*>(&part[w][ml * SK_BN + c8]);
+    const float4 x1 = *reinterpret_cast<const float4*>(&part[w][ml * SK_BN + c8 + 4]);
     v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w; v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
   }
 
@@ -197,8 +203,7 @@ bool gemm_f32_skinny_eligible(const float* A, long long lda, const float* B, lon
   if (!g_skinny || M > 128 || M < 1 || K > 256 * SK_MAX_SPLIT || N > SK_MAX_N || N < 8) return false;
   if ((lda & 3) || (ldb & 3) || ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15)) return false;
   if (K % 256 != 0) return false;                                            // every wavefront a whole number of 32-wide slices
-  if (K <= 512 && !g_skinny_all) return false;   // measured: 10 us, the same as gemm_f32_kernel<64,64> (whose 8 K steps of 32 are 8 short
-                                                 // round trips) -- the win is the long-K case, 64 serial K steps on 8 workgroups
+  if (K <= 512 && g_skinny_all < 0) return false;   // lab: -1 = the short-K problems stay on gemm_f32_kernel<64,64> (10 us at K = 256, 8 workgroups)
   if (K > 512 && N > 1024) return false;                                     // split-K workspace bound
   return true;
 }
@@ -214,10 +219,16 @@ int gemm_f32_skinny_launch(const float* A, long long lda, const float* B, long l
     p.ws = w.ws; p.counters = w.counters;
   }
   p.kw = K / split / SK_WAVES;
-  hipLaunchKernelGGL(gemm_f32_skinny_kernel, dim3(cdiv(N, SK_BN), split), dim3(512), 0, stream, p);
+  // K <= 512: one 32-row tile per workgroup (blockIdx.z), no split-K -- 4x the workgroups, a quarter of the MFMAs per wavefront
+  if (split == 1 && g_skinny_all <= 0)
+    hipLaunchKernelGGL(gemm_f32_skinny_kernel<1>, dim3(cdiv(N, SK_BN), 1, cdiv(M, 32)), dim3(512), 0, stream, p);
+  else
+    hipLaunchKernelGGL(gemm_f32_skinny_kernel<4>, dim3(cdiv(N, SK_BN), split), dim3(512), 0, stream, p);
   return check_launch("gemm_nt_f32 (skinny)");
 }
 
 }  // namespace ovis
 
-extern "C" int ovis_set_skinny_gemm(int on) { g_skinny = on ? 1 : 0; g_skinny_all = on == 2; return OVIS_OK; }   // 2: also K <= 512 (tests, lab)
+// 0: off (gemm_f32_kernel), 1 (default): K <= 512 on 32-row workgroups, long K on the split-K form; 2: K <= 512 on the 128-row form too
+// (round-2 layout, tests / lab); 3: K <= 512 stays on gemm_f32_kernel<64,64> (lab A/B)
+extern "C" int ovis_set_skinny_gemm(int on) { g_skinny = on ? 1 : 0; g_skinny_all = on == 2 ? 1 : on == 3 ? -1 : 0; return OVIS_OK; }

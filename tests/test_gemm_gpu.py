@@ -207,14 +207,16 @@ def test_skinny_f32_gemm_of_the_decoders(M, N, K, act, bias, res):
         ref = ref + r.double()
     ref = {0: lambda x: x, 1: torch.relu, 2: lambda x: x * torch.sigmoid(1.702 * x)}[act](ref)
     lib = ops._lib.lib()
-    lib.ovis_set_skinny_gemm(2)                             # every eligible shape (the default takes the long-K ones only)
-    try:
-        outs = [ops.gemm_nt(a, w, b, r, act) for _ in range(3)]
-    finally:
-        lib.ovis_set_skinny_gemm(1)
-    assert outs[0].shape == (M, N)
-    assert (outs[0].double() - ref).abs().max().item() < 2e-5
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # mode 1 (default): K <= 512 on 32-row workgroups (blockIdx.z = row tile), long K on the split-K form; mode 2: the 128-row form for every K
+    for mode in (1, 2):
+        lib.ovis_set_skinny_gemm(mode)
+        try:
+            outs = [ops.gemm_nt(a, w, b, r, act) for _ in range(3)]
+        finally:
+            lib.ovis_set_skinny_gemm(1)
+        assert outs[0].shape == (M, N)
+        assert (outs[0].double() - ref).abs().max().item() < 2e-5, mode
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     lib.ovis_set_skinny_gemm(0)                             # the general kernel on the same problem
     try:
         old = ops.gemm_nt(a, w, b, r, act)
