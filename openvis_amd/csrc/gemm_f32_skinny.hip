@@ -212,7 +212,9 @@ int gemm_f32_skinny_launch(const float* A, long long lda, const float* B, long l
                            const float* bias, const float* R, long long ldr, int act, hipStream_t stream) {
   SkArgs p{A, B, C, bias, R, lda, ldb, ldc, ldr, M, N, K, act, 0, nullptr, nullptr};
   int split = 1;
-  if (K > 512) {
+  // (K = 2048 without split-K on 32-row workgroups -- lab mode 4 -- is 27 -> 20 us, but its 256-long accumulation chains per wavefront
+  // cost the last bit that the C1 mask-bit test of the random-init model resolves: split-K stays)
+  if (K > 512 && g_skinny_all != 2) {
     split = K / 256;
     const SkWorkspace w = sk_workspace(stream);
     if (!w.ws) return fail(OVIS_EINVAL, "gemm_nt_f32 (skinny): cannot allocate the split-K workspace");
@@ -220,7 +222,7 @@ int gemm_f32_skinny_launch(const float* A, long long lda, const float* B, long l
   }
   p.kw = K / split / SK_WAVES;
   // K <= 512: one 32-row tile per workgroup (blockIdx.z), no split-K -- 4x the workgroups, a quarter of the MFMAs per wavefront
-  if (split == 1 && g_skinny_all <= 0)
+  if (split == 1 && (g_skinny_all <= 0 || g_skinny_all == 2))
     hipLaunchKernelGGL(gemm_f32_skinny_kernel<1>, dim3(cdiv(N, SK_BN), 1, cdiv(M, 32)), dim3(512), 0, stream, p);
   else
     hipLaunchKernelGGL(gemm_f32_skinny_kernel<4>, dim3(cdiv(N, SK_BN), split), dim3(512), 0, stream, p);
@@ -231,4 +233,4 @@ int gemm_f32_skinny_launch(const float* A, long long lda, const float* B, long l
 
 // 0: off (gemm_f32_kernel), 1 (default): K <= 512 on 32-row workgroups, long K on the split-K form; 2: K <= 512 on the 128-row form too
 // (round-2 layout, tests / lab); 3: K <= 512 stays on gemm_f32_kernel<64,64> (lab A/B)
-extern "C" int ovis_set_skinny_gemm(int on) { g_skinny = on ? 1 : 0; g_skinny_all = on == 2 ? 1 : on == 3 ? -1 : 0; return OVIS_OK; }
+extern "C" int ovis_set_skinny_gemm(int on) { g_skinny = on ? 1 : 0; g_skinny_all = on == 2 ? 1 : on == 3 ? -1 : on == 4 ? 2 : 0; return OVIS_OK; }   // 4 (lab): no split-K at all

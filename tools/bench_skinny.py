@@ -11,7 +11,7 @@ from openvis_amd import ops
 lib = ops._lib.lib()
 for (M, N, K) in [(100, 256, 256), (100, 768, 256), (100, 2048, 256), (100, 256, 2048)]:
     a, w, b = torch.randn(M, K).cuda(), torch.randn(N, K).cuda(), torch.randn(N).cuda()
-    for mode in (1, 2, 3):            # 1: 32-row workgroups (K <= 512) | 2: 128-row form | 3: gemm_f32_kernel<64,64> for K <= 512
+    for mode in (1, 2, 3, 4):            # 1: 32-row workgroups (K <= 512) | 2: 128-row form | 3: gemm_f32_kernel<64,64> for K <= 512
         lib.ovis_set_skinny_gemm(mode)
         for _ in range(20):
             ops.gemm_nt(a, w, b)
