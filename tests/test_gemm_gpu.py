@@ -429,6 +429,28 @@ def test_folded_gemm_race_screen_under_memory_traffic():
                     big_b.copy_(big_a, non_blocking=True)
             assert torch.equal(ops.gemm_nt_f16_ln(x, wg, s, c, st, act), ref), (M, N, K, it)
         torch.cuda.synchronize()
+    # the LayerNorm epilogue of the bf16x2 GEMM (one more workgroup barrier inside the tile transition, row sums through LDS) and the
+    # padded-map convolution (per-tile DMA row bases), same treatment
+    ops.set_f32_gemm_mode(2)
+    try:
+        g = torch.Generator().manual_seed(3)
+        a = torch.randn(96600, 256, generator=g).cuda()
+        w = (torch.randn(256, 256, generator=g) / 16).cuda()
+        b, gamma, beta = torch.randn(256, generator=g).cuda(), torch.rand(256, generator=g).cuda() + 0.5, torch.randn(256, generator=g).cuda()
+        r = torch.randn(96600, 256, generator=g).cuda()
+        xp = ops.groupnorm_nhwc(torch.randn(5, 92, 160, 256, generator=g).cuda(), gamma, beta, pad=True)
+        wc = (torch.randn(256, 3, 3, 256, generator=g) / 48).cuda()
+        ref_ln, ref_cv = ops.gemm_nt_layernorm(a, w, b, r, gamma, beta).clone(), ops.conv3x3_padded(xp, wc).clone()
+        torch.cuda.synchronize()
+        for it in range(30):
+            if it % 2 == 0:
+                with torch.cuda.stream(side):
+                    big_b.copy_(big_a, non_blocking=True)
+            assert torch.equal(ops.gemm_nt_layernorm(a, w, b, r, gamma, beta), ref_ln), it
+            assert torch.equal(ops.conv3x3_padded(xp, wc), ref_cv), it
+        torch.cuda.synchronize()
+    finally:
+        ops.set_f32_gemm_mode(1)
 
 
 @pytest.mark.parametrize("M,K", [(96600, 256), (96600, 1024), (100000 + 3, 256), (695520, 512)])
