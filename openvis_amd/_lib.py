@@ -67,7 +67,19 @@ def call(name, *args):
         raise OvisError(f"{name} failed (code {rc}): {lib().ovis_last_error().decode()}")
 
 
+_raw_stream = None
+
+
 def stream_ptr():
-    """Current torch HIP stream as a void* for the ABI's `stream` argument."""
+    """Current torch HIP stream (of the calling thread's current device) as a void* for the ABI's `stream` argument.
+    torch.cuda.current_stream() builds a Stream object through several Python layers (~8 us per call, 2.7 ms of host time per 720p clip
+    at ~330 C-ABI launches); the two C accessors behind it give the same handle in well under a microsecond."""
+    global _raw_stream
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if _raw_stream is None:
+        get, dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        if get is not None and dev is not None:
+            _raw_stream = lambda: get(dev())
+        else:                                                       # other torch builds: the public, slower path
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream
+    return ctypes.c_void_p(_raw_stream())

@@ -299,7 +299,7 @@ class ClipAdapter:
         valid, crops = self.preprocess_boxes(masks_lowres, Hp, Wp)
         if crops.shape[0] == 0:
             return None, valid, crops
-        crops_d = torch.from_numpy(crops).to(self.device)
+        crops_d = ops.to_device_async(crops, self.device)
         if self.mask_prompt_fwd:                                              # mask_adapted_adapter.py:68-69
             A, patch_open = ops.clip_crop_patches_masked(frames, masks_lowres, crops_d, Hp, Wp, self.input_resolution,
                                                          self.arch["patch"], PIXEL_MEAN, PIXEL_STD,

@@ -1,4 +1,5 @@
 """VideoMaskFormer — mirror of openvis/modeling/video_maskformer.py:23-298 (eval path)."""
+import numpy as np
 import torch
 
 from .. import ops
@@ -94,7 +95,8 @@ class VideoMaskFormer:
                     "pred_labels": [], "pred_masks": []}
         dev = probs.device
         K = probs.shape[1]
-        rid = torch.as_tensor(row_ids, dtype=torch.int32, device=dev)
+        rid = (row_ids.to(device=dev, dtype=torch.int32) if torch.is_tensor(row_ids)
+               else ops.to_device_async(np.ascontiguousarray(np.asarray(row_ids, dtype=np.int32)), dev))      # no host block (ops.to_device_async)
         # the kernel also emits the query id of every selected row, so the mask kernels are launched without waiting for
         # the host to read the indices back (the reference syncs on .tolist() here, video_maskformer.py:267-272)
         idx, score, ent, sel_q = ops.topk_entropy(probs, rid, topk)          # raises if rows*K < topk (as torch.topk)

@@ -77,7 +77,7 @@ class OpenVIS(VideoMaskFormer):
         T, Q = valid.shape
         slot = -np.ones((T, Q), np.int32)
         slot[valid] = np.arange(crops.shape[0], dtype=np.int32)
-        probs, _ = ops.openvis_aggregate(logits, torch.from_numpy(slot).to(self.device))
+        probs, _ = ops.openvis_aggregate(logits, ops.to_device_async(slot, self.device))
         row_ids = np.nonzero(valid.any(axis=0))[0].astype(np.int32)
         return probs, row_ids, {"crop_logits": logits, "valid": valid, "crops": crops}
 

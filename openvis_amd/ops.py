@@ -72,6 +72,19 @@ def _chk(*ts):
             raise _lib.OvisError("openvis_amd ops need contiguous HIP device tensors (no CPU fallback)")
 
 
+def to_device_async(arr, device):
+    """small host array (numpy) -> device tensor WITHOUT blocking the host: through a pinned staging buffer (torch's caching host
+    allocator keeps it alive until the copy has run).  `torch.from_numpy(a).to(device)` copies from pageable memory, which blocks the
+    host until everything queued on the stream before it has finished -- at the end of the CLIP stage that is 20 ms during which the
+    host could have queued the next clip."""
+    t = torch.from_numpy(arr) if not torch.is_tensor(arr) else arr
+    if not torch.device(device).type == "cuda":
+        return t.to(device)
+    p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    p.copy_(t)
+    return p.to(device, non_blocking=True)
+
+
 def f32_gemm_mode():
     return _MODE.v
 
@@ -131,7 +144,7 @@ def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None, cw
                       _lib.stream_ptr())
         return out.view(*a.shape[:-1], N)
     use_w3 = cw and w.is_contiguous() and K % 8 == 0 and _MODE.v >= 1 and ((M + 127) // 128) * ((N + 127) // 128) >= 256
-    label = _gemm_variant(M, N, "DenseA", K)
+    label = _gemm_variant(M, N, "DenseA", K) if PROFILE is not None else ""
     if PROFILE is not None and use_w3 and _MODE.v == 2:      # bf16x2: the ping-pong kernel's f32-A mode takes the eligible shapes
         label = _w3_kernel_name(a2, K, w3_of(w), K, w.numel(), out, N, M, N, K, bias, r2, N, act) or label
     with _Prof(label, 2.0 * M * N * K):
@@ -377,7 +390,7 @@ def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE, w
             _lib.call("ovis_conv2d_nhwc_f32a_f16w", x, w16, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act,
                       _lib.stream_ptr())
         return y
-    label = _gemm_variant(N * OH * OW, Cout, "ConvA", KH * KW * Cin)
+    label = _gemm_variant(N * OH * OW, Cout, "ConvA", KH * KW * Cin) if PROFILE is not None else ""
     if (PROFILE is not None and cw and _MODE.v == 2 and KH == 1 and KW == 1 and stride == 1 and pad == 0 and Cin % 8 == 0
             and ((N * OH * OW + 127) // 128) * ((Cout + 127) // 128) >= 256):
         label = _w3_kernel_name(x, Cin, w3_of(w), Cin, w.numel(), y, Cout, N * OH * OW, Cout, Cin, bias, residual, Cout, act) or label

@@ -96,3 +96,14 @@ def test_pipelined_side_adapter_models_equal_sequential(arch):
     for a, b in zip(outs, ref):
         assert a["pred_labels"] == b["pred_labels"] and a["pred_scores"] == b["pred_scores"]
         assert all(torch.equal(ma, mb) for ma, mb in zip(a["pred_masks"], b["pred_masks"]))
+
+
+def test_stream_ptr_follows_the_current_stream():
+    """_lib.stream_ptr (two C accessors instead of torch.cuda.current_stream()) hands the C ABI the calling thread's CURRENT stream"""
+    import torch
+    from openvis_amd import _lib
+    assert (_lib.stream_ptr().value or 0) == torch.cuda.current_stream().cuda_stream
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        assert (_lib.stream_ptr().value or 0) == s.cuda_stream != torch.cuda.default_stream().cuda_stream
+    assert (_lib.stream_ptr().value or 0) == torch.cuda.current_stream().cuda_stream
