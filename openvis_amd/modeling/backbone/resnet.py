@@ -44,7 +44,14 @@ class ResNet:
 
     def load_state_dict(self, sd, prefix="backbone.", device="cuda"):
         d = lambda t: t.to(device)
-        self.w["stem"] = tuple(map(d, _fold(sd, prefix + "stem.conv1", pad_cin_to=4)))
+        # stem 7x7: input channels padded 3 -> 4 (the NHWC4 frames), and -- fp16 policy -- an eighth, all-zero kernel COLUMN: K = 7*8*4 = 224
+        # is a multiple of 8, which puts the stem on the fp16-operand convolution like every other backbone conv (K = 196 fell through to
+        # the f32-class kernel: 0.53 ms per 720p clip).  Same output geometry (stride 2, pad 3: (W + 6 - 8) / 2 + 1 == (W + 6 - 7) / 2 + 1
+        # for even W), the extra tap multiplies by zero.
+        sw, sb = _fold(sd, prefix + "stem.conv1", pad_cin_to=4)
+        if self.precision == "fp16":
+            sw = torch.nn.functional.pad(sw, (0, 0, 0, 1)).contiguous()              # [64, 7, 7, 4] -> [64, 7, 8, 4]
+        self.w["stem"] = (d(sw), d(sb))
         for name, nblocks, _ in STAGES[self.depth]:
             for i in range(nblocks):
                 p = f"{prefix}{name}.{i}"
@@ -68,6 +75,8 @@ class ResNet:
 
     def forward(self, x):
         """x: f32 [T,Hp,Wp,4] (normalised, channel 3 zero) -> {res2..res5} NHWC."""
+        if self.w["stem"][0].shape[2] == 8 and x.shape[2] % 2 != 0:
+            raise ValueError("ResNet stem with the padded 7x8 kernel needs an even input width (frames are padded to a multiple of 32)")
         x = self._conv(x, "stem", stride=2, pad=3)
         x = ops.maxpool3x3s2(x)
         feats = {}
