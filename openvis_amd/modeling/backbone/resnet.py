@@ -47,7 +47,7 @@ class ResNet:
         # stem 7x7: input channels padded 3 -> 4 (the NHWC4 frames), and -- fp16 policy -- an eighth, all-zero kernel COLUMN: K = 7*8*4 = 224
         # is a multiple of 8, which puts the stem on the fp16-operand convolution like every other backbone conv (K = 196 fell through to
         # the f32-class kernel: 0.53 ms per 720p clip).  Same output geometry (stride 2, pad 3: (W + 6 - 8) / 2 + 1 == (W + 6 - 7) / 2 + 1
-        # for even W), the extra tap multiplies by zero.
+        # for even W), the extra tap multiplies by zero.  (f32-class policy: measured, no gain from the pre-split weight planes -- unpadded.)
         sw, sb = _fold(sd, prefix + "stem.conv1", pad_cin_to=4)
         if self.precision == "fp16":
             sw = torch.nn.functional.pad(sw, (0, 0, 0, 1)).contiguous()              # [64, 7, 7, 4] -> [64, 7, 8, 4]
