@@ -230,6 +230,8 @@ class ClipVisual:
                 x = self.run_blocks(x, i, i + 1)
                 if i + 1 < self.mask_prompt_depth:
                     ops.mask_prompt_select(x, patch_open, self.w["mask_embedding"][i + 1], 1)
+                    if hasattr(x, "_ovis_row_stats"):                 # rows rewritten in place: statistics handed over by the GEMM are stale
+                        del x._ovis_row_stats
         # the mask prompt after the last block (depth > layers) only rewrites patch tokens, which nothing reads any more
         return self.head(self.last_block_cls(x, last))
 
