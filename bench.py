@@ -192,9 +192,9 @@ def main():
                     help="frame height (16:9); default 720, *_swinl models: 1080 (BASELINE.json configs[4])")
     ap.add_argument("--precision", default="mixed", choices=["mixed", "fp32"],
                     help="dense-path policy: mixed = the reference's autocast policy, fp32 = exact f32 everywhere")
-    ap.add_argument("--f32-split", default="auto", choices=["auto", "bf16x3", "bf16x2", "f32"],
-                    help="MODEL.F32_GEMM_SPLIT: how large f32 GEMMs reach the bf16 MFMA (auto: bf16x2 under --precision mixed, "
-                         "the f32-grade bf16x3 under fp32)")
+    ap.add_argument("--f32-split", default="auto", choices=["auto", "fp16x2", "bf16x3", "bf16x2", "f32"],
+                    help="MODEL.F32_GEMM_SPLIT: how large f32 GEMMs reach the 16-bit MFMA (auto: the f32-grade fp16x2 under --precision "
+                         "mixed, the f32-grade bf16x3 under fp32; bf16x2 = 16 significand bits per operand, an explicit opt-in)")
     args = ap.parse_args()
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != env_world:
@@ -212,7 +212,7 @@ def main():
     device = torch.device("cuda", 0 if rig else local_rank)
 
     from openvis_amd import ops
-    f32_split = args.f32_split if args.f32_split != "auto" else ("bf16x3" if args.precision == "fp32" else "bf16x2")
+    f32_split = args.f32_split if args.f32_split != "auto" else ("bf16x3" if args.precision == "fp32" else "fp16x2")
     model, sd, text = build_model(device, clip_precision=args.clip_precision, precision=args.precision, model_name=args.model, f32_split=args.f32_split)
     frame_sharded = args.model.startswith("brivis") and world > 1
     T = args.frames or (36 if args.model.startswith("brivis") else T_CLIP)
@@ -270,17 +270,20 @@ def main():
         sync_all()
         elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, "cpu" if rig else device)
+    if out is not None and hasattr(out, "wait"):
+        out.wait()                                             # reads the last clip's outputs (and, under fp16x2, its range flag)
+    fell_back = f32_split == "fp16x2" and _model.f32_gemm_mode != 3     # an activation left the fp16 range: the model went to bf16x3
 
-    # ---- the same step with the OTHER f32-GEMM split, timed the same way (shorter) ---------------------------------------------
+    # ---- the same step with the OTHER f32-GEMM splits, timed the same way (shorter) --------------------------------------------
     # The pixel decoder / masked-attention decoder are f32 in the reference (msdeformattn.py:329 disables autocast).  Their large
-    # GEMMs run on the bf16 MFMA either as bf16x2 (16 significand bits per operand; the default under --precision mixed) or as
-    # the f32-grade bf16x3.  Whichever the headline uses, the other one stands beside it in `alt_f32_split`.
-    alt = None
-    if not (args.streams > 1 and not frame_sharded):
-        alt_name = "bf16x3" if f32_split == "bf16x2" else "bf16x2" if f32_split == "bf16x3" else None
-        if alt_name is not None:
-            from openvis_amd.config import F32_GEMM_SPLITS
-            keep_mode = _model.f32_gemm_mode
+    # GEMMs run on the 16-bit MFMA as the f32-grade fp16x2 (3 fp16 products of the 11 + 11 bit split; the default under --precision
+    # mixed), as the f32-grade bf16x3 (6 bf16 products) or as bf16x2 (3 bf16 products, 16 significand bits per operand: NOT f32-grade,
+    # listed for comparison only).  Whichever the headline uses, the others stand beside it in `alt_f32_splits`.
+    alts = []
+    if not (args.streams > 1 and not frame_sharded) and f32_split != "f32":
+        from openvis_amd.config import F32_GEMM_SPLITS
+        keep_mode = _model.f32_gemm_mode
+        for alt_name in [n for n in ("fp16x2", "bf16x3", "bf16x2") if n != f32_split]:
             _model.f32_gemm_mode = F32_GEMM_SPLITS[alt_name]
             n_alt = max(args.steps // 2, 1)
             for i in range(2):
@@ -291,11 +294,13 @@ def main():
                 model(inputs[i % len(inputs)])
             sync_all()
             e_alt = D.max_over_ranks(time.perf_counter() - t0, "cpu" if rig else device)
-            _model.f32_gemm_mode = keep_mode
-            model(inputs[0])                                   # back on the headline's split before the profiling passes
-            torch.cuda.synchronize()
-            alt = {"split": alt_name, "value": round(T * n_alt * (1 if frame_sharded else world) / e_alt, 3), "unit": "frames/s",
-                   "ms_per_step": round(e_alt / n_alt * 1e3, 3), "steps": n_alt}
+            alts.append({"split": alt_name, "f32_grade": alt_name != "bf16x2",
+                         "value": round(T * n_alt * (1 if frame_sharded else world) / e_alt, 3), "unit": "frames/s",
+                         "ms_per_step": round(e_alt / n_alt * 1e3, 3), "steps": n_alt})
+        _model.f32_gemm_mode = keep_mode
+        out = model(inputs[0])                                 # back on the headline's split before the profiling passes
+        torch.cuda.synchronize()
+    alt = alts[0] if alts else None
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream -----------
     # Per-launch events around every GEMM / K1 launch (ops.PROFILE).  Two untimed passes:
@@ -351,8 +356,9 @@ def main():
     achieved = flops / secs / 1e12
     iso = fam_iso.get(kbase, (n_launch, flops, secs))
     if "f32x3" in kbase or "[f32A]" in kbase:      # one f32 product = 6 (bf16x3) or 3 (bf16x2) bf16 MFMA products: ceiling = bf16 peak / that
-        nprod = 3 if (f32_split == "bf16x2" or "[f32A]" in kbase) else 6
-        peak, peak_note = round(PEAK_F16_MFMA_TFLOPS / nprod, 1), f"bf16 dense MFMA peak / {nprod} ({f32_split}: {nprod} bf16 products per f32 product)"
+        nprod = 3 if (f32_split in ("bf16x2", "fp16x2") or "[f32A]" in kbase) else 6
+        peak, peak_note = round(PEAK_F16_MFMA_TFLOPS / nprod, 1), (f"{'fp16' if f32_split == 'fp16x2' else 'bf16'} dense MFMA peak / {nprod} "
+                                                                   f"({f32_split}: {nprod} 16-bit products per f32 product)")
     elif "f16" in kbase:
         peak, peak_note = PEAK_F16_MFMA_TFLOPS, "fp16 dense MFMA peak"
     else:
@@ -375,7 +381,9 @@ def main():
             continue
 
     def _pmc_lookup(name):
-        v = pmc.get(_norm(name))
+        fh = name.endswith(",FH>")                            # fp16x2 instantiations: the template's LAST argument is true
+        name = name.replace(",FH>", ">")
+        v = pmc.get(_norm(name)) if not fh else None
         if v is None and "<" not in name:                     # un-templated kernels: prefix match
             v = next((x for k, x in pmc.items() if k.startswith(_norm(name))), None)
         if v is None and "<" in name:
@@ -400,8 +408,13 @@ def main():
             hits = []
             for k, x in pmc.items():
                 b, ta = _targs(k)
-                if b == base and len(ta) >= len(targs) and all(a.startswith(t) for a, t in zip(ta, targs)):
-                    hits.append(x)
+                if not (b == base and len(ta) >= len(targs) and all(a.startswith(t) for a, t in zip(ta, targs))):
+                    continue
+                is_fh = ((b == "gemm_f16_pp_kernel" and len(ta) >= 13 and ta[12] == "true") or           # FH (fp16x2): template argument 13
+                         (b == "gemm_f32x3_kernel" and len(ta) >= 6 and ta[5] == "true"))                 # ... and 6 of these two kernels
+                if is_fh != fh:
+                    continue
+                hits.append(x)
             if hits:
                 nl = sum(h["launches"] for h in hits)
                 v = {f: round(sum(h[f] * h["launches"] for h in hits) / nl) for f in
@@ -488,7 +501,8 @@ def main():
             "metric": ("frames/sec (whole node) OpenVIS R50 720p inference" if args.model == "openvis" and res == 720 else
                        f"frames/sec (whole node) {args.model} {bb_name} {res}p inference"), "value": round(frames_total / elapsed, 3),
             "unit": "frames/s", "n_gpus": world, "world_size_seen": D.world_size(), "frames_per_rank": frames_per_rank,
-            "steps": args.steps, "warmup": args.warmup, "f32_split": f32_split, "alt_f32_split": alt,
+            "steps": args.steps, "warmup": args.warmup, "f32_split": f32_split, "f32_split_f32_grade": f32_split != "bf16x2",
+            "f32_split_fell_back_to_bf16x3": bool(fell_back), "alt_f32_split": alt, "alt_f32_splits": alts,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if frame_sharded else "weak",
             "vs_baseline": None, "dtype": "f16" if "fp16" in (bb_prec, _model.clip_adapter.precision) else "f32", "data": "synthetic",
@@ -503,7 +517,7 @@ def main():
                                       + (", ln_1 / ln_2 folded into in_proj / c_fc with f32 statistics" if getattr(getattr(_model.clip_adapter, "visual", None), "fold_ln", False)
                                          and getattr(_model.clip_adapter.visual, "stream16", False) else "")
                                       if _model.clip_adapter.precision == "fp16" else "f32") + (f"; resampler {_model.resampler.precision}" if hasattr(_model, "resampler") else "")
-                                     + f"; large f32 GEMMs/convs as {f32_split} on the bf16 MFMA (MODEL.F32_GEMM_SPLIT)"),
+                                     + f"; large f32 GEMMs/convs as {f32_split} on the 16-bit MFMA (MODEL.F32_GEMM_SPLIT)"),
                        "valid_crops_per_clip": n_valid,
                        "parallelism": (f"frame-sharded x{world} + RCCL all-gather" if frame_sharded else f"clip-replicas x{world}")
                                       + (f", {args.streams} clips in flight per GPU (HIP streams)" if args.streams > 1 and not frame_sharded else "")},

@@ -56,6 +56,8 @@ int ovis_msda_forward_f64(const double* value, const int64_t* spatial_shapes,
  *   1 (default)  bf16x3: every f32 operand is split exactly into three bf16 values while staged into LDS and six bf16
  *                MFMA products are accumulated in f32 -- same accuracy class as an f32 fmaf chain, ~2.5x the rate of
  *   0            the native v_mfma_f32_32x32x2_f32 kernel (an exact f32 fmaf chain), which small problems always use.
+ *   2            bf16x2: the two leading planes, three products (16 significand bits per operand); 3 = what openvis_amd sets for its
+ *                "fp16x2" policy: these entry points behave as under 1, the constant-weight layers go through the *_h2 entry points.
  * Replaces nothing in the reference (torch picks cuBLAS algorithms implicitly); process-wide, not thread-safe. */
 int ovis_set_f32_gemm_mode(int mode);
 
@@ -69,6 +71,37 @@ int ovis_gemm_nt_f32_w3(const float* A, long long lda, const float* B, long long
 int ovis_conv2d_nhwc_f32_w3(const float* x, const float* w, const void* w3, long long plane, float* y, int N, int H, int W, int Cin,
                             int Cout, int KH, int KW, int stride, int pad, const float* bias, const float* residual, int act,
                             ovis_stream_t stream);
+
+/* "fp16x2" (round 4): f32-grade large GEMMs / convolutions at the MFMA cost of bf16x2.  Every f32 operand is carried as fp16 hi + fp16 lo
+ * (hi = fp16(x), lo = fp16(x - hi): 11 + 11 significand bits) and the three products hi hi + hi lo + lo hi run on v_mfma_f32_*_f16 with f32
+ * accumulation: every term down to 2^-22 |a b|.  fp16's narrow range is met by power-of-two scales (exact): constant weights are split ONCE
+ * into two fp16 planes of w * w_scale (ovis_split_f32_to_f16x2; callers pick w_scale = 2^k with max |w| w_scale in [2^14, 2^15)), activations are
+ * multiplied by a_scale while they are split in registers (ovis_set_f16x2, default 16: |a| < 4 094, absolute floor 2^-29), the accumulators
+ * carry a_scale * w_scale and are scaled back before bias-free epilogue work.  An activation beyond the range makes the result non-finite; the
+ * kernels then set *range_flag = 1 (device int, checked by the caller when it next synchronises: openvis_amd repeats the clip under bf16x3).
+ * The *_h2 entry points mirror the *_w3 ones (same shapes, same fall-back to the exact f32 kernels for small problems) and do not depend on
+ * ovis_set_f32_gemm_mode.  ovis_set_f16x2 is per host thread.  Replaces nothing in the reference (torch picks cuBLAS algorithms implicitly);
+ * the layers are those listed under "Dense layers" below (msdeformattn.py:329 keeps them in f32). */
+int ovis_set_f16x2(float a_scale, int* range_flag);
+int ovis_split_f32_to_f16x2(const float* x, void* planes, long long n, float scale, ovis_stream_t stream);
+int ovis_gemm_nt_f32_h2(const float* A, long long lda, const float* B, long long ldb, const void* H2, long long plane, float w_scale,
+                        float* C, long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr, int act,
+                        ovis_stream_t stream);
+int ovis_conv2d_nhwc_f32_h2(const float* x, const float* w, const void* h2, long long plane, float w_scale, float* y, int N, int H, int W,
+                            int Cin, int Cout, int KH, int KW, int stride, int pad, const float* bias, const float* residual, int act,
+                            ovis_stream_t stream);
+int ovis_gemm_nt_f32_h2_ln_eligible(const float* A, long long lda, const void* H2, long long ldb, long long plane, const float* C, long long ldc,
+                                    int M, int N, int K, const float* bias, const float* residual, long long ldr);
+int ovis_gemm_nt_f32_h2_ln(const float* A, long long lda, const void* H2, long long ldb, long long plane, float w_scale, float* C, long long ldc,
+                           int M, int N, int K, const float* bias, const float* residual, long long ldr, const float* gamma,
+                           const float* beta, float eps, ovis_stream_t stream);
+int ovis_conv3x3_padded_f32_h2_eligible(const float* xpad, const void* h2, long long plane, const float* y, int T, int H, int W, int Cin,
+                                        int Cout, const float* bias, int act);
+int ovis_conv3x3_padded_f32_h2(const float* xpad, const void* h2, long long plane, float w_scale, float* y, int T, int H, int W, int Cin,
+                               int Cout, const float* bias, int act, ovis_stream_t stream);
+const char* ovis_gemm_nt_f32_h2_kernel(const float* A, long long lda, const void* H2, long long ldb, long long plane, const float* C,
+                                       long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr,
+                                       int act);
 
 /* f32-grade GEMM from PRE-SPLIT operands (gemm_f16_pp.hip, X3 mode): A3 [3][M][lda] and W3 [3][N][ldb] are the exact 3-way bf16
  * splits of the f32 operands (plane strides in elements; ovis_split_f32_to_bf16x3[_v8], or a producer that writes planes), the

@@ -78,7 +78,9 @@ class BriVIS(SANOnline):
             self.mask_gather = lambda m: D.gather_frame_masks(m, T_total, gather_masks_to)
         try:
             out = self.inference_video(self.num_queries, len(class_names), probs, row_ids, pred_masks, padded, image_size,
-                                       inp.get("height", image_size[0]), inp.get("width", image_size[1]))
+                                       inp.get("height", image_size[0]), inp.get("width", image_size[1]),
+                                       redo=lambda: self.forward(batched_inputs, stages, frame_range, gather_masks_to),
+                                       sync_guard=frame_range is not None)
         finally:
             self.mask_gather = None
         if frame_range is not None and gather_masks_to is None:
@@ -95,7 +97,15 @@ class BriVIS(SANOnline):
         # mean over the local frames (kernel) weighted by the shard's share of the clip -> all-reduce = mean over ALL frames
         # -> softmax through the aggregate kernel.  The weighting is one elementwise scale of a [Q,K+1] tensor.
         local = ops.mean_over_dim0(logits.contiguous()) * (float(t) / float(T_total))
-        total = D.all_reduce_sum(local)
+        flag = ops.f16x2_flag() if self.f32_gemm_mode == 3 else None
+        if flag is not None:
+            # fp16x2: every constant-weight GEMM of this forward is queued by now; the range flags of the ranks ride on this all-reduce
+            # (one more element), so that all ranks agree on whether the clip has to be repeated under bf16x3 (inference_video, sync_guard)
+            packed = D.all_reduce_sum(torch.cat([local.reshape(-1), flag.to(torch.float32)]))
+            total = packed[:-1].view_as(local)
+            flag.copy_((packed[-1:] > 0).to(torch.int32))
+        else:
+            total = D.all_reduce_sum(local)
         one = torch.arange(Q, dtype=torch.int32, device=logits.device).view(1, Q)
         probs, _ = ops.openvis_aggregate(total.contiguous(), one)
         return probs[:, :-1].contiguous()

@@ -80,9 +80,14 @@ def get_cfg():
             #              finer than autocast's fp16 operands, 32 x finer than the TF32 the reference's f32 convolutions get
             #              from cuDNN by default), products and sums in f32, half the MFMA work;
             #   "f32"    = the native f32 MFMA (an fmaf chain) for every size;
-            #   "auto"   = "bf16x2" under MODEL.PRECISION "mixed", "bf16x3" under "fp32".  Measured at 720p against the f32
-            #              oracle (profiles/r02/bf16x2.txt): per-query mask IoU min 0.99928 vs 0.99927 (OpenVIS), 0.99964 vs
-            #              0.99988 (SANOnline), tracks identical, cosine error unchanged at 2e-7 -- for 5 % of the step.
+            #   "fp16x2" = (round 4) three products hi hi + hi lo + lo hi of the fp16 split (11 + 11 significand bits per operand: every
+            #              term down to 2^-22 |a b|, the f32 grade) on the FP16 MFMA at the cost of bf16x2, for the constant-weight layers;
+            #              operands are moved to the top of fp16's range by power-of-two scales (include/openvis_hip.h).  An activation
+            #              beyond 65 504 / 16 raises a device flag and the clip is repeated under bf16x3 (VideoMaskFormer._range_guard);
+            #              GEMMs between two activations stay on bf16x3;
+            #   "auto"   = "fp16x2" under MODEL.PRECISION "mixed" (the reference keeps these layers in f32, msdeformattn.py:329: the
+            #              timed policy is f32-grade), "bf16x3" under "fp32".  "bf16x2" is an explicit opt-in (16 significand bits per
+            #              operand; measured at 720p against the f32 oracle, profiles/r02/bf16x2.txt: per-query mask IoU min 0.99928).
             "F32_GEMM_SPLIT": "auto",
             "PIXEL_MEAN": [123.675, 116.280, 103.530], "PIXEL_STD": [58.395, 57.120, 57.375],
             "BACKBONE": {"NAME": "build_resnet_backbone", "FREEZE_AT": 0},
@@ -152,14 +157,14 @@ def build_model(cfg):
     return model
 
 
-F32_GEMM_SPLITS = {"f32": 0, "bf16x3": 1, "bf16x2": 2}
+F32_GEMM_SPLITS = {"f32": 0, "bf16x3": 1, "bf16x2": 2, "fp16x2": 3}
 
 
 def f32_gemm_split(cfg):
     """MODEL.F32_GEMM_SPLIT with "auto" resolved (see get_cfg)."""
     split = cfg.MODEL.get("F32_GEMM_SPLIT", "auto")
     if split == "auto":
-        return "bf16x3" if cfg.MODEL.get("PRECISION", "mixed") == "fp32" else "bf16x2"
+        return "bf16x3" if cfg.MODEL.get("PRECISION", "mixed") == "fp32" else "fp16x2"
     return split
 
 

@@ -34,6 +34,11 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 
 inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
+// "fp16x2" arithmetic of a large f32 GEMM (gemm_f16_pp.hip FH, gemm_f32x3.h FH): activations are multiplied by a_scale while they are split
+// into fp16 hi / lo, the weight planes hold fp16 hi / lo of w * w_scale (both powers of two); flag (device int, may be NULL) is set to 1
+// when a result is not finite, i.e. an operand left the fp16 range
+struct F16x2 { float a_scale, w_scale; int* flag; };
+
 }  // namespace ovis
 
 #define OVIS_REQUIRE(cond, ...) \

@@ -63,6 +63,7 @@ constexpr int PP_LDS = 160 * 1024;
 constexpr int PP_TAB = PP_LDS - 8192;      // this workgroup's tile list: 256 entries of 32 bytes (1000 crops x ViT-L/14@336 fc1: 141 per workgroup)
 constexpr int PP_MAX_TILES = 256;
 constexpr int PP_MAX_BIAS_N = (PP_TAB - PP_BIAS) / 4;
+constexpr int PP_FLAG = PP_BIAS + 16384;   // FH: one word behind 16 KB of bias (N <= 4096 there): "a result of this workgroup was not finite"
 // LNF (LayerNorm folded into the GEMM): the tile list is capped at 128 entries (4 KB) and the upper 4 KB of the list region hold two
 // 2 KB slots of per-row statistics (mean, rstd of the tile's 256 rows), filled by LDS-DMA one tile ahead
 constexpr int PP_STATS = PP_LDS - 4096;
@@ -90,7 +91,10 @@ struct PPArgs {
   const float* lno_beta = nullptr;
   float lno_eps = 0.f;
   int cv_H = 0, cv_W = 0, cv_C = 0;         // CV: 3x3 / stride 1 / pad 1 convolution; A = the ZERO-PADDED input [T][cv_H + 2][cv_W + 2][cv_C] (f32),
-};                                          //     M = T cv_H cv_W output pixels, K = 9 cv_C
+                                            //     M = T cv_H cv_W output pixels, K = 9 cv_C
+  float a_scale = 1.f, acc_scale = 1.f, out_scale = 1.f;   // FH: A is multiplied by a_scale while split; accumulators live at scale a_scale * w_scale
+  int* range_flag = nullptr;                // FH: set to 1 when a tile's result is not finite (an operand left the fp16 range)
+};
 
 #define PP_GLDS(src, dst) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
@@ -131,10 +135,23 @@ struct PPArgs {
 //      the LayerNorm kernel's pass over the [M, 256] tensor (99 MB in, 99 MB out per launch at 720p) disappears.  Row sums of the four
 //      wavefront columns meet in LDS (8 KB of the bias region) across one extra workgroup barrier inside the epilogue -- both wave groups
 //      run their epilogue in the same slot, so the barrier counts of the two groups stay equal.  Single pass (E[x^2] - mean^2) in f32.
+// FH (f32-A mode, round 4: "fp16x2"): the same three products on the FP16 matrix cores.  a = hi + lo with hi = fp16(a), lo = fp16(a - hi):
+//      11 + 11 significand bits per operand (bf16x2: 8 + 8), so hi hi + hi lo + lo hi carries every term down to 2^-22 |a b| -- the f32
+//      grade -- at the MFMA cost of bf16x2.  What fp16 lacks is range (max 65 504, subnormal spacing 2^-24), so both operands are moved
+//      to the top of it by powers of two: the constant weight planes are stored as fp16 hi / lo of w * w_scale (w_scale = 2^k with
+//      max |w| w_scale in [2^14, 2^15), chosen when the planes are built), the activations are multiplied by a_scale (a launch
+//      parameter, default 16: |a| < 4 094, absolute floor of lo 2^-29) while they are split in registers.  The accumulators then live
+//      at scale a_scale * w_scale; they start at ZERO and the epilogue multiplies by the inverse scale (exact) and adds bias / residual, as
+//      in the X3 mode: the 16-bit MFMA aligns its 32 products to the accumulator and truncates, so an O(1) start value cost 1.2e-6 of the
+//      row scale on rows whose products are small against bias + residual, 5 x the f32 MFMA kernel (profiles/r04/fp16x2_error.txt).  An
+//      activation beyond the range becomes inf, the tile's result inf / NaN: the epilogue tests its (scaled) accumulators with an
+//      fma-by-zero chain and raises p.range_flag through an LDS word (no extra vector-memory operation inside the counted waits);
+//      callers then repeat the work under bf16x3 (openvis_amd/modeling/video_maskformer.py).
 template <int OUT, int ACT, bool HAS_R, bool X3, bool FA = false, bool R16 = false, int TM = 256, int EPI = 0, bool LNF = false, bool PSTAT = false,
-          bool LNO = false, bool CV = false>
+          bool LNO = false, bool CV = false, bool FH = false>
 __global__ void __launch_bounds__(512)
 gemm_f16_pp_kernel(const PPArgs p) {
+  static_assert(!FH || FA, "FH: the fp16 split of the f32-A mode");
   // CV (f32-A mode): implicit GEMM of a 3x3 / stride 1 / pad 1 convolution over a zero-padded NHWC input.  Row m of the GEMM is output
   // pixel (t, y, x); K step k covers 32 channels of tap (kh, kw) = k / (C / 32): the row's 128 bytes sit at
   //   rowbase(m) + ((kh (W + 2) + kw) C + 32 (k % (C / 32))) 4,     rowbase(m) = ((t (H + 2) + y) (W + 2) + x) C 4
@@ -191,6 +208,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
       *reinterpret_cast<float4*>(lds + PP_BIAS + (p.N + i) * 4) = *reinterpret_cast<const float4*>(p.lno_gamma + i);
       *reinterpret_cast<float4*>(lds + PP_BIAS + (2 * p.N + i) * 4) = *reinterpret_cast<const float4*>(p.lno_beta + i);
     }
+  if constexpr (FH) { if (tid == 0) *reinterpret_cast<int*>(lds + PP_FLAG) = 0; }
   for (int i = tid; i < n_my; i += 512) {
     int tm, tn;
     tile_mn(first + i * nblk, tm, tn);
@@ -300,6 +318,20 @@ gemm_f16_pp_kernel(const PPArgs p) {
         if (i == 1 && mb < MB1_LO) continue;                         // TM = 192: only the upper two row blocks of half-tile 1
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(lds + buf + i * PP_HT + mb * 2048 + a_rd);
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(lds + buf + i * PP_HT + mb * 2048 + (a_rd ^ 16));
+        if constexpr (FH) {
+          // hi = fp16(s v), lo = fp16(s v - hi) (s v is exact, s v - hi too: one rounding each).  Plain C on purpose: as inline v_fma_mix asm
+          // the conversions were two instructions per element, but the optimiser sank the (pure) asm statements past the s_barrier into the
+          // MFMA segment, where a VALU write -> MFMA read needs wait states only the compiler's hazard recogniser inserts -- and it does not
+          // look into inline asm: stale lo fragments, 1e-4 errors that changed from run to run (profiles/r04/fp16x2_asm_hazard.txt).
+          f16x8 h0, h1;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = e < 4 ? x0[e & 3] : x1[e & 3];
+            const _Float16 a0 = (_Float16)(v * p.a_scale);
+            h0[e] = a0; h1[e] = (_Float16)__builtin_fmaf(v, p.a_scale, -(float)a0);
+          }
+          af[mb][0] = h0; af[mb][1] = h1;
+        } else {
         bf16x8 h0, h1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -308,6 +340,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
           h0[e] = a0; h1[e] = (__bf16)(v - (float)a0);
         }
         af[mb][0] = __builtin_bit_cast(f16x8, h0); af[mb][1] = __builtin_bit_cast(f16x8, h1);
+        }
       }
     } else {
 #pragma unroll
@@ -339,6 +372,9 @@ gemm_f16_pp_kernel(const PPArgs p) {
           for (int e = 0; e < 2; ++e) {
             if (i == 1 && mb < MB1_LO) continue;
             const int ar = i * 4 + mb - (i == 1 ? MB1_LO : 0);       // accumulator row block
+            if constexpr (FH)
+              acc[ar][j * 2 + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[e][PB2[t]], af[mb][PA2[t]], acc[ar][j * 2 + e], 0, 0, 0);
+            else
             acc[ar][j * 2 + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                 __builtin_bit_cast(bf16x8, bf[e][PB2[t]]), __builtin_bit_cast(bf16x8, af[mb][PA2[t]]), acc[ar][j * 2 + e], 0, 0, 0);
           }
@@ -427,6 +463,19 @@ gemm_f16_pp_kernel(const PPArgs p) {
     // count them as younger operations.  Masked lanes of an edge tile therefore write to the library's dump buffer instead of
     // being switched off (a wavefront whose lanes are all masked would otherwise skip the instruction).
     char* dump = reinterpret_cast<char*>(p.dump) + lane * 32;
+    if constexpr (FH) {
+      // An activation beyond the fp16 range became hi = inf, lo = -inf: EVERY output of its row is then NaN, and a lane's accumulators of one
+      // 16-row block all belong to one row -- one element per block tells (x * 0 != 0 for inf and NaN).  The accumulators go back to
+      // scale 1 (exact) where they are consumed (put / the LayerNorm sums): scaling all 128 up front costs ~30 registers and spills.
+      float chk = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < MBT; ++mb) chk = __builtin_fmaf(acc[mb][0][0], 0.f, chk);
+      if (chk != chk) {
+        const unsigned faddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(lds + PP_FLAG);
+        const int one = 1;
+        asm volatile("ds_write_b32 %0, %1" :: "v"(faddr), "v"(one) : "memory");
+      }
+    }
     auto act4 = [&](f32x4& x) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -449,8 +498,19 @@ gemm_f16_pp_kernel(const PPArgs p) {
       else if constexpr (((EPI >> 1) & 3) == 2) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(c), "v"(d) : "memory");
       else *reinterpret_cast<uint4*>(c) = o;
     };
-    const float* rp = nullptr;
-    if constexpr (X3 && HAS_R) rp = p.R + (long long)row0 * p.ldr + col0;
+    // residual of the modes that add it in the epilogue (X3, FH): wave-uniform tile base + a 32-bit lane offset computed HERE (opaque to the
+    // optimiser: hoisted out of the tile loop, the per-row-block 64-bit addresses are loop invariants that get spilled)
+    const char* rb = nullptr;
+    unsigned lane_r = 0, rstep = 0;
+    if constexpr ((X3 || FH) && HAS_R) {
+      rb = reinterpret_cast<const char*>(p.R) + ((long long)bml * p.ldr + bnl) * 4;
+      lane_r = (unsigned)(((long long)(wr * GS + l15) * p.ldr + wc * 64 + 8 * q) * 4);
+      rstep = (unsigned)(16 * p.ldr * 4);
+      asm volatile("" : "+v"(lane_r));
+    }
+    auto rload = [&](int mb, int col) {                              // 4 residual values of row block mb at column col of the lane's 64
+      return *reinterpret_cast<const f32x4*>(rb + (lane_r + (unsigned)mb * rstep + (unsigned)(col * 4)));
+    };
     // EPI bit 0: one 16-row block as two full-line stores.  low = lanes whose row is 0-7 of the block.  A: rows 0-7 (low lanes their own
     // columns 8q.., high lanes the low partner's columns 32 + 8q..), B: rows 8-15 (low lanes the high partner's columns 8q.., high lanes own).
     f32x2 lst[8];                                                    // LNF: (mean, rstd) of this lane's eight rows; c of its 16 columns
@@ -512,13 +572,14 @@ gemm_f16_pp_kernel(const PPArgs p) {
     };
     auto put = [&](int mb, int j) {
       f32x4 x0 = acc[mb][2 * j], x1 = acc[mb][2 * j + 1];
-      if constexpr (X3) {                                            // bias / residual enter here, not as the accumulators' start value
+      if constexpr (FH && !LNO) { x0 *= p.out_scale; x1 *= p.out_scale; }
+      if constexpr (X3 || (FH && !LNO)) {                            // bias / residual enter here, not as the accumulators' start value
         f32x4 b0, b1;
         bias8(col0 + 32 * j, b0, b1);
         x0 += b0; x1 += b1;
         if constexpr (HAS_R) {
-          x0 += *reinterpret_cast<const f32x4*>(rp + (long long)mb * 16 * p.ldr + 32 * j);
-          x1 += *reinterpret_cast<const f32x4*>(rp + (long long)mb * 16 * p.ldr + 32 * j + 4);
+          x0 += rload(mb, 32 * j);
+          x1 += rload(mb, 32 * j + 4);
         }
       }
       act4(x0); act4(x1);
@@ -552,6 +613,15 @@ gemm_f16_pp_kernel(const PPArgs p) {
 #pragma unroll
       for (int mb = 0; mb < MBT; ++mb) {
         float sm = 0.f, sq = 0.f;
+        if constexpr (FH) {                                            // accumulators started at zero: back to scale 1, + bias + residual
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            f32x4 b0, b1;
+            bias8(col0 + 32 * j, b0, b1);
+            acc[mb][2 * j] = acc[mb][2 * j] * p.out_scale + b0 + rload(mb, 32 * j);
+            acc[mb][2 * j + 1] = acc[mb][2 * j + 1] * p.out_scale + b1 + rload(mb, 32 * j + 4);
+          }
+        }
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -619,7 +689,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
 #pragma unroll
           for (int mb = 0; mb < MBT; ++mb) acc[mb][2 * j + e] = sv[e] * (-st[mb][0]);
       }
-    } else if constexpr (X3) {
+    } else if constexpr (X3 || FH) {
 #pragma unroll
       for (int mb = 0; mb < MBT; ++mb)
 #pragma unroll
@@ -799,6 +869,11 @@ gemm_f16_pp_kernel(const PPArgs p) {
   }
   if (wr == 0) PP_BARRIER();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (FH) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && *reinterpret_cast<volatile int*>(lds + PP_FLAG) != 0 && p.range_flag) *p.range_flag = 1;
+  }
 }
 
 // One 4 KB device buffer per device, allocated at the first launch there and kept for the life of the process.
@@ -977,14 +1052,19 @@ bool gemm_f32a_pp_eligible(const float* A, long long lda, const void* W3, long l
   return true;
 }
 
+// fh != nullptr: the fp16x2 arithmetic (template parameter FH): W3 = the two fp16 planes of w * fh->w_scale (ovis_split_f32_to_f16x2)
 int gemm_f32a_pp_launch(const float* A, long long lda, const void* W3, long long ldb, long long plane, float* C, long long ldc, int M, int N,
                         int K, const float* bias, const float* residual, long long ldr, int act, hipStream_t s,
-                        const float* ln_gamma = nullptr, const float* ln_beta = nullptr, float ln_eps = 0.f) {
+                        const float* ln_gamma = nullptr, const float* ln_beta = nullptr, float ln_eps = 0.f, const F16x2* fh = nullptr) {
   PPArgs p;
   p.lno_gamma = ln_gamma; p.lno_beta = ln_beta; p.lno_eps = ln_eps;
   p.A = reinterpret_cast<const _Float16*>(A); p.B = reinterpret_cast<const _Float16*>(W3); p.C = C; p.bias = bias; p.R = residual;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.M = M; p.N = N; p.K = K; p.act = act;
   p.planeA = 0; p.planeB = plane * 2; p.planeC = 0;                  // bytes
+  if (fh) {
+    if (N > 4096) return fail(OVIS_EINVAL, "gemm_nt_f32 (ping-pong, fp16x2): N = %d > 4096", N);
+    p.a_scale = fh->a_scale; p.acc_scale = fh->a_scale * fh->w_scale; p.out_scale = 1.f / p.acc_scale; p.range_flag = fh->flag;
+  }
   p.tiles_n = (int)cdiv(N, 256);
   // LNO runs on 192-row tiles only: with 128 accumulator registers (256-row tiles) the LayerNorm epilogue spills ~80 registers per tile,
   // which costs what the fused LayerNorm saves (BriVIS, M = 695 520: no gain); 192-row tiles cost <= 9 % more GEMM time there and spill 9
@@ -997,12 +1077,13 @@ int gemm_f32a_pp_launch(const float* A, long long lda, const void* W3, long long
   p.dump = pp_dump_buffer();
   if (!p.dump) return fail(OVIS_EINVAL, "gemm_nt_f32 (ping-pong, f32 A): cannot allocate the 4 KB dump buffer");
   const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
-#define PP_LAUNCH(A_, R_) do { if (tm == 192) hipLaunchKernelGGL((gemm_f16_pp_kernel<0, A_, R_, false, true, false, 192>), dim3(grid), dim3(512), 0, s, p); \
-                               else hipLaunchKernelGGL((gemm_f16_pp_kernel<0, A_, R_, false, true>), dim3(grid), dim3(512), 0, s, p); } while (0)
+#define PP_K(A_, R_, TM_, LNO_, FH_) hipLaunchKernelGGL((gemm_f16_pp_kernel<0, A_, R_, false, true, false, TM_, 0, false, false, LNO_, false, FH_>), dim3(grid), dim3(512), 0, s, p)
+#define PP_LAUNCH(A_, R_) do { if (fh) { if (tm == 192) PP_K(A_, R_, 192, false, true); else PP_K(A_, R_, 256, false, true); } \
+                               else { if (tm == 192) PP_K(A_, R_, 192, false, false); else PP_K(A_, R_, 256, false, false); } } while (0)
   if (ln_gamma) {                                                   // LayerNorm of the output rows in the epilogue (LNO): N == 256, residual, no activation
     if (N != 256 || !residual || act != 0 || !ln_beta) return fail(OVIS_EINVAL, "gemm_nt_f32_w3_ln: needs N == 256, a residual and act == 0");
-    hipLaunchKernelGGL((gemm_f16_pp_kernel<0, 0, true, false, true, false, 192, 0, false, false, true>), dim3(grid), dim3(512), 0, s, p);
-    return check_launch("gemm_nt_f32 (ping-pong, f32 A, bf16x2, LayerNorm epilogue)");
+    if (fh) PP_K(0, true, 192, true, true); else PP_K(0, true, 192, true, false);
+    return check_launch(fh ? "gemm_nt_f32 (ping-pong, f32 A, fp16x2, LayerNorm epilogue)" : "gemm_nt_f32 (ping-pong, f32 A, bf16x2, LayerNorm epilogue)");
   }
   if (residual) { if (act == 1) PP_LAUNCH(1, true); else PP_LAUNCH(0, true); }
   else if (act == 1) PP_LAUNCH(1, false);
@@ -1010,7 +1091,8 @@ int gemm_f32a_pp_launch(const float* A, long long lda, const void* W3, long long
   else if (act == 3) PP_LAUNCH(3, false);
   else PP_LAUNCH(0, false);
 #undef PP_LAUNCH
-  return check_launch("gemm_nt_f32 (ping-pong, f32 A, bf16x2)");
+#undef PP_K
+  return check_launch(fh ? "gemm_nt_f32 (ping-pong, f32 A, fp16x2)" : "gemm_nt_f32 (ping-pong, f32 A, bf16x2)");
 }
 
 // ---- CV: 3x3 / stride 1 / pad 1 convolution on the f32-A schedule, input already zero-padded ([T][H+2][W+2][Cin] f32) ----
@@ -1023,13 +1105,17 @@ bool conv3x3_pp_eligible(const float* xpad, const void* W3, long long plane, con
 }
 
 int conv3x3_pp_launch(const float* xpad, const void* W3, long long plane, float* y, int T, int H, int W, int Cin, int Cout, const float* bias,
-                      int act, hipStream_t s) {
+                      int act, hipStream_t s, const F16x2* fh = nullptr) {
   const int M = T * H * W, N = Cout, K = 9 * Cin;
   PPArgs p;
   p.A = reinterpret_cast<const _Float16*>(xpad); p.B = reinterpret_cast<const _Float16*>(W3); p.C = y; p.bias = bias; p.R = nullptr;
   p.lda = K; p.ldb = K; p.ldc = N; p.ldr = 0; p.M = M; p.N = N; p.K = K; p.act = act;
   p.planeA = 0; p.planeB = plane * 2; p.planeC = 0;
   p.cv_H = H; p.cv_W = W; p.cv_C = Cin;
+  if (fh) {
+    if (N > 4096) return fail(OVIS_EINVAL, "conv3x3 (ping-pong, fp16x2): Cout = %d > 4096", N);
+    p.a_scale = fh->a_scale; p.acc_scale = fh->a_scale * fh->w_scale; p.out_scale = 1.f / p.acc_scale; p.range_flag = fh->flag;
+  }
   p.tiles_n = (int)cdiv(N, 256);
   const int tm = pp_pick_tm(M, p.tiles_n);
   p.tiles_m = (int)cdiv(M, tm); p.n_tiles = p.tiles_m * p.tiles_n;
@@ -1039,11 +1125,13 @@ int conv3x3_pp_launch(const float* xpad, const void* W3, long long plane, float*
   p.dump = pp_dump_buffer();
   if (!p.dump) return fail(OVIS_EINVAL, "conv3x3 (ping-pong, f32 A): cannot allocate the 4 KB dump buffer");
   const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
-#define PP_CV(A_) do { if (tm == 192) hipLaunchKernelGGL((gemm_f16_pp_kernel<0, A_, false, false, true, false, 192, 0, false, false, false, true>), dim3(grid), dim3(512), 0, s, p); \
-                       else hipLaunchKernelGGL((gemm_f16_pp_kernel<0, A_, false, false, true, false, 256, 0, false, false, false, true>), dim3(grid), dim3(512), 0, s, p); } while (0)
+#define PP_K(A_, TM_, FH_) hipLaunchKernelGGL((gemm_f16_pp_kernel<0, A_, false, false, true, false, TM_, 0, false, false, false, true, FH_>), dim3(grid), dim3(512), 0, s, p)
+#define PP_CV(A_) do { if (fh) { if (tm == 192) PP_K(A_, 192, true); else PP_K(A_, 256, true); } \
+                       else { if (tm == 192) PP_K(A_, 192, false); else PP_K(A_, 256, false); } } while (0)
   if (act == 1) PP_CV(1); else PP_CV(0);
 #undef PP_CV
-  return check_launch("conv3x3 (ping-pong, f32 A, bf16x2, padded input)");
+#undef PP_K
+  return check_launch(fh ? "conv3x3 (ping-pong, f32 A, fp16x2, padded input)" : "conv3x3 (ping-pong, f32 A, bf16x2, padded input)");
 }
 
 // x [n] f32 -> planes [3][n] bf16 with x == p0 + p1 + p2 exactly, 8 elements per thread (16-byte stores)

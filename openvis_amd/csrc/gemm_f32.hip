@@ -23,6 +23,7 @@
 #include "gemm_epilogue.h"
 #include "gemm_loaders.h"
 #include "gemm_f32x3.h"
+#include <cmath>
 
 namespace {
 
@@ -186,7 +187,8 @@ int x3_planes() { return g_f32_gemm_mode == 2 ? 2 : 3; }
 bool gemm_f32a_pp_eligible(const float* A, long long lda, const void* W3, long long ldb, long long plane, const float* C, long long ldc,
                            int M, int N, int K, const float* bias, const float* residual, long long ldr, int act, bool long_k = false);
 int gemm_f32a_pp_launch(const float* A, long long lda, const void* W3, long long ldb, long long plane, float* C, long long ldc, int M, int N,
-                        int K, const float* bias, const float* residual, long long ldr, int act, hipStream_t s, const float* ln_gamma = nullptr, const float* ln_beta = nullptr, float ln_eps = 0.f);
+                        int K, const float* bias, const float* residual, long long ldr, int act, hipStream_t s, const float* ln_gamma = nullptr, const float* ln_beta = nullptr, float ln_eps = 0.f,
+                        const F16x2* fh = nullptr);
 }
 namespace ovis {   // gemm_f32_skinny.hip
 bool gemm_f32_skinny_eligible(const float* A, long long lda, const float* B, long long ldb, int M, int N, int K);
@@ -201,7 +203,7 @@ namespace ovis {
 bool conv3x3_pp_eligible(const float* xpad, const void* W3, long long plane, const float* y, int T, int H, int W, int Cin, int Cout,
                          const float* bias, int act);
 int conv3x3_pp_launch(const float* xpad, const void* W3, long long plane, float* y, int T, int H, int W, int Cin, int Cout, const float* bias,
-                      int act, hipStream_t s);
+                      int act, hipStream_t s, const F16x2* fh = nullptr);
 }  // namespace ovis
 
 // 3x3 / stride 1 / pad 1 convolution whose input arrives ZERO-PADDED ([T][H+2][W+2][Cin], e.g. from ovis_groupnorm_nhwc_f32 with pad = 1):
@@ -232,8 +234,9 @@ extern "C" const char* ovis_gemm_nt_f32_w3_kernel(const float* A, long long lda,
 }
 
 extern "C" int ovis_set_f32_gemm_mode(int mode) {
-  OVIS_REQUIRE(mode >= 0 && mode <= 2, "set_f32_gemm_mode: mode must be 0 (native f32 MFMA), 1 (bf16x3 split) or 2 (bf16x2: 3 products)");
-  g_f32_gemm_mode = mode;
+  OVIS_REQUIRE(mode >= 0 && mode <= 3, "set_f32_gemm_mode: mode must be 0 (native f32 MFMA), 1 (bf16x3 split), 2 (bf16x2: 3 products) or 3 (fp16x2 "
+               "for the *_h2 entry points, bf16x3 here)");
+  g_f32_gemm_mode = mode == 3 ? 1 : mode;          // the generic / *_w3 entry points have no fp16 planes: they stay f32-grade on bf16x3
   return 0;
 }
 
@@ -348,4 +351,107 @@ extern "C" int ovis_conv2d_nhwc_f32_w3(const float* x, const float* w, const voi
   ovis::launch_gemm_f32x3_w3(la, w3, (long long)K, plane, y, (long long)Cout, (int)M, Cout, K, bias, residual, (long long)Cout, act,
                              (hipStream_t)stream);
   return ovis::check_launch("conv_f32x3 (pre-split weights)");
+}
+
+// ---- "fp16x2": constant f32 weights pre-split into two fp16 planes of w * w_scale; three fp16 MFMA products (include/openvis_hip.h) -------
+namespace {
+thread_local float g_f16x2_a_scale = 16.f;      // activations are multiplied by this while split (|a| < 65504 / a_scale)
+thread_local int* g_f16x2_flag = nullptr;       // device int raised when a result is not finite
+bool pow2(float v) { int e; return v > 0.f && std::frexp(v, &e) == 0.5f; }
+ovis::F16x2 f16x2_of(float w_scale) { return ovis::F16x2{g_f16x2_a_scale, w_scale, g_f16x2_flag}; }
+bool h2_vec(const float* A, long long lda, const void* H2, long long ldb, long long plane, int K) {
+  return (K % 8 == 0) && ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0) && ldb % 8 == 0 && (((uintptr_t)H2 & 15) == 0) && plane % 8 == 0;
+}
+}  // namespace
+
+extern "C" int ovis_set_f16x2(float a_scale, int* range_flag) {
+  OVIS_REQUIRE(pow2(a_scale), "set_f16x2: a_scale must be a power of two");
+  g_f16x2_a_scale = a_scale; g_f16x2_flag = range_flag;
+  return OVIS_OK;
+}
+
+extern "C" int ovis_split_f32_to_f16x2(const float* x, void* planes, long long n, float scale, ovis_stream_t stream) {
+  OVIS_REQUIRE(x && planes && n > 0 && pow2(scale), "split_f32_to_f16x2: bad arguments (scale must be a power of two)");
+  hipLaunchKernelGGL(ovis::x2h_split_kernel, dim3(ovis::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)planes, n, scale);
+  return ovis::check_launch("split_f32_to_f16x2");
+}
+
+extern "C" const char* ovis_gemm_nt_f32_h2_kernel(const float* A, long long lda, const void* H2, long long ldb, long long plane, const float* C,
+                                                  long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr, int act) {
+  if (g_f32a_pp && N <= 4096 && ovis::gemm_f32a_pp_eligible(A, lda, H2, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, act))
+    return residual ? (act == 1 ? "gemm_f16_pp_kernel<0,1,true,false,true,false,FH>" : "gemm_f16_pp_kernel<0,0,true,false,true,false,FH>")
+                    : (act == 1 ? "gemm_f16_pp_kernel<0,1,false,false,true,false,FH>" : act == 2 ? "gemm_f16_pp_kernel<0,2,false,false,true,false,FH>" :
+                       act == 3 ? "gemm_f16_pp_kernel<0,3,false,false,true,false,FH>" : "gemm_f16_pp_kernel<0,0,false,false,true,false,FH>");
+  return "";
+}
+
+extern "C" int ovis_gemm_nt_f32_h2(const float* A, long long lda, const float* B, long long ldb, const void* H2, long long plane, float w_scale,
+                                   float* C, long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr,
+                                   int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(A && B && H2 && C, "gemm_nt_f32_h2: null pointer");
+  const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128);
+  if (!(h2_vec(A, lda, H2, ldb, plane, K) && blocks128 >= 256))          // small / unaligned: the exact f32 kernels on the f32 copy
+    return ovis_gemm_nt_f32(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, stream);
+  OVIS_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldb >= K && ldc >= N && act >= 0 && act <= 3 && (!residual || ldr >= N) && pow2(w_scale),
+               "gemm_nt_f32_h2: bad sizes / w_scale not a power of two");
+  const ovis::F16x2 fh = f16x2_of(w_scale);
+  if (g_f32a_pp && N <= 4096 && ovis::gemm_f32a_pp_eligible(A, lda, H2, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, act))
+    return ovis::gemm_f32a_pp_launch(A, lda, H2, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream, nullptr, nullptr, 0.f, &fh);
+  ovis::launch_gemm_f16x2_h2(DenseA<true>{A, lda, M, K}, H2, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, act, (hipStream_t)stream, fh);
+  return ovis::check_launch("gemm_f32x3 (fp16x2, pre-split weights)");
+}
+
+extern "C" int ovis_gemm_nt_f32_h2_ln_eligible(const float* A, long long lda, const void* H2, long long ldb, long long plane, const float* C,
+                                               long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr) {
+  return (h2_vec(A, lda, H2, ldb, plane, K) && N == 256 && residual && g_f32a_pp &&
+          ovis::gemm_f32a_pp_eligible(A, lda, H2, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, 0)) ? 1 : 0;
+}
+
+extern "C" int ovis_gemm_nt_f32_h2_ln(const float* A, long long lda, const void* H2, long long ldb, long long plane, float w_scale, float* C,
+                                      long long ldc, int M, int N, int K, const float* bias, const float* residual, long long ldr,
+                                      const float* gamma, const float* beta, float eps, ovis_stream_t stream) {
+  OVIS_REQUIRE(A && H2 && C && residual && gamma && beta && pow2(w_scale), "gemm_nt_f32_h2_ln: null pointer / w_scale not a power of two");
+  OVIS_REQUIRE(((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0, "gemm_nt_f32_h2_ln: gamma / beta must be 16-byte aligned");
+  OVIS_REQUIRE(ovis_gemm_nt_f32_h2_ln_eligible(A, lda, H2, ldb, plane, C, ldc, M, N, K, bias, residual, ldr),
+               "gemm_nt_f32_h2_ln: not a problem of the ping-pong kernel with N == 256 (M=%d N=%d K=%d): run the GEMM and the LayerNorm separately", M, N, K);
+  const ovis::F16x2 fh = f16x2_of(w_scale);
+  return ovis::gemm_f32a_pp_launch(A, lda, H2, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, 0, (hipStream_t)stream, gamma, beta, eps, &fh);
+}
+
+extern "C" int ovis_conv3x3_padded_f32_h2_eligible(const float* xpad, const void* h2, long long plane, const float* y, int T, int H, int W,
+                                                   int Cin, int Cout, const float* bias, int act) {
+  return (g_f32a_pp && Cout <= 4096 && (((uintptr_t)xpad | (uintptr_t)h2 | (uintptr_t)y) & 15) == 0 && plane % 8 == 0 &&
+          ovis::conv3x3_pp_eligible(xpad, h2, plane, y, T, H, W, Cin, Cout, bias, act)) ? 1 : 0;
+}
+
+extern "C" int ovis_conv3x3_padded_f32_h2(const float* xpad, const void* h2, long long plane, float w_scale, float* y, int T, int H, int W, int Cin,
+                                          int Cout, const float* bias, int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(xpad && h2 && y && pow2(w_scale), "conv3x3_padded_f32_h2: null pointer / w_scale not a power of two");
+  OVIS_REQUIRE(ovis_conv3x3_padded_f32_h2_eligible(xpad, h2, plane, y, T, H, W, Cin, Cout, bias, act),
+               "conv3x3_padded_f32_h2: not a problem of the ping-pong kernel (T=%d H=%d W=%d Cin=%d Cout=%d): use ovis_conv2d_nhwc_f32_h2 on the unpadded input",
+               T, H, W, Cin, Cout);
+  const ovis::F16x2 fh = f16x2_of(w_scale);
+  return ovis::conv3x3_pp_launch(xpad, h2, plane, y, T, H, W, Cin, Cout, bias, act, (hipStream_t)stream, &fh);
+}
+
+extern "C" int ovis_conv2d_nhwc_f32_h2(const float* x, const float* w, const void* h2, long long plane, float w_scale, float* y, int N, int H,
+                                       int W, int Cin, int Cout, int KH, int KW, int stride, int pad, const float* bias,
+                                       const float* residual, int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(x && w && h2 && y, "conv2d_nhwc_f32_h2: null pointer");
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  const long long M = (long long)N * OH * OW;
+  const int K = KH * KW * Cin;
+  const long long blocks128 = ovis::cdiv(M, 128) * (long long)ovis::cdiv(Cout, 128);
+  const bool ok = Cin % 4 == 0 && K % 8 == 0 && (((uintptr_t)x | (uintptr_t)h2) & 15) == 0 && plane % 8 == 0 && OH > 0 && OW > 0 &&
+                  M < (1ll << 31);
+  if (!(ok && blocks128 >= 256))
+    return ovis_conv2d_nhwc_f32(x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act, stream);
+  OVIS_REQUIRE(act >= 0 && act <= 3 && pow2(w_scale), "conv2d_nhwc_f32_h2: unknown activation %d / w_scale not a power of two", act);
+  const ovis::F16x2 fh = f16x2_of(w_scale);
+  if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && g_f32a_pp && Cout <= 4096 &&      // a 1x1 conv is the dense GEMM on [M, Cin]
+      ovis::gemm_f32a_pp_eligible(x, Cin, h2, K, plane, y, Cout, (int)M, Cout, K, bias, residual, Cout, act))
+    return ovis::gemm_f32a_pp_launch(x, Cin, h2, K, plane, y, Cout, (int)M, Cout, K, bias, residual, Cout, act, (hipStream_t)stream, nullptr, nullptr, 0.f, &fh);
+  ConvA la{x, ConvGeom{H, W, Cin, OH, OW, KH, KW, stride, pad}, (int)M, K};
+  ovis::launch_gemm_f16x2_h2(la, h2, (long long)K, plane, y, (long long)Cout, (int)M, Cout, K, bias, residual, (long long)Cout, act, (hipStream_t)stream, fh);
+  return ovis::check_launch("conv_f32x3 (fp16x2, pre-split weights)");
 }

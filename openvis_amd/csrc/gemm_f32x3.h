@@ -43,6 +43,20 @@ __device__ __forceinline__ X3Planes x3_split8(bool ok0, float4 a, bool ok1, floa
   return X3Planes{o0.u, o1.u, o2.u};
 }
 
+// fp16x2 (FH): hi = fp16(x * scale), lo = fp16(x * scale - hi): 11 + 11 significand bits; p2 unused
+__device__ __forceinline__ X3Planes x3_split8_f16(bool ok0, float4 a, bool ok1, float4 b, float scale) {
+  const float x[8] = {ok0 ? a.x : 0.f, ok0 ? a.y : 0.f, ok0 ? a.z : 0.f, ok0 ? a.w : 0.f,
+                      ok1 ? b.x : 0.f, ok1 ? b.y : 0.f, ok1 ? b.z : 0.f, ok1 ? b.w : 0.f};
+  union { _Float16 h[8]; uint4 u; } o0, o1;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = x[e] * scale;
+    const _Float16 h0 = (_Float16)v;
+    o0.h[e] = h0; o1.h[e] = (_Float16)(v - (float)h0);
+  }
+  return X3Planes{o0.u, o1.u, o1.u};
+}
+
 // B operand given as three pre-split bf16 planes [3][N][ldb] (constant weights: split once at load, x3_split_kernel)
 struct PlanesB {
   const __bf16* P;
@@ -54,11 +68,15 @@ struct PlanesB {
 // NP = 3: the six products above (f32-grade).  NP = 2 ("bf16x2"): planes 0 and 1 only and the three products a1 b0, a0 b1, a0 b0:
 // both operands are then carried with 16 significand bits (relative error 2^-17 = 7.6e-6 per operand -- 64 x finer than the fp16
 // operands of autocast, 32 x finer than the TF32 cuDNN uses for the reference's f32 convolutions by default) at half the MFMA work.
-template <int BM, int BN, typename LoaderA, typename LoaderB = DenseA<true>, int NP = 3>
+// FH (NP == 2, pre-split B): "fp16x2" -- the three products on the FP16 matrix cores, operands split into fp16 hi / lo (11 + 11 significand
+// bits: every term down to 2^-22 |a b|), activations scaled by fh.a_scale while split, weight planes = fp16 hi / lo of w * fh.w_scale
+// (common.h F16x2; gemm_f16_pp.hip explains the scales); the accumulators are scaled back (exactly) before the epilogue.
+template <int BM, int BN, typename LoaderA, typename LoaderB = DenseA<true>, int NP = 3, bool FH = false>
 __global__ void __launch_bounds__(256)
 gemm_f32x3_kernel(LoaderA la, LoaderB lb, float* __restrict__ C, long long ldc, int M, int N, int K,
                   const float* __restrict__ bias, const float* __restrict__ R, long long ldr, int act, int tiles_n,
-                  long long a_bs, long long b_bs, long long c_bs) {
+                  long long a_bs, long long b_bs, long long c_bs, F16x2 fh = F16x2{1.f, 1.f, nullptr}) {
+  static_assert(!FH || (NP == 2 && std::is_same<LoaderB, PlanesB>::value), "fp16x2: two pre-split weight planes");
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_IT = BM / 64, B_IT = BN / 64;   // thread stages rows srow + 64 i, 8 consecutive k each
   __shared__ __attribute__((aligned(16))) __bf16 As[NP][BM * X3_ROW];
@@ -114,7 +132,8 @@ gemm_f32x3_kernel(LoaderA la, LoaderB lb, float* __restrict__ C, long long ldc, 
   };
   auto split = [&]() {
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) sa[i] = x3_split8(oka[i][0], pa[i][0], oka[i][1], pa[i][1]);
+    for (int i = 0; i < A_IT; ++i)
+      sa[i] = FH ? x3_split8_f16(oka[i][0], pa[i][0], oka[i][1], pa[i][1], fh.a_scale) : x3_split8(oka[i][0], pa[i][0], oka[i][1], pa[i][1]);
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       if constexpr (BSPLIT) sb[i] = x3_split8(okb[i][0], pb[i][0], okb[i][1], pb[i][1]);
@@ -173,6 +192,11 @@ gemm_f32x3_kernel(LoaderA la, LoaderB lb, float* __restrict__ C, long long ldc, 
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
+          if constexpr (FH) {
+            using f16x8_t = __attribute__((ext_vector_type(8))) _Float16;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, bf[PB[t]][j]), __builtin_bit_cast(f16x8_t, af[PA[t]][i]),
+                                                               acc[i][j], 0, 0, 0);
+          } else
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[PB[t]][j], af[PA[t]][i], acc[i][j], 0, 0, 0);   // roles swapped
   };
 
@@ -191,6 +215,19 @@ gemm_f32x3_kernel(LoaderA la, LoaderB lb, float* __restrict__ C, long long ldc, 
     mma_step(1);
   }
 
+  if constexpr (FH) {                              // back to scale 1 (a power of two: exact); a non-finite result = an operand left the fp16 range
+    const float inv = 1.f / (fh.a_scale * fh.w_scale);
+    float chk = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {             // (an activation beyond the range makes every output of its row NaN: one element per tile tells)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+        chk = __builtin_fmaf(acc[i][j][0], 0.f, chk);
+      }
+    if (chk != chk && fh.flag) *fh.flag = 1;
+  }
   const bool vec_ok = ((ldc & 3) == 0) && (!R || (ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                       (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
 #pragma unroll
@@ -228,6 +265,25 @@ inline void launch_gemm_f32x3_w3(LoaderA la, const void* W3, long long ldb, long
   else
   hipLaunchKernelGGL((gemm_f32x3_kernel<128, 128, LoaderA, PlanesB>), dim3(tm * tn, 1), dim3(256), 0, stream, la,
                      PlanesB{(const __bf16*)W3, ldb, plane, N, K}, C, ldc, M, N, K, bias, R, ldr, act, tn, 0ll, 0ll, 0ll);
+}
+
+// fp16x2: H2 = the two fp16 planes of w * fh.w_scale (x2h_split_kernel)
+template <typename LoaderA>
+inline void launch_gemm_f16x2_h2(LoaderA la, const void* H2, long long ldb, long long plane, float* C, long long ldc, int M, int N,
+                                 int K, const float* bias, const float* R, long long ldr, int act, hipStream_t stream, F16x2 fh) {
+  const int tm = cdiv(M, 128), tn = cdiv(N, 128);
+  hipLaunchKernelGGL((gemm_f32x3_kernel<128, 128, LoaderA, PlanesB, 2, true>), dim3(tm * tn, 1), dim3(256), 0, stream, la,
+                     PlanesB{(const __bf16*)H2, ldb, plane, N, K}, C, ldc, M, N, K, bias, R, ldr, act, tn, 0ll, 0ll, 0ll, fh);
+}
+
+// x [n] f32 -> planes [2][n] fp16: hi = fp16(x * scale), lo = fp16(x * scale - hi)
+__global__ void __launch_bounds__(256)
+x2h_split_kernel(const float* __restrict__ x, _Float16* __restrict__ planes, long long n, float scale) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i] * scale;
+  const _Float16 h0 = (_Float16)v;
+  planes[i] = h0; planes[n + i] = (_Float16)(v - (float)h0);
 }
 
 // x [n] f32 -> planes [3][n] bf16 with x == p0 + p1 + p2 exactly

@@ -56,6 +56,8 @@ class VideoMaskFormer:
         a model's results never depend on which model ran before it."""
         if self.f32_gemm_mode is not None and ops.f32_gemm_mode() != self.f32_gemm_mode:
             ops.set_f32_gemm_mode(self.f32_gemm_mode)
+        if self.f32_gemm_mode == 3:
+            ops.f16x2_begin(self.device)          # fp16x2: this forward's range flag (read back with the outputs, _range_guard)
         frames = [f for video in batched_inputs for f in video["image"]]
         f0 = frames[0]
         if any(f.dtype != torch.uint8 for f in frames):
@@ -84,13 +86,39 @@ class VideoMaskFormer:
         Hp, Wp = ((H + d - 1) // d * d, (W + d - 1) // d * d) if d > 1 else (H, W)
         return ops.preprocess_u8(frames_u8, Hp, Wp, self.pixel_mean, self.pixel_std), (H, W), (Hp, Wp)
 
+    def _range_guard(self, flag_host, redo):
+        """fp16x2: `flag_host` is this forward's range flag on the host (after its copy has completed).  Set = an activation of a
+        constant-weight layer left the fp16 range (|a| >= 65 504 / a_scale) and the layer's output is NaN: this model switches to the
+        f32-grade bf16x3 split for good and repeats the clip (redo() -> the repeated forward's output).  Returns None when all is well."""
+        if flag_host is None or int(flag_host) == 0:
+            return None
+        import warnings
+        warnings.warn("fp16x2: an activation left the fp16 range; this model now runs MODEL.F32_GEMM_SPLIT = bf16x3 and the clip is repeated")
+        self.f32_gemm_mode = 1
+        if redo is None:
+            raise RuntimeError("fp16x2: an activation left the fp16 range and the forward cannot be repeated here: set MODEL.F32_GEMM_SPLIT to bf16x3")
+        out = redo()
+        return dict(out.items()) if hasattr(out, "items") else out
+
     output_rle = False        # MODEL.MASK_FORMER.TEST.OUTPUT_RLE (not a reference key): RLE hand-off instead of dense masks
     mask_gather = None        # frame-sharded runs: callable(device masks [n,t_local,H,W]) -> masks of all frames on the output rank / None
 
     def inference_video(self, num_queries, num_classes, probs, row_ids, pred_masks_lowres, padded_hw, img_size,
-                        output_height, output_width, topk=10):
-        """video_maskformer.py:262-298.  probs [Q,K] (rows of valid queries filled), row_ids = valid query ids."""
+                        output_height, output_width, topk=10, redo=None, sync_guard=False):
+        """video_maskformer.py:262-298.  probs [Q,K] (rows of valid queries filled), row_ids = valid query ids.
+        redo: callable repeating this forward (fp16x2 only: used when the range flag came back set, _range_guard); sync_guard: read the
+        flag back NOW instead of with the outputs (frame-sharded runs: every rank holds the all-reduced flag, distributed.reduce_flag, and
+        all of them must repeat the clip at the same point of their collective sequence)."""
+        flag = ops.f16x2_flag() if self.f32_gemm_mode == 3 else None
+        if flag is not None and sync_guard:
+            again = self._range_guard(flag.cpu()[0], redo)
+            if again is not None:
+                return again
+            flag = None
         if row_ids is None or len(row_ids) == 0:
+            again = self._range_guard(flag.cpu()[0] if flag is not None else None, redo)
+            if again is not None:
+                return again
             return {"image_size": (output_height, output_width), "pred_entropys": [], "pred_scores": [],
                     "pred_labels": [], "pred_masks": []}
         dev = probs.device
@@ -110,6 +138,9 @@ class VideoMaskFormer:
                                  output_height, output_width, column_major=True)
             counts, n_runs = ops.rle_encode(cm.view(-1, output_height * output_width))
             labels = [i % K for i in idx.cpu().tolist()]
+            again = self._range_guard(flag.cpu()[0] if flag is not None else None, redo)
+            if again is not None:
+                return again
             return {"image_size": (output_height, output_width), "pred_entropys": ent.cpu().tolist(),
                     "pred_scores": score.cpu().tolist(), "pred_labels": labels,
                     "pred_masks_rle": rle.encode_video_masks(counts, n_runs, topk, T, output_height, output_width),
@@ -119,6 +150,9 @@ class VideoMaskFormer:
         if self.mask_gather is not None:
             masks = self.mask_gather(masks)
             if masks is None:                                                 # not the output rank
+                again = self._range_guard(flag.cpu()[0] if flag is not None else None, redo)
+                if again is not None:
+                    return again
                 return {"image_size": (output_height, output_width), "pred_entropys": ent.cpu().tolist(),
                         "pred_scores": score.cpu().tolist(), "pred_labels": [i % K for i in idx.cpu().tolist()],
                         "pred_masks": [], "pred_queries": sel_q.cpu().tolist()}
@@ -135,11 +169,19 @@ class VideoMaskFormer:
             for h_, t in zip(small, (idx, score, ent, sel_q)):
                 h_.copy_(t, non_blocking=True)
                 t.record_stream(side)
+            flag_host = None
+            if flag is not None:
+                flag_host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+                flag_host.copy_(flag, non_blocking=True)
+                flag.record_stream(side)
             masks.record_stream(side)
             done = torch.cuda.Event()
             done.record(side)
 
         def finish():
+            again = self._range_guard(flag_host[0] if flag_host is not None else None, redo)
+            if again is not None:
+                return {k: v for k, v in again.items() if k != "image_size"}
             i_, s_, e_, q_ = (h_.tolist() for h_ in small)
             return {"pred_entropys": e_, "pred_scores": s_, "pred_labels": [i % K for i in i_],      # video_maskformer.py:269-270
                     "pred_masks": [m for m in host.view(torch.bool)], "pred_queries": q_}

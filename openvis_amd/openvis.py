@@ -55,7 +55,7 @@ class OpenVIS(VideoMaskFormer):
         height = inp.get("height", image_size[0])
         width = inp.get("width", image_size[1])
         return self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
-                                    height, width)
+                                    height, width, redo=lambda: self.forward(batched_inputs, stages))
 
     __call__ = forward
 
@@ -124,6 +124,7 @@ class OpenVISOnline(OpenVIS):
                                row_ids=row_ids, **extras))
         inp = batched_inputs[0]
         return self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
-                                    inp.get("height", image_size[0]), inp.get("width", image_size[1]))
+                                    inp.get("height", image_size[0]), inp.get("width", image_size[1]),
+                                    redo=lambda: self.forward(batched_inputs, stages))
 
     __call__ = forward

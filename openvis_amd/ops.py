@@ -33,15 +33,17 @@ PROFILE = None
 class _Mode(__import__("threading").local):
     """the library keeps the f32-GEMM split per host thread (thread_local in csrc/gemm_f32.hip): so does this mirror of it"""
     v = 1
+    flag = None          # fp16x2: the device int the kernels of this thread raise when an operand left the fp16 range (f16x2_begin)
+    a_scale = 16.0       # fp16x2: power of two the activations are multiplied by while they are split
 
 
 _MODE = _Mode()
 
 
-def _gemm_variant(M, N, loader, K=4, batch=1):
+def _gemm_variant(M, N, loader, K=4, batch=1, h2=False):
     big = ((M + 127) // 128) * ((N + 127) // 128) * batch >= 256       # mirrors launch_gemm() in csrc/gemm_f32.hip
     if big and _MODE.v >= 1 and K % 4 == 0:
-        return f"gemm_f32x3_kernel<128,128,{loader}>"
+        return f"gemm_f32x3_kernel<128,128,{loader},FH>" if h2 else f"gemm_f32x3_kernel<128,128,{loader}>"
     return f"gemm_f32_kernel<{'128,128' if big else '64,64'},{loader}>"
 
 
@@ -91,10 +93,27 @@ def f32_gemm_mode():
 
 def set_f32_gemm_mode(mode):
     """0: native f32 MFMA for every f32 GEMM/conv; 1 (library default): large problems use the exact bf16x3 split (gemm_f32x3.h);
-    2: the same kernel with the two leading planes only (bf16x2, three products).  Per HOST THREAD (MODEL.F32_GEMM_SPLIT): two models
-    with different splits on different ClipPipeline threads do not see each other's setting."""
+    2: the same kernel with the two leading planes only (bf16x2, three products); 3: "fp16x2" -- constant-weight layers (cw=True) run the
+    three products hi hi + hi lo + lo hi of the fp16 split (11 + 11 significand bits: f32 grade at the MFMA cost of bf16x2; the *_h2 entry
+    points of include/openvis_hip.h), everything else stays on bf16x3.  Per HOST THREAD (MODEL.F32_GEMM_SPLIT): two models with different
+    splits on different ClipPipeline threads do not see each other's setting."""
     _lib.call("ovis_set_f32_gemm_mode", int(mode))
     _MODE.v = int(mode)
+
+
+def f16x2_begin(device, a_scale=None):
+    """fp16x2: a fresh zeroed range flag for the work this thread queues from now on (one per forward: the previous forward's flag may still
+    be waiting for its device -> host copy) and the activation scale.  Returns the flag tensor (int32 [1])."""
+    if a_scale is not None:
+        _MODE.a_scale = float(a_scale)
+    _MODE.flag = torch.zeros((1,), dtype=torch.int32, device=device)
+    _lib.call("ovis_set_f16x2", ctypes.c_float(_MODE.a_scale), _MODE.flag)
+    return _MODE.flag
+
+
+def f16x2_flag():
+    """the range flag of this thread's current forward (None outside the fp16x2 policy)"""
+    return _MODE.flag if _MODE.v == 3 else None
 
 
 import weakref
@@ -125,6 +144,34 @@ def w3_of(w):
     return p
 
 
+_H2_CACHE = {}      # like _W3_CACHE: (two fp16 planes of w * scale, scale)
+
+
+def h2_of(w):
+    """The fp16x2 operand of a CONSTANT weight tensor: fp16 [2, *w.shape] = (hi, lo) of w * scale with scale = 2^k such that
+    max |w| * scale lies in [2^14, 2^15) -- the top of the fp16 range, so that lo keeps its 11 bits far below every weight that matters
+    (absolute floor 2^-25 against 2^14).  Cached like w3_of; the scale costs one host read-back per weight tensor, at its first use."""
+    base = w._base if w._base is not None else w
+    key = (id(base), w.storage_offset(), tuple(w.shape), tuple(w.stride()))
+    hit = _H2_CACHE.get(key)
+    if hit is not None and hit[0]() is base:
+        return hit[1], hit[2]
+    _chk(w)
+    amax = float(w.abs().max().item())
+    scale = 1.0 if not (amax > 0.0 and amax < float("inf")) else 2.0 ** (14 - __import__("math").frexp(amax)[1] + 1)
+    p = torch.empty((2,) + tuple(w.shape), dtype=torch.float16, device=w.device)
+    _lib.call("ovis_split_f32_to_f16x2", w, p, _ll(w.numel()), ctypes.c_float(scale), _lib.stream_ptr())
+    _H2_CACHE[key] = (weakref.ref(base, lambda _r, k=key: _H2_CACHE.pop(k, None)), p, scale)
+    return p, scale
+
+
+def _h2_kernel_name(a, lda, h2, ldb, plane, out, ldc, M, N, K, bias, residual, ldr, act):
+    fn = _lib.lib().ovis_gemm_nt_f32_h2_kernel
+    fn.restype = ctypes.c_char_p
+    return fn(_lib._conv(a), _ll(lda), _lib._conv(h2), _ll(ldb), _ll(plane), _lib._conv(out), _ll(ldc), M, N, K, _lib._conv(bias),
+              _lib._conv(residual), _ll(ldr), act).decode()
+
+
 def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None, cw=False):
     """out[m,n] = act(sum_k a[m,k] w[n,k] + bias[n] + residual[m,n]); a [...,K] -> out [...,N].
     w16 (an fp16 copy of w) selects the autocast arithmetic: operands rounded to fp16, f32 accumulation.
@@ -144,6 +191,15 @@ def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None, cw
                       _lib.stream_ptr())
         return out.view(*a.shape[:-1], N)
     use_w3 = cw and w.is_contiguous() and K % 8 == 0 and _MODE.v >= 1 and ((M + 127) // 128) * ((N + 127) // 128) >= 256
+    if use_w3 and _MODE.v == 3:                              # fp16x2: two fp16 planes of w * scale, three fp16 MFMA products
+        h2, ws = h2_of(w)
+        label = ""
+        if PROFILE is not None:
+            label = _h2_kernel_name(a2, K, h2, K, w.numel(), out, N, M, N, K, bias, r2, N, act) or _gemm_variant(M, N, "DenseA", K, h2=True)
+        with _Prof(label, 2.0 * M * N * K):
+            _lib.call("ovis_gemm_nt_f32_h2", a2, _ll(K), w, _ll(K), h2, _ll(w.numel()), ctypes.c_float(ws), out, _ll(N), M, N, K, bias, r2,
+                      _ll(N), act, _lib.stream_ptr())
+        return out.view(*a.shape[:-1], N)
     label = _gemm_variant(M, N, "DenseA", K) if PROFILE is not None else ""
     if PROFILE is not None and use_w3 and _MODE.v == 2:      # bf16x2: the ping-pong kernel's f32-A mode takes the eligible shapes
         label = _w3_kernel_name(a2, K, w3_of(w), K, w.numel(), out, N, M, N, K, bias, r2, N, act) or label
@@ -168,6 +224,15 @@ def gemm_nt_layernorm(a, w, bias, residual, gamma, beta, eps=1e-5):
     r2 = residual.reshape(-1, N)
     _chk(a2, w, bias, r2, gamma, beta)
     M = a2.shape[0]
+    if w.is_contiguous() and N == 256 and _MODE.v == 3 and K % 8 == 0 and ((M + 127) // 128) * ((N + 127) // 128) >= 256:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        h2, ws = h2_of(w)
+        if _lib.lib().ovis_gemm_nt_f32_h2_ln_eligible(_lib._conv(a2), _ll(K), _lib._conv(h2), _ll(K), _ll(w.numel()), _lib._conv(out), _ll(N), M, N, K,
+                                                      _lib._conv(bias), _lib._conv(r2), _ll(N)):
+            with _Prof("gemm_f16_pp_kernel<0,0,true,false,true,false,FH>", 2.0 * M * N * K):
+                _lib.call("ovis_gemm_nt_f32_h2_ln", a2, _ll(K), h2, _ll(K), _ll(w.numel()), ctypes.c_float(ws), out, _ll(N), M, N, K, bias, r2, _ll(N),
+                          gamma, beta, ctypes.c_float(eps), _lib.stream_ptr())
+            return out.view(*a.shape[:-1], N)
     if w.is_contiguous() and N == 256 and _MODE.v == 2 and K % 8 == 0 and ((M + 127) // 128) * ((N + 127) // 128) >= 256:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
         w3 = w3_of(w)
@@ -390,6 +455,17 @@ def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE, w
             _lib.call("ovis_conv2d_nhwc_f32a_f16w", x, w16, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, residual, act,
                       _lib.stream_ptr())
         return y
+    if cw and (KH * KW * Cin) % 8 == 0 and _MODE.v == 3 and ((N * OH * OW + 127) // 128) * ((Cout + 127) // 128) >= 256:     # fp16x2
+        h2, ws = h2_of(w)
+        label = ""
+        if PROFILE is not None:
+            label = _gemm_variant(N * OH * OW, Cout, "ConvA", KH * KW * Cin, h2=True)
+            if KH == 1 and KW == 1 and stride == 1 and pad == 0:
+                label = _h2_kernel_name(x, Cin, h2, Cin, w.numel(), y, Cout, N * OH * OW, Cout, Cin, bias, residual, Cout, act) or label
+        with _Prof(label, 2.0 * N * OH * OW * Cout * KH * KW * Cin):
+            _lib.call("ovis_conv2d_nhwc_f32_h2", x, w, h2, _ll(w.numel()), ctypes.c_float(ws), y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias,
+                      residual, act, _lib.stream_ptr())
+        return y
     label = _gemm_variant(N * OH * OW, Cout, "ConvA", KH * KW * Cin) if PROFILE is not None else ""
     if (PROFILE is not None and cw and _MODE.v == 2 and KH == 1 and KW == 1 and stride == 1 and pad == 0 and Cin % 8 == 0
             and ((N * OH * OW + 127) // 128) * ((Cout + 127) // 128) >= 256):
@@ -458,6 +534,9 @@ def conv3x3_padded_eligible(N, H, W, Cin, Cout, act=ACT_NONE):
     """whether conv3x3_padded takes this problem on the ping-pong kernel (bf16x2 policy, Cin % 32 == 0, enough tiles); alignment-only
     probe pointers (the library checks 16-byte alignment, it does not read them)"""
     big = ctypes.c_void_p(16 * 1024 * 1024)
+    if _MODE.v == 3:
+        return bool(_lib.lib().ovis_conv3x3_padded_f32_h2_eligible(big, big, _ll(Cout * 9 * Cin), big, int(N), int(H), int(W), int(Cin), int(Cout),
+                                                                   None, int(act)))
     return _MODE.v == 2 and bool(_lib.lib().ovis_conv3x3_padded_f32_w3_eligible(big, big, _ll(Cout * 9 * Cin), big, int(N), int(H), int(W), int(Cin),
                                                                                   int(Cout), None, int(act)))
 
@@ -474,6 +553,12 @@ def conv3x3_padded(xpad, w, bias=None, act=ACT_NONE):
         raise _lib.OvisError("conv3x3_padded: w must be [Cout, 3, 3, Cin]")
     if conv3x3_padded_eligible(N, H, W, Cin, Cout, act):
         y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=xpad.device)
+        if _MODE.v == 3:
+            h2, ws = h2_of(w)
+            with _Prof("gemm_f16_pp_kernel<0,%d,false,false,true,false,FH>" % act, 2.0 * N * H * W * Cout * 9 * Cin):
+                _lib.call("ovis_conv3x3_padded_f32_h2", xpad, h2, _ll(w.numel()), ctypes.c_float(ws), y, N, H, W, Cin, Cout, bias, int(act),
+                          _lib.stream_ptr())
+            return y
         with _Prof("gemm_f16_pp_kernel<0,%d,false,false,true,false>" % act, 2.0 * N * H * W * Cout * 9 * Cin):
             _lib.call("ovis_conv3x3_padded_f32_w3", xpad, w3_of(w), _ll(w.numel()), y, N, H, W, Cin, Cout, bias, int(act), _lib.stream_ptr())
         return y

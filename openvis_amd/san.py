@@ -74,7 +74,8 @@ class SAN(VideoMaskFormer):
         inp = batched_inputs[0]
         row_ids = np.arange(self.num_queries, dtype=np.int32)
         return self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
-                                    inp.get("height", image_size[0]), inp.get("width", image_size[1]))
+                                    inp.get("height", image_size[0]), inp.get("width", image_size[1]),
+                                    redo=lambda: self.forward(batched_inputs, stages))
 
     __call__ = forward
 
@@ -142,6 +143,7 @@ class SANOnline(MinVIS):
         inp = batched_inputs[0]
         row_ids = np.arange(self.num_queries, dtype=np.int32)
         return self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
-                                    inp.get("height", image_size[0]), inp.get("width", image_size[1]))
+                                    inp.get("height", image_size[0]), inp.get("width", image_size[1]),
+                                    redo=lambda: self.forward(batched_inputs, stages))
 
     __call__ = forward

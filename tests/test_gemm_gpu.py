@@ -118,7 +118,7 @@ def test_large_gemm_bf16x2_opt_in_carries_16_operand_bits(gemm_modes):
     wi = (torch.arange(130 * 72).reshape(130, 72) % 97 - 48).float()
     assert torch.equal(ops.gemm_nt(ai.cuda(), wi.cuda()).cpu(), (ai.double() @ wi.double().T).float())
     with pytest.raises(Exception):
-        ops.set_f32_gemm_mode(3)
+        ops.set_f32_gemm_mode(4)
 
 
 def test_large_gemm_bf16x3_integer_exact(gemm_modes):
