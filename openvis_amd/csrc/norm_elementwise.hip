@@ -18,9 +18,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ void __launch_bounds__(256)
 preprocess_kernel(const uint8_t* __restrict__ frames, float* __restrict__ out, int T, int H, int W, int Hp,
                   int Wp, float m0, float m1, float m2, float s0, float s1, float s2) {
-  const int x = blockIdx.x * 256 + threadIdx.x;
+  // rows on gridDim.x (limit 2^31 - 1), 256-column chunks on gridDim.y (limit 65 535): a whole video is pre-processed before it is
+  // windowed (openvis.py:109, san.py:62), so T * Hp exceeds 65 535 from ~90 frames of 720p on
+  const int x = blockIdx.y * 256 + threadIdx.x;
   if (x >= Wp) return;
-  const int row = blockIdx.y;                               // t * Hp + y
+  const int row = blockIdx.x;                               // t * Hp + y
   const int t = row / Hp, y = row - t * Hp;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (y < H && x < W) {
@@ -398,8 +400,8 @@ extern "C" int ovis_preprocess_u8_nhwc4(const uint8_t* frames, float* out, int T
                                         const float* mean3_host, const float* std3_host, ovis_stream_t stream) {
   OVIS_REQUIRE(frames && out && mean3_host && std3_host, "preprocess: null pointer");
   OVIS_REQUIRE(T > 0 && H > 0 && W > 0 && Hp >= H && Wp >= W, "preprocess: bad geometry");
-  OVIS_REQUIRE((long long)T * Hp <= 0x7fffffffll, "preprocess: too many rows");
-  hipLaunchKernelGGL(preprocess_kernel, dim3(ovis::cdiv(Wp, 256), (unsigned)(T * Hp)), dim3(256), 0, (hipStream_t)stream, frames, out,
+  OVIS_REQUIRE((long long)T * Hp <= 0x7fffffffll && ovis::cdiv(Wp, 256) <= 65535u, "preprocess: too many rows / columns for one launch");
+  hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)(T * Hp), ovis::cdiv(Wp, 256)), dim3(256), 0, (hipStream_t)stream, frames, out,
                      T, H, W, Hp, Wp, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1],
                      std3_host[2]);
   return ovis::check_launch("preprocess");

@@ -63,14 +63,24 @@ class ClipVisual:
             for k in ["conv1"] + [f"{i}.{n}" for i in range(self.layers)
                                   for n in ("attn.in_proj_weight", "attn.out_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight")]:
                 w[k + ".h"] = ops.cast_f16(w[k])
-            C = self.width
-            for i in range(self.layers):                              # LayerNorm-folded operands (wg fp16, s, c) of in_proj / c_fc
-                g1, b1 = w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"]
-                w[f"{i}.qkv.fold"] = ops.fold_layernorm(w[f"{i}.attn.in_proj_weight"], w[f"{i}.attn.in_proj_bias"], g1, b1)
-                w[f"{i}.fc.fold"] = ops.fold_layernorm(w[f"{i}.mlp.c_fc.weight"], w[f"{i}.mlp.c_fc.bias"], w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"])
-                if i == self.layers - 1:                              # last_block_cls: keys | values of every token only
-                    w[f"{i}.kv.fold"] = ops.fold_layernorm(w[f"{i}.attn.in_proj_weight"][C:].contiguous(), w[f"{i}.attn.in_proj_bias"][C:].contiguous(), g1, b1)
         return self
+
+    def _fold(self, i, which):
+        """LayerNorm-folded operands (wg fp16, s, c) of block i: "qkv" = ln_1 -> in_proj, "fc" = ln_2 -> c_fc, "kv" = ln_1 -> the key | value
+        rows of in_proj (last_block_cls).  Built at first use (only a tower that runs the folded fp16 stream pays for them: ~350 MB for
+        ViT-L/14) and cached; two ClipPipeline threads racing here build the same values."""
+        key = f"{i}.{which}.fold"
+        w = self.w
+        if key not in w:
+            C = self.width
+            g1, b1 = w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"]
+            if which == "qkv":
+                w[key] = ops.fold_layernorm(w[f"{i}.attn.in_proj_weight"], w[f"{i}.attn.in_proj_bias"], g1, b1)
+            elif which == "fc":
+                w[key] = ops.fold_layernorm(w[f"{i}.mlp.c_fc.weight"], w[f"{i}.mlp.c_fc.bias"], w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"])
+            else:
+                w[key] = ops.fold_layernorm(w[f"{i}.attn.in_proj_weight"][C:].contiguous(), w[f"{i}.attn.in_proj_bias"][C:].contiguous(), g1, b1)
+        return w[key]
 
     def embed(self, A, M, patch_open=None):
         """patch im2col matrix [M*G*G, 3*ps*ps] (f32 or fp16) -> ln_pre(tokens) [M, G*G+1, C] (model.py:328-343): f32, or fp16 when
@@ -83,8 +93,11 @@ class ClipVisual:
             ops.mask_prompt_select(x, patch_open, w["mask_embedding"][0], 0)
         return ops.vit_embed_ln(x, w["cls"], w["pos"], w["ln_pre.w"], w["ln_pre.b"], M, G * G + 1)
 
-    def run_blocks(self, x, i0, i1, attn_bias=None):
+    def run_blocks(self, x, i0, i1, attn_bias=None, stats=None, with_stats=False):
         """resblocks[i0:i1] on x [B, L, C] (model.py:238-268); attn_bias: additive f32 [B, heads, L, ld] (SideAdapter).
+        stats: (mean, rstd) f32 [B*L, 2] of the rows of x if the GEMM that wrote x left them (the folded fp16 stream), else None;
+        with_stats=True returns (x, stats of the rows of the returned x or None) -- the hand-over is explicit, the caller drops the statistics
+        when it rewrites rows in place (forward_patches' mask prompt).
         fp16 policy: GEMM operands rounded to fp16 (weights cast once), f32 accumulation / LayerNorm statistics / softmax; the
         residual stream is whatever dtype x has: f32, or fp16 (stream16: x_new = fp16(f32(x) + bias + sum), one rounding per
         sub-block -- what the reference's fp16 CLIP keeps between blocks).  fp32 policy: exact-f32 MFMA, f32 stream."""
@@ -94,7 +107,8 @@ class ClipVisual:
         D = C // Hh
         f16 = self.precision == "fp16"
         if f16 and attn_bias is None and x.dtype == torch.float16:
-            return self._run_blocks_stream16(x, i0, i1)
+            x, st = self._run_blocks_stream16(x, i0, i1, stats)
+            return (x, st) if with_stats else x
         for i in range(i0, i1):
             h = ops.layernorm(x, w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"], out_f16=f16)
             if f16 and attn_bias is None:
@@ -121,9 +135,9 @@ class ClipVisual:
                 h = ops.layernorm(x, w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"])
                 f = ops.gemm_nt(h.view(-1, C), w[f"{i}.mlp.c_fc.weight"], w[f"{i}.mlp.c_fc.bias"], None, ops.ACT_QUICKGELU, cw=True)
                 x = ops.gemm_nt(f, w[f"{i}.mlp.c_proj.weight"], w[f"{i}.mlp.c_proj.bias"], x.view(-1, C), cw=True).view(B, L, C)
-        return x
+        return (x, None) if with_stats else x
 
-    def _run_blocks_stream16(self, x, i0, i1):
+    def _run_blocks_stream16(self, x, i0, i1, stats=None):
         """run_blocks on the fp16 residual stream (plain blocks).  Where the ping-pong kernel takes the problem, ln_1 / ln_2 are folded
         into in_proj / c_fc (ops.gemm_nt_f16_ln: the normalised rows are never written) and the row statistics come out of the epilogue
         of the GEMM that wrote the stream (ops.gemm_nt_f16_res16_stats); otherwise LayerNorm kernel + plain GEMM, per GEMM."""
@@ -133,14 +147,14 @@ class ClipVisual:
         D = C // Hh
         M = B * L
         Q = ops.ACT_QUICKGELU
-        can = self.fold_ln and f"{i0}.qkv.fold" in w
+        can = self.fold_ln and i1 > i0
         fold_qkv = can and ops.gemm_nt_f16_ln_eligible(M, 3 * C, C)
         fold_fc = can and ops.gemm_nt_f16_ln_eligible(M, w[f"{i0}.mlp.c_fc.weight"].shape[0], C, Q)
-        st = self._stats_for(x) if fold_qkv else None                 # (mean, rstd) of the rows of x, if the GEMM that wrote x left them
+        st = stats if fold_qkv else None                              # (mean, rstd) of the rows of x, if the GEMM that wrote x left them
         x = x.view(M, C)
         for i in range(i0, i1):
             if fold_qkv:
-                qkv = ops.gemm_nt_f16_ln(x, *w[f"{i}.qkv.fold"], st if st is not None else ops.row_stats_f16(x))
+                qkv = ops.gemm_nt_f16_ln(x, *self._fold(i, "qkv"), st if st is not None else ops.row_stats_f16(x))
             else:
                 h = ops.layernorm(x, w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"], out_f16=True)
                 qkv = ops.gemm_nt_f16(h, w[f"{i}.attn.in_proj_weight.h"], w[f"{i}.attn.in_proj_bias"], out_f16=True)
@@ -148,7 +162,7 @@ class ClipVisual:
             wo, bo = w[f"{i}.attn.out_proj.weight.h"], w[f"{i}.attn.out_proj.bias"]
             if fold_fc:
                 x, st = ops.gemm_nt_f16_res16_stats(att.view(M, C), wo, bo, x)
-                f = ops.gemm_nt_f16_ln(x, *w[f"{i}.fc.fold"], st if st is not None else ops.row_stats_f16(x), Q)
+                f = ops.gemm_nt_f16_ln(x, *self._fold(i, "fc"), st if st is not None else ops.row_stats_f16(x), Q)
             else:
                 x = ops.gemm_nt_f16(att.view(M, C), wo, bo, x)
                 h = ops.layernorm(x, w[f"{i}.ln_2.weight"], w[f"{i}.ln_2.bias"], out_f16=True)
@@ -157,28 +171,21 @@ class ClipVisual:
             if fold_qkv:                                              # the next block's ln_1 (or last_block_cls) reads these statistics
                 x, st = ops.gemm_nt_f16_res16_stats(f, wp, bp, x)
             else:
-                x = ops.gemm_nt_f16(f, wp, bp, x)
-        x = x.view(B, L, C)
-        if fold_qkv and st is not None:
-            x._ovis_row_stats = st            # travels with THIS tensor object (no state on the model: clips in flight share the tower)
-        return x
+                x, st = ops.gemm_nt_f16(f, wp, bp, x), None
+        return x.view(B, L, C), (st if fold_qkv else None)            # no state on the model: clips in flight share the tower
 
-    @staticmethod
-    def _stats_for(x):
-        """statistics handed over by the GEMM that produced x (attached to the tensor by _run_blocks_stream16), or None"""
-        return getattr(x, "_ovis_row_stats", None)
-
-    def last_block_cls(self, x, i):
+    def last_block_cls(self, x, i, stats=None):
         """resblock i evaluated for the CLASS TOKEN only -> f32 [B, C].  ln_post reads x[:, 0] alone (model.py:356-358), so in
         the last block every token still contributes its key / value, but the query projection, the attention rows, the
         output projection and the whole MLP are needed for one token per crop: [B] rows instead of [B*L] (the same
-        arithmetic per element as run_blocks, so the result matches it to the last bit of the GEMM's accumulation order)."""
+        arithmetic per element as run_blocks, so the result matches it to the last bit of the GEMM's accumulation order).
+        stats: the row statistics run_blocks(with_stats=True) handed over for THIS x (never after an in-place edit of x), or None."""
         w = self.w
         B, L, C = x.shape
         Hh = self.heads
         D = C // Hh
         f16 = self.precision == "fp16"
-        fold = (f16 and self.fold_ln and x.dtype == torch.float16 and f"{i}.kv.fold" in w and ops.gemm_nt_f16_ln_eligible(B * L, 2 * C, C))
+        fold = (f16 and self.fold_ln and x.dtype == torch.float16 and ops.gemm_nt_f16_ln_eligible(B * L, 2 * C, C))
         if fold:                                                     # keys | values from the raw rows; ln_1 itself only for the class rows
             h = None
             hq = ops.layernorm(x[:, 0, :].contiguous(), w[f"{i}.ln_1.weight"], w[f"{i}.ln_1.bias"], out_f16=True)
@@ -191,8 +198,7 @@ class ClipVisual:
         if f16:
             wi = w[f"{i}.attn.in_proj_weight.h"]
             if fold:
-                st = self._stats_for(x)
-                kv = ops.gemm_nt_f16_ln(x.view(-1, C), *w[f"{i}.kv.fold"], st if st is not None else ops.row_stats_f16(x))
+                kv = ops.gemm_nt_f16_ln(x.view(-1, C), *self._fold(i, "kv"), stats if stats is not None else ops.row_stats_f16(x))
             else:
                 kv = ops.gemm_nt_f16(h.view(-1, C), wi[C:], bi[C:], out_f16=True)               # [B*L, 2C]: keys | values
             q = ops.gemm_nt_f16(hq, wi[:C], bi[:C], out_f16=True)                               # [B, C]
@@ -220,20 +226,20 @@ class ClipVisual:
         patch_open uint8 [M, G*G]: the mask-prompt path (model.py:344-352) — after block d < mask_prompt_depth the
         closed patch tokens are reset to mask_embedding[d]."""
         last = self.layers - 1
+        st = None
         if patch_open is None:
-            x = self.run_blocks(self.embed(A, M), 0, last)
+            x, st = self.run_blocks(self.embed(A, M), 0, last, with_stats=True)
         else:
             if self.mask_prompt_depth < 1:
                 raise ValueError("mask prompt requested on a tower built with mask_prompt_depth=0 (no mask_embedding)")
             x = self.embed(A, M, patch_open)
             for i in range(last):
-                x = self.run_blocks(x, i, i + 1)
+                x, st = self.run_blocks(x, i, i + 1, stats=st, with_stats=True)
                 if i + 1 < self.mask_prompt_depth:
                     ops.mask_prompt_select(x, patch_open, self.w["mask_embedding"][i + 1], 1)
-                    if hasattr(x, "_ovis_row_stats"):                 # rows rewritten in place: statistics handed over by the GEMM are stale
-                        del x._ovis_row_stats
+                    st = None                                         # rows rewritten in place: statistics handed over by the GEMM are stale
         # the mask prompt after the last block (depth > layers) only rewrites patch tokens, which nothing reads any more
-        return self.head(self.last_block_cls(x, last))
+        return self.head(self.last_block_cls(x, last, st))
 
 
 class ClipAdapter:

@@ -641,11 +641,11 @@ def msda_encoder_fused(value, oa, shapes, lsi, M=8, L=3, P=4, shapes_host=None):
     fine) -> the LDS-staged tiled kernel handles the finest level's queries."""
     _chk(value, oa, shapes, lsi)
     B, S, C = value.shape
-    out = torch.empty_like(value)
     # algorithmic bytes (DESIGN.md section 3 / SURVEY.md 8d): f32 value + offsets/logits + output rows, once each
     nbytes = 4.0 * B * S * (2 * C + oa.shape[-1])
     if shapes_host is not None and L == 3 and P == 4 and C // M == 32 and MSDA_TILE_RADIUS >= 0:
         sh = (ctypes.c_int * 6)(*[int(v) for hw in shapes_host for v in hw])
+        out = torch.empty_like(value)
         with _Prof(f"msda_encoder_tiled_kernel<{P}>+fused<{L},{P}>", nbytes, unit="byte"):
             _lib.call("ovis_msda_encoder_fused_tiled_f32", value, oa, oa.shape[-1], shapes, lsi, sh, out, B, S, M, C // M, L, P,
                       MSDA_TILE_RADIUS, _lib.stream_ptr())

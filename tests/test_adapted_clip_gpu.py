@@ -258,8 +258,8 @@ def test_layernorm_folded_tower_agrees_with_the_layernorm_kernels(arch):
     real_ln = ops.gemm_nt_f16_ln
     ops.gemm_nt_f16_ln = lambda *a, **k: (calls.append(a[1].shape[0]), real_ln(*a, **k))[1]
     try:
-        y_fold = vis.run_blocks(x16.clone(), 0, n - 1)
-        c_fold = vis.last_block_cls(y_fold, n - 1)
+        y_fold, st_fold = vis.run_blocks(x16.clone(), 0, n - 1, with_stats=True)     # explicit hand-over of the GEMM's row statistics
+        c_fold = vis.last_block_cls(y_fold, n - 1, st_fold)
     finally:
         ops.gemm_nt_f16_ln = real_ln
     C = arch["width"]

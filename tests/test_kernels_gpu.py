@@ -450,3 +450,17 @@ def test_crop_kernel_merged_taps_and_out_of_frame_tiles():
     assert not torch.equal(P[0, 7], P[0, 13])
     # tall box 3 (41 x 348 -> roi 348 wide from x = 560): bins from (640 - 560) / (348 / 224) = 51.5 on lie right of the frame
     assert torch.equal(P[3, :, 4:], zero.expand(14, 10, 3, 16, 16)) and not torch.equal(P[3, :, 3], P[3, :, 4])
+
+
+def test_preprocess_whole_video_beyond_65535_rows():
+    """A1 on a whole video (openvis.py:57-62 runs before the windowing, :109): T * Hp = 720 * 96 = 69 120 rows > 65 535, the y limit of a HIP
+    grid -- the rows sit on gridDim.x.  Bit-exact against the oracle's arithmetic ((x - mean) / std in f32, zero pad)."""
+    from openvis_amd import ops
+    from oracle import torch_ref as TR
+    g = torch.Generator().manual_seed(5)
+    T, H, W = 720, 90, 310                                     # Hp = 96, Wp = 320
+    frames = torch.randint(0, 256, (T, 3, H, W), generator=g, dtype=torch.uint8)
+    out = ops.preprocess_u8(frames.cuda(), 96, 320, TR.PIXEL_MEAN, TR.PIXEL_STD)
+    ref, _ = TR.preprocess([f for f in frames])
+    assert tuple(out.shape) == (T, 96, 320, 4) and T * 96 > 65535
+    assert torch.equal(out[..., :3].permute(0, 3, 1, 2).cpu(), ref) and out[..., 3].abs().max().item() == 0
