@@ -190,6 +190,9 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="frames per clip (default 5; brivis: 36)")
     ap.add_argument("--resolution", type=int, default=0, choices=[0, 720, 1080],
                     help="frame height (16:9); default 720, *_swinl models: 1080 (BASELINE.json configs[4])")
+    ap.add_argument("--gather-masks", action="store_true",
+                    help="frame-sharded runs: gather the ten output masks of all frames on rank 0 (the reference's single video_output); "
+                         "default: every rank keeps the masks of its own frames for a sharded evaluator (SURVEY.md 8e (3))")
     ap.add_argument("--precision", default="mixed", choices=["mixed", "fp32"],
                     help="dense-path policy: mixed = the reference's autocast policy, fp32 = exact f32 everywhere")
     ap.add_argument("--f32-split", default="auto", choices=["auto", "fp16x2", "bf16x3", "bf16x2", "f32"],
@@ -225,6 +228,8 @@ def main():
         # ONE clip, contiguous frame blocks per rank, all-gather of query embeddings before the linker
         fr = D.inference_shard(T, rank, world)
         fwd_kw = {"frame_range": (fr.start, fr.stop)}
+        if args.gather_masks:
+            fwd_kw["gather_masks_to"] = 0
         clips = [synth_frames(T, FH, FW, 1000 + i, "cpu").pin_memory() for i in range(2)]
     else:
         # clip-level sharding (InferenceSampler layout): 2*world clips, each rank owns a contiguous shard
@@ -301,6 +306,24 @@ def main():
         out = model(inputs[0])                                 # back on the headline's split before the profiling passes
         torch.cuda.synchronize()
     alt = alts[0] if alts else None
+
+    # ---- frame-sharded runs: what every rank spends in the exchange steps, untimed extra steps --------------------
+    # host=True spans are host wall time around the call (the wait for the side-stream all-gather, the all-reduce, the mask gather:
+    # what the rank loses to the collective including the wait for the slowest rank); the others are HIP-event times of replicated work
+    collective_ms = None
+    if frame_sharded:
+        D.SPANS = {}
+        for i in range(3):
+            o_ = model(inputs[i % len(inputs)])
+            if hasattr(o_, "wait"):
+                o_.wait()
+        torch.cuda.synchronize()
+        mine = D.spans_ms()
+        D.SPANS = None
+        per_rank = D.gather_objects(mine)
+        collective_ms = {"per_rank": per_rank, "max_over_ranks": {k: max(r.get(k, 0.0) for r in per_rank) for k in per_rank[0]},
+                         "note": "mean of 3 untimed steps; all_gather_wait / logit_all_reduce / mask_gather = host wall time around the call, "
+                                 "linker / temporal_resampler = HIP-event time of the replicated work"}
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream -----------
     # Per-launch events around every GEMM / K1 launch (ops.PROFILE).  Two untimed passes:
@@ -521,7 +544,7 @@ def main():
                        "valid_crops_per_clip": n_valid,
                        "parallelism": (f"frame-sharded x{world} + RCCL all-gather" if frame_sharded else f"clip-replicas x{world}")
                                       + (f", {args.streams} clips in flight per GPU (HIP streams)" if args.streams > 1 and not frame_sharded else "")},
-            "roofline": roofline, "roofline_k1": roofline_k1, "stage_ms": stage_ms,
+            "roofline": roofline, "roofline_k1": roofline_k1, "stage_ms": stage_ms, "collective_ms": collective_ms,
             "stage_ms_note": "one clip alone, device sync after every stage (clips in flight overlap these stages)",
         }
         if not args.no_cpu_baseline and world == 1 and args.model == "openvis":

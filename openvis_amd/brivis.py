@@ -60,9 +60,12 @@ class BriVIS(SANOnline):
         if frame_range is None:
             emb = emb_local
         else:                                          # (several windows: the hook saw partial blocks -> gather the whole block now)
-            emb = gather[0].wait() if len(gather) == 1 and gather[0] is not None else D.all_gather_frames(emb_local, T_total)
-        idx, frame_embeds = batch_video_match_via_embeds(emb.unsqueeze(0))                 # brivis.py:173
-        x = self.resampler.temporal(frame_embeds[0])                                       # [T,Q,C], replicated
+            with D.span("all_gather_wait", host=True):     # what the compute stream / the host still waits for when it needs the embeddings
+                emb = gather[0].wait() if len(gather) == 1 and gather[0] is not None else D.all_gather_frames(emb_local, T_total)
+        with D.span("linker"):                                                             # replicated on every rank
+            idx, frame_embeds = batch_video_match_via_embeds(emb.unsqueeze(0))             # brivis.py:173
+        with D.span("temporal_resampler"):
+            x = self.resampler.temporal(frame_embeds[0])                                   # [T,Q,C], replicated
         n = self.clip_adapter.num_heads
         pred_masks, biases, emb_out = self.resampler.prediction_heads(x[b0:b1], io["mask_feats"], io["attn_feats"], n)
         clip_feats = self.clip_adapter.post_encode_image(io["clip_tokens"], biases)        # resampler.py:313
@@ -75,7 +78,10 @@ class BriVIS(SANOnline):
         row_ids = np.arange(self.num_queries, dtype=np.int32)
         self.mask_gather = None
         if frame_range is not None and gather_masks_to is not None:
-            self.mask_gather = lambda m: D.gather_frame_masks(m, T_total, gather_masks_to)
+            def _mg(m):
+                with D.span("mask_gather", host=True):
+                    return D.gather_frame_masks(m, T_total, gather_masks_to)
+            self.mask_gather = _mg
         try:
             out = self.inference_video(self.num_queries, len(class_names), probs, row_ids, pred_masks, padded, image_size,
                                        inp.get("height", image_size[0]), inp.get("width", image_size[1]),
@@ -98,14 +104,15 @@ class BriVIS(SANOnline):
         # -> softmax through the aggregate kernel.  The weighting is one elementwise scale of a [Q,K+1] tensor.
         local = ops.mean_over_dim0(logits.contiguous()) * (float(t) / float(T_total))
         flag = ops.f16x2_flag() if self.f32_gemm_mode == 3 else None
-        if flag is not None:
-            # fp16x2: every constant-weight GEMM of this forward is queued by now; the range flags of the ranks ride on this all-reduce
-            # (one more element), so that all ranks agree on whether the clip has to be repeated under bf16x3 (inference_video, sync_guard)
-            packed = D.all_reduce_sum(torch.cat([local.reshape(-1), flag.to(torch.float32)]))
-            total = packed[:-1].view_as(local)
-            flag.copy_((packed[-1:] > 0).to(torch.int32))
-        else:
-            total = D.all_reduce_sum(local)
+        with D.span("logit_all_reduce", host=True):
+            if flag is not None:
+                # fp16x2: every constant-weight GEMM of this forward is queued by now; the range flags of the ranks ride on this all-reduce
+                # (one more element), so that all ranks agree on whether the clip has to be repeated under bf16x3 (inference_video, sync_guard)
+                packed = D.all_reduce_sum(torch.cat([local.reshape(-1), flag.to(torch.float32)]))
+                total = packed[:-1].view_as(local)
+                flag.copy_((packed[-1:] > 0).to(torch.int32))
+            else:
+                total = D.all_reduce_sum(local)
         one = torch.arange(Q, dtype=torch.int32, device=logits.device).view(1, Q)
         probs, _ = ops.openvis_aggregate(total.contiguous(), one)
         return probs[:, :-1].contiguous()

@@ -67,6 +67,56 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+# ---- per-rank timing of the exchange steps (bench.py --model brivis --gpus N prints them as `collective_ms`) ---------------------------
+SPANS = None          # None: off.  dict name -> list of (start, end): HIP events on the calling stream (device work) or perf_counter pairs
+
+
+class span:
+    """`with span("all_gather_wait"): ...` -- records how long the enclosed work takes ON THE CURRENT STREAM (HIP events; the host does not
+    wait), or host wall time for host-staged collectives (gloo rigs).  Off (no events, no cost) unless SPANS is a dict."""
+
+    def __init__(self, name, host=False):
+        self.name, self.host = name, host
+
+    def __enter__(self):
+        if SPANS is not None:
+            if self.host or not torch.cuda.is_available():
+                import time
+                self.t0 = time.perf_counter()
+            else:
+                self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if SPANS is not None:
+            if hasattr(self, "t0"):
+                import time
+                SPANS.setdefault(self.name, []).append((self.t0, time.perf_counter()))
+            else:
+                self.e1.record()
+                SPANS.setdefault(self.name, []).append((self.e0, self.e1))
+
+
+def spans_ms():
+    """mean milliseconds per recorded span name (call after torch.cuda.synchronize())."""
+    out = {}
+    for k, v in (SPANS or {}).items():
+        ms = [(b - a) * 1e3 if isinstance(a, float) else a.elapsed_time(b) for a, b in v]
+        out[k] = round(sum(ms) / max(len(ms), 1), 4)
+    return out
+
+
+def gather_objects(obj):
+    """every rank's python object on every rank (bench diagnostics; a list of one without a process group)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 _SIDE_STREAMS = {}
 
 

@@ -54,7 +54,7 @@ def test_bench_multi_rank_control_flow(model, scaling, tmp_path):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="29651",
                    OVIS_BENCH_TEST_RIG="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                                       "--model", model, "--frames", "6" if model == "brivis" else "0"], env=env,
+                                       "--model", model, "--frames", "6" if model == "brivis" else "0"] + (["--gather-masks"] if model == "brivis" else []), env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
@@ -65,6 +65,13 @@ def test_bench_multi_rank_control_flow(model, scaling, tmp_path):
     d = json.loads(outs[0][0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == scaling and d["value"] > 0
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and "roofline" in d
+    if model == "brivis":        # frame-sharded: the exchange steps of every rank stand on the line
+        cm = d["collective_ms"]
+        assert len(cm["per_rank"]) == 2 and all(set(r) >= {"all_gather_wait", "linker", "temporal_resampler", "logit_all_reduce", "mask_gather"}
+                                                for r in cm["per_rank"][:1])
+        assert {"all_gather_wait", "linker", "logit_all_reduce"} <= set(cm["per_rank"][1]) and all(v >= 0 for v in cm["max_over_ranks"].values())
+    else:
+        assert d["collective_ms"] is None
 
 
 def test_rccl_collectives_of_the_frame_sharded_path():
