@@ -2,6 +2,7 @@
 the f32 CPU oracle (oracle/torch_ref.py, pinned against the reference's own modules by tests/test_oracle_*.py) is run
 ONCE in the build container on seeded synthetic inputs, and what the GPU tests compare against is committed as data:
 
+  tests/golden/c2_openvis_720p_5f.npz    OpenVIS R50 + ClipAdapter ViT-B/16, the bench workload at full size: 5 frames of 720x1280, 482 classes
   tests/golden/c3_san_online_720p.npz    SANOnline R50 + SideAdapter ViT-B/16, 2 frames of 720x1280
   tests/golden/c4_brivis_720p_36f.npz    BriVIS R50, ONE 36-frame 720p clip (linker over all 36 frames, resampler, heads)
   tests/golden/c5_brivis_swinl_1080p.npz BriVIS Swin-L (embed 192, depths 2/2/18/2, window 12) + SideAdapter ViT-L/14@336,
@@ -72,6 +73,24 @@ def topk_arrays(res):
                 top_scores=np.asarray(res["pred_scores"], np.float32), top_entropys=np.asarray(res["pred_entropys"], np.float32))
 
 
+def c2():
+    """BASELINE.json configs[1] at its FULL size: OpenVIS R50, one 5-frame 720p clip (bench.py's clip 0), 100 queries, 482 classes."""
+    T, K2 = 5, 482
+    sd = weights.random_init(weights.openvis_spec("r50", None, Q), seed=42)
+    frames = bench.synth_frames(T, 720, 1280, 1000, "cpu")
+    text = bench.synth_text(K2, 512, spread=0.25)              # separated classes, as tests/test_c2_720p_gpu.py
+    st = {}
+    with torch.no_grad():
+        res = TR.openvis_forward(frames, sd, text, stages=st)
+    pm = st["pred_masks"][0]                                               # [Q,T,h,w]
+    valid = st["valid"].numpy()
+    margin = np.abs(pm.numpy()).min()
+    print(f"  valid crops {int(valid.sum())}, smallest |mask logit| {margin:.2e}", flush=True)
+    save("c2_openvis_720p_5f.npz", mask_bits=pack(pm), mask_shape=np.array(pm.shape), valid=valid.astype(np.uint8),
+         boxes=st["boxes"].numpy().astype(np.int32), crop_logits=st["crop_logits"].numpy().astype(np.float32), probs=st["probs"].numpy(),
+         mask_counts=(pm > 0).sum(dim=(-1, -2)).numpy().astype(np.int32), **topk_arrays(res))
+
+
 def c3():
     T = 2
     sd = weights.random_init(weights.san_spec("r50", None, Q), seed=42)
@@ -131,5 +150,5 @@ if __name__ == "__main__":
     for case in sys.argv[1:] or ["c3", "c4", "c5"]:
         t0 = time.time()
         print(f"== {case}", flush=True)
-        {"c3": c3, "c4": c4, "c5": c5}[case]()
+        {"c2": c2, "c3": c3, "c4": c4, "c5": c5}[case]()
         print(f"== {case} done in {time.time() - t0:.0f} s", flush=True)

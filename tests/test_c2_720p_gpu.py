@@ -77,3 +77,65 @@ def test_c2_720p_clip_under_the_bench_policy_matches_oracle():
     # north-star IoU; with an fp16-operand decoder two of the ten dip to 0.9984 (tools/exp_policy_mix.py)
     print("C2 per-mask IoU:", [round(float(v), 5) for v in ious])
     assert min(ious) > 0.999, ious
+
+
+@pytest.mark.parametrize("split", ["auto", "bf16x3", "bf16x2"])
+def test_c2_full_size_5_frames_against_the_oracle_golden(split):
+    """configs[1] at FULL size -- the very clip bench.py times first (5 frames of 720x1280, seed 1000, 100 queries, 482 classes) -- against
+    the f32 CPU oracle's outputs committed as tests/golden/c2_openvis_720p_5f.npz (oracle/make_golden_workload.py c2; the oracle needs
+    minutes for it).  Under the timed policy (auto = fp16x2), the f32-grade bf16x3 and the 16-bit bf16x2; the exact-bit rate of the mask
+    signs is printed for each.  North star: every query mask IoU >= 0.999, cosine logits within 1e-3 (x100: 1e-1) on crops with the same box."""
+    import os
+    import bench
+    from openvis_amd import config, weights
+    from openvis_amd.catalog import MetadataCatalog
+    from tests._logits import check_top10
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c2_openvis_720p_5f.npz"))
+    K, T = 482, 5
+    sd = weights.random_init(weights.openvis_spec("r50", None, 100), seed=42)
+    cfg = config.get_cfg()
+    cfg.MODEL.F32_GEMM_SPLIT = split
+    model = config.build_model(cfg)
+    model.load_state_dict(sd)
+    names = [f"class_{i}" for i in range(K)]
+    MetadataCatalog.get("synthetic_c2").set(thing_classes=names)
+    model.clip_adapter.set_text_features(names, bench.synth_text(K, 512, spread=0.25))
+    frames = bench.synth_frames(T, 720, 1280, 1000, "cpu")
+    st = {}
+    out = model([{"image": [f for f in frames], "dataset_name": "synthetic_c2"}], stages=st)
+    out.wait()
+    assert model.f32_gemm_mode == config.F32_GEMM_SPLITS["fp16x2" if split == "auto" else split]          # no range fall-back
+    ref = np.unpackbits(g["mask_bits"], axis=-1)[..., : int(g["mask_shape"][-1])].astype(bool)               # [Q,T,h,w]
+    got = (st["pred_masks"][0].cpu() > 0).numpy()
+    assert got.shape == ref.shape == (100, T, 184, 320)
+    inter, union = (got & ref).sum(axis=(1, 2, 3)).astype(np.float64), (got | ref).sum(axis=(1, 2, 3)).astype(np.float64)
+    iq = np.where(union > 0, inter / np.maximum(union, 1), 1.0)
+    print("C2 full size [%s]: exact bit match rate %.6f (%d of %d bits differ), per-query IoU min %.5f median %.5f, %d of 100 query masks bit-identical"
+          % (split, (got == ref).mean(), int((got != ref).sum()), got.size, iq.min(), np.median(iq), int((got == ref).all(axis=(1, 2, 3)).sum())))
+    assert iq.min() >= 0.999, (iq.min(), int((iq < 0.999).sum()))
+    vg, vr = st["valid"], g["valid"].astype(bool)
+    assert (vg == vr).mean() > 0.99
+    # cosine logits on the crops whose box is identical on both sides
+    lg = st["crop_logits"].cpu().numpy()
+    gb = {(int(c[0]), int(c[1])): (i, c[2:]) for i, c in enumerate(st["crops"])}
+    same, moved = [], 0
+    for i, (t, q) in enumerate(np.argwhere(vr)):
+        hit = gb.get((int(t), int(q)))
+        if hit is None:
+            continue
+        j, (x0, y0, x1, y1) = hit
+        side = max(x1 + 1 - x0, y1 + 1 - y0)
+        b = g["boxes"][i]
+        if b[0] == x0 and b[1] == y0 and b[2] == x0 + side and b[3] == y0 + side:
+            same.append(float(np.abs(lg[j] - g["crop_logits"][i]).max()))
+        else:
+            moved += 1
+    same = np.array(same)
+    print("C2 full size [%s]: %d crops with identical boxes, max logit err %.4f (x100 scale), %d crops with a moved box" % (split, len(same), same.max(), moved))
+    assert len(same) >= 0.95 * (len(same) + moved) and same.max() <= 1e-1
+    rows_ref = np.nonzero(vr.any(axis=0))[0].tolist()
+    refd = {"rows": g["top_rows"].tolist(), "pred_labels": g["top_labels"].tolist(), "pred_scores": g["top_scores"].tolist()}
+    n_common, margin = check_top10(out, refd, g["probs"], rows_ref, tol=1e-3)
+    print("C2 full size [%s] top-10: %d of 10 (query, label) pairs in common, reference margin 10th - 11th %.2e" % (split, n_common, margin))
+    assert n_common == 10 or margin <= 2e-3
+    assert len(out["pred_masks"]) == 10 and tuple(out["pred_masks"][0].shape) == (T, 720, 1280)

@@ -61,3 +61,14 @@ def test_product_host_codec_matches_the_checker():
     assert rle.string_to_counts(rle_ref.rle_to_string(counts)) == counts
     for value, text in SINGLE:
         assert rle.counts_to_string([7, 40, 9, 40 + value]).decode("ascii") == "7X19" + text
+
+
+def test_vectorised_checker_equals_the_loop_checker():
+    """oracle/rle_ref.rle_encode_np (used at 720p, where the loop takes too long) against rle_encode, the restatement of maskApi.c rleEncode"""
+    rng = np.random.default_rng(11)
+    for h, w, p in [(1, 1, 0.0), (1, 1, 1.0), (7, 5, 0.5), (64, 48, 0.1), (33, 130, 0.9), (50, 50, 0.0), (50, 50, 1.0), (120, 77, 0.5), (3, 200, 0.3)]:
+        mask = rng.random((h, w)) < p
+        assert rle_ref.rle_encode_np(mask) == rle_ref.rle_encode(mask.tolist())
+    yy, xx = np.mgrid[:90, :160]
+    blob = (yy - 40) ** 2 + (xx - 70) ** 2 < 900
+    assert rle_ref.rle_encode_np(blob) == rle_ref.rle_encode(blob.tolist())

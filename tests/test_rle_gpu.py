@@ -22,8 +22,8 @@ def test_rle_kernel_vs_numpy(n, H, W, p):
     counts, n_runs = ops.rle_encode(cm)
     counts, n_runs = counts.cpu().numpy(), n_runs.cpu().numpy()
     for i in range(n):
-        ref = rle_ref.rle_encode(masks[i].tolist()) if H * W <= 20000 else rle.mask_to_counts(masks[i])   # (the loop checker on the small cases;
-        assert n_runs[i] == len(ref)                                                                       #  tests/test_oracle_rle.py ties the two)
+        ref = rle_ref.rle_encode(masks[i].tolist()) if H * W <= 20000 else rle_ref.rle_encode_np(masks[i])   # the checker at every size (loop /
+        assert n_runs[i] == len(ref)                                                                          # vectorised: tests/test_oracle_rle.py)
         got = counts[i, :n_runs[i]].tolist()
         assert got == ref
         assert (rle.counts_to_mask(got, H, W) == masks[i]).all()

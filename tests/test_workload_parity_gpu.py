@@ -20,7 +20,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 K, Q = 40, 100
 
 
-def _build(arch, backbone="r50", clip="ViT-B/16"):
+def _build(arch, backbone="r50", clip="ViT-B/16", split="auto"):
     import bench
     from openvis_amd import config, weights
     from openvis_amd.catalog import MetadataCatalog
@@ -38,7 +38,9 @@ def _build(arch, backbone="r50", clip="ViT-B/16"):
         cfg.MODEL.SWIN.EMBED_DIM, cfg.MODEL.SWIN.DEPTHS = a["embed_dim"], list(a["depths"])
         cfg.MODEL.SWIN.NUM_HEADS, cfg.MODEL.SWIN.WINDOW_SIZE = list(a["num_heads"]), a["window"]
     assert cfg.MODEL.PRECISION == "mixed"
+    cfg.MODEL.F32_GEMM_SPLIT = split
     model = config.build_model(cfg)
+    assert model.f32_gemm_mode == config.F32_GEMM_SPLITS["fp16x2" if split == "auto" else split]
     spec = weights.san_spec(backbone, _CLIP_ARCH[clip], Q) if arch == "SANOnline" else weights.brivis_spec(backbone, _CLIP_ARCH[clip], Q)
     sd = weights.random_init(spec, seed=42)
     model.load_state_dict(sd)
@@ -89,10 +91,10 @@ def test_c3_san_online_720p_under_the_bench_policy():
     assert len(out["pred_masks"]) == 10 and tuple(out["pred_masks"][0].shape) == (2, 720, 1280)
 
 
-def _brivis_case(gold_name, backbone, clip, T, H, W, seed):
+def _brivis_case(gold_name, backbone, clip, T, H, W, seed, split="auto"):
     import bench
     g = np.load(os.path.join(GOLDEN, gold_name))
-    model, scale = _build("BriVIS", backbone, clip)
+    model, scale = _build("BriVIS", backbone, clip, split)
     assert (model.backbone.precision, model.resampler.precision) == ("fp32", "fp32")
     frames = bench.synth_frames(T, H, W, seed, "cpu")
     st = {}
@@ -103,7 +105,12 @@ def _brivis_case(gold_name, backbone, clip, T, H, W, seed):
     keep = [int(t) for t in g["keep_frames"]]
     pm = st["pred_masks"][0]                                                                   # [Q,T,h,w]
     iou = _per_query_iou(pm[:, keep], g["mask_bits"], g["mask_shape"])
-    print("%s per-query IoU on frames %s: min %.5f median %.5f" % (gold_name, keep, iou.min(), np.median(iou)))
+    ref_bits = np.unpackbits(g["mask_bits"], axis=-1)[..., : int(g["mask_shape"][-1])].astype(bool)
+    got_bits = (pm[:, keep].cpu() > 0).numpy()
+    print("%s [%s] per-query IoU on frames %s: min %.5f median %.5f; exact bit match rate %.6f (%d of %d bits differ), %d of %d query masks "
+          "bit-identical" % (gold_name, split, keep, iou.min(), np.median(iou), (got_bits == ref_bits).mean(), int((got_bits != ref_bits).sum()),
+                             got_bits.size, int((got_bits == ref_bits).all(axis=(1, 2, 3)).sum()), got_bits.shape[0]))
+    assert model.f32_gemm_mode == __import__("openvis_amd.config", fromlist=["x"]).F32_GEMM_SPLITS["fp16x2" if split == "auto" else split]  # no fall-back
     assert iou.min() >= 0.999, (iou.min(), int((iou < 0.999).sum()))
     # every frame: positive-pixel count of every (query, frame) mask within 0.2 % of the mask area of the oracle's
     cnt = (pm > 0).sum(dim=(-1, -2)).cpu().numpy()
@@ -118,8 +125,10 @@ def _brivis_case(gold_name, backbone, clip, T, H, W, seed):
     assert len(out["pred_masks"]) == 10 and tuple(out["pred_masks"][0].shape) == (T, H, W)
 
 
-def test_c4_brivis_36_frames_720p_under_the_bench_policy():
-    _brivis_case("c4_brivis_720p_36f.npz", "r50", "ViT-B/16", 36, 720, 1280, 1000)
+@pytest.mark.parametrize("split", ["auto", "bf16x3", "bf16x2"])
+def test_c4_brivis_36_frames_720p_under_the_bench_policy(split):
+    """auto = fp16x2 (what bench.py times); the f32-grade bf16x3 and the 16-bit bf16x2 beside it, exact-bit rates printed"""
+    _brivis_case("c4_brivis_720p_36f.npz", "r50", "ViT-B/16", 36, 720, 1280, 1000, split)
 
 
 def test_c5_brivis_swinl_vitl14_336_1080p_under_the_bench_policy():
