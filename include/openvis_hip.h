@@ -273,6 +273,23 @@ int ovis_gemm_nt_f32a_f16w_batched(const float* A, long long lda, long long a_bs
 int ovis_conv2d_nhwc_f32a_f16w(const float* x, const void* w16, float* y, int N, int H, int W, int Cin, int Cout, int KH,
                                int KW, int stride, int pad, const float* bias, const float* residual, int act,
                                ovis_stream_t stream);
+/* fp16 STORAGE between the convolutions of a ResNet bottleneck (round 4; detectron2 BottleneckBlock, configs/openvoc_ytvis/Base.yaml:2-16,
+ * under torch.cuda.amp.autocast, train_net.py:241).  The tensors conv1 -> conv2 -> conv3 (and stem -> pool -> res2.0) have exactly one
+ * kind of reader, the next convolution, which rounds them to fp16 while staging: writing them as fp16 leaves every MFMA operand
+ * bit-identical and halves their bytes; the block outputs (residual stream) stay f32.
+ *   ovis_gemm_nt_x16: ovis_gemm_nt_f32a_f16w with A f32 or fp16 (a_f16) and C f32 (+ f32 residual) or fp16 (c_f16, no residual);
+ *   ovis_conv2d_nhwc_f32a_f16w_o16: ovis_conv2d_nhwc_f32a_f16w writing fp16 (the stem);
+ *   ovis_maxpool3x3s2_nhwc_f16: the stem's pool on the fp16 map (max commutes with the rounding);
+ *   ovis_conv_h16: 3x3 (pad 1) / 1x1 convolution, stride 1 / 2, of an fp16 NHWC map (Cin, Cout multiples of 64) with fp16 weights
+ *     [Cout, k, k, Cin]: LDS-DMA operand ring (three K steps of 64 in flight), v_mfma_f32_32x32x16_f16, bias + ReLU (+ f32 residual when
+ *     the output is f32) in the epilogue; y fp16 or f32 [T, OH, OW, Cout].  csrc/conv_h16.hip. */
+int ovis_gemm_nt_x16(const void* A, int a_f16, long long lda, const void* B16, long long ldb, void* C, int c_f16, long long ldc, int M, int N,
+                     int K, const float* bias, const float* residual, long long ldr, int act, ovis_stream_t stream);
+int ovis_conv2d_nhwc_f32a_f16w_o16(const float* x, const void* w16, void* y_f16, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                   int stride, int pad, const float* bias, int act, ovis_stream_t stream);
+int ovis_maxpool3x3s2_nhwc_f16(const void* x, void* y, int N, int H, int W, int C, ovis_stream_t stream);
+int ovis_conv_h16(const void* x_f16, const void* w_f16, void* y, int out_f16, int T, int H, int W, int Cin, int Cout, int ksize, int stride,
+                  const float* bias, const float* residual, int act, ovis_stream_t stream);
 /* y (fp16) = x (f32), n % 4 == 0 (weights are cast once at load). */
 int ovis_cast_f32_to_f16(const float* x, void* y, long long n, ovis_stream_t stream);
 

@@ -1,0 +1,283 @@
+// fp16-activation convolutions of the ResNet backbone (A2) under the reference's autocast policy: 3x3 (stride 1 / 2, pad 1) and 1x1
+// (stride 1 / 2) implicit GEMMs on fp16 NHWC activations with fp16 weights, f32 accumulation, bias (+ f32 residual) + ReLU epilogue,
+// fp16 or f32 output.
+//
+//   y[t,oy,ox,co] = act( sum_{kh,kw,c} x[t, oy s - p + kh, ox s - p + kw, c] * w[co,kh,kw,c] + bias[co] + R[t,oy,ox,co] )
+//
+// Replaces the cuDNN calls behind detectron2's BottleneckBlock (configs/openvoc_ytvis/Base.yaml:2-16: ResNet-50, STRIDE_IN_1X1 False)
+// as torch.cuda.amp.autocast runs them (train_net.py:241: fp16 operands, f32 accumulation).  Why a kernel of its own: the 3x3
+// convolutions of the four stages are all ~21.7 GFLOP (M N K = const) and took 80-104 us each on the register-staged 64x64 kernel
+// (gemm_f16cvt.hip: ~240 TFLOP/s, bound by the latency of its global -> register -> LDS staging with two K tiles in flight;
+// profiles/r04/backbone_launches_before.txt) -- 1.45 ms of the 4.3 ms backbone.  Here:
+//   * activations between the convolutions of a bottleneck are STORED in fp16 (conv1 -> conv2 -> conv3): the next convolution rounded
+//     them to fp16 while staging anyway, so the values that reach the MFMA are bit-identical, the tensor is half the bytes and the
+//     operand tile can go global -> LDS by LDS-DMA (global_load_lds_dwordx4) with no conversion pass;
+//   * 128 x BN x 64 tiles (BN = 128, or 64 for Cout = 64), 4 wavefronts (2 x 2), v_mfma_f32_32x32x16_f16; a 3-slot LDS ring: the DMA of
+//     K step s + 2 is issued right behind the barrier of step s, the only waits are counted (`s_waitcnt vmcnt(PER)`: one K step stays
+//     in flight across every barrier), raw s_barrier -- one barrier per K step;
+//   * implicit im2col without padding the input: a lane owns 4 of the tile's 128 pixels; per pixel one 32-bit byte offset of its top-left
+//     tap and a 9-bit mask of the taps that fall inside the image, computed once; a K step (64 channels of one tap) adds a wave-uniform
+//     offset, taps outside the image read a page of zeros instead (address select, no branch);
+//   * LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7 on the DMA's per-lane SOURCE address and on the
+//     fragment reads (conflict-free ds_read_b128 for the 32-row fragments, as in gemm_f16_pp.hip);
+//   * operand roles swapped (weights as the MFMA's A operand) so that a lane owns one output pixel and 4 x 4 consecutive channels:
+//     the vectorised epilogue of gemm_epilogue.h (fp16: 16-byte stores via v_permlane32_swap).
+#include "common.h"
+#include "gemm_epilogue.h"
+#include <mutex>
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+struct CH16Args {
+  const _Float16* X; const _Float16* Wt; void* Y; const float* bias; const float* R; const char* zeros;
+  int T, H, W, Cin, OH, OW, Cout, stride, act, M, tiles_n;
+};
+
+#define CH_GLDS(src, dst) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+template <int BN, int TAPS, bool OUT16, int NST = 3>
+__global__ void __launch_bounds__(256)
+conv_h16_kernel(const CH16Args p) {
+  constexpr int BM = 128;
+  constexpr int STAGE = (BM + BN) * 128;                 // bytes of one K step: A rows, then B rows, 128 B each
+  constexpr int BJ = BN / 32;                            // B DMA instructions per wavefront and K step (A: 4)
+  constexpr int PER = 4 + BJ;
+  constexpr int TM = 2, TN = BN / 64;                    // 32x32 accumulator tiles of a wavefront (64 x BN/2 outputs)
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];   // ONE LDS object (a second one de-pipelines the DMA)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const unsigned bid = ovis::xcd_remap(blockIdx.x, gridDim.x);
+  const int bn = (int)(bid % p.tiles_n) * BN;
+  const int bm = (int)(bid / p.tiles_n) * BM;
+  const int K = TAPS * p.Cin;
+  const int cpt = p.Cin >> 6;                            // K steps per tap
+  const int nk = TAPS * cpt;
+
+  // ---- this lane's four pixels (rows 32 wave + 8 j + lane / 8 of the tile): byte offset of tap (0, 0), mask of the taps inside the image
+  int base[4];
+  unsigned mask[4];
+  const int dr = lane >> 3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = min(bm + (4 * wave + j) * 8 + dr, p.M - 1);
+    const int ox = m % p.OW, t1 = m / p.OW, oy = t1 % p.OH, t = t1 / p.OH;
+    const int iy0 = oy * p.stride - (TAPS == 9 ? 1 : 0), ix0 = ox * p.stride - (TAPS == 9 ? 1 : 0);
+    base[j] = ((t * p.H + iy0) * p.W + ix0) * p.Cin * 2;            // may be negative at the border: those taps are masked
+    unsigned mk = 0;
+    if constexpr (TAPS == 9) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          if (iy0 + kh >= 0 && iy0 + kh < p.H && ix0 + kw >= 0 && ix0 + kw < p.W) mk |= 1u << (kh * 3 + kw);
+    } else {
+      mk = 1u;
+    }
+    mask[j] = mk;
+  }
+  // logical 16-byte chunk this lane fetches for LDS slot (row, lane & 7): (lane & 7) ^ ((row >> 1) & 7); row = 8 g + dr
+  int cA[4], cB[BJ];
+  long long wB[BJ];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cA[j] = ((lane & 7) ^ ((((4 * wave + j) * 8 + dr) >> 1) & 7)) * 16;
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int row = (wave * BJ + j) * 8 + dr;
+    cB[j] = ((lane & 7) ^ ((row >> 1) & 7)) * 16;
+    wB[j] = (long long)min(bn + row, p.Cout - 1) * K * 2 + cB[j];
+  }
+  const char* Xb = reinterpret_cast<const char*>(p.X);
+  const char* Wb = reinterpret_cast<const char*>(p.Wt);
+  const char* Zb = p.zeros + (lane & 7) * 16;
+
+  auto issue = [&](int ks, int buf) {
+    const int tap = ks / cpt, kc = ks - tap * cpt;
+    int off;
+    if constexpr (TAPS == 9) { const int kh = tap / 3, kw = tap - 3 * kh; off = ((kh * p.W + kw) * p.Cin + kc * 64) * 2; }
+    else off = kc * 128;
+    unsigned char* dst = lds + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = (mask[j] >> tap) & 1u;
+      const char* src = ok ? Xb + (long long)(base[j] + off) + cA[j] : Zb;
+      CH_GLDS(src, dst + (4 * wave + j) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) CH_GLDS(Wb + wB[j] + (long long)ks * 128, dst + BM * 128 + (wave * BJ + j) * 1024);
+  };
+
+  const int r32 = lane & 31, h = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets inside a stage: row * 128 + ((4 h + s) ^ ((row >> 1) & 7)) * 16
+  unsigned aoff[TM], boff[TN], asw[TM], bsw[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) { const int row = wr * 64 + i * 32 + r32; aoff[i] = row * 128; asw[i] = (row >> 1) & 7; }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { const int row = wc * (BN / 2) + j * 32 + r32; boff[j] = BM * 128 + row * 128; bsw[j] = (row >> 1) & 7; }
+
+  // all 4 x (TM + TN) fragments of a K step are requested before the first MFMA (one wavefront per SIMD: nothing else hides the LDS
+  // latency); the compiler retires them with counted lgkmcnt waits in issue order
+  auto compute = [&](int buf) {
+    const unsigned char* st = lds + buf * STAGE;
+    f16x8 af[4][TM], bf[4][TN];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[s][j] = *reinterpret_cast<const f16x8*>(st + boff[j] + (((4 * h + s) ^ bsw[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[s][i] = *reinterpret_cast<const f16x8*>(st + aoff[i] + (((4 * h + s) ^ asw[i]) << 4));
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);   // roles swapped
+  };
+
+  // NST slots: NST - 1 K steps in flight.  K step ks has landed for THIS wavefront once at most the (NST - 2) PER instructions of the later
+  // steps are outstanding; the barrier then makes every wavefront's share visible -- and says that all of them are done reading slot
+  // (ks - 1) % NST, which is refilled next (step ks + NST - 1).
+  static_assert(NST == 2 || NST == 3, "2 or 3 LDS slots");
+#pragma unroll
+  for (int q = 0; q < NST - 1; ++q)
+    if (q < nk) issue(q, q);
+  for (int ks = 0; ks < nk; ++ks) {
+    if (NST == 3 && ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ks + NST - 1 < nk) issue(ks + NST - 1, (ks + NST - 1) % NST);
+    compute(ks % NST);
+  }
+
+  const bool vec_ok = ovis::epilogue_vec_ok(p.Y, p.Cout, p.bias, p.R, p.Cout);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const long long m = bm + wr * 64 + i * 32 + r32;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      ovis::epilogue_tile<OUT16>(acc[i][j], m, m < p.M, bn + wc * (BN / 2) + j * 32, h, p.Cout, p.Y, p.Cout, p.bias, p.R, p.Cout, p.act, vec_ok);
+  }
+}
+
+int g_ch_nst = 0;         // LDS slots of conv_h16_kernel (lab switch ovis_conv_h16_slots): 0 = automatic; 3 = two K steps in flight (96 KB at BN = 128:
+                         // one workgroup per CU); 2 = one in flight, two workgroups per CU
+int g_ch_bn = 0;          // lab switch: 0 automatic, 64 / 128 forced
+
+// One 4 KB page of zeros per device (what a masked tap reads), allocated at the first launch there and kept for the life of the process.
+const char* zero_page() {
+  static void* buf[64] = {};
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!buf[dev]) {
+    if (hipMalloc(&buf[dev], 4096) != hipSuccess) { buf[dev] = nullptr; return nullptr; }
+    if (hipMemset(buf[dev], 0, 4096) != hipSuccess) { hipFree(buf[dev]); buf[dev] = nullptr; return nullptr; }
+  }
+  return reinterpret_cast<const char*>(buf[dev]);
+}
+
+// 2x2 / 3x3 stride-2 pad-1 max pool on fp16 NHWC (the stem's pool; max commutes with the fp16 rounding, so pooling the fp16 map gives
+// exactly the fp16 rounding of the pooled f32 map)
+__global__ void __launch_bounds__(256)
+maxpool3x3s2_h16_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int N, int H, int W, int C8, int OH, int OW) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)N * OH * OW * C8;
+  if (i >= total) return;
+  const int c = (int)(i % C8);
+  long long r = i / C8;
+  const int ow = (int)(r % OW); r /= OW;
+  const int oh = (int)(r % OH);
+  const int n = (int)(r / OH);
+  union U { uint4 u; _Float16 h[8]; } best;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) best.h[e] = (_Float16)(-65504.f);
+  for (int kh = 0; kh < 3; ++kh) {
+    const int ih = oh * 2 - 1 + kh;
+    if (ih < 0 || ih >= H) continue;
+    for (int kw = 0; kw < 3; ++kw) {
+      const int iw = ow * 2 - 1 + kw;
+      if (iw < 0 || iw >= W) continue;
+      U v;
+      v.u = x[(((long long)n * H + ih) * W + iw) * C8 + c];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) best.h[e] = v.h[e] > best.h[e] ? v.h[e] : best.h[e];
+    }
+  }
+  y[i] = best.u;
+}
+
+}  // namespace
+
+extern "C" int ovis_conv_h16(const void* x_f16, const void* w_f16, void* y, int out_f16, int T, int H, int W, int Cin, int Cout, int ksize,
+                             int stride, const float* bias, const float* residual, int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(x_f16 && w_f16 && y, "conv_h16: null pointer");
+  OVIS_REQUIRE(T > 0 && H > 0 && W > 0 && (ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "conv_h16: 1x1 / 3x3 (pad 1), stride 1 / 2");
+  OVIS_REQUIRE(Cin % 64 == 0 && Cin >= 64 && Cout % 64 == 0 && Cout >= 64, "conv_h16: Cin (%d) and Cout (%d) must be multiples of 64", Cin, Cout);
+  OVIS_REQUIRE(act >= 0 && act <= 3 && !(out_f16 && residual), "conv_h16: bad activation, or an fp16 output with a residual");
+  const int pad = ksize / 2;
+  const int OH = (H + 2 * pad - ksize) / stride + 1, OW = (W + 2 * pad - ksize) / stride + 1;
+  const long long M = (long long)T * OH * OW;
+  OVIS_REQUIRE(OH > 0 && OW > 0 && M < (1ll << 31) && (long long)T * H * W * Cin * 2 + (2ll * W + 2) * Cin * 2 < (1ll << 31),
+               "conv_h16: tensor too large for 32-bit byte offsets");
+  OVIS_REQUIRE((((uintptr_t)x_f16 | (uintptr_t)w_f16 | (uintptr_t)y) & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
+               (!residual || ((uintptr_t)residual & 15) == 0), "conv_h16: 16-byte alignment");
+  CH16Args p;
+  p.X = (const _Float16*)x_f16; p.Wt = (const _Float16*)w_f16; p.Y = y; p.bias = bias; p.R = residual;
+  p.zeros = zero_page();
+  OVIS_REQUIRE(p.zeros, "conv_h16: cannot allocate the page of zeros");
+  p.T = T; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.stride = stride; p.act = act; p.M = (int)M;
+  // Tile width and LDS slots, measured on the four 3x3 shapes of ResNet-50 at 5 x 736 x 1280 (profiles/r04/conv_h16_tiles.txt): the kernel is
+  // bound by the L2 -> LDS rate per CU, so it wants two workgroups per CU (two slots: 64 / 72 KB of LDS each) wherever the grid fills them --
+  // res4 46.7 us (128 columns) / 44.9 (64) against 69 with three slots; with 128-column tiles below 256 workgroups (res5: 144) one workgroup per
+  // CU runs alone and three slots win, 62.8 us against 76.5 (64-column tiles, 288 workgroups: 58.8 with three slots, 67 with two).
+  int bn = (Cout % 128 == 0) ? 128 : 64;
+  if (bn == 128 && ovis::cdiv(M, 128) * (Cout / 128) < 256) bn = 64;
+  if (g_ch_bn == 64 || (g_ch_bn == 128 && Cout % 128 == 0)) bn = g_ch_bn;
+  p.tiles_n = Cout / bn;
+  const unsigned grid = ovis::cdiv(M, 128) * (unsigned)p.tiles_n;
+  const int nst = g_ch_nst ? g_ch_nst : (grid >= 512 ? 2 : 3);
+  hipStream_t s = (hipStream_t)stream;
+#define CH_LAUNCH(BN_, TAPS_, O16_) do { if (nst == 2) hipLaunchKernelGGL((conv_h16_kernel<BN_, TAPS_, O16_, 2>), dim3(grid), dim3(256), 0, s, p); \
+                                         else hipLaunchKernelGGL((conv_h16_kernel<BN_, TAPS_, O16_, 3>), dim3(grid), dim3(256), 0, s, p); } while (0)
+  if (ksize == 3) {
+    if (bn == 128) { if (out_f16) CH_LAUNCH(128, 9, true); else CH_LAUNCH(128, 9, false); }
+    else { if (out_f16) CH_LAUNCH(64, 9, true); else CH_LAUNCH(64, 9, false); }
+  } else {
+    if (bn == 128) { if (out_f16) CH_LAUNCH(128, 1, true); else CH_LAUNCH(128, 1, false); }
+    else { if (out_f16) CH_LAUNCH(64, 1, true); else CH_LAUNCH(64, 1, false); }
+  }
+#undef CH_LAUNCH
+  return ovis::check_launch("conv_h16");
+}
+
+extern "C" int ovis_conv_h16_slots(int nst) { g_ch_nst = (nst == 2 || nst == 3) ? nst : 0; return OVIS_OK; }   // lab / tests only: 0 automatic
+extern "C" int ovis_conv_h16_bn(int bn) { g_ch_bn = (bn == 64 || bn == 128) ? bn : 0; return OVIS_OK; }          // lab only
+
+extern "C" int ovis_maxpool3x3s2_nhwc_f16(const void* x, void* y, int N, int H, int W, int C, ovis_stream_t stream) {
+  OVIS_REQUIRE(x && y, "maxpool (fp16): null pointer");
+  OVIS_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, "maxpool (fp16): C %% 8 == 0, 16-byte alignment");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long long total = (long long)N * OH * OW * (C / 8);
+  hipLaunchKernelGGL(maxpool3x3s2_h16_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)y, N, H,
+                     W, C / 8, OH, OW);
+  return ovis::check_launch("maxpool (fp16)");
+}

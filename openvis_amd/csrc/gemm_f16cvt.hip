@@ -11,12 +11,14 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "gemm_loaders.h"
+#include <type_traits>
 
 namespace {
 
 using ovis::ConvA;
 using ovis::ConvGeom;
 using ovis::DenseA;
+using ovis::DenseH;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
@@ -32,11 +34,16 @@ __device__ __forceinline__ uint4 cvt8(bool ok0, float4 a, bool ok1, float4 b) {
   return o.u;
 }
 
-template <int BM, int BN, typename LoaderA>
+// LoaderA = DenseH: A is already fp16 in memory (one 16-byte load per 8 k, no conversion).  OUT16: C is written as fp16 (no residual) --
+// the tensors between the convolutions of a bottleneck (round 4): their only reader is the next convolution, which rounded the f32 copy
+// to fp16 while staging, so the operands that reach the MFMA are bit-identical and the tensor costs half the bytes.
+template <int BM, int BN, typename LoaderA, bool OUT16 = false>
 __global__ void __launch_bounds__(256)
-gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, float* __restrict__ C, long long ldc,
+gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, void* __restrict__ C_, long long ldc,
                    int M, int N, int K, const float* __restrict__ bias, const float* __restrict__ R, long long ldr,
                    int act, int tiles_n, long long a_bs, long long b_bs, long long c_bs) {
+  constexpr bool AH = std::is_same<LoaderA, DenseH>::value;
+  float* C = reinterpret_cast<float*>(C_);                   // (OUT16: only passed on to the epilogue as void*)
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_LD = BM * 8 / 256, B_LD = BN * 8 / 256;   // 8-element chunks per thread per K tile
   __shared__ __attribute__((aligned(16))) _Float16 As[BM * LDS_ROW];
@@ -45,7 +52,7 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, fl
   if (gridDim.y > 1) {   // batched: independent problems along blockIdx.y
     la.advance((long long)blockIdx.y * a_bs);
     B += (long long)blockIdx.y * b_bs;
-    C += (long long)blockIdx.y * c_bs;
+    C = OUT16 ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(C) + (long long)blockIdx.y * c_bs) : C + (long long)blockIdx.y * c_bs;
     if (R) R += (long long)blockIdx.y * c_bs;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -63,11 +70,19 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, fl
   for (int i = 0; i < A_LD; ++i) rca[i] = la.row(bm + srow + i * 32);
   auto gload = [&](Stage& st, int k0) {
     const int k = k0 + scol;
+    if constexpr (AH) {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        const uint4 u = la.load8(rca[i], k, st.oka[i][0]);
+        st.pa[i][0] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));   // raw bits
+      }
+    } else {
     const auto kc0 = la.kctx(k), kc1 = la.kctx(k + 4);
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       st.pa[i][0] = la.load(rca[i], kc0, st.oka[i][0]);
       st.pa[i][1] = la.load(rca[i], kc1, st.oka[i][1]);
+    }
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
@@ -78,8 +93,15 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, fl
   };
   auto lstore = [&](const Stage& st) {
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i)
+    for (int i = 0; i < A_LD; ++i) {
+      if constexpr (AH) {
+        const bool ok = st.oka[i][0];
+        const float4 v = st.pa[i][0];
+        *reinterpret_cast<uint4*>(&As[(srow + i * 32) * LDS_ROW + scol]) =
+            make_uint4(ok ? __float_as_uint(v.x) : 0u, ok ? __float_as_uint(v.y) : 0u, ok ? __float_as_uint(v.z) : 0u, ok ? __float_as_uint(v.w) : 0u);
+      } else
       *reinterpret_cast<uint4*>(&As[(srow + i * 32) * LDS_ROW + scol]) = cvt8(st.oka[i][0], st.pa[i][0], st.oka[i][1], st.pa[i][1]);
+    }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)
       *reinterpret_cast<uint4*>(&Bs[(srow + i * 32) * LDS_ROW + scol]) =
@@ -88,7 +110,7 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, fl
 
   const int r32 = lane & 31, h = lane >> 5;
   const bool vec_ok = ovis::epilogue_vec_ok(C, ldc, bias, R, ldr);
-  const bool pre = vec_ok && bn + BN <= N && (bias || R);       // accumulators start at bias + residual (gemm_epilogue.h)
+  const bool pre = !OUT16 && vec_ok && bn + BN <= N && (bias || R);       // accumulators start at bias + residual (gemm_epilogue.h)
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -153,7 +175,7 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, fl
     const long long m = bm + wr * (BM / 2) + i * 32 + r32;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      ovis::epilogue_tile<false>(acc[i][j], m, m < M, bn + wc * (BN / 2) + j * 32, h, N, C, ldc, pre ? nullptr : bias,
+      ovis::epilogue_tile<OUT16>(acc[i][j], m, m < M, bn + wc * (BN / 2) + j * 32, h, N, C, ldc, pre ? nullptr : bias,
                                  pre ? nullptr : R, ldr, act, vec_ok);
   }
 }
@@ -161,8 +183,8 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, fl
 int g_cvt_small_n = 2;             // 0 = 128x128 tiles from 256 tiles on (round 2); 1 = 64x64 for N <= 64; 2 (default) = also below 1024 tiles of 128
                                    // (ResNet-50 on 5 x 720p: 4.70 / 4.42 / 4.41 ms, tools/bench_backbone.py, profiles/r03/backbone_tiles.txt)
 
-template <typename LoaderA>
-int launch(LoaderA la, const _Float16* B, long long ldb, float* C, long long ldc, int M, int N, int K, const float* bias,
+template <typename LoaderA, bool OUT16 = false>
+int launch(LoaderA la, const _Float16* B, long long ldb, void* C, long long ldc, int M, int N, int K, const float* bias,
            const float* R, long long ldr, int act, hipStream_t stream, int batch = 1, long long a_bs = 0, long long b_bs = 0,
            long long c_bs = 0) {
   const long long blocks128 = (long long)ovis::cdiv(M, 128) * ovis::cdiv(N, 128) * batch;
@@ -170,11 +192,11 @@ int launch(LoaderA la, const _Float16* B, long long ldb, float* C, long long ldc
   // 64x64 instantiation (92 VGPRs, five workgroups per CU instead of two) keeps more of the K loop's loads in flight
   if (blocks128 >= (g_cvt_small_n == 2 ? 1024 : 256) && (N > 64 || !g_cvt_small_n)) {
     const int tm = ovis::cdiv(M, 128), tn = ovis::cdiv(N, 128);
-    hipLaunchKernelGGL((gemm_f16cvt_kernel<128, 128, LoaderA>), dim3(tm * tn, batch), dim3(256), 0, stream, la, B, ldb, C, ldc,
+    hipLaunchKernelGGL((gemm_f16cvt_kernel<128, 128, LoaderA, OUT16>), dim3(tm * tn, batch), dim3(256), 0, stream, la, B, ldb, C, ldc,
                        M, N, K, bias, R, ldr, act, tn, a_bs, b_bs, c_bs);
   } else {
     const int tm = ovis::cdiv(M, 64), tn = ovis::cdiv(N, 64);
-    hipLaunchKernelGGL((gemm_f16cvt_kernel<64, 64, LoaderA>), dim3(tm * tn, batch), dim3(256), 0, stream, la, B, ldb, C, ldc, M,
+    hipLaunchKernelGGL((gemm_f16cvt_kernel<64, 64, LoaderA, OUT16>), dim3(tm * tn, batch), dim3(256), 0, stream, la, B, ldb, C, ldc, M,
                        N, K, bias, R, ldr, act, tn, a_bs, b_bs, c_bs);
   }
   return ovis::check_launch("gemm_f16cvt");
@@ -226,6 +248,45 @@ extern "C" int ovis_conv2d_nhwc_f32a_f16w(const float* x, const void* w16, float
   ConvA la{x, ConvGeom{H, W, Cin, OH, OW, KH, KW, stride, pad}, (int)M, K};
   return launch(la, (const _Float16*)w16, (long long)K, y, (long long)Cout, (int)M, Cout, K, bias, residual, (long long)Cout,
                 act, (hipStream_t)stream);
+}
+
+// General form for the fp16-storage path of the backbone: A f32 (rounded to fp16 while staged) or already fp16, C f32 (+ f32 residual) or
+// fp16 (no residual).  Same kernel, same arithmetic: fp16 operands, f32 accumulation.
+extern "C" int ovis_gemm_nt_x16(const void* A, int a_f16, long long lda, const void* B16, long long ldb, void* C, int c_f16, long long ldc,
+                                int M, int N, int K, const float* bias, const float* residual, long long ldr, int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(A && B16 && C, "gemm_nt_x16: null pointer");
+  OVIS_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && ldc >= N && lda % (a_f16 ? 8 : 4) == 0,
+               "gemm_nt_x16: need K %% 8 == 0, ldb %% 8 == 0, lda %% 4 (f32) / 8 (fp16) == 0");
+  OVIS_REQUIRE((((uintptr_t)A | (uintptr_t)B16 | (uintptr_t)C) & 15) == 0, "gemm_nt_x16: A / B / C must be 16-byte aligned");
+  OVIS_REQUIRE(act >= 0 && act <= 3 && !(c_f16 && residual) && (!residual || ldr >= N), "gemm_nt_x16: bad activation / an fp16 output takes no residual");
+  OVIS_REQUIRE(!c_f16 || ldc % 8 == 0, "gemm_nt_x16: fp16 output rows must be 16-byte aligned (ldc %% 8 == 0)");
+  hipStream_t s = (hipStream_t)stream;
+  const _Float16* B = (const _Float16*)B16;
+  if (a_f16) {
+    DenseH la{(const _Float16*)A, lda, M, K};
+    return c_f16 ? launch<DenseH, true>(la, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, act, s)
+                 : launch<DenseH, false>(la, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, s);
+  }
+  DenseA<true> la{(const float*)A, lda, M, K};
+  return c_f16 ? launch<DenseA<true>, true>(la, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, act, s)
+               : launch<DenseA<true>, false>(la, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, s);
+}
+
+// ovis_conv2d_nhwc_f32a_f16w with the result written as fp16 (the stem of the fp16-storage backbone; no residual)
+extern "C" int ovis_conv2d_nhwc_f32a_f16w_o16(const float* x, const void* w16, void* y_f16, int N, int H, int W, int Cin, int Cout, int KH,
+                                              int KW, int stride, int pad, const float* bias, int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(x && w16 && y_f16, "conv2d_nhwc_f32a_f16w_o16: null pointer");
+  OVIS_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "conv2d_nhwc_f32a_f16w_o16: bad geometry");
+  OVIS_REQUIRE(Cin % 4 == 0 && (KH * KW * Cin) % 8 == 0 && Cout % 8 == 0, "conv2d_nhwc_f32a_f16w_o16: need Cin %% 4 == 0, KH*KW*Cin %% 8 == 0, Cout %% 8 == 0");
+  OVIS_REQUIRE((((uintptr_t)x | (uintptr_t)w16 | (uintptr_t)y_f16) & 15) == 0, "conv2d_nhwc_f32a_f16w_o16: 16-byte alignment");
+  OVIS_REQUIRE(act >= 0 && act <= 3, "conv2d_nhwc_f32a_f16w_o16: unknown activation %d", act);
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  OVIS_REQUIRE(OH > 0 && OW > 0, "conv2d_nhwc_f32a_f16w_o16: empty output");
+  const long long M = (long long)N * OH * OW;
+  OVIS_REQUIRE(M < (1ll << 31), "conv2d_nhwc_f32a_f16w_o16: too many output pixels");
+  const int K = KH * KW * Cin;
+  ConvA la{x, ConvGeom{H, W, Cin, OH, OW, KH, KW, stride, pad}, (int)M, K};
+  return launch<ConvA, true>(la, (const _Float16*)w16, (long long)K, y_f16, (long long)Cout, (int)M, Cout, K, bias, nullptr, 0, act, (hipStream_t)stream);
 }
 
 extern "C" int ovis_f16cvt_small_n(int mode) { g_cvt_small_n = mode; return OVIS_OK; }   // 0 old rule, 1 N <= 64 -> 64x64, 2 also < 1024 tiles -> 64x64   // lab / tests only

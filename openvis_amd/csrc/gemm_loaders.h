@@ -49,6 +49,21 @@ struct DenseA {
   }
 };
 
+// dense row-major fp16 [M,K] (K % 8 == 0, lda % 8 == 0, 16-byte aligned base): 8 consecutive k of a row are ONE 16-byte load, already in
+// the MFMA's operand format (activations stored in fp16 between the convolutions of a bottleneck: conv_h16.hip, gemm_f16cvt.hip)
+struct DenseH {
+  const _Float16* A;
+  long long lda;
+  int M, K;
+  __device__ __forceinline__ void advance(long long elems) { A += elems; }
+  struct RowCtx { int m; };
+  __device__ __forceinline__ RowCtx row(int m) const { return RowCtx{m}; }
+  __device__ __forceinline__ uint4 load8(const RowCtx& r, int k, bool& ok) const {
+    ok = r.m < M && k < K;
+    return *reinterpret_cast<const uint4*>(A + (ok ? (long long)r.m * lda + k : 0));
+  }
+};
+
 // Implicit im2col over an NHWC input; k = (kh*KW + kw)*Cin + c, Cin % 4 == 0 (float4 never straddles a pixel).
 struct ConvA {
   const float* X;

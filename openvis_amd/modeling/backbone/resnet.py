@@ -34,6 +34,11 @@ class ResNet:
         # "fp16": conv operands rounded to fp16, f32 accumulation (= the reference under autocast, train_net.py:241);
         # "fp32": exact-f32 MFMA.  Activations are f32 in HBM either way.
         self.precision = precision
+        # fp16 policy only: the tensors BETWEEN the convolutions of a bottleneck (conv1 -> conv2 -> conv3) and stem -> pool -> res2.0 are
+        # stored in fp16.  Their only readers are convolutions that round them to fp16 while staging, so every MFMA operand is bit-identical
+        # to the f32-storage path; the block outputs (the residual stream, and what the pixel decoder reads) stay f32.  The 3x3 convolutions
+        # then run on the LDS-DMA kernel of csrc/conv_h16.hip.  False = f32 storage everywhere (rounds 1-3).
+        self.h16_storage = True
         self.w = {}
         self.w16 = {}
 
@@ -73,10 +78,45 @@ class ResNet:
             return y.view(N, H, W, -1)
         return ops.conv2d_nhwc(x, w, stride, pad, b, residual, act, w16=w16, cw=True)
 
+    def _forward_h16(self, x):
+        """forward() with fp16 storage of the intra-bottleneck tensors (see __init__).  Same arithmetic per convolution: fp16 operands,
+        f32 accumulation, f32 bias / residual / ReLU; one rounding to fp16 where the f32-storage path rounds while staging."""
+        w, w16 = self.w, self.w16
+        relu = ops.ACT_RELU
+        x = ops.conv2d_nhwc_o16(x, w16["stem"], 2, 3, w["stem"][1], relu)                      # fp16 [T,H/2,W/2,64]
+        x = ops.maxpool3x3s2(x)                                                                # fp16 [T,H/4,W/4,64]
+        feats = {}
+        for name, nblocks, first_stride in STAGES[self.depth]:
+            for i in range(nblocks):
+                stride = first_stride if i == 0 else 1
+                k = f"{name}.{i}"
+                c1, c2, c3 = k + ".conv1", k + ".conv2", k + ".conv3"
+                if (k + ".shortcut") in w:
+                    if x.dtype == torch.float16:                                               # res2.0: the pooled stem output
+                        N_, H_, W_, C_ = x.shape
+                        ws = w16[k + ".shortcut"]
+                        sc = ops.gemm_nt_x16(x.view(-1, C_), ws.view(ws.shape[0], C_), w[k + ".shortcut"][1]).view(N_, H_, W_, -1)
+                    else:
+                        sc = self._conv(x, k + ".shortcut", stride=stride, relu=False)         # f32 in (strided pixels), f32 out
+                else:
+                    sc = x
+                N_, H_, W_, C_ = x.shape
+                wc1 = w16[c1]
+                out = ops.gemm_nt_x16(x.view(-1, C_), wc1.view(wc1.shape[0], C_), w[c1][1], None, relu, out_f16=True).view(N_, H_, W_, -1)
+                out = ops.conv_h16(out, w16[c2], 3, stride, w[c2][1], None, relu, out_f16=True)
+                N2, H2, W2, C2 = out.shape                                                     # relu(conv3 + shortcut), f32 (HBM-bound: the
+                wc3 = w16[c3]                                                                  # register-staged kernel with fp16 A rows)
+                x = ops.gemm_nt_x16(out.view(-1, C2), wc3.view(wc3.shape[0], C2), w[c3][1], sc.view(-1, wc3.shape[0]), relu).view(N2, H2, W2, -1)
+            if name in self.out_features:
+                feats[name] = x
+        return feats
+
     def forward(self, x):
         """x: f32 [T,Hp,Wp,4] (normalised, channel 3 zero) -> {res2..res5} NHWC."""
         if self.w["stem"][0].shape[2] == 8 and x.shape[2] % 2 != 0:
             raise ValueError("ResNet stem with the padded 7x8 kernel needs an even input width (frames are padded to a multiple of 32)")
+        if self.precision == "fp16" and self.h16_storage:
+            return self._forward_h16(x)
         x = self._conv(x, "stem", stride=2, pad=3)
         x = ops.maxpool3x3s2(x)
         feats = {}

@@ -480,6 +480,52 @@ def conv2d_nhwc(x, w, stride=1, pad=0, bias=None, residual=None, act=ACT_NONE, w
     return y
 
 
+# ---- fp16 storage between the convolutions of a ResNet bottleneck (csrc/conv_h16.hip, gemm_f16cvt.hip; include/openvis_hip.h) -----------
+def conv_h16(x16, w16, ksize, stride=1, bias=None, residual=None, act=ACT_NONE, out_f16=True):
+    """x16 fp16 [T,H,W,Cin], w16 fp16 [Cout,k,k,Cin] (k = 1 or 3, pad k // 2) -> fp16 or f32 [T,OH,OW,Cout] = act(conv + bias (+ f32 residual))."""
+    _chk(x16, w16, bias, residual)
+    if x16.dtype != torch.float16 or w16.dtype != torch.float16:
+        raise _lib.OvisError("conv_h16 needs fp16 activations and weights")
+    T, H, W, Cin = x16.shape
+    Cout = w16.shape[0]
+    pad = ksize // 2
+    OH, OW = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+    y = torch.empty((T, OH, OW, Cout), dtype=torch.float16 if out_f16 else torch.float32, device=x16.device)
+    with _Prof(f"conv_h16_kernel<{128 if Cout % 128 == 0 else 64},{ksize * ksize},{'true' if out_f16 else 'false'}>", 2.0 * T * OH * OW * Cout * ksize * ksize * Cin):
+        _lib.call("ovis_conv_h16", x16, w16, y, int(out_f16), T, H, W, Cin, Cout, ksize, stride, bias, residual, act, _lib.stream_ptr())
+    return y
+
+
+def gemm_nt_x16(a, w16, bias=None, residual=None, act=ACT_NONE, out_f16=False):
+    """a f32 or fp16 [..., K] x w16 fp16 [N, K] -> f32 (+ f32 residual) or fp16 [..., N]; fp16 MFMA operands, f32 accumulation (gemm_nt with
+    w16, plus the fp16 storage of the operands / result)."""
+    K = a.shape[-1]
+    N = w16.shape[0]
+    a2 = a.reshape(-1, K)
+    _chk(a2, w16, bias, residual)
+    M = a2.shape[0]
+    out = torch.empty((M, N), dtype=torch.float16 if out_f16 else torch.float32, device=a.device)
+    r2 = residual.reshape(-1, N) if residual is not None else None
+    big = ((M + 127) // 128) * ((N + 127) // 128) >= 1024 and N > 64
+    a_h = a2.dtype == torch.float16
+    with _Prof(f"gemm_f16cvt_kernel<{'128,128' if big else '64,64'},{'DenseH' if a_h else 'DenseA'}{',o16' if out_f16 else ''}>", 2.0 * M * N * K):
+        _lib.call("ovis_gemm_nt_x16", a2, int(a_h), _ll(K), w16, _ll(K), out, int(out_f16), _ll(N), M, N, K, bias, r2, _ll(N), act, _lib.stream_ptr())
+    return out.view(*a.shape[:-1], N)
+
+
+def conv2d_nhwc_o16(x, w16, stride, pad, bias=None, act=ACT_NONE):
+    """conv2d_nhwc with fp16 weights (autocast arithmetic) writing an fp16 map (the ResNet stem of the fp16-storage backbone)."""
+    _chk(x, w16, bias)
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w16.shape
+    OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    y = torch.empty((N, OH, OW, Cout), dtype=torch.float16, device=x.device)
+    big = ((N * OH * OW + 127) // 128) * ((Cout + 127) // 128) >= 1024 and Cout > 64
+    with _Prof(f"gemm_f16cvt_kernel<{'128,128' if big else '64,64'},ConvA,o16>", 2.0 * N * OH * OW * Cout * KH * KW * Cin):
+        _lib.call("ovis_conv2d_nhwc_f32a_f16w_o16", x, w16, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bias, act, _lib.stream_ptr())
+    return y
+
+
 # ---------------------------------------------------------------------------------------------
 def _f3(vals):
     return (ctypes.c_float * 3)(*[float(v) for v in vals])
@@ -497,8 +543,8 @@ def preprocess_u8(frames, Hp, Wp, mean, std):
 def maxpool3x3s2(x):
     _chk(x)
     N, H, W, C = x.shape
-    y = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float32, device=x.device)
-    _lib.call("ovis_maxpool3x3s2_nhwc_f32", x, y, N, H, W, C, _lib.stream_ptr())
+    y = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=x.dtype, device=x.device)
+    _lib.call("ovis_maxpool3x3s2_nhwc_f16" if x.dtype == torch.float16 else "ovis_maxpool3x3s2_nhwc_f32", x, y, N, H, W, C, _lib.stream_ptr())
     return y
 
 

@@ -1,0 +1,121 @@
+"""GPU: fp16-storage kernels of the ResNet backbone (round 4; csrc/conv_h16.hip, gemm_f16cvt.hip): 3x3 / 1x1 convolutions on fp16 NHWC maps
+(LDS-DMA ring), the fp16-in / fp16-out forms of the 1x1 GEMM, the fp16 max pool and the stem writing fp16 -- against f64 convolutions of the
+SAME fp16-rounded operands (the arithmetic contract: fp16 operands, f32 accumulation; detectron2 BottleneckBlock under autocast,
+configs/openvoc_ytvis/Base.yaml:2-16, train_net.py:241) -- and the whole backbone with fp16 storage against the f32-storage path."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_conv(x16, w16, bias, stride, pad, residual=None, relu=True):
+    y = F.conv2d(x16.double().permute(0, 3, 1, 2), w16.double().permute(0, 3, 1, 2), bias.double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    if residual is not None:
+        y = y + residual.double()
+    return y.relu() if relu else y
+
+
+@pytest.mark.parametrize("T,H,W,Cin,Cout,k,stride", [(2, 46, 80, 64, 64, 3, 1), (1, 37, 53, 128, 128, 3, 1), (2, 46, 80, 128, 128, 3, 2), (1, 23, 40, 256, 256, 3, 1),
+                                                      (1, 31, 45, 512, 512, 3, 2), (3, 184, 320, 64, 64, 3, 1), (2, 33, 47, 64, 256, 1, 1), (1, 23, 40, 512, 2048, 1, 1),
+                                                      (1, 46, 80, 256, 512, 1, 2)])
+@pytest.mark.parametrize("slots", [0, 3, 2])
+def test_conv_h16_against_f64_on_the_same_fp16_operands(T, H, W, Cin, Cout, k, stride, slots):
+    from openvis_amd import ops, _lib
+    _lib.call("ovis_conv_h16_slots", slots)
+    try:
+        g = torch.Generator().manual_seed(H * W + Cin + k)
+        x16 = torch.randn(T, H, W, Cin, generator=g).relu().half().cuda()
+        w16 = (torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).half().cuda()
+        b = torch.randn(Cout, generator=g).cuda()
+        ref = _ref_conv(x16, w16, b, stride, k // 2)
+        y16 = ops.conv_h16(x16, w16, k, stride, b, None, ops.ACT_RELU, out_f16=True)
+        y32 = ops.conv_h16(x16, w16, k, stride, b, None, ops.ACT_RELU, out_f16=False)
+        assert y16.dtype == torch.float16 and y32.dtype == torch.float32 and tuple(y32.shape) == tuple(ref.shape)
+        scale = ref.abs().max().item()
+        assert (y32.double() - ref).abs().max().item() < 2e-5 * scale + 1e-5          # f32 accumulation of exact fp16 products
+        assert torch.equal(y16, y32.half())                                          # fp16 output = ONE rounding of the f32 result
+        if k == 1 or stride == 1:
+            r = torch.randn(tuple(ref.shape), generator=g).cuda()
+            yr = ops.conv_h16(x16, w16, k, stride, b, r, ops.ACT_RELU, out_f16=False)
+            assert (yr.double() - _ref_conv(x16, w16, b, stride, k // 2, r)).abs().max().item() < 2e-5 * scale + 1e-5
+        again = ops.conv_h16(x16, w16, k, stride, b, None, ops.ACT_RELU, out_f16=True)
+        assert torch.equal(again, y16)                                               # run-to-run identical
+    finally:
+        _lib.call("ovis_conv_h16_slots", 0)
+
+
+def test_conv_h16_race_screen_under_memory_traffic():
+    """counted vmcnt waits + LDS-DMA ring: repeat while a side stream streams 512 MB copies through HBM"""
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(9)
+    big_a = torch.empty(512 * 1024 * 1024, dtype=torch.uint8, device="cuda")
+    big_b = torch.empty_like(big_a)
+    side = torch.cuda.Stream()
+    for (T, H, W, Cin, Cout, k, s) in [(5, 184, 320, 64, 64, 3, 1), (5, 46, 80, 256, 256, 3, 1), (5, 23, 40, 512, 512, 3, 1), (5, 92, 160, 128, 512, 1, 1)]:
+        x16 = torch.randn(T, H, W, Cin, generator=g).relu().half().cuda()
+        w16 = (torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).half().cuda()
+        b = torch.randn(Cout, generator=g).cuda()
+        ref = ops.conv_h16(x16, w16, k, s, b, None, ops.ACT_RELU, out_f16=True).clone()
+        torch.cuda.synchronize()
+        for it in range(30):
+            if it % 2 == 0:
+                with torch.cuda.stream(side):
+                    big_b.copy_(big_a, non_blocking=True)
+            assert torch.equal(ops.conv_h16(x16, w16, k, s, b, None, ops.ACT_RELU, out_f16=True), ref), (H, W, Cin, it)
+        torch.cuda.synchronize()
+
+
+def test_x16_gemm_forms_pool_and_stem():
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn(73600, 512, generator=g).relu().cuda()
+    w16 = (torch.randn(128, 512, generator=g) / 512 ** 0.5).half().cuda()
+    b = torch.randn(128, generator=g).cuda()
+    # f32 A rounded while staged == fp16 A stored: bit-identical results; fp16 C == one rounding of the f32 C
+    c32 = ops.gemm_nt_x16(a, w16, b, None, ops.ACT_RELU)
+    c32h = ops.gemm_nt_x16(a.half(), w16, b, None, ops.ACT_RELU)
+    assert torch.equal(c32, c32h)
+    c16 = ops.gemm_nt_x16(a, w16, b, None, ops.ACT_RELU, out_f16=True)          # (bias added in the epilogue instead of as the accumulators'
+    assert torch.equal(c16, ops.gemm_nt_x16(a.half(), w16, b, None, ops.ACT_RELU, out_f16=True))   # start value: f32 sums in another order)
+    assert (c16.float() - c32).abs().max().item() <= 2.0 ** -10 * c32.abs().max().item()
+    ref = (a.half().double() @ w16.double().T + b.double()).relu()
+    assert (c32.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    r = torch.randn(73600, 128, generator=g).cuda()
+    cr = ops.gemm_nt_x16(a.half(), w16, b, r, ops.ACT_RELU)
+    assert (cr.double() - (a.half().double() @ w16.double().T + b.double() + r.double()).relu()).abs().max().item() < 2e-5 * ref.abs().max().item()
+    # pool: max commutes with the fp16 rounding
+    x = torch.randn(2, 61, 90, 64, generator=g).relu().cuda()
+    assert torch.equal(ops.maxpool3x3s2(x.half()), ops.maxpool3x3s2(x).half())
+    # stem writing fp16 == fp16 of the stem writing f32
+    img = torch.randn(2, 96, 128, 4, generator=g).cuda()
+    ws = (torch.randn(64, 7, 8, 4, generator=g) / 14).cuda()
+    ws16 = ops.cast_f16(ws)
+    bs = torch.randn(64, generator=g).cuda()
+    y32 = ops.conv2d_nhwc(img, ws, 2, 3, bs, None, ops.ACT_RELU, w16=ws16)
+    y16 = ops.conv2d_nhwc_o16(img, ws16, 2, 3, bs, ops.ACT_RELU)                # (bias in the epilogue instead of as the start value: another f32 order)
+    assert y16.dtype == torch.float16 and (y16.float() - y32).abs().max().item() <= 2.0 ** -10 * y32.abs().max().item()
+
+
+def test_backbone_fp16_storage_equals_f32_storage_up_to_summation_order():
+    """A2 with fp16 storage of the intra-bottleneck tensors against the f32-storage path.  Given identical f32 inputs, a convolution's fp16
+    operands are identical on both paths (the f32 path rounds the same values while staging); the new kernels sum in another f32 order, so a
+    value that sits within 1e-7 of an fp16 rounding boundary can round the other way and move a few downstream values by up to an fp16 ulp:
+    the MEAN difference is at the f32-rounding level, the maximum a fraction of an fp16 ulp of the feature scale."""
+    import bench
+    model, sd, _ = bench.build_model("cuda")
+    bb = model.backbone
+    assert bb.precision == "fp16" and bb.h16_storage
+    frames = bench.synth_frames(2, 360, 640, 3, "cuda")
+    images, _, _ = model.preprocess(frames)
+    new = bb(images)
+    bb.h16_storage = False
+    try:
+        old = bb(images)
+    finally:
+        bb.h16_storage = True
+    for k in ("res2", "res3", "res4", "res5"):
+        scale = old[k].abs().max().item()
+        d, dm = (new[k] - old[k]).abs().max().item() / scale, (new[k] - old[k]).abs().mean().item() / scale
+        print(f"A2 {k}: fp16 storage vs f32 storage, max rel diff {d:.2e}, mean {dm:.2e}")
+        assert new[k].dtype == torch.float32 and new[k].shape == old[k].shape and d < 2e-3 and dm < 2e-6
