@@ -52,6 +52,18 @@ int ovis_msda_forward_f64(const double* value, const int64_t* spatial_shapes,
                           int num_heads, int channels, int num_levels, int num_query,
                           int num_point, ovis_stream_t stream);
 
+/* 16-bit VALUE storage (SURVEY.md 8(b) "+ bf16-value variant"): value is bf16 (or fp16) [batch, spatial_size, num_heads, channels]
+ * (channels % 4 == 0), sampling_loc / attn_weight / out f32.  The taps are widened exactly and the arithmetic is that of
+ * ovis_msda_forward_f32: the result equals the f32 op on the widened value tensor BIT FOR BIT, while a tap moves half the bytes.
+ * The model path keeps f32 values (the reference's pixel decoder is f32, msdeformattn.py:329); these entry points serve callers
+ * whose value projection is already 16-bit. */
+int ovis_msda_forward_bf16v(const void* value_bf16, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                            const float* sampling_loc, const float* attn_weight, float* out, int batch, int spatial_size,
+                            int num_heads, int channels, int num_levels, int num_query, int num_point, ovis_stream_t stream);
+int ovis_msda_forward_f16v(const void* value_f16, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                           const float* sampling_loc, const float* attn_weight, float* out, int batch, int spatial_size,
+                           int num_heads, int channels, int num_levels, int num_query, int num_point, ovis_stream_t stream);
+
 /* Arithmetic used by the f32 GEMM / convolution entry points for large problems (>= 256 tiles of 128x128):
  *   1 (default)  bf16x3: every f32 operand is split exactly into three bf16 values while staged into LDS and six bf16
  *                MFMA products are accumulated in f32 -- same accuracy class as an f32 fmaf chain, ~2.5x the rate of

@@ -190,7 +190,7 @@ const char* zero_page() {
   std::lock_guard<std::mutex> lock(mu);
   if (!buf[dev]) {
     if (hipMalloc(&buf[dev], 4096) != hipSuccess) { buf[dev] = nullptr; return nullptr; }
-    if (hipMemset(buf[dev], 0, 4096) != hipSuccess) { hipFree(buf[dev]); buf[dev] = nullptr; return nullptr; }
+    if (hipMemset(buf[dev], 0, 4096) != hipSuccess) { (void)hipFree(buf[dev]); buf[dev] = nullptr; return nullptr; }
   }
   return reinterpret_cast<const char*>(buf[dev]);
 }

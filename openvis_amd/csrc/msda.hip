@@ -28,6 +28,14 @@ template <> struct VecOf<float, 4> { using type = float4; };
 template <> struct VecOf<float, 1> { using type = float; };
 template <> struct VecOf<double, 1> { using type = double; };
 
+// 16-bit VALUE storage ("+ bf16-value variant"): the value tensor holds bf16 / fp16, everything else is f32.  The taps are
+// widened exactly, the arithmetic is the f32 kernel's -- the result equals ovis_msda_forward_f32 on the widened tensor bit for bit -- and a tap
+// is a 64-byte row segment instead of a 128-byte one: half the bytes through the gather path that bounds K1.
+struct BF16 { unsigned short b; };
+struct FP16 { unsigned short b; };
+__device__ __forceinline__ float widen(BF16 v) { return __uint_as_float((unsigned)v.b << 16); }
+__device__ __forceinline__ float widen(FP16 v) { return (float)__builtin_bit_cast(_Float16, v.b); }
+
 template <typename T> __device__ __forceinline__ T tfloor(T x);
 template <> __device__ __forceinline__ float tfloor<float>(float x) { return floorf(x); }
 template <> __device__ __forceinline__ double tfloor<double>(double x) { return floor(x); }
@@ -44,6 +52,82 @@ __device__ __forceinline__ void load_vec(T (&v)[VEC], const T* p, bool pred) {
     const T t = p[0];
     v[0] = pred ? t : T(0);
   }
+}
+
+// four 16-bit values (8 bytes) of a tap, widened to f32
+template <typename V16>
+__device__ __forceinline__ void load_vec16(float (&v)[4], const V16* p, bool pred) {
+  const uint2 t = *reinterpret_cast<const uint2*>(p);
+  const V16 e0{(unsigned short)(t.x & 0xffffu)}, e1{(unsigned short)(t.x >> 16)}, e2{(unsigned short)(t.y & 0xffffu)}, e3{(unsigned short)(t.y >> 16)};
+  v[0] = pred ? widen(e0) : 0.f; v[1] = pred ? widen(e1) : 0.f; v[2] = pred ? widen(e2) : 0.f; v[3] = pred ? widen(e3) : 0.f;
+}
+
+template <typename V16>
+__device__ __forceinline__ void sample_point16(float (&acc)[4], const V16* vp, int H, int W, int qid_stride, float loc_w, float loc_h, float weight) {
+  const float h_im = loc_h * (float)H - 0.5f;
+  const float w_im = loc_w * (float)W - 0.5f;
+  if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+    const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    const float lh = h_im - h_low, lw = w_im - w_low;
+    const float hh = 1 - lh, hw = 1 - lw;
+    const long long h_stride = (long long)W * qid_stride;
+    const int yl = h_low < 0 ? 0 : h_low, yh = h_high > H - 1 ? H - 1 : h_high;
+    const int xl = w_low < 0 ? 0 : w_low, xh = w_high > W - 1 ? W - 1 : w_high;
+    const V16* r0 = vp + yl * h_stride;
+    const V16* r1 = vp + yh * h_stride;
+    float v1[4], v2[4], v3[4], v4[4];
+    load_vec16<V16>(v1, r0 + (long long)xl * qid_stride, h_low >= 0 && w_low >= 0);
+    load_vec16<V16>(v2, r0 + (long long)xh * qid_stride, h_low >= 0 && w_high <= W - 1);
+    load_vec16<V16>(v3, r1 + (long long)xl * qid_stride, h_high <= H - 1 && w_low >= 0);
+    load_vec16<V16>(v4, r1 + (long long)xh * qid_stride, h_high <= H - 1 && w_high <= W - 1);
+    const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float val = (w1 * v1[i] + w2 * v2[i] + w3 * v3[i] + w4 * v4[i]);
+      acc[i] += val * weight;
+    }
+  }
+}
+
+// value in 16-bit storage, 4 channels per lane (8-byte taps), runtime levels / points; loc / attw / out f32
+template <typename V16>
+__global__ void __launch_bounds__(256)
+msda_fwd16_kernel(const V16* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi, const float* __restrict__ loc,
+                  const float* __restrict__ attw, float* __restrict__ out, long long n_items, int S, int M, int D, int L, int Lq, int P) {
+  const unsigned blk = ovis::xcd_remap(blockIdx.x, gridDim.x);
+  const long long item = (long long)blk * blockDim.x + threadIdx.x;
+  if (item >= n_items) return;
+  const int dv = D / 4;
+  const int cv = (int)(item % dv);
+  const long long sidx = item / dv;
+  const int m = (int)(sidx % M);
+  const long long b = sidx / ((long long)M * Lq);
+  const int qid_stride = M * D;
+  const float* lp = loc + sidx * L * P * 2;
+  const float* wp = attw + sidx * L * P;
+  const V16* vbase = value + b * (long long)S * qid_stride + m * D + cv * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const V16* vp = vbase + lsi[l] * (long long)qid_stride;
+    for (int p = 0; p < P; ++p)
+      sample_point16<V16>(acc, vp, H, W, qid_stride, lp[(l * P + p) * 2], lp[(l * P + p) * 2 + 1], wp[l * P + p]);
+  }
+  *reinterpret_cast<float4*>(out + sidx * D + cv * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+template <typename V16>
+int msda_dispatch16(const void* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attw, float* out, int B, int S,
+                    int M, int D, int L, int Lq, int P, hipStream_t stream) {
+  OVIS_REQUIRE(value && shapes && lsi && loc && attw && out, "msda_forward (16-bit value): null pointer");
+  OVIS_REQUIRE(B > 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq > 0 && P > 0, "msda_forward (16-bit value): non-positive dimension");
+  OVIS_REQUIRE(D % 4 == 0 && ((uintptr_t)value % 8) == 0 && ((uintptr_t)out % 16) == 0,
+               "msda_forward (16-bit value): channels must be a multiple of 4, value 8-byte and out 16-byte aligned");
+  const long long n_items = (long long)B * Lq * M * (D / 4);
+  hipLaunchKernelGGL((msda_fwd16_kernel<V16>), dim3(ovis::cdiv(n_items, 256)), dim3(256), 0, stream, reinterpret_cast<const V16*>(value), shapes, lsi,
+                     loc, attw, out, n_items, S, M, D, L, Lq, P);
+  return ovis::check_launch("msda_forward (16-bit value)");
 }
 
 // One sampling point: 4 predicated row loads + bilinear blend, accumulated into acc.
@@ -186,4 +270,18 @@ extern "C" int ovis_msda_forward_f64(const double* value, const int64_t* spatial
   return msda_dispatch<double>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                                out, batch, spatial_size, num_heads, channels, num_levels, num_query,
                                num_point, (hipStream_t)stream);
+}
+
+extern "C" int ovis_msda_forward_bf16v(const void* value_bf16, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                       const float* sampling_loc, const float* attn_weight, float* out, int batch, int spatial_size,
+                                       int num_heads, int channels, int num_levels, int num_query, int num_point, ovis_stream_t stream) {
+  return msda_dispatch16<BF16>(value_bf16, spatial_shapes, level_start_index, sampling_loc, attn_weight, out, batch, spatial_size, num_heads,
+                               channels, num_levels, num_query, num_point, (hipStream_t)stream);
+}
+
+extern "C" int ovis_msda_forward_f16v(const void* value_f16, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                      const float* sampling_loc, const float* attn_weight, float* out, int batch, int spatial_size,
+                                      int num_heads, int channels, int num_levels, int num_query, int num_point, ovis_stream_t stream) {
+  return msda_dispatch16<FP16>(value_f16, spatial_shapes, level_start_index, sampling_loc, attn_weight, out, batch, spatial_size, num_heads,
+                               channels, num_levels, num_query, num_point, (hipStream_t)stream);
 }

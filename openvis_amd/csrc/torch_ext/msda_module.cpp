@@ -29,10 +29,13 @@ void check_forward_args(const at::Tensor& value, const at::Tensor& spatial_shape
   TORCH_CHECK(attn_weight.is_cuda(), "attn_weight must be a CUDA tensor");
   TORCH_CHECK(spatial_shapes.scalar_type() == at::kLong && level_start_index.scalar_type() == at::kLong,
               "spatial_shapes / level_start_index must be int64");                                    // data<int64_t>(), cuda.cu:72-73
-  TORCH_CHECK(value.scalar_type() == at::kFloat || value.scalar_type() == at::kDouble,
+  // MI355X extension of the dtype set (AT_DISPATCH_FLOATING_TYPES, cuda.cu:69): a bf16 / fp16 VALUE tensor with f32 locations and weights
+  const bool v16 = value.scalar_type() == at::kBFloat16 || value.scalar_type() == at::kHalf;
+  TORCH_CHECK(value.scalar_type() == at::kFloat || value.scalar_type() == at::kDouble || v16,
               "\"ms_deform_attn_forward_cuda\" not implemented for '", toString(value.scalar_type()), "'");   // cuda.cu:69
-  TORCH_CHECK(sampling_loc.scalar_type() == value.scalar_type() && attn_weight.scalar_type() == value.scalar_type(),
-              "value / sampling_loc / attn_weight dtype mismatch");
+  const auto ctl = v16 ? at::kFloat : value.scalar_type();
+  TORCH_CHECK(sampling_loc.scalar_type() == ctl && attn_weight.scalar_type() == ctl,
+              "value / sampling_loc / attn_weight dtype mismatch (a bf16 / fp16 value goes with float32 locations and weights)");
   TORCH_CHECK(value.dim() == 4 && spatial_shapes.dim() == 2 && sampling_loc.dim() == 6 && attn_weight.dim() == 5,
               "ms_deform_attn_forward: value [N,S,M,D], spatial_shapes [L,2], sampling_loc [N,Lq,M,L,P,2], attn_weight [N,Lq,M,L,P]");
   const int64_t batch = value.size(0);
@@ -47,10 +50,15 @@ at::Tensor ms_deform_attn_forward(const at::Tensor& value, const at::Tensor& spa
   const int batch = (int)value.size(0), spatial_size = (int)value.size(1), num_heads = (int)value.size(2), channels = (int)value.size(3);
   const int num_levels = (int)spatial_shapes.size(0), num_query = (int)sampling_loc.size(1), num_point = (int)sampling_loc.size(4);
   c10::hip::HIPGuardMasqueradingAsCUDA guard(value.device());
-  at::Tensor out = at::empty({batch, num_query, (int64_t)num_heads * channels}, value.options());      // fully overwritten (cuda.cu:59 zero-inits)
+  at::Tensor out = at::empty({batch, num_query, (int64_t)num_heads * channels}, sampling_loc.options());      // fully overwritten (cuda.cu:59 zero-inits)
   hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
   int rc;
-  if (value.scalar_type() == at::kFloat)
+  if (value.scalar_type() == at::kBFloat16 || value.scalar_type() == at::kHalf) {
+    auto fn = value.scalar_type() == at::kBFloat16 ? ovis_msda_forward_bf16v : ovis_msda_forward_f16v;
+    rc = fn(value.data_ptr(), spatial_shapes.data_ptr<int64_t>(), level_start_index.data_ptr<int64_t>(), sampling_loc.data_ptr<float>(),
+            attn_weight.data_ptr<float>(), out.data_ptr<float>(), batch, spatial_size, num_heads, channels, num_levels, num_query, num_point,
+            (ovis_stream_t)stream);
+  } else if (value.scalar_type() == at::kFloat)
     rc = ovis_msda_forward_f32(value.data_ptr<float>(), spatial_shapes.data_ptr<int64_t>(), level_start_index.data_ptr<int64_t>(),
                                sampling_loc.data_ptr<float>(), attn_weight.data_ptr<float>(), out.data_ptr<float>(), batch, spatial_size,
                                num_heads, channels, num_levels, num_query, num_point, (ovis_stream_t)stream);
@@ -64,7 +72,7 @@ at::Tensor ms_deform_attn_forward(const at::Tensor& value, const at::Tensor& spa
 
 at::Tensor ms_deform_attn_forward_meta(const at::Tensor& value, const at::Tensor& spatial_shapes, const at::Tensor& level_start_index,
                                        const at::Tensor& sampling_loc, const at::Tensor& attn_weight, int64_t im2col_step) {
-  return at::empty_symint({value.sym_size(0), sampling_loc.sym_size(1), value.sym_size(2) * value.sym_size(3)}, value.options());
+  return at::empty_symint({value.sym_size(0), sampling_loc.sym_size(1), value.sym_size(2) * value.sym_size(3)}, sampling_loc.options());
 }
 
 std::vector<at::Tensor> ms_deform_attn_backward(const at::Tensor& value, const at::Tensor& spatial_shapes, const at::Tensor& level_start_index,

@@ -124,3 +124,27 @@ def test_reference_call_sequence_and_dispatcher_op_give_the_same_bits():
     ref = oracle_msda.msda_forward(*[t.cpu().numpy() for t in (v, sh, lsi, loc, w)])
     for o in (a, b, c):
         assert np.array_equal(o.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("vdtype", ["bfloat16", "float16"])
+def test_k1_16bit_value_variant_equals_the_f32_op_on_the_widened_values(vdtype):
+    """SURVEY.md 8(b) "+ bf16-value variant": value stored as bf16 (or fp16), locations / weights / output f32.  The taps are widened exactly
+    and the arithmetic is the f32 kernel's, so the result must equal oracle/msda_ref.c (and ovis_msda_forward_f32) on the widened value tensor
+    BIT FOR BIT -- encoder shape at 480p, 2 frames, locations partly outside the maps."""
+    import torch
+    import MultiScaleDeformableAttention as MSDA
+    g = torch.Generator().manual_seed(11)
+    shapes = torch.tensor([(15, 27), (30, 54), (60, 107)], dtype=torch.long)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    dt = getattr(torch, vdtype)
+    v16 = torch.randn(2, S, 8, 32, generator=g).to(dt)
+    loc = torch.rand(2, S, 8, 3, 4, 2, generator=g) * 1.3 - 0.15
+    w = torch.softmax(torch.randn(2, S, 8, 12, generator=g), -1).view(2, S, 8, 3, 4)
+    out = MSDA.ms_deform_attn_forward(v16.cuda(), shapes.cuda(), lsi.cuda(), loc.cuda(), w.cuda(), 64)
+    assert out.dtype == torch.float32
+    wide = v16.float()
+    ref = oracle_msda.msda_forward(wide.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), w.numpy())
+    assert np.array_equal(out.cpu().numpy(), ref)
+    out32 = MSDA.ms_deform_attn_forward(wide.cuda(), shapes.cuda(), lsi.cuda(), loc.cuda(), w.cuda(), 64)
+    assert torch.equal(out, out32)
