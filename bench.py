@@ -65,7 +65,7 @@ MODELS = {   # --model: META_ARCHITECTURE, decoder, weight spec, backbone, CLIP 
 }
 
 
-def build_model(device, seed=42, clip_precision="fp16", precision="mixed", model_name="openvis", f32_split="auto"):
+def build_model(device, seed=42, clip_precision="fp16", precision="mixed", model_name="openvis", f32_split="auto", crop_list="auto"):
     from openvis_amd import config, weights
     from openvis_amd.catalog import MetadataCatalog
     from openvis_amd.modeling.clip_adapter.adapter import _CLIP_ARCH
@@ -88,6 +88,7 @@ def build_model(device, seed=42, clip_precision="fp16", precision="mixed", model
         cfg.MODEL.SWIN.NUM_HEADS, cfg.MODEL.SWIN.WINDOW_SIZE = list(a["num_heads"]), a["window"]
     cfg.MODEL.PRECISION = precision
     cfg.MODEL.F32_GEMM_SPLIT = f32_split
+    cfg.MODEL.CLIP_ADAPTER.CROP_LIST = crop_list
     model = config.build_model(cfg)
     model.device = torch.device(device)
     sd = weights.random_init(getattr(weights, m["spec"])(backbone, _CLIP_ARCH[clip], queries), seed=seed)
@@ -190,6 +191,9 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="frames per clip (default 5; brivis: 36)")
     ap.add_argument("--resolution", type=int, default=0, choices=[0, 720, 1080],
                     help="frame height (16:9); default 720, *_swinl models: 1080 (BASELINE.json configs[4])")
+    ap.add_argument("--crop-list", default="auto", choices=["auto", "host", "device"],
+                    help="MODEL.CLIP_ADAPTER.CROP_LIST: where ClipAdapter's crop list is built (host = the reference's read-back of the boxes in the "
+                         "middle of the forward; device = no read-back, static shapes; auto = device while >= 90 %% of the masks are non-empty)")
     ap.add_argument("--gather-masks", action="store_true",
                     help="frame-sharded runs: gather the ten output masks of all frames on rank 0 (the reference's single video_output); "
                          "default: every rank keeps the masks of its own frames for a sharded evaluator (SURVEY.md 8e (3))")
@@ -216,7 +220,8 @@ def main():
 
     from openvis_amd import ops
     f32_split = args.f32_split if args.f32_split != "auto" else ("bf16x3" if args.precision == "fp32" else "fp16x2")
-    model, sd, text = build_model(device, clip_precision=args.clip_precision, precision=args.precision, model_name=args.model, f32_split=args.f32_split)
+    model, sd, text = build_model(device, clip_precision=args.clip_precision, precision=args.precision, model_name=args.model, f32_split=args.f32_split,
+                                  crop_list=args.crop_list)
     frame_sharded = args.model.startswith("brivis") and world > 1
     T = args.frames or (36 if args.model.startswith("brivis") else T_CLIP)
     res = args.resolution or (1080 if args.model.endswith("_swinl") else 720)
@@ -525,7 +530,8 @@ def main():
                        f"frames/sec (whole node) {args.model} {bb_name} {res}p inference"), "value": round(frames_total / elapsed, 3),
             "unit": "frames/s", "n_gpus": world, "world_size_seen": D.world_size(), "frames_per_rank": frames_per_rank,
             "steps": args.steps, "warmup": args.warmup, "f32_split": f32_split, "f32_split_f32_grade": f32_split != "bf16x2",
-            "f32_split_fell_back_to_bf16x3": bool(fell_back), "alt_f32_split": alt, "alt_f32_splits": alts,
+            "f32_split_fell_back_to_bf16x3": bool(fell_back),
+            "crop_list": getattr(getattr(_model, "clip_adapter", None), "crop_list", None), "alt_f32_split": alt, "alt_f32_splits": alts,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if frame_sharded else "weak",
             "vs_baseline": None, "dtype": "f16" if "fp16" in (bb_prec, _model.clip_adapter.precision) else "f32", "data": "synthetic",

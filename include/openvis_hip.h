@@ -357,6 +357,11 @@ int ovis_center_pool_nhwc_f32(const float* x, float* y, int N, int H, int W, int
 /* boxes[t,q] = inclusive (x0,y0,x1,y1) of { sigmoid(bilinear_up(masks[q,t]) to Hp x Wp) > 0.5 }, x1 < 0 if empty
  *   (openvis.py:87-96,118; adapter.py:88-94; detectron2 BitMasks.get_bounding_boxes). masks [Q,T,h,w] logits. */
 int ovis_mask_bbox(const float* masks, int* boxes, int Q, int T, int h, int w, int Hp, int Wp, ovis_stream_t stream);
+/* Crop list built on the device (adapter.py:86-102 without the host read-back of the boxes): boxes int32 [T,Q,4] (ovis_mask_bbox) ->
+ *   crops int32 [T*Q,6] = (t, q, x0, y0, x1, y1) for EVERY (frame, query) in that order (not compacted: no downstream shape depends on
+ *   the data; an empty mask gets a box far outside the frame, for which ovis_clip_crop_patches writes the normalised zero image),
+ *   slot int32 [T*Q] = t*Q + q or -1 (the aggregation's crop-row map), counts[0] += number of non-empty masks (caller zeroes it). */
+int ovis_crop_list_static(const int* boxes, int* crops, int* slot, int* counts, int T, int Q, int Hp, int Wp, ovis_stream_t stream);
 /* CLIP crops (adapter.py:96-116,140-143) written as the patch-embedding im2col matrix
  *   A[(m*G*G + py*G + px), c*ps*ps + iy*ps + ix]; crops int32 [M,6] = (t,q,x0,y0,x1,y1);
  *   frames uint8 [T,3,H,W] (raw, un-padded); masks [Q,T,h,w] logits; mean/std = CLIP's (HOST, in [0,1] units);

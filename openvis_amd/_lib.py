@@ -59,12 +59,42 @@ def _conv(a):
     return a
 
 
+# ---- bounded launch run-ahead --------------------------------------------------------------------------------------------------------
+# LAUNCH_WINDOW > 0: the calling thread never has more than ~3 x LAUNCH_WINDOW library launches queued ahead of the GPU: every LAUNCH_WINDOW
+# launches it records an event on its stream and waits for the event recorded two windows earlier (already complete in the steady state of
+# a GPU-bound forward, so the wait costs nothing -- it only stops the host from running whole clips ahead).  Measured on the headline
+# (profiles/r04/launch_window.txt): once the forward has no read-back in its middle (MODEL.CLIP_ADAPTER.CROP_LIST device) the host queues
+# clips ahead without bound and the step gets 1.7 % SLOWER (131.9 frames/s against 133.8 with the read-back; kernel time unchanged, the
+# loss is between the kernels); a window of 32-64 gives 134.3, a window of 128-256 133.2.  0 = unlimited (OVIS_LAUNCH_WINDOW overrides).
+LAUNCH_WINDOW = int(os.environ.get("OVIS_LAUNCH_WINDOW", "64"))
+_tls = __import__("threading").local()
+
+
+def _throttle():
+    n = getattr(_tls, "n", 0) + 1
+    if n < LAUNCH_WINDOW:
+        _tls.n = n
+        return
+    _tls.n = 0
+    import torch
+    ev = torch.cuda.Event()
+    ev.record()
+    q = getattr(_tls, "q", None)
+    if q is None:
+        q = _tls.q = []
+    q.append(ev)
+    if len(q) > 2:
+        q.pop(0).synchronize()
+
+
 def call(name, *args):
     """Call an int-returning ovis_* entry point; raise OvisError on a non-zero code."""
     fn = getattr(lib(), name)
     rc = fn(*[_conv(a) for a in args])
     if rc != 0:
         raise OvisError(f"{name} failed (code {rc}): {lib().ovis_last_error().decode()}")
+    if LAUNCH_WINDOW > 0:
+        _throttle()
 
 
 _raw_stream = None

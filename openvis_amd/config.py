@@ -134,6 +134,15 @@ def get_cfg():
                              # come out of the epilogue of out_proj / c_proj (one fp16 rounding LESS than LayerNorm kernel + GEMM; -1.0 ms
                              # per 720p clip); False = LayerNorm kernels (the round-2 arithmetic)
                              "FOLD_LAYERNORM": True,
+                             # not a reference key -- where ClipAdapter's crop list (adapter.py:86-102) is built:
+                             #   "host"   = as the reference: the boxes are read back (one device -> host sync in the middle of the forward),
+                             #              the valid (frame, query) pairs are compacted on the host and the tower runs on exactly those;
+                             #   "device" = a kernel builds the list for EVERY (frame, query) (empty masks become zero images whose logits
+                             #              the aggregation ignores): no read-back, no data-dependent shape, the host runs ahead of the
+                             #              GPU through the whole forward -- but the tower also spends work on the empty masks;
+                             #   "auto"   = "device" while the previous clips had >= 90 % non-empty masks (the count rides back with the
+                             #              outputs), "host" otherwise and for the first clip.  Same results either way.
+                             "CROP_LIST": "auto",
                              # SideAdapter (SAN / SANOnline / BriVIS) tower: "auto" = fp32 (see BACKBONE_PRECISION)
                              "SIDE_PRECISION": "auto"},
         },

@@ -1294,6 +1294,37 @@ extern "C" int ovis_mask_bbox(const float* masks, int* boxes, int Q, int T, int 
 }
 
 static int g_crop_tile = 0;        // lab: 8 = the 8x8-bin tiles even where 16x16 fit (measured 1.5x slower: profiles/r03/negative_crop.txt)
+// Crop list on the DEVICE (adapter.py:86-102 without the host round trip): one entry per (frame, query) in (t, q) order -- NOT compacted, so
+// that no downstream shape depends on the data.  crops [T*Q,6] = (t, q, x0, y0, x1, y1); an empty mask (boxes[..][2] < 0) gets a box far
+// outside the padded frame: every tile of the crop kernel then takes its "no valid sample" exit and writes the normalised zero pixel.
+// slot [T*Q] = row of the (t, q) crop in the logits (= t*Q + q) or -1 for an empty mask; counts[0] += number of valid crops.
+namespace {
+__global__ void __launch_bounds__(256)
+crop_list_kernel(const int* __restrict__ boxes, int* __restrict__ crops, int* __restrict__ slot, int* __restrict__ counts, int T, int Q,
+                 int far_x, int far_y) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool in = i < T * Q;
+  bool valid = false;
+  if (in) {
+    const int* b = boxes + (long long)i * 4;
+    valid = b[2] >= 0;
+    int* c = crops + (long long)i * 6;
+    c[0] = i / Q; c[1] = i % Q;
+    c[2] = valid ? b[0] : far_x; c[3] = valid ? b[1] : far_y; c[4] = valid ? b[2] : far_x; c[5] = valid ? b[3] : far_y;
+    slot[i] = valid ? i : -1;
+  }
+  const unsigned long long m = __ballot(valid);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(counts, __popcll(m));
+}
+}  // namespace
+
+extern "C" int ovis_crop_list_static(const int* boxes, int* crops, int* slot, int* counts, int T, int Q, int Hp, int Wp, ovis_stream_t stream) {
+  OVIS_REQUIRE(boxes && crops && slot && counts && T > 0 && Q > 0 && Hp > 0 && Wp > 0, "crop_list_static: bad arguments");
+  hipLaunchKernelGGL(crop_list_kernel, dim3(ovis::cdiv((long long)T * Q, 256)), dim3(256), 0, (hipStream_t)stream, boxes, crops, slot, counts, T, Q,
+                     4 * Wp + 4096, 4 * Hp + 4096);
+  return ovis::check_launch("crop_list_static");
+}
+
 extern "C" int ovis_crop_tile(int t) { g_crop_tile = t; return OVIS_OK; }
 
 static int clip_crop_impl(const uint8_t* frames, const float* masks, const int* crops, void* A, unsigned char* patch_open,

@@ -20,4 +20,7 @@ def build_clip_adapter(cfg):
         raise NotImplementedError(f"clip adapter {cfg.NAME} is not in ADAPTER_REGISTER {sorted(ADAPTER_REGISTER)}")
     ad.visual.stream16 = precision == "fp16" and stream == "fp16"
     ad.visual.fold_ln = bool(cfg.get("FOLD_LAYERNORM", True))
+    ad.crop_list = cfg.get("CROP_LIST", "auto")
+    if ad.crop_list not in ("auto", "host", "device"):
+        raise ValueError(f"MODEL.CLIP_ADAPTER.CROP_LIST must be 'auto', 'host' or 'device', got {ad.crop_list!r}")
     return ad

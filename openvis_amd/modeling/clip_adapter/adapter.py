@@ -242,9 +242,24 @@ class ClipVisual:
         return self.head(self.last_block_cls(x, last, st))
 
 
+class DeviceCrops:
+    """Crop bookkeeping of a forward whose crop list was built on the device (MODEL.CLIP_ADAPTER.CROP_LIST): everything stays a device
+    tensor of data-independent shape -- crops [T*Q,6], slot [T,Q] (logit row or -1), counts [1] (non-empty masks)."""
+
+    def __init__(self, crops, slot, counts):
+        self.crops, self.slot, self.counts = crops, slot, counts
+
+    def valid_host(self):
+        """numpy bool [T,Q] (synchronises: tests / stage dumps only)"""
+        return (self.slot >= 0).cpu().numpy()
+
+
 class ClipAdapter:
     mask_prompt_depth = 0            # AdaptedClipAdapter: > 0 (the tower owns a mask_embedding)
     mask_prompt_fwd = False
+    crop_list = "auto"               # MODEL.CLIP_ADAPTER.CROP_LIST (config.py)
+    _valid_frac = None               # share of non-empty masks of the most recent clip whose count is known (auto mode)
+    _pending_count = None            # (event, pinned host int32 [1], T*Q) of a device-list forward whose count is still on its way
 
     def __init__(self, clip_model_name="ViT-B/16", text_templates="vild", arch=None, precision="fp16"):
         self.clip_model_name = clip_model_name
@@ -300,11 +315,48 @@ class ClipAdapter:
         crops = np.concatenate([tq, boxes[valid]], axis=1).astype(np.int32) if len(tq) else np.zeros((0, 6), np.int32)
         return valid, crops
 
+    def _use_device_list(self):
+        """MODEL.CLIP_ADAPTER.CROP_LIST resolved for this forward; "auto" looks at the newest known share of non-empty masks."""
+        if self.crop_list != "auto":
+            return self.crop_list == "device"
+        pend = self._pending_count
+        if pend is not None and pend[0].query():                 # the count of an earlier device-list forward has arrived (never waits)
+            self._valid_frac = float(pend[1][0]) / float(pend[2])
+            self._pending_count = None
+        return self._valid_frac is not None and self._valid_frac >= 0.9
+
     def forward(self, frames, text, masks_lowres, padded_hw):
         """frames uint8 [T,3,H,W] (device); masks_lowres [Q,T,h,w] logits; returns (sim_logits [M,K] or None, valid [T,Q],
-        crops int32 [M,6])."""
+        crops int32 [M,6]) -- host crop list -- or (sim_logits [T*Q,K], DeviceCrops, DeviceCrops.crops) -- device crop list."""
         Hp, Wp = padded_hw
+        if self._use_device_list():
+            boxes = ops.mask_bbox(masks_lowres, Hp, Wp)                       # [T,Q,4] stays on the device
+            crops_d, slot, counts = ops.crop_list_static(boxes, Hp, Wp)
+            dc = DeviceCrops(crops_d, slot, counts)
+            if self.crop_list == "auto":                                      # the count rides back on the hand-off stream, nobody waits for it
+                from ...output import copy_stream
+                side = copy_stream(counts.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+                    host.copy_(counts, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                counts.record_stream(side)
+                self._pending_count = (ev, host, slot.numel())
+            M = crops_d.shape[0]
+            if self.mask_prompt_fwd:
+                A, patch_open = ops.clip_crop_patches_masked(frames, masks_lowres, crops_d, Hp, Wp, self.input_resolution, self.arch["patch"],
+                                                             PIXEL_MEAN, PIXEL_STD, out_f16=(self.precision == "fp16"))
+                feat = self.visual.forward_patches(A, M, patch_open)
+            else:
+                A = ops.clip_crop_patches(frames, masks_lowres, crops_d, Hp, Wp, self.input_resolution, self.arch["patch"], PIXEL_MEAN, PIXEL_STD,
+                                          out_f16=(self.precision == "fp16"))
+                feat = self.visual.forward_patches(A, M)
+            feat = ops.l2norm_rows(feat, 100.0)
+            return ops.gemm_nt(feat, self.encode_text(text)), dc, crops_d
         valid, crops = self.preprocess_boxes(masks_lowres, Hp, Wp)
+        self._valid_frac = float(valid.mean()) if valid.size else 0.0
         if crops.shape[0] == 0:
             return None, valid, crops
         crops_d = ops.to_device_async(crops, self.device)

@@ -104,11 +104,13 @@ class VideoMaskFormer:
     mask_gather = None        # frame-sharded runs: callable(device masks [n,t_local,H,W]) -> masks of all frames on the output rank / None
 
     def inference_video(self, num_queries, num_classes, probs, row_ids, pred_masks_lowres, padded_hw, img_size,
-                        output_height, output_width, topk=10, redo=None, sync_guard=False):
+                        output_height, output_width, topk=10, redo=None, sync_guard=False, n_valid=None):
         """video_maskformer.py:262-298.  probs [Q,K] (rows of valid queries filled), row_ids = valid query ids.
         redo: callable repeating this forward (fp16x2 only: used when the range flag came back set, _range_guard); sync_guard: read the
         flag back NOW instead of with the outputs (frame-sharded runs: every rank holds the all-reduced flag, distributed.reduce_flag, and
-        all of them must repeat the clip at the same point of their collective sequence)."""
+        all of them must repeat the clip at the same point of their collective sequence).  n_valid: device int32 [1], the number of
+        non-empty masks when the crop list was built on the device (row_ids then names EVERY query): read back with the outputs; 0 means
+        what `row_ids is None` means on the host path -- an empty result."""
         flag = ops.f16x2_flag() if self.f32_gemm_mode == 3 else None
         if flag is not None and sync_guard:
             again = self._range_guard(flag.cpu()[0], redo)
@@ -137,6 +139,9 @@ class VideoMaskFormer:
             cm = ops.final_masks(pred_masks_lowres, sel_q, padded_hw[0], padded_hw[1], img_size[0], img_size[1],
                                  output_height, output_width, column_major=True)
             counts, n_runs = ops.rle_encode(cm.view(-1, output_height * output_width))
+            if n_valid is not None and int(n_valid.cpu()[0]) == 0:
+                return {"image_size": (output_height, output_width), "pred_entropys": [], "pred_scores": [], "pred_labels": [], "pred_masks_rle": [],
+                        "pred_queries": []}
             labels = [i % K for i in idx.cpu().tolist()]
             again = self._range_guard(flag.cpu()[0] if flag is not None else None, redo)
             if again is not None:
@@ -169,6 +174,11 @@ class VideoMaskFormer:
             for h_, t in zip(small, (idx, score, ent, sel_q)):
                 h_.copy_(t, non_blocking=True)
                 t.record_stream(side)
+            nv_host = None
+            if n_valid is not None:
+                nv_host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+                nv_host.copy_(n_valid, non_blocking=True)
+                n_valid.record_stream(side)
             flag_host = None
             if flag is not None:
                 flag_host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
@@ -182,6 +192,8 @@ class VideoMaskFormer:
             again = self._range_guard(flag_host[0] if flag_host is not None else None, redo)
             if again is not None:
                 return {k: v for k, v in again.items() if k != "image_size"}
+            if nv_host is not None and int(nv_host[0]) == 0:                  # no mask had a positive pixel (openvis.py:127-128)
+                return {"pred_entropys": [], "pred_scores": [], "pred_labels": [], "pred_masks": [], "pred_queries": []}
             i_, s_, e_, q_ = (h_.tolist() for h_ in small)
             return {"pred_entropys": e_, "pred_scores": s_, "pred_labels": [i % K for i in i_],      # video_maskformer.py:269-270
                     "pred_masks": [m for m in host.view(torch.bool)], "pred_queries": q_}

@@ -19,6 +19,7 @@ class OpenVIS(VideoMaskFormer):
     def __init__(self, *, clip_adapter, **kwargs):
         super().__init__(**kwargs)
         self.clip_adapter = clip_adapter
+        self._all_rows = {}                       # (Q, device) -> arange(Q) int32: the row ids of the device crop-list path
 
     @classmethod
     def from_config(cls, cfg):
@@ -48,16 +49,31 @@ class OpenVIS(VideoMaskFormer):
         masks_lowres = outputs["pred_masks"][0]                               # [Q,T,h,w] logits
 
         probs, row_ids, extras = self.open_vocabulary_inference(mask_score, masks_lowres, frames, class_names, padded)
+        extras = self._host_view_of_crops(extras) if stages is not None else extras
         if stages is not None:
             stages.update(dict(images=images, features=features, pred_masks=outputs["pred_masks"],
                                pred_logits=outputs["pred_logits"], probs=probs, row_ids=row_ids, **extras))
         inp = batched_inputs[0]
         height = inp.get("height", image_size[0])
         width = inp.get("width", image_size[1])
+        dc = extras.get("device_crops")
         return self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
-                                    height, width, redo=lambda: self.forward(batched_inputs, stages))
+                                    height, width, redo=lambda: self.forward(batched_inputs, stages), n_valid=dc.counts if dc is not None else None)
 
     __call__ = forward
+
+    @staticmethod
+    def _host_view_of_crops(extras):
+        """stage dumps (tests, bench): the device crop list in the host path's form -- valid [T,Q] numpy, crops / crop_logits of the valid
+        (frame, query) pairs in (t, q) order.  Synchronises; the forward itself never calls it."""
+        dc = extras.get("device_crops")
+        if dc is None:
+            return extras
+        valid = dc.valid_host()
+        keep = torch.from_numpy(valid.reshape(-1)).to(dc.crops.device)
+        out = dict(extras)
+        out.update(valid=valid, crops=dc.crops[keep].cpu().numpy(), crop_logits=extras["crop_logits_all"][keep])
+        return out
 
     def open_vocabulary_inference(self, scores, masks_lowres, frames, class_names, padded_hw):
         """openvis.py:110-147. The reference walks the clip in chunks of 5 frames (part_len) only to bound memory; the
@@ -66,6 +82,21 @@ class OpenVIS(VideoMaskFormer):
         if len(scores) == 0:
             return None, None, {}
         logits, valid, crops = self.clip_adapter(frames, class_names, masks_lowres, padded_hw)
+        from .modeling.clip_adapter.adapter import DeviceCrops
+        if isinstance(valid, DeviceCrops):
+            # crop list built on the device (MODEL.CLIP_ADAPTER.CROP_LIST): one logit row per (frame, query), empty masks ignored through
+            # slot = -1; EVERY query row takes part in the top-k, rows without a crop hold -1 and lose against any probability; nothing
+            # here depends on the data, so the host never waits for the GPU (inference_video reads the count back with the outputs)
+            dc = valid
+            if logits.shape[1] != len(class_names):
+                raise ValueError(f"{type(self.clip_adapter).__name__} returns {logits.shape[1]} logits for {len(class_names)} classes; OpenVIS needs "
+                                 "ClipAdapter or AdaptedClipAdapter")
+            probs, _ = ops.openvis_aggregate(logits, dc.slot, fill=-1.0)
+            Q = dc.slot.shape[1]
+            rid = self._all_rows.get((Q, str(probs.device)))
+            if rid is None:
+                rid = self._all_rows[(Q, str(probs.device))] = torch.arange(Q, dtype=torch.int32, device=probs.device)
+            return probs, rid, {"device_crops": dc, "crop_logits_all": logits}
         if logits is None:                                                    # openvis.py:127-128
             return None, None, {"valid": valid}
         if logits.shape[1] != len(class_names):
@@ -119,12 +150,14 @@ class OpenVISOnline(OpenVIS):
         probs, row_ids, extras = self.open_vocabulary_inference(outputs["pred_logits"][0], masks_lowres, frames,
                                                                 class_names, padded)
         if stages is not None:
+            extras = self._host_view_of_crops(extras)
             stages.update(dict(images=images, features=features, pred_masks=outputs["pred_masks"],
                                pred_embeds=outputs["pred_embeds"], indices=outputs["indices"], probs=probs,
                                row_ids=row_ids, **extras))
         inp = batched_inputs[0]
+        dc = extras.get("device_crops")
         return self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
                                     inp.get("height", image_size[0]), inp.get("width", image_size[1]),
-                                    redo=lambda: self.forward(batched_inputs, stages))
+                                    redo=lambda: self.forward(batched_inputs, stages), n_valid=dc.counts if dc is not None else None)
 
     __call__ = forward

@@ -728,6 +728,18 @@ def mask_bbox(masks, Hp, Wp):
     return boxes
 
 
+def crop_list_static(boxes, Hp, Wp):
+    """boxes int32 [T,Q,4] (device) -> (crops int32 [T*Q,6], slot int32 [T,Q], counts int32 [1] = number of non-empty masks), all on the
+    device and of data-independent shape (include/openvis_hip.h: ovis_crop_list_static)."""
+    _chk(boxes)
+    T, Q = boxes.shape[:2]
+    crops = torch.empty((T * Q, 6), dtype=torch.int32, device=boxes.device)
+    slot = torch.empty((T, Q), dtype=torch.int32, device=boxes.device)
+    counts = torch.zeros((1,), dtype=torch.int32, device=boxes.device)
+    _lib.call("ovis_crop_list_static", boxes, crops, slot, counts, T, Q, int(Hp), int(Wp), _lib.stream_ptr())
+    return crops, slot, counts
+
+
 def clip_crop_patches(frames, masks, crops, Hp, Wp, resolution, patch, mean, std, out_f16=False):
     _chk(frames, masks, crops)
     return _mi().clip_crop_patches(frames, masks, crops, int(Hp), int(Wp), int(resolution), int(patch), [float(v) for v in mean],
@@ -779,11 +791,13 @@ def l2norm_rows(x, scale=1.0):
     return y
 
 
-def openvis_aggregate(crop_logits, slot):
+def openvis_aggregate(crop_logits, slot, fill=0.0):
+    """fill: value of the probability rows of queries without a valid crop (the kernel leaves them untouched): 0 (the compacted host path
+    never selects them by row id) or -1 (device crop list: every row takes part in the top-k and must lose against any probability)."""
     _chk(crop_logits, slot)
     T, Q = slot.shape
     K = crop_logits.shape[1]
-    probs = torch.zeros((Q, K), dtype=torch.float32, device=slot.device)
+    probs = torch.full((Q, K), float(fill), dtype=torch.float32, device=slot.device)
     qvalid = torch.empty((Q,), dtype=torch.int32, device=slot.device)
     _lib.call("ovis_openvis_aggregate_f32", crop_logits, slot, probs, qvalid, T, Q, K, _lib.stream_ptr())
     return probs, qvalid
