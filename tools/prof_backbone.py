@@ -13,6 +13,8 @@ model, sd, _ = bench.build_model("cuda", precision=prec if prec in ("mixed", "fp
 frames = bench.synth_frames(5, 720, 1280, 1000, "cuda")
 images, _, _ = model.preprocess(frames)
 bb = model.backbone
+if os.environ.get("H16") == "0":
+    bb.h16_storage = False            # the round-3 path: f32 storage everywhere
 log = []
 real_conv, real_gemm, real_pool = ops.conv2d_nhwc, ops.gemm_nt, ops.maxpool3x3s2
 
