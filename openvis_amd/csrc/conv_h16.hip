@@ -245,16 +245,18 @@ extern "C" int ovis_conv_h16(const void* x_f16, const void* w_f16, void* y, int 
   p.zeros = zero_page();
   OVIS_REQUIRE(p.zeros, "conv_h16: cannot allocate the page of zeros");
   p.T = T; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.stride = stride; p.act = act; p.M = (int)M;
-  // Tile width and LDS slots, measured on the four 3x3 shapes of ResNet-50 at 5 x 736 x 1280 (profiles/r04/conv_h16_tiles.txt): the kernel is
-  // bound by the L2 -> LDS rate per CU, so it wants two workgroups per CU (two slots: 64 / 72 KB of LDS each) wherever the grid fills them --
-  // res4 46.7 us (128 columns) / 44.9 (64) against 69 with three slots; with 128-column tiles below 256 workgroups (res5: 144) one workgroup per
-  // CU runs alone and three slots win, 62.8 us against 76.5 (64-column tiles, 288 workgroups: 58.8 with three slots, 67 with two).
+  // Tile width and LDS slots, measured on the four 3x3 shapes of ResNet-50 at 5 x 736 x 1280 (profiles/r04/conv_h16_tiles.txt).  The kernel is
+  // bound by the L2 -> LDS rate per CU, so what matters is how many workgroups are RESIDENT: three slots = 96 KB (128 columns: one workgroup
+  // per CU) / 72 KB (64 columns: two), two slots = 64 / 48 KB (two / three).  Three slots while the whole grid is resident with them (res5,
+  // 64-column tiles, 288 workgroups: 58.8 us against 67 with two), two slots as soon as that adds resident workgroups (res4, 128 columns, 288
+  // workgroups: 46.7 us against 69 -- with three slots the 32 workgroups of a second round run alone); 64-column tiles where 128-column
+  // ones would leave CUs empty (res5: 144 workgroups, 62.8 us).
   int bn = (Cout % 128 == 0) ? 128 : 64;
   if (bn == 128 && ovis::cdiv(M, 128) * (Cout / 128) < 256) bn = 64;
   if (g_ch_bn == 64 || (g_ch_bn == 128 && Cout % 128 == 0)) bn = g_ch_bn;
   p.tiles_n = Cout / bn;
   const unsigned grid = ovis::cdiv(M, 128) * (unsigned)p.tiles_n;
-  const int nst = g_ch_nst ? g_ch_nst : (grid >= 512 ? 2 : 3);
+  const int nst = g_ch_nst ? g_ch_nst : (grid <= 256u * (bn == 128 ? 1u : 2u) ? 3 : 2);
   hipStream_t s = (hipStream_t)stream;
 #define CH_LAUNCH(BN_, TAPS_, O16_) do { if (nst == 2) hipLaunchKernelGGL((conv_h16_kernel<BN_, TAPS_, O16_, 2>), dim3(grid), dim3(256), 0, s, p); \
                                          else hipLaunchKernelGGL((conv_h16_kernel<BN_, TAPS_, O16_, 3>), dim3(grid), dim3(256), 0, s, p); } while (0)
