@@ -40,7 +40,9 @@ struct CH16Args {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-template <int BN, int TAPS, bool OUT16, int NST = 3>
+// DBG (lab instantiations only, ovis_conv_h16_debug): 1 = no DMA after the prologue, 2 = no fragment reads / MFMAs.  A compile-time switch: as a
+// run-time branch around compute() it made the register allocator carry the accumulators in VGPRs and copy all 64 to AGPRs and back per K step.
+template <int BN, int TAPS, bool OUT16, int NST = 3, int DBG = 0>
 __global__ void __launch_bounds__(256)
 conv_h16_kernel(const CH16Args p) {
   constexpr int BM = 128;
@@ -93,24 +95,36 @@ conv_h16_kernel(const CH16Args p) {
     cB[j] = ((lane & 7) ^ ((row >> 1) & 7)) * 16;
     wB[j] = (long long)min(bn + row, p.Cout - 1) * K * 2 + cB[j];
   }
-  const char* Xb = reinterpret_cast<const char*>(p.X);
-  const char* Wb = reinterpret_cast<const char*>(p.Wt);
+  // per-lane source pointers, complete except for the wave-uniform part of a K step (no 64-bit arithmetic beyond one add per DMA instruction,
+  // no integer division in the loop: the issue cursor walks (tap, channel chunk) by increments)
+  const char* pa[4];
+  const char* pb[BJ];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pa[j] = reinterpret_cast<const char*>(p.X) + (long long)base[j] + cA[j];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) pb[j] = reinterpret_cast<const char*>(p.Wt) + wB[j];
   const char* Zb = p.zeros + (lane & 7) * 16;
+  int i_tap = 0, i_kc = 0, i_kh = 0, i_kw = 0;        // the NEXT K step to issue: tap (kh, kw), channel chunk kc; all wave-uniform
+  long long i_woff = 0;                              // its byte offset in a weight row
 
-  auto issue = [&](int ks, int buf) {
-    const int tap = ks / cpt, kc = ks - tap * cpt;
-    int off;
-    if constexpr (TAPS == 9) { const int kh = tap / 3, kw = tap - 3 * kh; off = ((kh * p.W + kw) * p.Cin + kc * 64) * 2; }
-    else off = kc * 128;
+  auto issue = [&](int buf) {
+    long long off;
+    if constexpr (TAPS == 9) off = ((long long)(i_kh * p.W + i_kw) * p.Cin + i_kc * 64) * 2;
+    else off = (long long)i_kc * 128;
+    const unsigned tapbit = 1u << i_tap;
     unsigned char* dst = lds + buf * STAGE;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const bool ok = (mask[j] >> tap) & 1u;
-      const char* src = ok ? Xb + (long long)(base[j] + off) + cA[j] : Zb;
+      const char* src = (mask[j] & tapbit) ? pa[j] + off : Zb;
       CH_GLDS(src, dst + (4 * wave + j) * 1024);
     }
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) CH_GLDS(Wb + wB[j] + (long long)ks * 128, dst + BM * 128 + (wave * BJ + j) * 1024);
+    for (int j = 0; j < BJ; ++j) CH_GLDS(pb[j] + i_woff, dst + BM * 128 + (wave * BJ + j) * 1024);
+    i_woff += 128;
+    if (++i_kc == cpt) {
+      i_kc = 0; ++i_tap;
+      if (++i_kw == 3) { i_kw = 0; ++i_kh; }
+    }
   };
 
   const int r32 = lane & 31, h = lane >> 5;
@@ -129,25 +143,30 @@ conv_h16_kernel(const CH16Args p) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) { const int row = wc * (BN / 2) + j * 32 + r32; boff[j] = BM * 128 + row * 128; bsw[j] = (row >> 1) & 7; }
 
-  // all 4 x (TM + TN) fragments of a K step are requested before the first MFMA (one wavefront per SIMD: nothing else hides the LDS
-  // latency); the compiler retires them with counted lgkmcnt waits in issue order
+  // fragment reads run ONE k chunk ahead of the MFMAs (two register sets): while the four / two MFMAs of chunk s run, the reads of chunk
+  // s + 1 are in flight and the compiler's counted lgkmcnt wait retires only chunk s.  The order is pinned (sched_barrier): left alone, the
+  // scheduler sinks every read group next to its MFMAs behind a full lgkmcnt(0) -- one exposed LDS round trip per chunk, four per K step.
   auto compute = [&](int buf) {
     const unsigned char* st = lds + buf * STAGE;
-    f16x8 af[4][TM], bf[4][TN];
+    f16x8 af[2][TM], bf[2][TN];
+    auto rd = [&](int s, int set) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[set][j] = *reinterpret_cast<const f16x8*>(st + boff[j] + (((4 * h + s) ^ bsw[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[set][i] = *reinterpret_cast<const f16x8*>(st + aoff[i] + (((4 * h + s) ^ asw[i]) << 4));
+    };
+    rd(0, 0);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[s][j] = *reinterpret_cast<const f16x8*>(st + boff[j] + (((4 * h + s) ^ bsw[j]) << 4));
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[s][i] = *reinterpret_cast<const f16x8*>(st + aoff[i] + (((4 * h + s) ^ asw[i]) << 4));
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
+      if (s < 3) rd(s + 1, (s + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);   // roles swapped
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0);   // roles swapped
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
 
   // NST slots: NST - 1 K steps in flight.  K step ks has landed for THIS wavefront once at most the (NST - 2) PER instructions of the later
@@ -156,15 +175,15 @@ conv_h16_kernel(const CH16Args p) {
   static_assert(NST == 2 || NST == 3, "2 or 3 LDS slots");
 #pragma unroll
   for (int q = 0; q < NST - 1; ++q)
-    if (q < nk) issue(q, q);
+    if (q < nk) issue(q);
   for (int ks = 0; ks < nk; ++ks) {
     if (NST == 3 && ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (ks + NST - 1 < nk) issue(ks + NST - 1, (ks + NST - 1) % NST);
-    compute(ks % NST);
+    if ((DBG & 1) == 0 && ks + NST - 1 < nk) issue((ks + NST - 1) % NST);
+    if constexpr ((DBG & 2) == 0) compute(ks % NST);
   }
 
   const bool vec_ok = ovis::epilogue_vec_ok(p.Y, p.Cout, p.bias, p.R, p.Cout);
@@ -180,6 +199,7 @@ conv_h16_kernel(const CH16Args p) {
 int g_ch_nst = 0;         // LDS slots of conv_h16_kernel (lab switch ovis_conv_h16_slots): 0 = automatic; 3 = two K steps in flight (96 KB at BN = 128:
                          // one workgroup per CU); 2 = one in flight, two workgroups per CU
 int g_ch_bn = 0;          // lab switch: 0 automatic, 64 / 128 forced
+int g_ch_dbg = 0;
 
 // One 4 KB page of zeros per device (what a masked tap reads), allocated at the first launch there and kept for the life of the process.
 const char* zero_page() {
@@ -260,7 +280,12 @@ extern "C" int ovis_conv_h16(const void* x_f16, const void* w_f16, void* y, int 
   hipStream_t s = (hipStream_t)stream;
 #define CH_LAUNCH(BN_, TAPS_, O16_) do { if (nst == 2) hipLaunchKernelGGL((conv_h16_kernel<BN_, TAPS_, O16_, 2>), dim3(grid), dim3(256), 0, s, p); \
                                          else hipLaunchKernelGGL((conv_h16_kernel<BN_, TAPS_, O16_, 3>), dim3(grid), dim3(256), 0, s, p); } while (0)
-  if (ksize == 3) {
+  if (g_ch_dbg && ksize == 3 && out_f16 && nst == 2) {              // lab: DMA-only / MFMA-only variants of the 3x3 kernel
+    if (bn == 128) { if (g_ch_dbg == 1) hipLaunchKernelGGL((conv_h16_kernel<128, 9, true, 2, 1>), dim3(grid), dim3(256), 0, s, p);
+                     else hipLaunchKernelGGL((conv_h16_kernel<128, 9, true, 2, 2>), dim3(grid), dim3(256), 0, s, p); }
+    else { if (g_ch_dbg == 1) hipLaunchKernelGGL((conv_h16_kernel<64, 9, true, 2, 1>), dim3(grid), dim3(256), 0, s, p);
+           else hipLaunchKernelGGL((conv_h16_kernel<64, 9, true, 2, 2>), dim3(grid), dim3(256), 0, s, p); }
+  } else if (ksize == 3) {
     if (bn == 128) { if (out_f16) CH_LAUNCH(128, 9, true); else CH_LAUNCH(128, 9, false); }
     else { if (out_f16) CH_LAUNCH(64, 9, true); else CH_LAUNCH(64, 9, false); }
   } else {
@@ -272,6 +297,7 @@ extern "C" int ovis_conv_h16(const void* x_f16, const void* w_f16, void* y, int 
 }
 
 extern "C" int ovis_conv_h16_slots(int nst) { g_ch_nst = (nst == 2 || nst == 3) ? nst : 0; return OVIS_OK; }   // lab / tests only: 0 automatic
+extern "C" int ovis_conv_h16_debug(int d) { g_ch_dbg = (d == 1 || d == 2) ? d : 0; return OVIS_OK; }   // lab only
 extern "C" int ovis_conv_h16_bn(int bn) { g_ch_bn = (bn == 64 || bn == 128) ? bn : 0; return OVIS_OK; }          // lab only
 
 extern "C" int ovis_maxpool3x3s2_nhwc_f16(const void* x, void* y, int N, int H, int W, int C, ovis_stream_t stream) {
