@@ -312,6 +312,25 @@ def main():
         torch.cuda.synchronize()
     alt = alts[0] if alts else None
 
+    # ---- the same clips with TWO in flight (openvis_amd.runtime.ClipPipeline: one HIP stream + host thread per slot) --------------------
+    # What a serving process would run: the tails of the persistent GEMMs and the latency-bound decoder of one clip fill with the other
+    # clip's kernels.  Reported BESIDE the headline, not as it: per-launch HIP-event times of overlapping clips include each other's kernels,
+    # so the `roofline` below could not be read from such a timed region (`--streams 2` makes it the timed region).
+    in_flight2 = None
+    if args.streams == 1 and not frame_sharded and not rig:
+        from openvis_amd.runtime import ClipPipeline
+        pipe2 = ClipPipeline(_model, 2)
+        n2 = max(args.steps // 2, 4)
+        pipe2.run([inputs[i % len(inputs)] for i in range(3)])
+        sync_all()
+        t0 = time.perf_counter()
+        pipe2.run([inputs[i % len(inputs)] for i in range(n2)])
+        sync_all()
+        e2 = D.max_over_ranks(time.perf_counter() - t0, device)
+        in_flight2 = {"value": round(T * n2 * world / e2, 3), "unit": "frames/s", "ms_per_step": round(e2 / n2 * 1e3, 3), "steps": n2,
+                      "note": "2 clips in flight per GPU (HIP streams), same clips and outputs; not the headline"}
+        torch.cuda.synchronize()
+
     # ---- frame-sharded runs: what every rank spends in the exchange steps, untimed extra steps --------------------
     # host=True spans are host wall time around the call (the wait for the side-stream all-gather, the all-reduce, the mask gather:
     # what the rank loses to the collective including the wait for the slowest rank); the others are HIP-event times of replicated work
@@ -532,6 +551,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "f32_split": f32_split, "f32_split_f32_grade": f32_split != "bf16x2",
             "f32_split_fell_back_to_bf16x3": bool(fell_back),
             "crop_list": getattr(getattr(_model, "clip_adapter", None), "crop_list", None), "alt_f32_split": alt, "alt_f32_splits": alts,
+            "two_clips_in_flight": in_flight2,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if frame_sharded else "weak",
             "vs_baseline": None, "dtype": "f16" if "fp16" in (bb_prec, _model.clip_adapter.precision) else "f32", "data": "synthetic",

@@ -107,6 +107,18 @@ int ovis_gemm_nt_f32_h2_ln_eligible(const float* A, long long lda, const void* H
 int ovis_gemm_nt_f32_h2_ln(const float* A, long long lda, const void* H2, long long ldb, long long plane, float w_scale, float* C, long long ldc,
                            int M, int N, int K, const float* bias, const float* residual, long long ldr, const float* gamma,
                            const float* beta, float eps, ovis_stream_t stream);
+/* One fp16x2 GEMM with two outputs and a row-periodic term on the second (round 4): W [N, K] = [W1 ; W2] (H2 = its ovis_split_f32_to_f16x2
+ * planes), C1[m, n] = sum_k A[m,k] W[n,k] + bias[n] for n < col0 and C2[m, n - col0] = sum_k A[m,k] W[n,k] + bias[n] + R[m % r_rows, n - col0]
+ * for n >= col0.  col0 a multiple of 256, N - col0 >= 256, r_rows >= 256; _eligible tells whether the ping-pong kernel takes the problem
+ * (otherwise run two GEMMs).  Replaces value_proj and the sampling_offsets / attention_weights projections of a deformable-attention
+ * encoder layer, whose inputs differ only by the frame-independent position embedding (/root/reference/openvis/modeling/pixel_decoder/ops/
+ * modules/ms_deform_attn.py:98-104 called with query = with_pos_embed(src, pos), msdeformattn.py:138): R = pos W2^T, once per shape. */
+int ovis_gemm_nt_f32_h2_dual_eligible(const float* A, long long lda, const void* H2, long long ldb, long long plane, const float* C1,
+                                      long long ldc1, const float* C2, long long ldc2, int M, int N, int K, const float* bias, const float* R,
+                                      long long ldr, int r_rows, int col0);
+int ovis_gemm_nt_f32_h2_dual(const float* A, long long lda, const void* H2, long long ldb, long long plane, float w_scale, float* C1,
+                             long long ldc1, float* C2, long long ldc2, int M, int N, int K, const float* bias, const float* R, long long ldr,
+                             int r_rows, int col0, ovis_stream_t stream);
 int ovis_conv3x3_padded_f32_h2_eligible(const float* xpad, const void* h2, long long plane, const float* y, int T, int H, int W, int Cin,
                                         int Cout, const float* bias, int act);
 int ovis_conv3x3_padded_f32_h2(const float* xpad, const void* h2, long long plane, float w_scale, float* y, int T, int H, int W, int Cin,

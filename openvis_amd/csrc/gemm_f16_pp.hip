@@ -94,6 +94,9 @@ struct PPArgs {
                                             //     M = T cv_H cv_W output pixels, K = 9 cv_C
   float a_scale = 1.f, acc_scale = 1.f, out_scale = 1.f;   // FH: A is multiplied by a_scale while split; accumulators live at scale a_scale * w_scale
   int* range_flag = nullptr;                // FH: set to 1 when a tile's result is not finite (an operand left the fp16 range)
+  void* C2 = nullptr; long long ldc2 = 0;   // DUAL: the columns [r_col0, N) go to C2 [M, N - r_col0] (row stride ldc2), the columns [0, r_col0) to C
+  int r_mod = 0, r_col0 = 0;                // DUAL: ... and get R[m % r_mod][n - r_col0] added (R: r_mod rows of N - r_col0 columns, row stride ldr)
+  int dual_T = 0;                           // DUAL: M / r_mod (rows are tiled per period)
 };
 
 #define PP_GLDS(src, dst) \
@@ -148,10 +151,17 @@ struct PPArgs {
 //      fma-by-zero chain and raises p.range_flag through an LDS word (no extra vector-memory operation inside the counted waits);
 //      callers then repeat the work under bf16x3 (openvis_amd/modeling/video_maskformer.py).
 template <int OUT, int ACT, bool HAS_R, bool X3, bool FA = false, bool R16 = false, int TM = 256, int EPI = 0, bool LNF = false, bool PSTAT = false,
-          bool LNO = false, bool CV = false, bool FH = false>
+          bool LNO = false, bool CV = false, bool FH = false, bool DUAL = false>
 __global__ void __launch_bounds__(512)
 gemm_f16_pp_kernel(const PPArgs p) {
   static_assert(!FH || FA, "FH: the fp16 split of the f32-A mode");
+  // DUAL (fp16x2, round 4): one GEMM, two outputs, a row-periodic residual on the second -- the value projection and the fused
+  // sampling-offset / attention-weight projection of a deformable-attention encoder layer (ms_deform_attn.py:98-104) read the same rows:
+  // value = src Wv^T + bv, oa = (src + pos) Woa^T + boa = src Woa^T + (pos Woa^T) + boa with pos identical for every frame.  W = [Wv ; Woa]
+  // ([N, K], N = 256 + 288), the columns below r_col0 (a multiple of 256: no tile straddles it) are stored to C, the others to C2 after
+  // R[m % r_mod] (= pos Woa^T, computed once per shape) is added.  src is read once instead of three times (add, value GEMM, oa GEMM) and
+  // the 288-column GEMM, which no 256-column tiling fits, disappears into a launch whose tail tile is shifted like any edge tile.
+  static_assert(!DUAL || (FH && HAS_R && OUT == 0 && ACT == 0 && !LNO && !CV), "DUAL: fp16x2, f32 outputs, residual added in the epilogue");
   // CV (f32-A mode): implicit GEMM of a 3x3 / stride 1 / pad 1 convolution over a zero-padded NHWC input.  Row m of the GEMM is output
   // pixel (t, y, x); K step k covers 32 channels of tap (kh, kw) = k / (C / 32): the row's 128 bytes sit at
   //   rowbase(m) + ((kh (W + 2) + kw) C + 32 (k % (C / 32))) 4,     rowbase(m) = ((t (H + 2) + y) (W + 2) + x) C 4
@@ -211,9 +221,20 @@ gemm_f16_pp_kernel(const PPArgs p) {
   if constexpr (FH) { if (tid == 0) *reinterpret_cast<int*>(lds + PP_FLAG) = 0; }
   for (int i = tid; i < n_my; i += 512) {
     int tm, tn;
-    tile_mn(first + i * nblk, tm, tn);
     PPTile t;
+    if constexpr (DUAL) {
+      // rows are tiled PER FRAME (M = frames x r_mod; the last tile of a frame is shifted inside it) and enumerated row-tile major, frame,
+      // column tile: the tiles that read the same rows of the periodic term R -- one per frame and second-output column tile -- are
+      // consecutive, i.e. run on one XCD at the same time, and R comes from that XCD's L2 instead of once per frame from memory
+      const int L = first + i * nblk, per = p.dual_T * p.tiles_n;
+      const int rt = L / per, rem = L - rt * per, f = rem / p.tiles_n;
+      tn = rem - f * p.tiles_n;
+      t.bm = f * p.r_mod + rt * TM; t.bml = min(t.bm, (f + 1) * p.r_mod - TM);
+      t.bn = tn * 256; t.bnl = min(t.bn, p.N - 256);
+    } else {
+    tile_mn(first + i * nblk, tm, tn);
     t.bm = tm * TM; t.bn = tn * 256; t.bml = min(t.bm, p.M - TM); t.bnl = min(t.bn, p.N - 256);
+    }
     t.a_off = (long long)t.bml * p.lda * (FA ? 4 : 2); t.b_off = (long long)t.bnl * p.ldb * 2;
     *reinterpret_cast<PPTile*>(lds + PP_TAB + i * 32) = t;
   }
@@ -456,8 +477,16 @@ gemm_f16_pp_kernel(const PPArgs p) {
     const int row0 = bml + wr * GS + l15, col0 = bnl + wc * 64 + 8 * q;
     // wave-uniform tile base + 32-bit lane offset (one VGPR live across the K loop; 256 rows of C stay far below 4 GB)
     char* cp = reinterpret_cast<char*>(p.C) + ((long long)bml * p.ldc + bnl) * ESZ;
-    const unsigned row_step = (unsigned)(16 * p.ldc * ESZ);
+    unsigned row_step = (unsigned)(16 * p.ldc * ESZ);
     unsigned lane_off = lane_c;
+    const bool second = DUAL && bnl >= p.r_col0;                      // wave-uniform: this tile's columns belong to C2
+    if constexpr (DUAL) {
+      if (second) {
+        cp = reinterpret_cast<char*>(p.C2) + ((long long)bml * p.ldc2 + (bnl - p.r_col0)) * ESZ;
+        row_step = (unsigned)(16 * p.ldc2 * ESZ);
+        lane_off = (unsigned)(((long long)(wr * GS + l15) * p.ldc2 + wc * 64 + 8 * q) * ESZ);
+      }
+    }
     asm volatile("" : "+v"(lane_off));                               // opaque: the per-row offsets are not worth 16 registers across the K loop
     // Every store below must be ISSUED by every wavefront, with at least one active lane: the counted vmcnt waits of the K loop
     // count them as younger operations.  Masked lanes of an edge tile therefore write to the library's dump buffer instead of
@@ -501,15 +530,31 @@ gemm_f16_pp_kernel(const PPArgs p) {
     // residual of the modes that add it in the epilogue (X3, FH): wave-uniform tile base + a 32-bit lane offset computed HERE (opaque to the
     // optimiser: hoisted out of the tile loop, the per-row-block 64-bit addresses are loop invariants that get spilled)
     const char* rb = nullptr;
-    unsigned lane_r = 0, rstep = 0;
-    if constexpr ((X3 || FH) && HAS_R) {
+    unsigned lane_r = 0, rstep = 0, r_row0 = 0;
+    if constexpr (DUAL) {
+      // rows repeat every r_mod rows (>= 256 = a tile's height: one wrap at most); a first-output tile loads too (from column 0, discarded):
+      // every wavefront issues the same number of vector-memory operations per tile, which the counted waits of the K loop rely on
+      rb = reinterpret_cast<const char*>(p.R) + (long long)(second ? bnl - p.r_col0 : 0) * 4;
+      r_row0 = (unsigned)(bml % p.r_mod) + (unsigned)(wr * GS + l15);
+      lane_r = (unsigned)((wc * 64 + 8 * q) * 4);
+      rstep = (unsigned)(p.ldr * 4);
+      asm volatile("" : "+v"(lane_r), "+v"(r_row0));
+    } else if constexpr ((X3 || FH) && HAS_R) {
       rb = reinterpret_cast<const char*>(p.R) + ((long long)bml * p.ldr + bnl) * 4;
       lane_r = (unsigned)(((long long)(wr * GS + l15) * p.ldr + wc * 64 + 8 * q) * 4);
       rstep = (unsigned)(16 * p.ldr * 4);
       asm volatile("" : "+v"(lane_r));
     }
     auto rload = [&](int mb, int col) {                              // 4 residual values of row block mb at column col of the lane's 64
-      return *reinterpret_cast<const f32x4*>(rb + (lane_r + (unsigned)mb * rstep + (unsigned)(col * 4)));
+      if constexpr (DUAL) {
+        unsigned row = r_row0 + (unsigned)(mb * 16);
+        row = row >= (unsigned)p.r_mod ? row - (unsigned)p.r_mod : row;
+        row = second ? row : (unsigned)l15;                            // (a first-output tile's discarded loads stay on 16 cached rows)
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rb + (row * rstep + lane_r + (unsigned)(col * 4)));   // R stays below 4 GB (host check)
+        return second ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        return *reinterpret_cast<const f32x4*>(rb + (lane_r + (unsigned)mb * rstep + (unsigned)(col * 4)));
+      }
     };
     // EPI bit 0: one 16-row block as two full-line stores.  low = lanes whose row is 0-7 of the block.  A: rows 0-7 (low lanes their own
     // columns 8q.., high lanes the low partner's columns 32 + 8q..), B: rows 8-15 (low lanes the high partner's columns 8q.., high lanes own).
@@ -570,7 +615,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
       store16(cA, dA);
       store16(cB, dB);
     };
-    auto put = [&](int mb, int j) {
+    auto put = [&](int mb, int j, const f32x4* pre = nullptr) {      // pre: the two residual vectors of (mb, j), loaded by the caller
       f32x4 x0 = acc[mb][2 * j], x1 = acc[mb][2 * j + 1];
       if constexpr (FH && !LNO) { x0 *= p.out_scale; x1 *= p.out_scale; }
       if constexpr (X3 || (FH && !LNO)) {                            // bias / residual enter here, not as the accumulators' start value
@@ -578,8 +623,8 @@ gemm_f16_pp_kernel(const PPArgs p) {
         bias8(col0 + 32 * j, b0, b1);
         x0 += b0; x1 += b1;
         if constexpr (HAS_R) {
-          x0 += rload(mb, 32 * j);
-          x1 += rload(mb, 32 * j + 4);
+          x0 += pre ? pre[0] : rload(mb, 32 * j);
+          x1 += pre ? pre[1] : rload(mb, 32 * j + 4);
         }
       }
       act4(x0); act4(x1);
@@ -662,6 +707,24 @@ gemm_f16_pp_kernel(const PPArgs p) {
         for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (acc[mb][nb] - mean) * rstd * gm[nb] + bt[nb];
 #pragma unroll
         for (int j = 0; j < 2; ++j) put(mb, j);
+      }
+    } else if constexpr (DUAL) {
+      // the residual loads of four row blocks go out together, ahead of those blocks' stores: a load that follows a store in the in-order
+      // vmcnt queue waits for it, and the compiler's wait for any load is vmcnt(0) here (LDS-DMA outstanding) -- one drain per batch
+      // instead of one per load (16 per tile, ~25 us of a 40 us tile when the loads sat between the stores)
+#pragma unroll
+      for (int hb = 0; hb < MBT; hb += 4) {
+        f32x4 rr[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (hb + u < MBT) rr[u][c] = rload(hb + u, 32 * (c >> 1) + 4 * (c & 1));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (hb + u < MBT) put(hb + u, j, &rr[u][2 * j]);
       }
     } else {
 #pragma unroll
@@ -1093,6 +1156,46 @@ int gemm_f32a_pp_launch(const float* A, long long lda, const void* W3, long long
 #undef PP_LAUNCH
 #undef PP_K
   return check_launch(fh ? "gemm_nt_f32 (ping-pong, f32 A, fp16x2)" : "gemm_nt_f32 (ping-pong, f32 A, bf16x2)");
+}
+
+// ---- DUAL (fp16x2): C1 = A W[0:col0]^T + bias, C2 = A W[col0:N]^T + bias + R[m % r_rows] (template parameter DUAL) ----
+bool gemm_f32a_pp_dual_eligible(const float* A, long long lda, const void* H2, long long ldb, long long plane, const float* C1, long long ldc1,
+                                const float* C2, long long ldc2, int M, int N, int K, const float* bias, const float* R, long long ldr, int r_rows,
+                                int col0) {
+  if (!A || !H2 || !C1 || !C2 || !R || M < 256 || K % 32 != 0 || K < 64 || N % 8 != 0) return false;
+  if (col0 <= 0 || col0 % 256 != 0 || N - col0 < 256 || r_rows < 256 || M % r_rows != 0) return false;   // no tile straddles col0 (the last one is
+  const long long tiles_n = cdiv(N, 256), blocks = (long long)cdiv(r_rows, 192) * (M / r_rows) * tiles_n;  // shifted to N - 256); whole periods
+  if (blocks > 256ll * PP_MAX_TILES || N > PP_MAX_BIAS_N || N > 4096) return false;
+  if (lda % 4 != 0 || ldb % 8 != 0 || plane % 8 != 0 || ldc1 % 4 != 0 || ldc2 % 4 != 0 || ldr % 4 != 0) return false;
+  if (ldc1 < col0 || ldc2 < N - col0 || ldr < N - col0 || (long long)r_rows * ldr * 4 >= (1ll << 32)) return false;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(H2) | reinterpret_cast<uintptr_t>(C1) | reinterpret_cast<uintptr_t>(C2) |
+       reinterpret_cast<uintptr_t>(R)) & 15) return false;
+  if (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) return false;
+  if (256 * lda * 4 >= (1ll << 31) || plane * 2 + 256 * ldb * 2 >= (1ll << 31) || 256 * ldc1 * 4 >= (1ll << 32) || 256 * ldc2 * 4 >= (1ll << 32)) return false;
+  return true;
+}
+
+int gemm_f32a_pp_dual_launch(const float* A, long long lda, const void* H2, long long ldb, long long plane, float* C1, long long ldc1, float* C2,
+                             long long ldc2, int M, int N, int K, const float* bias, const float* R, long long ldr, int r_rows, int col0,
+                             hipStream_t s, const F16x2& fh) {
+  PPArgs p;
+  p.A = reinterpret_cast<const _Float16*>(A); p.B = reinterpret_cast<const _Float16*>(H2); p.C = C1; p.bias = bias; p.R = R;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc1; p.ldr = ldr; p.M = M; p.N = N; p.K = K; p.act = 0;
+  p.planeA = 0; p.planeB = plane * 2; p.planeC = 0;
+  p.C2 = C2; p.ldc2 = ldc2; p.r_mod = r_rows; p.r_col0 = col0;
+  p.a_scale = fh.a_scale; p.acc_scale = fh.a_scale * fh.w_scale; p.out_scale = 1.f / p.acc_scale; p.range_flag = fh.flag;
+  p.tiles_n = (int)cdiv(N, 256);
+  p.dual_T = M / r_rows;
+  const int tm = pp_pick_tm(r_rows, p.dual_T * p.tiles_n);
+  p.tiles_m = (int)cdiv(r_rows, tm) * p.dual_T; p.n_tiles = p.tiles_m * p.tiles_n;
+  p.grp_w = p.tiles_n; p.grp_rem = 0;
+  p.desync_ns = 0; p.dbg = g_pp_dbg; p.stamps = nullptr;
+  p.dump = pp_dump_buffer();
+  if (!p.dump) return fail(OVIS_EINVAL, "gemm_nt_f32_h2_dual: cannot allocate the 4 KB dump buffer");
+  const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
+  if (tm == 192) hipLaunchKernelGGL((gemm_f16_pp_kernel<0, 0, true, false, true, false, 192, 0, false, false, false, false, true, true>), dim3(grid), dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((gemm_f16_pp_kernel<0, 0, true, false, true, false, 256, 0, false, false, false, false, true, true>), dim3(grid), dim3(512), 0, s, p);
+  return check_launch("gemm_nt_f32_h2_dual (ping-pong, f32 A, fp16x2, two outputs)");
 }
 
 // ---- CV: 3x3 / stride 1 / pad 1 convolution on the f32-A schedule, input already zero-padded ([T][H+2][W+2][Cin] f32) ----

@@ -189,6 +189,12 @@ bool gemm_f32a_pp_eligible(const float* A, long long lda, const void* W3, long l
 int gemm_f32a_pp_launch(const float* A, long long lda, const void* W3, long long ldb, long long plane, float* C, long long ldc, int M, int N,
                         int K, const float* bias, const float* residual, long long ldr, int act, hipStream_t s, const float* ln_gamma = nullptr, const float* ln_beta = nullptr, float ln_eps = 0.f,
                         const F16x2* fh = nullptr);
+bool gemm_f32a_pp_dual_eligible(const float* A, long long lda, const void* H2, long long ldb, long long plane, const float* C1, long long ldc1,
+                                const float* C2, long long ldc2, int M, int N, int K, const float* bias, const float* R, long long ldr, int r_rows,
+                                int col0);
+int gemm_f32a_pp_dual_launch(const float* A, long long lda, const void* H2, long long ldb, long long plane, float* C1, long long ldc1, float* C2,
+                             long long ldc2, int M, int N, int K, const float* bias, const float* R, long long ldr, int r_rows, int col0,
+                             hipStream_t s, const F16x2& fh);
 }
 namespace ovis {   // gemm_f32_skinny.hip
 bool gemm_f32_skinny_eligible(const float* A, long long lda, const float* B, long long ldb, int M, int N, int K);
@@ -416,6 +422,27 @@ extern "C" int ovis_gemm_nt_f32_h2_ln(const float* A, long long lda, const void*
                "gemm_nt_f32_h2_ln: not a problem of the ping-pong kernel with N == 256 (M=%d N=%d K=%d): run the GEMM and the LayerNorm separately", M, N, K);
   const ovis::F16x2 fh = f16x2_of(w_scale);
   return ovis::gemm_f32a_pp_launch(A, lda, H2, ldb, plane, C, ldc, M, N, K, bias, residual, ldr, 0, (hipStream_t)stream, gamma, beta, eps, &fh);
+}
+
+// One GEMM, two outputs (fp16x2): C1[m, n] = sum_k A[m,k] W[n,k] + bias[n] for n < col0, C2[m, n - col0] = the same + R[m % r_rows, n - col0] for
+// n >= col0 -- value_proj and the fused sampling_offsets / attention_weights projection of a deformable-attention ENCODER layer
+// (ms_deform_attn.py:98-104 with query = src + pos, msdeformattn.py:138: the position term of the second projection is the row-periodic R).
+extern "C" int ovis_gemm_nt_f32_h2_dual_eligible(const float* A, long long lda, const void* H2, long long ldb, long long plane, const float* C1,
+                                                 long long ldc1, const float* C2, long long ldc2, int M, int N, int K, const float* bias,
+                                                 const float* R, long long ldr, int r_rows, int col0) {
+  return (g_f32a_pp && h2_vec(A, lda, H2, ldb, plane, K) &&
+          ovis::gemm_f32a_pp_dual_eligible(A, lda, H2, ldb, plane, C1, ldc1, C2, ldc2, M, N, K, bias, R, ldr, r_rows, col0)) ? 1 : 0;
+}
+
+extern "C" int ovis_gemm_nt_f32_h2_dual(const float* A, long long lda, const void* H2, long long ldb, long long plane, float w_scale, float* C1,
+                                        long long ldc1, float* C2, long long ldc2, int M, int N, int K, const float* bias, const float* R,
+                                        long long ldr, int r_rows, int col0, ovis_stream_t stream) {
+  OVIS_REQUIRE(A && H2 && C1 && C2 && R && pow2(w_scale), "gemm_nt_f32_h2_dual: null pointer / w_scale not a power of two");
+  OVIS_REQUIRE(ovis_gemm_nt_f32_h2_dual_eligible(A, lda, H2, ldb, plane, C1, ldc1, C2, ldc2, M, N, K, bias, R, ldr, r_rows, col0),
+               "gemm_nt_f32_h2_dual: not a problem of the two-output kernel (M=%d N=%d K=%d col0=%d r_rows=%d): run the two GEMMs separately",
+               M, N, K, col0, r_rows);
+  return ovis::gemm_f32a_pp_dual_launch(A, lda, H2, ldb, plane, C1, ldc1, C2, ldc2, M, N, K, bias, R, ldr, r_rows, col0, (hipStream_t)stream,
+                                        f16x2_of(w_scale));
 }
 
 extern "C" int ovis_conv3x3_padded_f32_h2_eligible(const float* xpad, const void* h2, long long plane, const float* y, int T, int H, int W,

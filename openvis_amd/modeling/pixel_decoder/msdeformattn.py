@@ -35,10 +35,10 @@ class MSDeformAttnTransformerEncoderLayer:
 
     def forward(self, src, pos, spatial_shapes, level_start_index, shapes_host=None):
         w = self.w
-        q = ops.add_bcast(src, pos)                                                 # with_pos_embed (:138)
+        # with_pos_embed (:138) happens inside: query = src + pos, as an add or -- fp16x2 -- as the row-periodic term of the two-output GEMM.
         # output_proj + residual + norm1, linear2 + residual + norm2: the LayerNorm rides in the GEMM's epilogue where the kernel allows it
-        src = self.self_attn.forward_encoder_fused(q, src, spatial_shapes, level_start_index, residual=src, shapes_host=shapes_host,
-                                                   norm=(w["norm1.weight"], w["norm1.bias"]))    # :139-141
+        src = self.self_attn.forward_encoder_fused(None, src, spatial_shapes, level_start_index, residual=src, shapes_host=shapes_host,
+                                                   norm=(w["norm1.weight"], w["norm1.bias"]), pos=pos)    # :139-141
         h = ops.gemm_nt(src, w["linear1.weight"], w["linear1.bias"], None, ops.ACT_RELU, cw=True)
         return ops.gemm_nt_layernorm(h, w["linear2.weight"], w["linear2.bias"], src, w["norm2.weight"], w["norm2.bias"])   # :118-121, 144-146
 

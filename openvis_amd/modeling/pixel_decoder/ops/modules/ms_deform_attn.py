@@ -24,7 +24,20 @@ class MSDeformAttn:
         # one GEMM for [sampling_offsets | attention_weights] (both consume the same query)
         self.w["oa.weight"] = torch.cat([self.w["sampling_offsets.weight"], self.w["attention_weights.weight"]], 0).contiguous()
         self.w["oa.bias"] = torch.cat([self.w["sampling_offsets.bias"], self.w["attention_weights.bias"]], 0).contiguous()
+        # ... and, in the encoder under fp16x2, one GEMM for [value_proj | sampling_offsets | attention_weights] (forward_encoder_fused)
+        self.w["voa.weight"] = torch.cat([self.w["value_proj.weight"], self.w["oa.weight"]], 0).contiguous()
+        self.w["voa.bias"] = torch.cat([self.w["value_proj.bias"], self.w["oa.bias"]], 0).contiguous()
+        self._pos_oa = {}
         return self
+
+    def _pos_term(self, pos):
+        """pos Woa^T [S, 288]: what the position embedding adds to the offset / weight projection -- frame independent, cached per pos tensor."""
+        key = (pos.data_ptr(), tuple(pos.shape))
+        hit = self._pos_oa.get(key)
+        if hit is None or hit[0] is not pos:
+            hit = (pos, ops.gemm_nt(pos, self.w["oa.weight"], None, cw=True))
+            self._pos_oa = {key: hit}
+        return hit[1]
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
@@ -55,12 +68,23 @@ class MSDeformAttn:
                                          loc.contiguous(), aw.contiguous(), self.im2col_step)
         return ops.gemm_nt(out, self.w["output_proj.weight"], self.w["output_proj.bias"], cw=True)
 
-    def forward_encoder_fused(self, query, src, spatial_shapes, level_start_index, residual, shapes_host=None, norm=None):
+    def forward_encoder_fused(self, query, src, spatial_shapes, level_start_index, residual, shapes_host=None, norm=None, pos=None):
         """Encoder fast path: value_proj + fused [offsets|weights] GEMM + fused softmax/location/sampling kernel +
         output_proj with the residual add fused.  Reference points are the encoder's (msdeformattn.py:155-168).
-        norm = (gamma, beta): also the layer's norm1 over the result (ops.gemm_nt_layernorm)."""
-        value = ops.gemm_nt(src, self.w["value_proj.weight"], self.w["value_proj.bias"], cw=True)
-        oa = ops.gemm_nt(query, self.w["oa.weight"], self.w["oa.bias"], cw=True)
+        norm = (gamma, beta): also the layer's norm1 over the result (ops.gemm_nt_layernorm).
+        query = None with pos [S, C] (the frame-independent position embedding, query = src + pos): the three projections run as ONE
+        two-output GEMM over src where the kernel allows it (ops.gemm_nt_dual: (src + pos) Woa^T = src Woa^T + pos Woa^T)."""
+        value = oa = None
+        if query is None:
+            C = self.d_model
+            both = ops.gemm_nt_dual(src, self.w["voa.weight"], self.w["voa.bias"], self._pos_term(pos), C) if (C % 256 == 0 and pos.dim() == 2) else None
+            if both is not None:
+                value, oa = both
+            else:
+                query = ops.add_bcast(src, pos)
+        if value is None:
+            value = ops.gemm_nt(src, self.w["value_proj.weight"], self.w["value_proj.bias"], cw=True)
+            oa = ops.gemm_nt(query, self.w["oa.weight"], self.w["oa.bias"], cw=True)
         samp = ops.msda_encoder_fused(value, oa, spatial_shapes, level_start_index, self.n_heads, self.n_levels,
                                       self.n_points, shapes_host=shapes_host)
         if norm is not None:

@@ -55,16 +55,24 @@ class FrameMultiScaleMaskedTransformerDecoder(VideoMultiScaleMaskedTransformerDe
             return ops.attn_mask_from_logits(logits)                                     # mask [T*Q, ld], row_open [T*Q]
 
         amask, row_open = head_mask(output, 0)
+        kv_lvl = {}
         for i in range(self.num_layers):
             li = i % self.num_feature_levels
             Nk = sizes[li][0] * sizes[li][1]
             qp = self._mm(ops.add_bcast(output, query_embed), f"ca{i}.wq", f"ca{i}.bq")
-            kp = self._mm(kin[li], f"ca{i}.wk", f"ca{i}.bk")
-            vp = self._mm(src[li], f"ca{i}.wv", f"ca{i}.bv")
+            if self.batch_kv:                                                            # one K and one V GEMM per level (video decoder, load_state_dict)
+                if li not in kv_lvl:
+                    kv_lvl[li] = (self._mm(kin[li], f"cak_lvl{li}.w", f"cak_lvl{li}.b"), self._mm(src[li], f"cav_lvl{li}.w", f"cav_lvl{li}.b"))
+                kp, vp = (t[:, (i // self.num_feature_levels) * C:] for t in kv_lvl[li])
+                ldkv = kv_lvl[li][0].shape[1]
+            else:
+                kp = self._mm(kin[li], f"ca{i}.wk", f"ca{i}.bk")
+                vp = self._mm(src[li], f"ca{i}.wv", f"ca{i}.bv")
+                ldkv = C
             # split the keys over workgroups until ~1000 are in flight: with one split a 5-frame clip runs the 14 720-key level on
             # 40 workgroups (231 us per launch on average, 13 % of the SANOnline step)
             nsplit = max(1, min(64, Nk // 256, max(1, 2048 // (T * H8))))
-            att = ops.attention(qp, kp, vp, T, H8, Q, Nk, D, Q * C, C, Nk * C, C, Nk * C, C, amask, row_open, nsplit,
+            att = ops.attention(qp, kp, vp, T, H8, Q, Nk, D, Q * C, C, Nk * ldkv, ldkv, Nk * ldkv, ldkv, amask, row_open, nsplit,
                                 mask_per_batch=True)
             y = self._mm(att.view(T * Q, C), f"ca{i}.wo", f"ca{i}.bo", output.view(T * Q, C))
             output = ops.layernorm(y, w[f"ca{i}.nw"], w[f"ca{i}.nb"]).view(T, Q, C)

@@ -213,6 +213,30 @@ def gemm_nt(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w16=None, cw
     return out.view(*a.shape[:-1], N)
 
 
+def gemm_nt_dual(a, w, bias, r, col0):
+    """One GEMM, two outputs (fp16x2 only): c1 = a w[:col0]^T + bias[:col0], c2 = a w[col0:]^T + bias[col0:] + r[m % r.shape[0]] -- two
+    projections of the same rows whose inputs differ by a row-periodic term (ovis_gemm_nt_f32_h2_dual).  Returns (c1, c2), or None when
+    MODEL.F32_GEMM_SPLIT is not fp16x2 or the kernel does not take the shape: the caller then runs the two GEMMs."""
+    if _MODE.v != 3 or not w.is_contiguous():
+        return None
+    K = a.shape[-1]
+    N = w.shape[0]
+    a2 = a.reshape(-1, K)
+    _chk(a2, w, bias, r)
+    M = a2.shape[0]
+    h2, ws = h2_of(w)
+    c1 = torch.empty((M, col0), dtype=torch.float32, device=a.device)
+    c2 = torch.empty((M, N - col0), dtype=torch.float32, device=a.device)
+    args = (_lib._conv(a2), _ll(K), _lib._conv(h2), _ll(K), _ll(w.numel()))
+    tail = (_lib._conv(c1), _ll(col0), _lib._conv(c2), _ll(N - col0), M, N, K, _lib._conv(bias), _lib._conv(r), _ll(r.shape[-1]), r.shape[0], col0)
+    if not _lib.lib().ovis_gemm_nt_f32_h2_dual_eligible(*args, *tail):
+        return None
+    with _Prof("gemm_f16_pp_kernel<0,0,true,false,true,false,DUAL,FH>", 2.0 * M * N * K):
+        _lib.call("ovis_gemm_nt_f32_h2_dual", a2, _ll(K), h2, _ll(K), _ll(w.numel()), ctypes.c_float(ws), c1, _ll(col0), c2, _ll(N - col0), M, N, K,
+                  bias, r, _ll(r.shape[-1]), r.shape[0], col0, _lib.stream_ptr())
+    return c1.view(*a.shape[:-1], col0), c2.view(*a.shape[:-1], N - col0)
+
+
 def gemm_nt_layernorm(a, w, bias, residual, gamma, beta, eps=1e-5):
     """LayerNorm(a w^T + bias + residual) over the last dimension (post-norm of the pixel decoder's encoder layers, msdeformattn.py:139-146).
     Where the bf16x2 ping-pong kernel takes the GEMM and N == 256, the LayerNorm runs in that kernel's epilogue (ovis_gemm_nt_f32_w3_ln:

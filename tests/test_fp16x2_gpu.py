@@ -206,3 +206,55 @@ def test_model_falls_back_to_bf16x3_when_an_activation_leaves_the_fp16_range():
     finally:
         ops._MODE.a_scale = 16.0
         ops.set_f32_gemm_mode(1)
+
+
+@pytest.mark.parametrize("T,S,N2", [(5, 19320, 288), (3, 1001, 288), (2, 4600, 256)])
+def test_dual_gemm_indexing_is_exact_on_small_integers(modes, T, S, N2):
+    """ovis_gemm_nt_f32_h2_dual (value_proj + offset / weight projection of an encoder layer as one launch): with small-integer operands
+    every product and sum is exact in any arithmetic, so the two outputs must EQUAL a w[:256]^T + b and a w[256:]^T + b + r[m % S] bit for
+    bit -- row-periodic term, column split, shifted edge tiles (M = T S is no multiple of 192 / 256, the last column tile starts at N - 256)."""
+    ops = modes
+    ops.set_f32_gemm_mode(3)
+    flag = ops.f16x2_begin("cuda")
+    g = torch.Generator().manual_seed(S)
+    C = 256
+    a = torch.randint(-8, 9, (T, S, C), generator=g).float().cuda()
+    w = torch.randint(-4, 5, (C + N2, C), generator=g).float().cuda()
+    b = torch.randint(-50, 51, (C + N2,), generator=g).float().cuda()
+    r = torch.randint(-100, 101, (S, N2), generator=g).float().cuda()
+    both = ops.gemm_nt_dual(a, w, b, r, C)
+    assert both is not None, "the two-output kernel must take the encoder's shapes"
+    c1, c2 = both
+    ref = a.double().view(-1, C) @ w.double().t() + b.double()
+    ref2 = ref[:, C:].view(T, S, N2) + r.double()
+    assert torch.equal(c1.double().view(-1, C), ref[:, :C])
+    assert torch.equal(c2.double(), ref2)
+    assert int(flag.item()) == 0
+
+
+def test_dual_gemm_matches_the_two_projections(modes):
+    """... and on real-valued data it is the f32-grade approximation of the same two projections: (src + pos) Woa^T computed as
+    src Woa^T + pos Woa^T (ms_deform_attn.py:98-104, msdeformattn.py:138)."""
+    ops = modes
+    g = torch.Generator().manual_seed(5)
+    T, S, C, N2 = 5, 19320, 256, 288
+    src = (torch.randn(T, S, C, generator=g) * torch.exp(torch.randn(T, S, 1, generator=g))).cuda()
+    pos = torch.randn(S, C, generator=g).cuda()
+    w = (torch.randn(C + N2, C, generator=g) / 16).cuda()
+    b = torch.randn(C + N2, generator=g).cuda()
+    ref_v = src.double() @ w[:C].double().t() + b[:C].double()
+    ref_o = (src.double() + pos.double()) @ w[C:].double().t() + b[C:].double()
+    sv = src.double().abs() @ w[:C].double().abs().t() + b[:C].double().abs()
+    so = (src.double().abs() + pos.double().abs()) @ w[C:].double().abs().t() + b[C:].double().abs()
+    ops.set_f32_gemm_mode(3)
+    flag = ops.f16x2_begin("cuda")
+    posw = ops.gemm_nt(pos, w[C:].contiguous(), None, cw=True)
+    c1, c2 = ops.gemm_nt_dual(src, w, b, posw, C)
+    e1 = ((c1.double() - ref_v).abs() / sv).max().item()
+    e2 = ((c2.double() - ref_o).abs() / so).max().item()
+    ops.set_f32_gemm_mode(0)                                       # the exact-f32 MFMA kernel on the same problem
+    n1 = ((ops.gemm_nt(src, w[:C].contiguous(), b[:C].contiguous()).double() - ref_v).abs() / sv).max().item()
+    n2 = ((ops.gemm_nt(ops.add_bcast(src, pos), w[C:].contiguous(), b[C:].contiguous()).double() - ref_o).abs() / so).max().item()
+    print(f"dual GEMM, condition-aware error: value {e1:.2e} (native f32 {n1:.2e}), offsets / weights {e2:.2e} (native f32 {n2:.2e})")
+    assert int(flag.item()) == 0
+    assert e1 < max(2 * n1, 4e-7) and e2 < max(2 * n2, 4e-7)
