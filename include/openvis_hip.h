@@ -178,6 +178,12 @@ int ovis_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, in
  *   msdeformattn.py:139-141,118-122 (norm1/norm2), video decoder:57-60,117-120,175-179, model.py:223-229. */
 int ovis_layernorm_f32(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                        long long rows, int C, float eps, ovis_stream_t stream);
+/* dec = LayerNorm(x) * gamma + beta; out = W2 relu(W1 relu(W0 dec + b0) + b1) + b2 in ONE launch: decoder_norm and the mask-embedding MLP of
+ * the masked-attention decoders' prediction heads (/root/reference/openvis/modeling/transformer_decoder/video_mask2former_transformer_decoder.py:
+ * 454-458, MLP :204-216).  x [rows, C], C == 256; wt0..wt2 are the Linear weights TRANSPOSED ([in, out], row-major); dec may be NULL. */
+int ovis_ln_mlp3_f32(const float* x, const float* gamma, const float* beta, const float* wt0, const float* b0, const float* wt1,
+                     const float* b1, const float* wt2, const float* b2, float* dec, float* out, int rows, int C, float eps,
+                     ovis_stream_t stream);
 /* Same, output written as fp16 (operand of the fp16 CLIP GEMMs; statistics and affine in f32). */
 int ovis_layernorm_f32_to_f16(const float* x, const float* residual, const float* gamma, const float* beta, void* y_f16,
                               long long rows, int C, float eps, ovis_stream_t stream);

@@ -431,6 +431,75 @@ static int layernorm_launch(const float* x, const float* residual, const float* 
   return ovis::check_launch("layernorm");
 }
 
+// decoder_norm + the three Linear layers of the mask-embedding MLP (ReLU between them) on the query rows of a masked-attention decoder
+// (forward_prediction_heads, video_mask2former_transformer_decoder.py:454-458 with MLP :204-216), as ONE launch: ten times per clip on 100
+// (video decoder) or T x 100 (frame decoders) rows, where four launches of ~5 us each are latency, not work.  A workgroup owns R rows: one
+// wavefront per row normalises it (layernorm_kernel's two-pass f32 formulas), then thread j owns output column j of every layer for the R
+// rows -- the rows sit in LDS (broadcast reads), the weights are read TRANSPOSED ([in][out]: consecutive threads, consecutive addresses) from
+// L2.  f32 FMA chains in k order.
+template <int C, int R>
+__global__ void __launch_bounds__(C)
+ln_mlp3_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ wt0,
+               const float* __restrict__ b0, const float* __restrict__ wt1, const float* __restrict__ b1, const float* __restrict__ wt2,
+               const float* __restrict__ b2, float* __restrict__ dec, float* __restrict__ out, int rows, float eps) {
+  static_assert(C == 256 && R == C / 64, "one wavefront per row, one float4 per lane");
+  __shared__ __attribute__((aligned(16))) float buf[2][R][C];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int row0 = blockIdx.x * R;
+  {
+    const int row = min(row0 + w, rows - 1);
+    const float4 v = reinterpret_cast<const float4*>(x + (long long)row * C)[lane];
+    const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) / (float)C;
+    const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+    const float rstd = 1.f / sqrtf(wave_sum((a * a + b * b) + (c * c + d * d)) / (float)C + eps);
+    const float4 g = reinterpret_cast<const float4*>(gamma)[lane], bt = reinterpret_cast<const float4*>(beta)[lane];
+    const float4 y = make_float4(a * rstd * g.x + bt.x, b * rstd * g.y + bt.y, c * rstd * g.z + bt.z, d * rstd * g.w + bt.w);
+    reinterpret_cast<float4*>(&buf[0][w][0])[lane] = y;
+    if (dec && row0 + w < rows) reinterpret_cast<float4*>(dec + (long long)row * C)[lane] = y;
+  }
+  __syncthreads();
+  auto layer = [&](const float (*in)[C], const float* __restrict__ wt, const float* __restrict__ bias, bool relu, float (*o)[C]) {
+    float acc[R];
+    const float bj = bias[tid];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = bj;
+#pragma unroll 4
+    for (int k = 0; k < C; k += 4) {
+      const float w0 = wt[(long long)(k + 0) * C + tid], w1 = wt[(long long)(k + 1) * C + tid];
+      const float w2 = wt[(long long)(k + 2) * C + tid], w3 = wt[(long long)(k + 3) * C + tid];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float4 xv = *reinterpret_cast<const float4*>(&in[r][k]);
+        acc[r] = __builtin_fmaf(xv.x, w0, acc[r]); acc[r] = __builtin_fmaf(xv.y, w1, acc[r]);
+        acc[r] = __builtin_fmaf(xv.z, w2, acc[r]); acc[r] = __builtin_fmaf(xv.w, w3, acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float v = relu ? fmaxf(acc[r], 0.f) : acc[r];
+      if (o) o[r][tid] = v;
+      else if (row0 + r < rows) out[(long long)(row0 + r) * C + tid] = v;
+    }
+  };
+  layer(buf[0], wt0, b0, true, buf[1]);
+  __syncthreads();
+  layer(buf[1], wt1, b1, true, buf[0]);
+  __syncthreads();
+  layer(buf[0], wt2, b2, false, nullptr);
+}
+
+extern "C" int ovis_ln_mlp3_f32(const float* x, const float* gamma, const float* beta, const float* wt0, const float* b0, const float* wt1,
+                                const float* b1, const float* wt2, const float* b2, float* dec, float* out, int rows, int C, float eps,
+                                ovis_stream_t stream) {
+  OVIS_REQUIRE(x && gamma && beta && wt0 && b0 && wt1 && b1 && wt2 && b2 && out, "ln_mlp3: null pointer");
+  OVIS_REQUIRE(rows > 0 && C == 256, "ln_mlp3: C must be 256 (hidden_dim = mask_dim of every reference config)");
+  OVIS_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
+                 reinterpret_cast<uintptr_t>(dec)) & 15) == 0, "ln_mlp3: 16-byte alignment");
+  hipLaunchKernelGGL((ln_mlp3_kernel<256, 4>), dim3(ovis::cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, wt0, b0, wt1, b1, wt2,
+                     b2, dec, out, rows, eps);
+  return ovis::check_launch("ln_mlp3");
+}
+
 extern "C" int ovis_layernorm_f32(const float* x, const float* residual, const float* gamma, const float* beta,
                                   float* y, long long rows, int C, float eps, ovis_stream_t stream) {
   return layernorm_launch<false>(x, residual, gamma, beta, y, rows, C, eps, (hipStream_t)stream);

@@ -59,7 +59,10 @@ class FrameMultiScaleMaskedTransformerDecoder(VideoMultiScaleMaskedTransformerDe
         for i in range(self.num_layers):
             li = i % self.num_feature_levels
             Nk = sizes[li][0] * sizes[li][1]
-            qp = self._mm(ops.add_bcast(output, query_embed), f"ca{i}.wq", f"ca{i}.bq")
+            if self.fold_query_pos:                                                       # the constant query-embedding terms as residuals
+                qp = self._mm(output.view(T * Q, C), f"ca{i}.wq", None, self._rep(f"ca{i}.rq", T)).view(T, Q, C)
+            else:
+                qp = self._mm(ops.add_bcast(output, query_embed), f"ca{i}.wq", f"ca{i}.bq")
             if self.batch_kv:                                                            # one K and one V GEMM per level (video decoder, load_state_dict)
                 if li not in kv_lvl:
                     kv_lvl[li] = (self._mm(kin[li], f"cak_lvl{li}.w", f"cak_lvl{li}.b"), self._mm(src[li], f"cav_lvl{li}.w", f"cav_lvl{li}.b"))
@@ -76,9 +79,13 @@ class FrameMultiScaleMaskedTransformerDecoder(VideoMultiScaleMaskedTransformerDe
                                 mask_per_batch=True)
             y = self._mm(att.view(T * Q, C), f"ca{i}.wo", f"ca{i}.bo", output.view(T * Q, C))
             output = ops.layernorm(y, w[f"ca{i}.nw"], w[f"ca{i}.nb"]).view(T, Q, C)
-            qk = self._mm(ops.add_bcast(output, query_embed), f"sa{i}.wqk", f"sa{i}.bqk").view(T * Q, 2 * C)
-            vv = self._mm(output, f"sa{i}.wv", f"sa{i}.bv")
-            att = ops.attention(qk, qk[:, C:], vv, T, H8, Q, Q, D, Q * 2 * C, 2 * C, Q * 2 * C, 2 * C, Q * C, C)
+            if self.fold_query_pos:
+                qkv = self._mm(output.view(T * Q, C), f"sa{i}.wqkv", None, self._rep(f"sa{i}.rqkv", T))      # [T Q, 3C] = q | k | v
+                att = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], T, H8, Q, Q, D, Q * 3 * C, 3 * C, Q * 3 * C, 3 * C, Q * 3 * C, 3 * C)
+            else:
+                qk = self._mm(ops.add_bcast(output, query_embed), f"sa{i}.wqk", f"sa{i}.bqk").view(T * Q, 2 * C)
+                vv = self._mm(output, f"sa{i}.wv", f"sa{i}.bv")
+                att = ops.attention(qk, qk[:, C:], vv, T, H8, Q, Q, D, Q * 2 * C, 2 * C, Q * 2 * C, 2 * C, Q * C, C)
             y = self._mm(att.view(T * Q, C), f"sa{i}.wo", f"sa{i}.bo", output.view(T * Q, C))
             output = ops.layernorm(y, w[f"sa{i}.nw"], w[f"sa{i}.nb"]).view(T, Q, C)
             hdn = self._mm(output, f"ffn{i}.linear1.weight", f"ffn{i}.linear1.bias", None, ops.ACT_RELU)

@@ -33,6 +33,10 @@ class VideoMultiScaleMaskedTransformerDecoder:
         # "fp16": Linear / einsum operands rounded to fp16 with f32 accumulation (the reference decoder runs under
         # autocast, train_net.py:241); LayerNorm, softmax, residuals f32.  "fp32": exact-f32 MFMA everywhere.
         self.precision = precision
+        # (x + query_embed) W^T + b as x W^T + constant (load_state_dict); False: add kernel + separate q | k and v GEMMs.  Off under the autocast
+        # policy, where the reference rounds the SUM to fp16 before the Linear
+        self.fold_query_pos = precision != "fp16"
+        self.fuse_heads = precision != "fp16"   # decoder_norm + mask-embedding MLP as one launch (f32 arithmetic; the autocast policy keeps the GEMMs)
         self.batch_kv = True           # K / V projections of a level's three layers as one GEMM each (load_state_dict); False: one per layer
         self.w = {}
         self.h = {}
@@ -86,15 +90,35 @@ class VideoMultiScaleMaskedTransformerDecoder:
                 w[f"ca{n}_lvl{li}.b"] = torch.cat([w[f"ca{i}.b{n}"] for i in ids]).contiguous()
         for k in ("decoder_norm.weight", "decoder_norm.bias", "query_feat.weight", "query_embed.weight", "level_embed.weight"):
             w[k] = g(k)
+        # with_pos_embed(tgt, query_pos) in front of a Linear (cross-attention query :110-113, self-attention q = k :52-55) is linear in the
+        # CONSTANT query embedding: (x + e) W^T + b = x W^T + (e W^T + b).  The second term is folded here (f64 accumulate, stored f32) and rides
+        # as the GEMM's residual: no add kernel, and the self-attention's q | k and v projections become one GEMM [Q, C] x [C, 3C].
+        e64 = w["query_embed.weight"].double()
+        for i in range(self.num_layers):
+            w[f"ca{i}.rq"] = (e64 @ w[f"ca{i}.wq"].double().t() + w[f"ca{i}.bq"].double()).float().contiguous()
+            w[f"sa{i}.wqkv"] = torch.cat([w[f"sa{i}.wqk"], w[f"sa{i}.wv"]]).contiguous()
+            rqk = e64 @ w[f"sa{i}.wqk"].double().t() + w[f"sa{i}.bqk"].double()
+            w[f"sa{i}.rqkv"] = torch.cat([rqk, w[f"sa{i}.bv"].double().expand(rqk.shape[0], -1)], 1).float().contiguous()
+        self._rep_cache = {}
         if self.mask_classification:
             w["class_embed.weight"], w["class_embed.bias"] = g("class_embed.weight"), g("class_embed.bias")
         for j in range(3):
             w[f"mask_embed.{j}.w"], w[f"mask_embed.{j}.b"] = g(f"mask_embed.layers.{j}.weight"), g(f"mask_embed.layers.{j}.bias")
+            w[f"mask_embed.{j}.wt"] = w[f"mask_embed.{j}.w"].t().contiguous()          # [in, out]: operand layout of ops.ln_mlp3
         self._pos_cache.clear()
         self.h = {k: ops.cast_f16(v) for k, v in w.items() if v.dim() == 2 and v.shape[1] % 8 == 0 and
                   (k.split(".")[-1].startswith("w") or k.endswith("weight")) and "query" not in k and "level_embed" not in k} \
             if self.precision == "fp16" else {}
         return self
+
+    def _rep(self, key, T):
+        """Constant residual w[key] [Q, N] repeated for the T frames of a per-frame decoder ([T * Q, N]); T = 1: the tensor itself."""
+        if T == 1:
+            return self.w[key]
+        hit = self._rep_cache.get((key, T))
+        if hit is None:
+            hit = self._rep_cache[(key, T)] = self.w[key].repeat(T, 1).contiguous()
+        return hit
 
     def _mm(self, x, wk, bk=None, residual=None, act=ops.ACT_NONE):
         return ops.gemm_nt(x, self.w[wk], self.w[bk] if bk else None, residual, act, w16=self.h.get(wk), cw=True)
@@ -107,6 +131,9 @@ class VideoMultiScaleMaskedTransformerDecoder:
 
     def _mask_embed(self, output):
         w = self.w
+        if self.fuse_heads and output.shape[-1] == 256 and all(w[f"mask_embed.{j}.w"].shape == (256, 256) for j in range(3)):
+            return ops.ln_mlp3(output, w["decoder_norm.weight"], w["decoder_norm.bias"], [w[f"mask_embed.{j}.wt"] for j in range(3)],
+                               [w[f"mask_embed.{j}.b"] for j in range(3)])
         dec = ops.layernorm(output, w["decoder_norm.weight"], w["decoder_norm.bias"])
         h = self._mm(dec, "mask_embed.0.w", "mask_embed.0.b", None, ops.ACT_RELU)
         h = self._mm(h, "mask_embed.1.w", "mask_embed.1.b", None, ops.ACT_RELU)
@@ -148,7 +175,10 @@ class VideoMultiScaleMaskedTransformerDecoder:
             li = i % self.num_feature_levels
             Nk = src[li].shape[0]
             # masked cross-attention (:417-426, CrossAttentionLayer.forward_post :110-122)
-            qp = self._mm(ops.add_bcast(output, query_embed), f"ca{i}.wq", f"ca{i}.bq")
+            if self.fold_query_pos:
+                qp = self._mm(output, f"ca{i}.wq", None, w[f"ca{i}.rq"])
+            else:
+                qp = self._mm(ops.add_bcast(output, query_embed), f"ca{i}.wq", f"ca{i}.bq")
             if self.batch_kv:
                 if li not in kv_lvl:
                     kv_lvl[li] = (self._mm(kin[li], f"cak_lvl{li}.w", f"cak_lvl{li}.b"), self._mm(src[li], f"cav_lvl{li}.w", f"cav_lvl{li}.b"))
@@ -162,9 +192,13 @@ class VideoMultiScaleMaskedTransformerDecoder:
             y = self._mm(att.view(Q, C), f"ca{i}.wo", f"ca{i}.bo", output)
             output = ops.layernorm(y, w[f"ca{i}.nw"], w[f"ca{i}.nb"])
             # self-attention (:428-432, SelfAttentionLayer.forward_post :52-62)
-            qk = self._mm(ops.add_bcast(output, query_embed), f"sa{i}.wqk", f"sa{i}.bqk")   # [Q, 2C] = q | k
-            vv = self._mm(output, f"sa{i}.wv", f"sa{i}.bv")
-            att = ops.attention(qk, qk[:, C:], vv, 1, H8, Q, Q, D, 0, 2 * C, 0, 2 * C, 0, C)
+            if self.fold_query_pos:
+                qkv = self._mm(output, f"sa{i}.wqkv", None, w[f"sa{i}.rqkv"])                 # [Q, 3C] = q | k | v
+                att = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], 1, H8, Q, Q, D, 0, 3 * C, 0, 3 * C, 0, 3 * C)
+            else:
+                qk = self._mm(ops.add_bcast(output, query_embed), f"sa{i}.wqk", f"sa{i}.bqk")   # [Q, 2C] = q | k
+                vv = self._mm(output, f"sa{i}.wv", f"sa{i}.bv")
+                att = ops.attention(qk, qk[:, C:], vv, 1, H8, Q, Q, D, 0, 2 * C, 0, 2 * C, 0, C)
             y = self._mm(att.view(Q, C), f"sa{i}.wo", f"sa{i}.bo", output)
             output = ops.layernorm(y, w[f"sa{i}.nw"], w[f"sa{i}.nb"])
             # FFN (:434-437, FFNLayer.forward_post :175-179)

@@ -635,6 +635,18 @@ def conv3x3_padded(xpad, w, bias=None, act=ACT_NONE):
     return conv2d_nhwc(xpad[:, 1:-1, 1:-1, :].contiguous(), w, 1, 1, bias=bias, act=act, cw=True)
 
 
+def ln_mlp3(x, gamma, beta, wts, biases, want_dec=True, eps=1e-5):
+    """decoder_norm + 3-layer MLP (ReLU between) in one launch; wts = the three Linear weights TRANSPOSED [in, out].  Returns (dec, out)."""
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    _chk(x2, gamma, beta, *wts, *biases)
+    out = torch.empty_like(x2)
+    dec = torch.empty_like(x2) if want_dec else None
+    _lib.call("ovis_ln_mlp3_f32", x2, gamma, beta, wts[0], biases[0], wts[1], biases[1], wts[2], biases[2], dec, out, x2.shape[0], C,
+              ctypes.c_float(eps), _lib.stream_ptr())
+    return (dec.view(x.shape) if want_dec else None), out.view(x.shape)
+
+
 def add_bcast(a, b):
     """a + b with b broadcast over the leading dims of a (b.numel() divides a.numel())."""
     _chk(a, b)

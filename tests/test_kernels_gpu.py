@@ -464,3 +464,29 @@ def test_preprocess_whole_video_beyond_65535_rows():
     ref, _ = TR.preprocess([f for f in frames])
     assert tuple(out.shape) == (T, 96, 320, 4) and T * 96 > 65535
     assert torch.equal(out[..., :3].permute(0, 3, 1, 2).cpu(), ref) and out[..., 3].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("rows", [100, 501, 3])
+def test_ln_mlp3_matches_layernorm_and_three_linears(rows):
+    """ovis_ln_mlp3_f32 (decoder_norm + mask-embedding MLP of forward_prediction_heads, video_mask2former_transformer_decoder.py:454-458, one
+    launch) against torch in f64: both outputs, row counts that are no multiple of the 4 rows a workgroup owns."""
+    import torch.nn.functional as F
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    C = 256
+    x = (torch.randn(rows, C, generator=g) * 3 + 0.5)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ws = [torch.randn(C, C, generator=g) / 16 for _ in range(3)]
+    bs = [torch.randn(C, generator=g) for _ in range(3)]
+    dec_ref = F.layer_norm(x.double(), (C,), gamma.double(), beta.double())
+    h = dec_ref
+    for j in range(3):
+        h = h @ ws[j].double().t() + bs[j].double()
+        if j < 2:
+            h = h.relu()
+    dec, out = ops.ln_mlp3(x.cuda(), gamma.cuda(), beta.cuda(), [w.t().contiguous().cuda() for w in ws], [b.cuda() for b in bs])
+    torch.cuda.synchronize()
+    assert (dec.cpu().double() - dec_ref).abs().max().item() < 1e-5
+    assert (out.cpu().double() - h).abs().max().item() < 1e-4 * h.abs().max().item()
+    _, out2 = ops.ln_mlp3(x.cuda(), gamma.cuda(), beta.cuda(), [w.t().contiguous().cuda() for w in ws], [b.cuda() for b in bs], want_dec=False)
+    assert torch.equal(out2, out)

@@ -21,6 +21,8 @@ vals = {"HEAD": f"{head['value']:.1f}", "HEADMS": f"{head['ms_per_step']:.1f}",
 for a in head.get("alt_f32_splits") or ([head["alt_f32_split"]] if head.get("alt_f32_split") else []):
     key = {"bf16x3": "ALT", "bf16x2": "ALT2", "fp16x2": "ALT3"}.get(a["split"], "ALT")
     vals[key], vals[key + "MS"] = f"{a['value']:.1f}", f"{a['ms_per_step']:.1f}"
+if head.get("two_clips_in_flight"):
+    vals["S2I"] = f"{head['two_clips_in_flight']['value']:.1f}"
 if head.get("stage_ms"):
     st = head["stage_ms"]
     vals.update({"A2": f"{st['A2_backbone']:.2f}", "A36": f"{st['A3-A6_pixel_decoder']:.2f}", "A78": f"{st['A7-A8_decoder']:.2f}",
