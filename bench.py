@@ -180,6 +180,9 @@ def main():
                     help="timed steps (default 100 = 5 s of GPU work: long enough for the driver's 5 s GPU-busy sampling)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-in-flight", action="store_true",
+                    help="skip the `two_clips_in_flight` side measurement (profiling runs: its overlapping launches would mix into rocprofv3's "
+                         "per-kernel averages, which are meant to be compared with the sequential per-launch times of `roofline`)")
     ap.add_argument("--streams", type=int, default=1,
                     help="clips in flight per GPU (openvis_amd.runtime.ClipPipeline: one HIP stream + host thread each); "
                          "the default 1 keeps every launch alone on the GPU, which is what the roofline figures describe -- "
@@ -317,7 +320,7 @@ def main():
     # clip's kernels.  Reported BESIDE the headline, not as it: per-launch HIP-event times of overlapping clips include each other's kernels,
     # so the `roofline` below could not be read from such a timed region (`--streams 2` makes it the timed region).
     in_flight2 = None
-    if args.streams == 1 and not frame_sharded and not rig:
+    if args.streams == 1 and not frame_sharded and not rig and not args.no_in_flight:
         from openvis_amd.runtime import ClipPipeline
         pipe2 = ClipPipeline(_model, 2)
         n2 = max(args.steps // 2, 4)

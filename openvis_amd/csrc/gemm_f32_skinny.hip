@@ -90,7 +90,7 @@ gemm_f32_skinny_kernel(const SkArgs p) {
     for (int i = 0; i < 16; ++i)
       part[wave][(t * 32 + 8 * (i >> 2) + 4 * h + (i & 3)) * SK_BN + r32] = acc[t][i];
   __syncthreads();
-  if (RT != 4 && tid >= RT * 32 * 4) return;                         // (RT = 1 runs without split-K: no barrier behind this point)
+  if (RT != 4 && tid >= RT * 32 * 4) return;                         // (the wavefronts 2-7 END here: the barriers of the split-K tail count the live ones only)
 
   // thread -> row ml of the workgroup's rows (m globally), 8 consecutive columns
   const int ml = tid >> 2, c8 = (tid & 3) * 8;
@@ -119,7 +119,8 @@ gemm_f32_skinny_kernel(const SkArgs p) {
     }
     __threadfence();
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&p.counters[blockIdx.x], 1u) == (unsigned)(split - 1);
+    const unsigned cidx = blockIdx.z * gridDim.x + blockIdx.x;              // one counter per (row tile, column block)
+    if (tid == 0) s_last = atomicAdd(&p.counters[cidx], 1u) == (unsigned)(split - 1);
     __syncthreads();
     if (!s_last) return;
     __threadfence();
@@ -148,7 +149,7 @@ gemm_f32_skinny_kernel(const SkArgs p) {
           }
       }
     }
-    if (tid == 0) p.counters[blockIdx.x] = 0;                               // ready for the next launch on this stream
+    if (tid == 0) p.counters[cidx] = 0;                                     // ready for the next launch on this stream
   }
 
   if (m >= p.M) return;
@@ -222,8 +223,10 @@ int gemm_f32_skinny_launch(const float* A, long long lda, const float* B, long l
   }
   p.kw = K / split / SK_WAVES;
   // K <= 512: one 32-row tile per workgroup (blockIdx.z), no split-K -- 4x the workgroups, a quarter of the MFMAs per wavefront
-  if (split == 1 && (g_skinny_all <= 0 || g_skinny_all == 2))
-    hipLaunchKernelGGL(gemm_f32_skinny_kernel<1>, dim3(cdiv(N, SK_BN), 1, cdiv(M, 32)), dim3(512), 0, stream, p);
+  // ... and, round 4, the split-K problems too (FFN2 of a decoder layer, 100 x 256 x 2048: 8 x 8 x 4 = 256 workgroups instead of 64; the same
+  // per-wavefront k ranges and the same summation order, so the same bits: 32 -> ~12 us)
+  if (g_skinny_all <= 0 || (split == 1 && g_skinny_all == 2))
+    hipLaunchKernelGGL(gemm_f32_skinny_kernel<1>, dim3(cdiv(N, SK_BN), split, cdiv(M, 32)), dim3(512), 0, stream, p);
   else
     hipLaunchKernelGGL(gemm_f32_skinny_kernel<4>, dim3(cdiv(N, SK_BN), split), dim3(512), 0, stream, p);
   return check_launch("gemm_nt_f32 (skinny)");

@@ -435,8 +435,8 @@ static int layernorm_launch(const float* x, const float* residual, const float* 
 // (forward_prediction_heads, video_mask2former_transformer_decoder.py:454-458 with MLP :204-216), as ONE launch: ten times per clip on 100
 // (video decoder) or T x 100 (frame decoders) rows, where four launches of ~5 us each are latency, not work.  A workgroup owns R rows: one
 // wavefront per row normalises it (layernorm_kernel's two-pass f32 formulas), then thread j owns output column j of every layer for the R
-// rows -- the rows sit in LDS (broadcast reads), the weights are read TRANSPOSED ([in][out]: consecutive threads, consecutive addresses) from
-// L2.  f32 FMA chains in k order.
+// rows -- the rows sit in LDS (broadcast reads), the weights are read TRANSPOSED ([in][out]: consecutive lanes, consecutive addresses) from
+// L2.  f32 FMA chains, four partial sums per output (one per k quarter).
 template <int C, int R>
 __global__ void __launch_bounds__(C)
 ln_mlp3_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ wt0,
@@ -444,6 +444,7 @@ ln_mlp3_kernel(const float* __restrict__ x, const float* __restrict__ gamma, con
                const float* __restrict__ b2, float* __restrict__ dec, float* __restrict__ out, int rows, float eps) {
   static_assert(C == 256 && R == C / 64, "one wavefront per row, one float4 per lane");
   __shared__ __attribute__((aligned(16))) float buf[2][R][C];
+  __shared__ __attribute__((aligned(16))) float red[C / 64][R][C];      // partial sums of the 4 k ranges
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int row0 = blockIdx.x * R;
   {
@@ -458,33 +459,47 @@ ln_mlp3_kernel(const float* __restrict__ x, const float* __restrict__ gamma, con
     if (dec && row0 + w < rows) reinterpret_cast<float4*>(dec + (long long)row * C)[lane] = y;
   }
   __syncthreads();
+  // one layer: wavefront w takes the k range [64 w, 64 w + 64), lane l the 4 output columns 4 l .. 4 l + 3 (one 16-byte load per k: a wavefront
+  // reads whole 1 KB weight rows) for the R rows -- 64 independent loads per thread, issued 16 at a time; the 4 partial sums of an output meet
+  // in LDS and are added in wavefront order.  (Thread j = column j over all 256 k, 4 loads in flight, was latency bound: 26 us per call.)
   auto layer = [&](const float (*in)[C], const float* __restrict__ wt, const float* __restrict__ bias, bool relu, float (*o)[C]) {
-    float acc[R];
-    const float bj = bias[tid];
+    float4 acc[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = bj;
-#pragma unroll 4
-    for (int k = 0; k < C; k += 4) {
-      const float w0 = wt[(long long)(k + 0) * C + tid], w1 = wt[(long long)(k + 1) * C + tid];
-      const float w2 = wt[(long long)(k + 2) * C + tid], w3 = wt[(long long)(k + 3) * C + tid];
+    for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* wp = reinterpret_cast<const float4*>(wt + (long long)(64 * w) * C) + lane;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float4 xv = *reinterpret_cast<const float4*>(&in[r][k]);
-        acc[r] = __builtin_fmaf(xv.x, w0, acc[r]); acc[r] = __builtin_fmaf(xv.y, w1, acc[r]);
-        acc[r] = __builtin_fmaf(xv.z, w2, acc[r]); acc[r] = __builtin_fmaf(xv.w, w3, acc[r]);
-      }
+    for (int kk = 0; kk < 64; kk += 16) {
+      float4 wv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) wv[u] = wp[(long long)(kk + u) * (C / 4)];
+#pragma unroll
+      for (int u4 = 0; u4 < 16; u4 += 4)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float4 xv = *reinterpret_cast<const float4*>(&in[r][64 * w + kk + u4]);
+          const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[r].x = __builtin_fmaf(xs[e], wv[u4 + e].x, acc[r].x); acc[r].y = __builtin_fmaf(xs[e], wv[u4 + e].y, acc[r].y);
+            acc[r].z = __builtin_fmaf(xs[e], wv[u4 + e].z, acc[r].z); acc[r].w = __builtin_fmaf(xs[e], wv[u4 + e].w, acc[r].w);
+          }
+        }
     }
 #pragma unroll
+    for (int r = 0; r < R; ++r) reinterpret_cast<float4*>(&red[w][r][0])[lane] = acc[r];
+    __syncthreads();
+    const float bj = bias[tid];
+#pragma unroll
     for (int r = 0; r < R; ++r) {
-      const float v = relu ? fmaxf(acc[r], 0.f) : acc[r];
+      float v = ((red[0][r][tid] + red[1][r][tid]) + (red[2][r][tid] + red[3][r][tid])) + bj;
+      v = relu ? fmaxf(v, 0.f) : v;
       if (o) o[r][tid] = v;
       else if (row0 + r < rows) out[(long long)(row0 + r) * C + tid] = v;
     }
+    __syncthreads();
   };
   layer(buf[0], wt0, b0, true, buf[1]);
-  __syncthreads();
   layer(buf[1], wt1, b1, true, buf[0]);
-  __syncthreads();
   layer(buf[0], wt2, b2, false, nullptr);
 }
 
