@@ -8,7 +8,7 @@ import torch
 
 from ... import ops
 from ...registry import TRANSFORMER_DECODER_REGISTRY
-from .video_mask2former_transformer_decoder import VideoMultiScaleMaskedTransformerDecoder
+from .video_mask2former_transformer_decoder import VideoMultiScaleMaskedTransformerDecoder, _EmbeddingHead, _Kw, _ProposalHead, _variant_init
 
 
 @TRANSFORMER_DECODER_REGISTRY.register()
@@ -103,7 +103,34 @@ class FrameMultiScaleMaskedTransformerDecoder(VideoMultiScaleMaskedTransformerDe
         out = {"pred_masks": pred_masks.view(1, Q, T, hm, wm), "pred_embeds": dec.view(1, T, Q, C),
                "mask_feats": mask_features, "size_list": sizes}
         if self.mask_classification:
-            out["pred_logits"] = ops.gemm_nt(dec, w["class_embed.weight"], w["class_embed.bias"]).view(1, T, Q, -1)
+            out["pred_logits"] = self._class_head(dec.view(T * Q, C)).view(1, T, Q, -1)
         return out
 
     __call__ = forward
+
+
+@TRANSFORMER_DECODER_REGISTRY.register()
+class EmbeddingFrameMultiScaleMaskedTransformerDecoder(_EmbeddingHead, FrameMultiScaleMaskedTransformerDecoder):
+    """frame decoder:157-193 (configs/openvoc_ytvis_coco/simplebsl_online*.yaml)."""
+
+    def __init__(self, clip_dims, mask_classification, **kwargs):
+        _variant_init(self, FrameMultiScaleMaskedTransformerDecoder, mask_classification, kwargs)
+        self.clip_dims = clip_dims
+
+    @classmethod
+    def from_config(cls, cfg, in_channels, mask_classification):
+        base = VideoMultiScaleMaskedTransformerDecoder.from_config.__func__(_Kw, cfg, in_channels, mask_classification)
+        return cls(cfg.MODEL.CLIP_ADAPTER.CLIP_EMBED_DIMS, mask_classification, **base)
+
+
+@TRANSFORMER_DECODER_REGISTRY.register()
+class ProposalFrameMultiScaleMaskedTransformerDecoder(_ProposalHead, FrameMultiScaleMaskedTransformerDecoder):
+    """frame decoder:196-207."""
+
+    def __init__(self, mask_classification, **kwargs):
+        _variant_init(self, FrameMultiScaleMaskedTransformerDecoder, mask_classification, kwargs)
+
+    @classmethod
+    def from_config(cls, cfg, in_channels, mask_classification):
+        return cls(mask_classification, **VideoMultiScaleMaskedTransformerDecoder.from_config.__func__(_Kw, cfg, in_channels, mask_classification))
+

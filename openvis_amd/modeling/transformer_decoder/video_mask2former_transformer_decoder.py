@@ -100,8 +100,7 @@ class VideoMultiScaleMaskedTransformerDecoder:
             rqk = e64 @ w[f"sa{i}.wqk"].double().t() + w[f"sa{i}.bqk"].double()
             w[f"sa{i}.rqkv"] = torch.cat([rqk, w[f"sa{i}.bv"].double().expand(rqk.shape[0], -1)], 1).float().contiguous()
         self._rep_cache = {}
-        if self.mask_classification:
-            w["class_embed.weight"], w["class_embed.bias"] = g("class_embed.weight"), g("class_embed.bias")
+        self._load_class_head(g)
         for j in range(3):
             w[f"mask_embed.{j}.w"], w[f"mask_embed.{j}.b"] = g(f"mask_embed.layers.{j}.weight"), g(f"mask_embed.layers.{j}.bias")
             w[f"mask_embed.{j}.wt"] = w[f"mask_embed.{j}.w"].t().contiguous()          # [in, out]: operand layout of ops.ln_mlp3
@@ -110,6 +109,15 @@ class VideoMultiScaleMaskedTransformerDecoder:
                   (k.split(".")[-1].startswith("w") or k.endswith("weight")) and "query" not in k and "level_embed" not in k} \
             if self.precision == "fp16" else {}
         return self
+
+    # ---- the class head: nn.Linear(hidden_dim, num_classes + 1) here (video decoder:303-304); the Embedding* / Proposal* variants below
+    # replace these two methods only (video decoder:487-537, frame decoder:157-207)
+    def _load_class_head(self, g):
+        if self.mask_classification:
+            self.w["class_embed.weight"], self.w["class_embed.bias"] = g("class_embed.weight"), g("class_embed.bias")
+
+    def _class_head(self, dec):
+        return ops.gemm_nt(dec, self.w["class_embed.weight"], self.w["class_embed.bias"])
 
     def _rep(self, key, T):
         """Constant residual w[key] [Q, N] repeated for the T frames of a per-frame decoder ([T * Q, N]); T = 1: the tensor itself."""
@@ -212,7 +220,64 @@ class VideoMultiScaleMaskedTransformerDecoder:
         pred_masks = ops.gemm_nt(me, mf2, w16=ops.cast_f16(mf2) if f16 else None).view(1, Q, T, hm, wm)   # einsum (:460)
         out = {"pred_masks": pred_masks, "pred_embeds": dec}
         if self.mask_classification:
-            out["pred_logits"] = ops.gemm_nt(dec, w["class_embed.weight"], w["class_embed.bias"]).view(1, Q, -1)
+            out["pred_logits"] = self._class_head(dec).view(1, Q, -1)
         return out
 
     __call__ = forward
+
+
+class _EmbeddingHead:
+    """class_embed = MLP(hidden_dim, 2 clip_dims, clip_dims, 2): the query's CLIP-space embedding (video decoder:487-524, frame decoder:157-193;
+    configs/openvoc_ytvis_coco/simplebsl*.yaml)."""
+
+    def _load_class_head(self, g):
+        if self.mask_classification:
+            for j in range(2):
+                self.w[f"class_embed.{j}.w"], self.w[f"class_embed.{j}.b"] = g(f"class_embed.layers.{j}.weight"), g(f"class_embed.layers.{j}.bias")
+
+    def _class_head(self, dec):
+        h = ops.gemm_nt(dec, self.w["class_embed.0.w"], self.w["class_embed.0.b"], None, ops.ACT_RELU, w16=self.h.get("class_embed.0.w"), cw=True)
+        return ops.gemm_nt(h, self.w["class_embed.1.w"], self.w["class_embed.1.b"], w16=self.h.get("class_embed.1.w"), cw=True)
+
+
+class _ProposalHead:
+    """class_embed = nn.Linear(hidden_dim, 1 + 1): object / no-object (video decoder:527-537, frame decoder:196-207)."""
+
+    def _load_class_head(self, g):
+        if self.mask_classification:
+            self.w["class_embed.weight"], self.w["class_embed.bias"] = g("class_embed.weight"), g("class_embed.bias")
+
+
+def _variant_init(self, base, mask_classification, kwargs):
+    base.__init__(self, kwargs.pop("in_channels"), False, **kwargs)       # the reference builds the parent without a class head ...
+    self.mask_classification = mask_classification                        # ... and adds its own
+
+
+@TRANSFORMER_DECODER_REGISTRY.register()
+class EmbeddingVideoMultiScaleMaskedTransformerDecoder(_EmbeddingHead, VideoMultiScaleMaskedTransformerDecoder):
+    def __init__(self, clip_dims, mask_classification, **kwargs):
+        _variant_init(self, VideoMultiScaleMaskedTransformerDecoder, mask_classification, kwargs)
+        self.clip_dims = clip_dims
+
+    @classmethod
+    def from_config(cls, cfg, in_channels, mask_classification):
+        base = VideoMultiScaleMaskedTransformerDecoder.from_config.__func__(_Kw, cfg, in_channels, mask_classification)
+        return cls(cfg.MODEL.CLIP_ADAPTER.CLIP_EMBED_DIMS, mask_classification, **base)
+
+
+@TRANSFORMER_DECODER_REGISTRY.register()
+class ProposalVideoMultiScaleMaskedTransformerDecoder(_ProposalHead, VideoMultiScaleMaskedTransformerDecoder):
+    def __init__(self, mask_classification, **kwargs):
+        _variant_init(self, VideoMultiScaleMaskedTransformerDecoder, mask_classification, kwargs)
+
+    @classmethod
+    def from_config(cls, cfg, in_channels, mask_classification):
+        return cls(mask_classification, **VideoMultiScaleMaskedTransformerDecoder.from_config.__func__(_Kw, cfg, in_channels, mask_classification))
+
+
+class _Kw:
+    """from_config of the base class called with this in place of `cls`: returns the constructor's keyword arguments instead of an instance."""
+
+    def __new__(cls, in_channels, mask_classification=True, **kw):
+        return dict(in_channels=in_channels, **kw)
+

@@ -229,6 +229,48 @@ def gen_frame_decoder_and_tracker():
     print("wrote frame_decoder_tracker.npz", out["pred_masks"].shape, idx.shape)
 
 
+def gen_decoder_head_variants():
+    """Reference Embedding* / Proposal* decoder variants (frame decoder:157-207, video decoder:487-537): the parent decoder with another
+    class head.  They get the PARENT fixture's weights (same seeds, so the stable inputs of those fixtures stay stable) plus separately
+    seeded class_embed weights; stored: pred_logits of each variant (the masks are checked here to equal the parent fixture's bit for bit and are not stored again)."""
+    import json
+    from tests._synth import synth_inputs, synth_weights, spec_of
+    fd = R.ref("openvis.modeling.transformer_decoder.frame_mask2former_transformer_decoder")
+    vd = R.ref("openvis.modeling.transformer_decoder.video_mask2former_transformer_decoder")
+    gf = np.load(os.path.join(GOLD, "frame_decoder_tracker.npz"))
+    gv = np.load(os.path.join(GOLD, "pixel_decoder_decoder.npz"))
+    spec_of_arr = lambda arr: [(k, tuple(sh)) for k, sh in json.loads(bytes(arr.tolist()).decode())]
+    s_dec, s_ms, s_mf, _ = [int(x) for x in gf["seeds"]]
+    T = 3
+    kw = dict(num_classes=1, hidden_dim=256, num_queries=100, nheads=8, dim_feedforward=2048, dec_layers=9, pre_norm=False, mask_dim=256,
+              enforce_input_project=False)
+    ms_f = synth_inputs([(T, 256, 2, 3), (T, 256, 4, 6), (T, 256, 8, 12)], s_ms)
+    mf_f = synth_inputs([(T, 256, 16, 24)], s_mf)[0]
+    ms_v = [torch.from_numpy(gv[f"ms{i}"]) for i in range(3)]
+    mf_v = torch.from_numpy(gv["mask_features"])
+    out = {}
+    HEAD_SEED, CLIP_DIMS = 181, 64
+    cases = {"embedding_frame": (fd.EmbeddingFrameMultiScaleMaskedTransformerDecoder, dict(clip_dims=CLIP_DIMS), spec_of_arr(gf["spec"]), s_dec, T, ms_f, mf_f),
+             "proposal_frame": (fd.ProposalFrameMultiScaleMaskedTransformerDecoder, {}, spec_of_arr(gf["spec"]), s_dec, T, ms_f, mf_f),
+             "embedding_video": (vd.EmbeddingVideoMultiScaleMaskedTransformerDecoder, dict(clip_dims=CLIP_DIMS), spec_of_arr(gv["spec_dec"]), int(gv["seeds"][2]), 2, ms_v, mf_v),
+             "proposal_video": (vd.ProposalVideoMultiScaleMaskedTransformerDecoder, {}, spec_of_arr(gv["spec_dec"]), int(gv["seeds"][2]), 2, ms_v, mf_v)}
+    for name, (cls, extra, parent_spec, parent_seed, nf, ms, mf) in cases.items():
+        dec = cls(mask_classification=True, in_channels=256, num_frames=nf, **extra, **kw).eval()
+        parent = {k: v for k, v in synth_weights(parent_spec, parent_seed).items() if not k.startswith("class_embed")}
+        head_spec = [(k, sh) for k, sh in spec_of(dec.state_dict()) if k.startswith("class_embed")]
+        head = synth_weights(head_spec, HEAD_SEED)
+        missing = dec.load_state_dict({**parent, **head}, strict=False)
+        assert not missing.unexpected_keys and not missing.missing_keys, missing
+        with torch.no_grad():
+            o = dec(ms, mf)
+        out[name + "_logits"] = o["pred_logits"].numpy()
+        assert np.array_equal(o["pred_masks"].numpy(), (gf if "frame" in name else gv)["pred_masks"])     # the parent fixture's masks, bit for bit
+        out[name + "_head_spec"] = _spec_arrays(head_spec)
+        print(name, o["pred_logits"].shape, o["pred_masks"].shape)
+    np.savez_compressed(os.path.join(GOLD, "decoder_head_variants.npz"), head_seed=np.array([HEAD_SEED]), clip_dims=np.array([CLIP_DIMS]), **out)
+    print("wrote decoder_head_variants.npz")
+
+
 SAN_CLIP = dict(embed_dim=64, image_resolution=64, vision_layers=4, vision_width=256, vision_patch_size=16,
                 mask_prompt_depth=0, context_length=8, vocab_size=64, transformer_width=64, transformer_heads=2,
                 transformer_layers=1)
@@ -504,7 +546,7 @@ def gen_window_inference():
 
 
 GENERATORS = {"window": gen_window_inference, "sidevideo": gen_side_video_decoder, "text": gen_clip_text, "swin": gen_swin, "swinape": gen_swin_ape, "msda": gen_msda, "framedec": gen_frame_decoder_and_tracker, "san": gen_side_adapter, "resampler": gen_resampler, "pixdec": gen_pixel_decoder_and_decoder, "clip": gen_clip_visual, "clipmask": gen_clip_visual_mask_prompt,
-              "pe": gen_position_encodings}
+              "pe": gen_position_encodings, "heads": gen_decoder_head_variants}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

@@ -39,8 +39,14 @@ def test_registry_names_of_the_reference_surface():
     for n in ("MaskFormerHead", "MSDeformAttnPixelDecoder"):
         assert SEM_SEG_HEADS_REGISTRY.get(n) is not None
     for n in ("VideoMultiScaleMaskedTransformerDecoder", "FrameMultiScaleMaskedTransformerDecoder",
-              "SideAdapterFrameMultiScaleMaskedTransformerDecoder", "SideAdapterVideoMultiScaleMaskedTransformerDecoder"):
+              "SideAdapterFrameMultiScaleMaskedTransformerDecoder", "SideAdapterVideoMultiScaleMaskedTransformerDecoder",
+              "EmbeddingVideoMultiScaleMaskedTransformerDecoder", "ProposalVideoMultiScaleMaskedTransformerDecoder",
+              "EmbeddingFrameMultiScaleMaskedTransformerDecoder", "ProposalFrameMultiScaleMaskedTransformerDecoder"):
         assert TRANSFORMER_DECODER_REGISTRY.get(n) is not None
+    cfg = config.get_cfg()
+    emb = TRANSFORMER_DECODER_REGISTRY.get("EmbeddingFrameMultiScaleMaskedTransformerDecoder").from_config(cfg, 256, True)
+    assert emb.clip_dims == cfg.MODEL.CLIP_ADAPTER.CLIP_EMBED_DIMS and emb.mask_classification       # frame decoder:157-193
+    assert TRANSFORMER_DECODER_REGISTRY.get("ProposalVideoMultiScaleMaskedTransformerDecoder").from_config(cfg, 256, False).mask_classification is False
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference configs only exist in the build container")

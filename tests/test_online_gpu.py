@@ -106,3 +106,42 @@ def test_openvis_online_end_to_end(policy):
     assert len(common) >= 8
     tol = 2e-3 if policy == "fp32" else 3e-2
     assert max(abs(sg[k] - sr[k]) for k in common) < tol
+
+
+@pytest.mark.parametrize("name", ["embedding_frame", "proposal_frame", "embedding_video", "proposal_video"])
+def test_decoder_head_variants_match_reference_golden(name):
+    """Embedding* / Proposal* decoders (frame decoder:157-207, video decoder:487-537; configs/openvoc_ytvis_coco/simplebsl*.yaml): the parent
+    decoder with another class head, against outputs of the reference's own classes (oracle/make_golden.py heads).  The variants carry the
+    parent fixtures' weights and inputs, so their masks must also match those fixtures."""
+    from openvis_amd.modeling import transformer_decoder as TD
+    from openvis_amd.modeling.transformer_decoder import frame_mask2former_transformer_decoder as FD, video_mask2former_transformer_decoder as VD
+    g = np.load(os.path.join(GOLDEN, "decoder_head_variants.npz"))
+    gf = np.load(os.path.join(GOLDEN, "frame_decoder_tracker.npz"))
+    gv = np.load(os.path.join(GOLDEN, "pixel_decoder_decoder.npz"))
+    frame = name.endswith("frame")
+    cls = {"embedding_frame": FD.EmbeddingFrameMultiScaleMaskedTransformerDecoder, "proposal_frame": FD.ProposalFrameMultiScaleMaskedTransformerDecoder,
+           "embedding_video": VD.EmbeddingVideoMultiScaleMaskedTransformerDecoder, "proposal_video": VD.ProposalVideoMultiScaleMaskedTransformerDecoder}[name]
+    kw = dict(in_channels=256, num_classes=1, hidden_dim=256, num_queries=100, nheads=8, dim_feedforward=2048, dec_layers=9, pre_norm=False,
+              mask_dim=256, enforce_input_project=False, precision="fp32")
+    if frame:
+        s_dec, s_ms, s_mf, _ = [int(x) for x in gf["seeds"]]
+        T, parent_spec, ref_masks = 3, _spec(gf["spec"]), gf["pred_masks"]
+        ms = synth_inputs([(T, 256, 2, 3), (T, 256, 4, 6), (T, 256, 8, 12)], s_ms)
+        mf = synth_inputs([(T, 256, 16, 24)], s_mf)[0]
+    else:
+        s_dec, T, parent_spec, ref_masks = int(gv["seeds"][2]), 2, _spec(gv["spec_dec"]), gv["pred_masks"]
+        ms = [torch.from_numpy(gv[f"ms{i}"]) for i in range(3)]
+        mf = torch.from_numpy(gv["mask_features"])
+    extra = dict(clip_dims=int(g["clip_dims"][0])) if name.startswith("embedding") else {}
+    dec = cls(mask_classification=True, num_frames=T, **extra, **kw)
+    pre = "sem_seg_head.predictor."
+    sd = {k: v for k, v in synth_weights(parent_spec, s_dec, pre).items() if not k.startswith(pre + "class_embed")}
+    sd.update(synth_weights(_spec(g[name + "_head_spec"]), int(g["head_seed"][0]), pre))
+    dec.load_state_dict(sd, pre, "cuda")
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    out = dec([nhwc(m) for m in ms], nhwc(mf))
+    pm = out["pred_masks"].cpu().numpy()
+    assert np.abs(pm - ref_masks).max() < 2e-3 and ((pm > 0) == (ref_masks > 0)).mean() > 0.9999
+    lg = out["pred_logits"].cpu().numpy()
+    assert lg.shape == g[name + "_logits"].shape
+    assert np.abs(lg - g[name + "_logits"]).max() < 2e-4 * max(1.0, float(np.abs(g[name + "_logits"]).max()))
