@@ -513,78 +513,95 @@ mask_bbox4_kernel(const float* __restrict__ masks, int* __restrict__ boxes, int 
   const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
   const int cy_begin = blockIdx.x * rows_per_blk, cy_end = min(h, cy_begin + rows_per_blk);
   int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
-  for (int cy = cy_begin + ly; cy < cy_end; cy += 4) {
+  auto cell = [&](int cy, int cx) {
     const int ry[3] = {max(cy - 1, 0), cy, min(cy + 1, h - 1)};
-    for (int cx = lx; cx < w; cx += 64) {
-      const int rx[3] = {max(cx - 1, 0), cx, min(cx + 1, w - 1)};
-      float n[3][3];
+    const int rx[3] = {max(cx - 1, 0), cx, min(cx + 1, w - 1)};
+    float n[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) n[a][b] = mp[(long long)ry[a] * w + rx[b]];
+    float lo = n[0][0], hi = n[0][0];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) { lo = fminf(lo, n[a][b]); hi = fmaxf(hi, n[a][b]); }
+    if (!(hi > 0.f)) return;                                   // no tap positive: no pixel of the cell is on
+    if (lo > 4e-6f) {                                            // every tap clearly on (margin over mask_on's 1e-6 for the rounding of the blend)
+      x0 = min(x0, 4 * cx); x1 = max(x1, 4 * cx + 3); y0 = min(y0, 4 * cy); y1 = max(y1, 4 * cy + 3);
+      return;
+    }
+    if (cy > 0 && cy < h - 1 && cx > 0 && cx < w - 1) {
+      // interior cell: make_tap(4 c + i, 1/4, n) is exact arithmetic -- source coordinate c + (2 i - 3) / 8, taps (c - 1, c) for i < 2 and
+      // (c, c + 1) for i >= 2, weight of the second tap 5/8, 7/8, 1/8, 3/8 -- so the 16 pixels are the same bilerp() expressions on
+      // constants: 12 horizontal blends shared by the rows, 16 vertical ones (the general path below re-derives taps and picks
+      // neighbours with selects for each pixel: ~6 x the instructions; it keeps the border cells, where the taps clamp).
+      constexpr float L1[4] = {0.625f, 0.875f, 0.125f, 0.375f};
+      float hx[3][4];
 #pragma unroll
       for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) n[a][b] = mp[(long long)ry[a] * w + rx[b]];
-      float lo = n[0][0], hi = n[0][0];
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) { lo = fminf(lo, n[a][b]); hi = fmaxf(hi, n[a][b]); }
-      if (!(hi > 0.f)) continue;                                   // no tap positive: no pixel of the cell is on
-      if (lo > 4e-6f) {                                            // every tap clearly on (margin over mask_on's 1e-6 for the rounding of the blend)
-        x0 = min(x0, 4 * cx); x1 = max(x1, 4 * cx + 3); y0 = min(y0, 4 * cy); y1 = max(y1, 4 * cy + 3);
-        continue;
-      }
-      if (cy > 0 && cy < h - 1 && cx > 0 && cx < w - 1) {
-        // interior cell: make_tap(4 c + i, 1/4, n) is exact arithmetic -- source coordinate c + (2 i - 3) / 8, taps (c - 1, c) for i < 2 and
-        // (c, c + 1) for i >= 2, weight of the second tap 5/8, 7/8, 1/8, 3/8 -- so the 16 pixels are the same bilerp() expressions on
-        // constants: 12 horizontal blends shared by the rows, 16 vertical ones (the general path below re-derives taps and picks
-        // neighbours with selects for each pixel: ~6 x the instructions; it keeps the border cells, where the taps clamp).
-        constexpr float L1[4] = {0.625f, 0.875f, 0.125f, 0.375f};
-        float hx[3][4];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float l1 = L1[i], l0 = 1.f - L1[i];
-            const float pa = i < 2 ? n[a][0] : n[a][1], pb = i < 2 ? n[a][1] : n[a][2];
-            hx[a][i] = l0 * pa + l1 * pb;
-          }
-        unsigned rows_on = 0, cols_on = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float l1 = L1[j], l0 = 1.f - L1[j];
-          const int r0 = j < 2 ? 0 : 1;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float v = l0 * hx[r0][i] + l1 * hx[r0 + 1][i];
-            if (mask_on(v)) { rows_on |= 1u << j; cols_on |= 1u << i; }
-          }
-        }
-        if (rows_on) {
-          x0 = min(x0, 4 * cx + __builtin_ctz(cols_on)); x1 = max(x1, 4 * cx + 31 - __builtin_clz(cols_on));
-          y0 = min(y0, 4 * cy + __builtin_ctz(rows_on)); y1 = max(y1, 4 * cy + 31 - __builtin_clz(rows_on));
-        }
-        continue;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int y = 4 * cy + j;
-        const Tap ty = make_tap(y, sy, h);
-        const int k0 = ty.i0 - (cy - 1), k1 = ty.i1 - (cy - 1);      // 0 .. 2 (row index inside the neighbourhood)
-        float r0[3], r1[3];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          r0[b] = k0 == 0 ? n[0][b] : (k0 == 1 ? n[1][b] : n[2][b]);
-          r1[b] = k1 == 0 ? n[0][b] : (k1 == 1 ? n[1][b] : n[2][b]);
-        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int x = 4 * cx + i;
-          const Tap tx = make_tap(x, sx, w);
-          const int c0 = tx.i0 - (cx - 1), c1 = tx.i1 - (cx - 1);
-          const float a = c0 == 0 ? r0[0] : (c0 == 1 ? r0[1] : r0[2]), b = c1 == 0 ? r0[0] : (c1 == 1 ? r0[1] : r0[2]);
-          const float c = c0 == 0 ? r1[0] : (c0 == 1 ? r1[1] : r1[2]), d = c1 == 0 ? r1[0] : (c1 == 1 ? r1[1] : r1[2]);
-          const float v = ty.l0 * (tx.l0 * a + tx.l1 * b) + ty.l1 * (tx.l0 * c + tx.l1 * d);      // == bilerp()
-          if (mask_on(v)) { x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y); }
+          const float l1 = L1[i], l0 = 1.f - L1[i];
+          const float pa = i < 2 ? n[a][0] : n[a][1], pb = i < 2 ? n[a][1] : n[a][2];
+          hx[a][i] = l0 * pa + l1 * pb;
         }
+      unsigned rows_on = 0, cols_on = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float l1 = L1[j], l0 = 1.f - L1[j];
+        const int r0 = j < 2 ? 0 : 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = l0 * hx[r0][i] + l1 * hx[r0 + 1][i];
+          if (mask_on(v)) { rows_on |= 1u << j; cols_on |= 1u << i; }
+        }
+      }
+      if (rows_on) {
+        x0 = min(x0, 4 * cx + __builtin_ctz(cols_on)); x1 = max(x1, 4 * cx + 31 - __builtin_clz(cols_on));
+        y0 = min(y0, 4 * cy + __builtin_ctz(rows_on)); y1 = max(y1, 4 * cy + 31 - __builtin_clz(rows_on));
+      }
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = 4 * cy + j;
+      const Tap ty = make_tap(y, sy, h);
+      const int k0 = ty.i0 - (cy - 1), k1 = ty.i1 - (cy - 1);      // 0 .. 2 (row index inside the neighbourhood)
+      float r0[3], r1[3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        r0[b] = k0 == 0 ? n[0][b] : (k0 == 1 ? n[1][b] : n[2][b]);
+        r1[b] = k1 == 0 ? n[0][b] : (k1 == 1 ? n[1][b] : n[2][b]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = 4 * cx + i;
+        const Tap tx = make_tap(x, sx, w);
+        const int c0 = tx.i0 - (cx - 1), c1 = tx.i1 - (cx - 1);
+        const float a = c0 == 0 ? r0[0] : (c0 == 1 ? r0[1] : r0[2]), b = c1 == 0 ? r0[0] : (c1 == 1 ? r0[1] : r0[2]);
+        const float c = c0 == 0 ? r1[0] : (c0 == 1 ? r1[1] : r1[2]), d = c1 == 0 ? r1[0] : (c1 == 1 ? r1[1] : r1[2]);
+        const float v = ty.l0 * (tx.l0 * a + tx.l1 * b) + ty.l1 * (tx.l0 * c + tx.l1 * d);      // == bilerp()
+        if (mask_on(v)) { x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y); }
+      }
+    }
+  };
+  // A cell inside the box already found cannot extend it: skipped before its loads.  The box is kept per WAVEFRONT (merged after every
+  // iteration in which a lane looked at a cell), so the decision is nearly uniform: on noise -- the random-init bench -- the 64 cells of an
+  // iteration are all outside (first row of cells: the box grows to the full width) or all inside (the rest of a row once one iteration has
+  // extended the box downwards).  Per-LANE boxes skipped 60 % of the cells and not one wavefront iteration (no gain: measured).
+  for (int cy = cy_begin + ly; cy < cy_end; cy += 4) {
+    for (int cx0 = 0; cx0 < w; cx0 += 64) {
+      const int cx = cx0 + lx;
+      const bool look = cx < w && !(4 * cx >= x0 && 4 * cx + 3 <= x1 && 4 * cy >= y0 && 4 * cy + 3 <= y1);
+      if (__ballot(look) == 0ull) continue;
+      const int px0 = x0, py0 = y0, px1 = x1, py1 = y1;
+      if (look) cell(cy, cx);
+      if (__ballot(x0 != px0 || y0 != py0 || x1 != px1 || y1 != py1) == 0ull) continue;     // no lane's box grew: nothing to merge
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        x0 = min(x0, __shfl_xor(x0, o, 64)); y0 = min(y0, __shfl_xor(y0, o, 64));
+        x1 = max(x1, __shfl_xor(x1, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
       }
     }
   }
@@ -1307,7 +1324,10 @@ extern "C" int ovis_center_pool_nhwc_f32(const float* x, float* y, int N, int H,
 }
 
 static int g_bbox4 = 1;           // lab / tests: 0 = mask_bbox_kernel for every size
+static int g_bbox_rows = 24;      // low-resolution rows per workgroup of mask_bbox4_kernel (lab: ovis_mask_bbox_set_rows): tall blocks let a wavefront's
+                                  // box grow early, which is what lets it skip cells
 extern "C" int ovis_mask_bbox_set_cells(int on) { g_bbox4 = on ? 1 : 0; return OVIS_OK; }
+extern "C" int ovis_mask_bbox_set_rows(int rows) { g_bbox_rows = rows >= 4 ? rows : 24; return OVIS_OK; }   // lab
 
 extern "C" int ovis_mask_bbox(const float* masks, int* boxes, int Q, int T, int h, int w, int Hp, int Wp, ovis_stream_t stream) {
   OVIS_REQUIRE(masks && boxes, "mask_bbox: null pointer");
@@ -1315,7 +1335,7 @@ extern "C" int ovis_mask_bbox(const float* masks, int* boxes, int Q, int T, int 
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bbox_init_kernel, dim3(ovis::cdiv(T * Q * 4, 256)), dim3(256), 0, s, boxes, T * Q * 4);
   if (Hp == 4 * h && Wp == 4 * w && g_bbox4) {                       // masks at stride 4: the cell kernel (identical boxes)
-    const int rows = 8;
+    const int rows = g_bbox_rows;
     hipLaunchKernelGGL(mask_bbox4_kernel, dim3(ovis::cdiv(h, rows), T * Q), dim3(256), 0, s, masks, boxes, Q, T, h, w, rows);
     return ovis::check_launch("mask_bbox");
   }
