@@ -315,6 +315,16 @@ int ovis_conv2d_nhwc_f32a_f16w(const float* x, const void* w16, float* y, int N,
  *     the output is f32) in the epilogue; y fp16 or f32 [T, OH, OW, Cout].  csrc/conv_h16.hip. */
 int ovis_gemm_nt_x16(const void* A, int a_f16, long long lda, const void* B16, long long ldb, void* C, int c_f16, long long ldc, int M, int N,
                      int K, const float* bias, const float* residual, long long ldr, int act, ovis_stream_t stream);
+/* conv3 + projection shortcut of a bottleneck as ONE GEMM over a concatenated K axis (round 4; detectron2 BottleneckBlock.forward:
+ * out = conv3(out); out += shortcut(x); relu -- the shortcut tensor is neither written nor read back): y = act([A1 | A2] B^T + bias) with
+ * B16 [N, K1 + K2] = [w3 | w_shortcut] (fp16) and bias = b3 + b_shortcut; fp16 operands, f32 accumulation, f32 output.  K1 % 64 == 0.
+ *   ovis_gemm_nt_x16_2a: A1 [M, K1] and A2 [M, K2] dense fp16 (res2.0: conv2's output and the pooled stem output);
+ *   ovis_conv1x1_pair_x16: A1 [T OH OW, K1] dense fp16, second source the f32 block input x2 [T, H, W, C2] at the pixels (s oy, s ox)
+ *     (the stride-s 1x1 shortcut of res3.0 / res4.0 / res5.0), rounded to fp16 while staged. */
+int ovis_gemm_nt_x16_2a(const void* A1_f16, long long lda1, int K1, const void* A2_f16, long long lda2, int K2, const void* B16, long long ldb,
+                        float* C, long long ldc, int M, int N, const float* bias, int act, ovis_stream_t stream);
+int ovis_conv1x1_pair_x16(const void* A1_f16, int K1, const float* x2, int T, int H, int W, int C2, int stride, const void* B16, float* y,
+                          int N, const float* bias, int act, ovis_stream_t stream);
 int ovis_conv2d_nhwc_f32a_f16w_o16(const float* x, const void* w16, void* y_f16, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                                    int stride, int pad, const float* bias, int act, ovis_stream_t stream);
 int ovis_maxpool3x3s2_nhwc_f16(const void* x, void* y, int N, int H, int W, int C, ovis_stream_t stream);

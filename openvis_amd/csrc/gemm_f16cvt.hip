@@ -19,6 +19,7 @@ using ovis::ConvA;
 using ovis::ConvGeom;
 using ovis::DenseA;
 using ovis::DenseH;
+using ovis::DualA;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
@@ -43,6 +44,8 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, vo
                    int M, int N, int K, const float* __restrict__ bias, const float* __restrict__ R, long long ldr,
                    int act, int tiles_n, long long a_bs, long long b_bs, long long c_bs) {
   constexpr bool AH = std::is_same<LoaderA, DenseH>::value;
+  constexpr bool AD = std::is_same<LoaderA, DualA<true>>::value || std::is_same<LoaderA, DualA<false>>::value;   // two sources along K (gemm_loaders.h)
+  constexpr bool AD_F32 = std::is_same<LoaderA, DualA<false>>::value;
   float* C = reinterpret_cast<float*>(C_);                   // (OUT16: only passed on to the epilogue as void*)
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_LD = BM * 8 / 256, B_LD = BN * 8 / 256;   // 8-element chunks per thread per K tile
@@ -64,13 +67,28 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, vo
 
   // staging registers of one K tile; the 64x64 instantiation (92 VGPRs) keeps TWO tiles in flight (set 0 / set 1 alternate), the
   // 128x128 one (208+ VGPRs) one: with 64-column tiles the kernel is bound by the latency of these loads, not by the MFMAs
-  struct Stage { float4 pa[A_LD][2]; bool oka[A_LD][2]; uint4 pb[B_LD]; bool okb[B_LD]; };
+  struct Stage { float4 pa[A_LD][2]; bool oka[A_LD][2]; uint4 pb[B_LD]; bool okb[B_LD]; bool raw; };   // raw (DualA): pa[.][0] holds 8 fp16 values
   typename LoaderA::RowCtx rca[A_LD];                     // the staged rows of this thread, decomposed once (gemm_loaders.h)
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) rca[i] = la.row(bm + srow + i * 32);
   auto gload = [&](Stage& st, int k0) {
     const int k = k0 + scol;
-    if constexpr (AH) {
+    if constexpr (AD) {
+      st.raw = !AD_F32 || k0 < la.K1;                          // wave-uniform (K1 % 64 == 0: the whole K tile lies in one source)
+      if (st.raw) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+          const uint4 u = la.load8(rca[i], k, st.oka[i][0]);
+          st.pa[i][0] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+        }
+      } else if constexpr (AD_F32) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+          st.pa[i][0] = la.load4(rca[i], k, st.oka[i][0]);
+          st.pa[i][1] = la.load4(rca[i], k + 4, st.oka[i][1]);
+        }
+      }
+    } else if constexpr (AH) {
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         const uint4 u = la.load8(rca[i], k, st.oka[i][0]);
@@ -94,12 +112,12 @@ gemm_f16cvt_kernel(LoaderA la, const _Float16* __restrict__ B, long long ldb, vo
   auto lstore = [&](const Stage& st) {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-      if constexpr (AH) {
+      if (AH || (AD && st.raw)) {
         const bool ok = st.oka[i][0];
         const float4 v = st.pa[i][0];
         *reinterpret_cast<uint4*>(&As[(srow + i * 32) * LDS_ROW + scol]) =
             make_uint4(ok ? __float_as_uint(v.x) : 0u, ok ? __float_as_uint(v.y) : 0u, ok ? __float_as_uint(v.z) : 0u, ok ? __float_as_uint(v.w) : 0u);
-      } else
+      } else if constexpr (!AH)
       *reinterpret_cast<uint4*>(&As[(srow + i * 32) * LDS_ROW + scol]) = cvt8(st.oka[i][0], st.pa[i][0], st.oka[i][1], st.pa[i][1]);
     }
 #pragma unroll
@@ -270,6 +288,33 @@ extern "C" int ovis_gemm_nt_x16(const void* A, int a_f16, long long lda, const v
   DenseA<true> la{(const float*)A, lda, M, K};
   return c_f16 ? launch<DenseA<true>, true>(la, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, act, s)
                : launch<DenseA<true>, false>(la, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, s);
+}
+
+// conv3 + projection shortcut of a bottleneck as one GEMM over the concatenated K axis (DualA, gemm_loaders.h): y = act([A1 | A2] B^T + bias),
+// B16 [N, K1 + K2] = [w3 | w_shortcut], bias = b3 + b_shortcut.  _2a: both sources dense fp16 (res2.0: conv2's output and the pooled stem
+// output); _pair: second source = the f32 block input x [T, H, W, C2] read at the pixels (s oy, s ox) (the stride-s 1x1 shortcut of res3-5.0).
+extern "C" int ovis_gemm_nt_x16_2a(const void* A1_f16, long long lda1, int K1, const void* A2_f16, long long lda2, int K2, const void* B16,
+                                   long long ldb, float* C, long long ldc, int M, int N, const float* bias, int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(A1_f16 && A2_f16 && B16 && C, "gemm_nt_x16_2a: null pointer");
+  OVIS_REQUIRE(M > 0 && N > 0 && K1 > 0 && K2 > 0 && K1 % 64 == 0 && K2 % 8 == 0 && lda1 >= K1 && lda2 >= K2 && lda1 % 8 == 0 && lda2 % 8 == 0 &&
+               ldb >= K1 + K2 && ldb % 8 == 0 && ldc >= N, "gemm_nt_x16_2a: need K1 %% 64 == 0, K2 %% 8 == 0, leading dimensions multiples of 8");
+  OVIS_REQUIRE((((uintptr_t)A1_f16 | (uintptr_t)A2_f16 | (uintptr_t)B16 | (uintptr_t)C) & 15) == 0 && act >= 0 && act <= 3, "gemm_nt_x16_2a: alignment / activation");
+  DualA<true> la{(const _Float16*)A1_f16, lda1, K1, A2_f16, lda2, 0, 0, 0, 0, 0, 0, M, K1 + K2};
+  return launch<DualA<true>, false>(la, (const _Float16*)B16, ldb, C, ldc, M, N, K1 + K2, bias, nullptr, 0, act, (hipStream_t)stream);
+}
+
+extern "C" int ovis_conv1x1_pair_x16(const void* A1_f16, int K1, const float* x2, int T, int H, int W, int C2, int stride, const void* B16,
+                                     float* y, int N, const float* bias, int act, ovis_stream_t stream) {
+  OVIS_REQUIRE(A1_f16 && x2 && B16 && y, "conv1x1_pair_x16: null pointer");
+  OVIS_REQUIRE(T > 0 && H > 0 && W > 0 && N > 0 && K1 > 0 && K1 % 64 == 0 && C2 > 0 && C2 % 8 == 0 && (stride == 1 || stride == 2),
+               "conv1x1_pair_x16: need K1 %% 64 == 0, C2 %% 8 == 0, stride 1 / 2");
+  OVIS_REQUIRE((((uintptr_t)A1_f16 | (uintptr_t)x2 | (uintptr_t)B16 | (uintptr_t)y) & 15) == 0 && act >= 0 && act <= 3, "conv1x1_pair_x16: alignment / activation");
+  const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  const long long M = (long long)T * OH * OW;
+  OVIS_REQUIRE(M < (1ll << 31), "conv1x1_pair_x16: too many output pixels");
+  DualA<false> la{(const _Float16*)A1_f16, (long long)K1, K1, x2, 0, H, W, C2, OH, OW, stride, (int)M, K1 + C2};
+  return launch<DualA<false>, false>(la, (const _Float16*)B16, (long long)(K1 + C2), y, (long long)N, (int)M, N, K1 + C2, bias, nullptr, 0, act,
+                                     (hipStream_t)stream);
 }
 
 // ovis_conv2d_nhwc_f32a_f16w with the result written as fp16 (the stem of the fp16-storage backbone; no residual)

@@ -64,6 +64,39 @@ struct DenseH {
   }
 };
 
+// Two A sources along K (round 4): columns [0, K1) from a dense fp16 matrix [M, K1], columns [K1, K) from a second map whose row m starts at
+// element base2(m) -- a dense fp16 matrix (A2H) or the f32 pixels (t, s oy, s ox) of an NHWC map [T, H, W, C2] (a 1x1 / stride-s convolution's
+// rows).  conv3 and the projection shortcut of a ResNet bottleneck (detectron2 BottleneckBlock.forward: out = conv3(out) + shortcut(x)) are
+// then ONE GEMM over the concatenated K axis: the shortcut tensor is neither written nor read back.  K1 % 64 == 0: a 64-wide K tile lies in
+// one source, so the choice is uniform per tile.
+template <bool A2H>
+struct DualA {
+  const _Float16* A1; long long lda1; int K1;
+  const void* A2; long long lda2;            // A2H: dense fp16 rows (lda2 elements apart); else the f32 map X
+  int H, W, C2, OH, OW, stride;              // !A2H: geometry of the strided pixel rows
+  int M, K;
+  __device__ __forceinline__ void advance(long long) {}
+  struct RowCtx { int m; long long base2; };
+  __device__ __forceinline__ RowCtx row(int m) const {
+    RowCtx r; r.m = m;
+    if constexpr (A2H) r.base2 = (long long)m * lda2;
+    else { const int ox = m % OW, t = m / OW, oy = t % OH, n = t / OH; r.base2 = (((long long)n * H + oy * stride) * W + ox * stride) * C2; }
+    return r;
+  }
+  // first source (and a fp16 second one): 8 halfs of row r at column k as raw bits
+  __device__ __forceinline__ uint4 load8(const RowCtx& r, int k, bool& ok) const {
+    ok = r.m < M && k < K;
+    const bool first = k < K1;
+    const _Float16* p = first ? A1 + (ok ? (long long)r.m * lda1 + k : 0) : reinterpret_cast<const _Float16*>(A2) + (ok ? r.base2 + (k - K1) : 0);
+    return *reinterpret_cast<const uint4*>(p);
+  }
+  // f32 second source: 4 floats of row r at column k (k >= K1)
+  __device__ __forceinline__ float4 load4(const RowCtx& r, int k, bool& ok) const {
+    ok = r.m < M && k < K;
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(A2) + (ok ? r.base2 + (k - K1) : 0));
+  }
+};
+
 // Implicit im2col over an NHWC input; k = (kh*KW + kw)*Cin + c, Cin % 4 == 0 (float4 never straddles a pixel).
 struct ConvA {
   const float* X;

@@ -39,6 +39,7 @@ class ResNet:
         # to the f32-storage path; the block outputs (the residual stream, and what the pixel decoder reads) stay f32.  The 3x3 convolutions
         # then run on the LDS-DMA kernel of csrc/conv_h16.hip.  False = f32 storage everywhere (rounds 1-3).
         self.h16_storage = True
+        self.fuse_shortcut = True      # (h16_storage) conv3 + projection shortcut of a stage's first block as one GEMM (load_state_dict)
         self.w = {}
         self.w16 = {}
 
@@ -64,6 +65,16 @@ class ResNet:
                     if f"{p}.{c}.weight" in sd:
                         self.w[f"{name}.{i}.{c}"] = tuple(map(d, _fold(sd, f"{p}.{c}")))
         self.w16 = {k: ops.cast_f16(v[0]) for k, v in self.w.items()} if self.precision == "fp16" else {}
+        # fp16-storage path: conv3 and the projection shortcut of a stage's first block as ONE GEMM over the concatenated K axis
+        # ([conv2 output | block input] x [w3 | w_shortcut]^T + (b3 + b_shortcut)): the shortcut tensor is never materialised
+        self.pair = {}
+        if self.precision == "fp16":
+            for name, _, _ in STAGES[self.depth]:
+                k = f"{name}.0"
+                if k + ".shortcut" in self.w:
+                    (w3, b3), (ws, bs) = self.w[k + ".conv3"], self.w[k + ".shortcut"]
+                    cat = torch.cat([w3.reshape(w3.shape[0], -1), ws.reshape(ws.shape[0], -1)], 1).contiguous()
+                    self.pair[k] = (ops.cast_f16(cat), (b3 + bs).contiguous())
         return self
 
     def _conv(self, x, key, stride=1, pad=0, residual=None, relu=True):
@@ -91,7 +102,10 @@ class ResNet:
                 stride = first_stride if i == 0 else 1
                 k = f"{name}.{i}"
                 c1, c2, c3 = k + ".conv1", k + ".conv2", k + ".conv3"
-                if (k + ".shortcut") in w:
+                fused = self.fuse_shortcut and k in self.pair and w[c2][0].shape[0] % 64 == 0
+                if fused:
+                    sc = None                                                                  # folded into conv3's GEMM below
+                elif (k + ".shortcut") in w:
                     if x.dtype == torch.float16:                                               # res2.0: the pooled stem output
                         N_, H_, W_, C_ = x.shape
                         ws = w16[k + ".shortcut"]
@@ -106,6 +120,13 @@ class ResNet:
                 out = ops.conv_h16(out, w16[c2], 3, stride, w[c2][1], None, relu, out_f16=True)
                 N2, H2, W2, C2 = out.shape                                                     # relu(conv3 + shortcut), f32 (HBM-bound: the
                 wc3 = w16[c3]                                                                  # register-staged kernel with fp16 A rows)
+                if fused:
+                    wcat, bcat = self.pair[k]
+                    if x.dtype == torch.float16:                                               # res2.0: both sources dense fp16
+                        x = ops.gemm_nt_x16_2a(out.view(-1, C2), x.view(-1, x.shape[-1]), wcat, bcat, relu).view(N2, H2, W2, -1)
+                    else:                                                                      # res3-5.0: the f32 block input at stride 2
+                        x = ops.conv1x1_pair_x16(out, x, stride, wcat, bcat, relu)
+                    continue
                 x = ops.gemm_nt_x16(out.view(-1, C2), wc3.view(wc3.shape[0], C2), w[c3][1], sc.view(-1, wc3.shape[0]), relu).view(N2, H2, W2, -1)
             if name in self.out_features:
                 feats[name] = x

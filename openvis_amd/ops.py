@@ -537,6 +537,37 @@ def gemm_nt_x16(a, w16, bias=None, residual=None, act=ACT_NONE, out_f16=False):
     return out.view(*a.shape[:-1], N)
 
 
+def gemm_nt_x16_2a(a1, a2, w16, bias=None, act=ACT_NONE):
+    """[a1 | a2] w16^T + bias with a1 [..., K1], a2 [..., K2] fp16 and w16 fp16 [N, K1 + K2] -> f32 [..., N]: conv3 + projection shortcut of
+    res2.0 as one GEMM (ovis_gemm_nt_x16_2a)."""
+    K1, K2, N = a1.shape[-1], a2.shape[-1], w16.shape[0]
+    x1, x2 = a1.reshape(-1, K1), a2.reshape(-1, K2)
+    _chk(x1, x2, w16, bias)
+    M = x1.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=a1.device)
+    big = ((M + 127) // 128) * ((N + 127) // 128) >= 1024 and N > 64
+    with _Prof(f"gemm_f16cvt_kernel<{'128,128' if big else '64,64'},DualA>", 2.0 * M * N * (K1 + K2)):
+        _lib.call("ovis_gemm_nt_x16_2a", x1, _ll(K1), K1, x2, _ll(K2), K2, w16, _ll(K1 + K2), out, _ll(N), M, N, bias, act, _lib.stream_ptr())
+    return out.view(*a1.shape[:-1], N)
+
+
+def conv1x1_pair_x16(a1, x2, stride, w16, bias=None, act=ACT_NONE):
+    """a1 fp16 [T, OH, OW, K1] (conv2's output) and the f32 block input x2 [T, H, W, C2] at stride `stride` -> f32 [T, OH, OW, N]:
+    conv3 + the strided 1x1 shortcut of res3.0 / res4.0 / res5.0 as one GEMM over [K1 | C2] (ovis_conv1x1_pair_x16)."""
+    _chk(a1, x2, w16, bias)
+    T, OH, OW, K1 = a1.shape
+    _, H, W, C2 = x2.shape
+    N = w16.shape[0]
+    if (OH, OW) != ((H - 1) // stride + 1, (W - 1) // stride + 1) or w16.shape[1] != K1 + C2:
+        raise _lib.OvisError("conv1x1_pair_x16: shapes of the two sources / the weight do not match")
+    y = torch.empty((T, OH, OW, N), dtype=torch.float32, device=a1.device)
+    M = T * OH * OW
+    big = ((M + 127) // 128) * ((N + 127) // 128) >= 1024 and N > 64
+    with _Prof(f"gemm_f16cvt_kernel<{'128,128' if big else '64,64'},DualA>", 2.0 * M * N * (K1 + C2)):
+        _lib.call("ovis_conv1x1_pair_x16", a1, K1, x2, T, H, W, C2, stride, w16, y, N, bias, act, _lib.stream_ptr())
+    return y
+
+
 def conv2d_nhwc_o16(x, w16, stride, pad, bias=None, act=ACT_NONE):
     """conv2d_nhwc with fp16 weights (autocast arithmetic) writing an fp16 map (the ResNet stem of the fp16-storage backbone)."""
     _chk(x, w16, bias)

@@ -123,3 +123,48 @@ def test_backbone_fp16_storage_equals_f32_storage_up_to_summation_order():
         d, dm = (new[k] - old[k]).abs().max().item() / scale, (new[k] - old[k]).abs().mean().item() / scale
         print(f"A2 {k}: fp16 storage vs f32 storage, max rel diff {d:.2e}, mean {dm:.2e}")
         assert new[k].dtype == torch.float32 and new[k].shape == old[k].shape and d < 5e-3 and dm < 3e-4
+
+
+def test_two_source_gemms_against_f64_on_the_same_fp16_operands():
+    """conv3 + projection shortcut of a bottleneck as one GEMM (ovis_gemm_nt_x16_2a: both sources fp16; ovis_conv1x1_pair_x16: the f32 block
+    input read at stride 2 and rounded to fp16 while staged) against f64 on the same fp16-rounded operands: relu([a1 | a2] [w3 | ws]^T + b)."""
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(11)
+    # res2.0: M = 3 x 23 x 41 pixels, K1 = K2 = 64, N = 256
+    T, H, W, K1, K2, N = 3, 23, 41, 64, 64, 256
+    a1 = torch.randn(T, H, W, K1, generator=g).relu().half().cuda(); a2 = torch.randn(T, H, W, K2, generator=g).relu().half().cuda()
+    w = (torch.randn(N, K1 + K2, generator=g) / (K1 + K2) ** 0.5).half().cuda(); b = torch.randn(N, generator=g).cuda()
+    ref = (torch.cat([a1, a2], -1).double() @ w.double().t() + b.double()).relu()
+    y = ops.gemm_nt_x16_2a(a1, a2, w, b, ops.ACT_RELU)
+    assert y.dtype == torch.float32 and (y.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    # res3.0 / res5.0 shapes: second source f32 [T, H, W, C2] at stride 2 (odd sizes: OH = (H - 1) // 2 + 1)
+    for (T, H, W, K1, C2, N) in ((2, 37, 51, 128, 256, 512), (1, 23, 40, 512, 1024, 2048), (2, 16, 24, 64, 64, 256)):
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        a1 = torch.randn(T, OH, OW, K1, generator=g).relu().half().cuda(); x2 = torch.randn(T, H, W, C2, generator=g).relu().cuda()
+        w = (torch.randn(N, K1 + C2, generator=g) / (K1 + C2) ** 0.5).half().cuda(); b = torch.randn(N, generator=g).cuda()
+        x2s = x2[:, ::2, ::2].half()                                                    # the pixels the stride-2 1x1 shortcut reads, as the MFMA sees them
+        ref = (torch.cat([a1, x2s], -1).double() @ w.double().t() + b.double()).relu()
+        y = ops.conv1x1_pair_x16(a1, x2, 2, w, b, ops.ACT_RELU)
+        assert y.shape == (T, OH, OW, N) and (y.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item(), (T, H, W)
+
+
+def test_backbone_fused_shortcut_equals_separate_shortcut_up_to_summation_order():
+    """The first block of every stage with conv3 and the projection shortcut as one GEMM against the two-GEMM form: the same fp16 operands, one
+    f32 accumulation chain instead of two added in f32 -- differences of the f32 summation order only."""
+    import bench
+    model, sd, _ = bench.build_model("cuda")
+    bb = model.backbone
+    assert bb.fuse_shortcut and len(bb.pair) == 4
+    frames = bench.synth_frames(2, 360, 640, 3, "cuda")
+    images, _, _ = model.preprocess(frames)
+    new = bb(images)
+    bb.fuse_shortcut = False
+    try:
+        old = bb(images)
+    finally:
+        bb.fuse_shortcut = True
+    for k in ("res2", "res3", "res4", "res5"):
+        scale = old[k].abs().max().item()
+        d, dm = (new[k] - old[k]).abs().max().item() / scale, (new[k] - old[k]).abs().mean().item() / scale
+        print(f"A2 {k}: fused vs separate shortcut, max rel diff {d:.2e}, mean {dm:.2e}")
+        assert d < 5e-3 and dm < 3e-4
