@@ -328,6 +328,10 @@ int ovis_conv1x1_pair_x16(const void* A1_f16, int K1, const float* x2, int T, in
 int ovis_conv2d_nhwc_f32a_f16w_o16(const float* x, const void* w16, void* y_f16, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                                    int stride, int pad, const float* bias, int act, ovis_stream_t stream);
 int ovis_maxpool3x3s2_nhwc_f16(const void* x, void* y, int N, int H, int W, int C, ovis_stream_t stream);
+/* ... and stem + pool in ONE launch (round 4): conv 7x7 / stride 2 / pad 3 (kernel padded to 7 x 8 taps, FrozenBN folded) + ReLU -> fp16 ->
+ * max pool 3x3 / stride 2 / pad 1 (detectron2 BasicStem).  x f32 [T, H, W, 4] (W even), w16 fp16 [64, 7, 8, 4], bias f32 [64] ->
+ * y fp16 [T, PH, PW, 64].  Same values as ovis_conv2d_nhwc_f32a_f16w_o16 + ovis_maxpool3x3s2_nhwc_f16 up to the f32 summation order. */
+int ovis_resnet_stem_pool_f16(const float* x, const void* w16, const float* bias, void* y_f16, int T, int H, int W, ovis_stream_t stream);
 int ovis_conv_h16(const void* x_f16, const void* w_f16, void* y, int out_f16, int T, int H, int W, int Cin, int Cout, int ksize, int stride,
                   const float* bias, const float* residual, int act, ovis_stream_t stream);
 /* y (fp16) = x (f32), n % 4 == 0 (weights are cast once at load). */

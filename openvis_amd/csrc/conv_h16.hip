@@ -245,7 +245,135 @@ maxpool3x3s2_h16_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int 
   y[i] = best.u;
 }
 
+
+// ---- ResNet stem + max pool in one kernel (round 4) ---------------------------------------------------------------------------------------
+// conv 7x7 / stride 2 / pad 3 on the normalised NHWC4 frames (3 channels + a zero one; the kernel is padded to 7 x 8 taps: K = 7 * 8 * 4 = 224),
+// FrozenBN folded, ReLU, rounded to fp16, then the 3x3 / stride 2 / pad 1 max pool (detectron2 BasicStem, configs/openvoc_ytvis/Base.yaml:2-16).
+// As an implicit GEMM (gemm_f16cvt_kernel<64,64,ConvA>) every input pixel is fetched ~12 times through the load path (0.22 ms at 720p, all
+// L2 -> L1 traffic) and the 150 MB conv map makes a round trip to memory for the pool.  Here a workgroup owns 4 x 16 POOLED pixels: it stages
+// the 23 x 72 input pixels under them once (fp16, 13 KB of LDS), computes the 9 x 33 conv pixels the pool windows need on the MFMA -- the
+// tile's 297 pixels flattened into 19 blocks of 16, weights as the A operand (64 channels x (kh: 8 taps x 4 channels = one K step of 32)) held
+// in registers, pixels as the B operand read from the patch (a lane's 8 k = two neighbouring input pixels = 16 contiguous bytes) -- writes
+// relu(acc + bias) as fp16 into a 38 KB LDS tile and pools from there.  Positions outside the conv map are written as 0: every pool window
+// holds a valid position and all values are >= 0 after the ReLU, so 0 behaves as the pool's -inf padding.
+constexpr int ST_PH = 4, ST_PW = 16;                   // pooled pixels per tile
+int g_stem_xt = 2;                                     // tiles per workgroup (lab: ovis_stem_tiles)
+constexpr int ST_CH = 2 * ST_PH + 1, ST_CW = 2 * ST_PW + 1;        // conv pixels: 9 x 33
+constexpr int ST_IH = 2 * ST_CH + 5, ST_IW = 2 * ST_CW + 6;        // input pixels: 23 x 72 (8-tap rows)
+constexpr int ST_M = ST_CH * ST_CW, ST_MT = (ST_M + 15) / 16;      // 297 conv pixels, 19 blocks of 16
+
+__global__ void __launch_bounds__(256)
+stem_pool_kernel(const float4* __restrict__ x, const uint4* __restrict__ w16, const float* __restrict__ bias, uint4* __restrict__ y, int T, int H,
+                 int W, int OH, int OW, int PH, int PW, int tiles_x, int tiles_y, int xt) {
+  using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+  using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  __shared__ __attribute__((aligned(16))) f16x4 patch[ST_IH * ST_IW];          // [row][col] x 4 channels
+  __shared__ __attribute__((aligned(16))) _Float16 conv[ST_M * 64];            // [conv pixel][channel]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  // a workgroup walks xt neighbouring tiles of one tile row with the 28 KB of weight fragments per wavefront fetched once.  Measured at
+  // 5 x 736 x 1280 (tools/bench_stem.py, us): xt = 1: 131, 2: 126, 4: 140, 8: 170, 20: 194 -- the weight traffic (515 MB per clip at xt = 1)
+  // is not what bounds the kernel, the number of workgroups in flight is; conv + pool as two launches: 228
+  const int groups_x = (tiles_x + xt - 1) / xt;
+  const int gx = blockIdx.x % groups_x, by = (blockIdx.x / groups_x) % tiles_y, t = blockIdx.x / (groups_x * tiles_y);
+
+  // weights: A fragments of the 4 channel blocks x 7 kernel rows, 8 halfs each: W[n][kh][2 kq .. 2 kq + 1][0..3]
+  uint4 wf[7][4];
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) wf[kh][nt] = w16[((nt * 16 + l15) * 7 + kh) * 4 + kq];
+
+  const float4* xp = x + (long long)t * H * W;
+  for (int bx = gx * xt; bx < min(tiles_x, (gx + 1) * xt); ++bx) {
+  const int py0 = by * ST_PH, px0 = bx * ST_PW;
+  const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;                      // first conv pixel of the tile
+  const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;                      // first input pixel of the patch
+  // input patch -> LDS as fp16 (zero outside the frame: the convolution's padding)
+  for (int idx = tid; idx < ST_IH * ST_IW; idx += 256) {
+    const int r = idx / ST_IW, c = idx - r * ST_IW;
+    const int iy = iy0 + r, ix = ix0 + c;
+    const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const float4 v = xp[in ? (long long)iy * W + ix : 0];
+    patch[idx] = in ? f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w} : f16x4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+  }
+  __syncthreads();
+
+  const float4 bz = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int mt = wave; mt < ST_MT; mt += 4) {
+    const int m = mt * 16 + l15;                                       // this lane's conv pixel as the B operand's column
+    const int mc = min(m, ST_M - 1);
+    const int cyl = mc / ST_CW, cxl = mc - cyl * ST_CW;
+    const f16x4* pb = patch + (2 * cyl) * ST_IW + 2 * cxl + 2 * kq;     // + kh * ST_IW: input row 2 cyl + kh, columns 2 cxl + 2 kq, + 1
+    f32x4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh) {
+      const f16x8 xb = *reinterpret_cast<const f16x8*>(pb + kh * ST_IW);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[kh][nt]), xb, acc[nt], 0, 0, 0);
+    }
+    // D[n = 16 nt + 4 kq + j][m = l15]: four consecutive channels of one conv pixel per lane and channel block
+    const bool ok = m < ST_M;
+    const int cy = cy0 + cyl, cx = cx0 + cxl;
+    const bool valid = cy >= 0 && cy < OH && cx >= 0 && cx < OW;
+    if (ok) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float4 b4 = valid ? *reinterpret_cast<const float4*>(bias + nt * 16 + 4 * kq) : bz;
+        f16x4 o;
+        o[0] = (_Float16)(valid ? fmaxf(acc[nt][0] + b4.x, 0.f) : 0.f); o[1] = (_Float16)(valid ? fmaxf(acc[nt][1] + b4.y, 0.f) : 0.f);
+        o[2] = (_Float16)(valid ? fmaxf(acc[nt][2] + b4.z, 0.f) : 0.f); o[3] = (_Float16)(valid ? fmaxf(acc[nt][3] + b4.w, 0.f) : 0.f);
+        *reinterpret_cast<f16x4*>(&conv[m * 64 + nt * 16 + 4 * kq]) = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  // pool: thread -> (pooled pixel tid / 4, 16 channels)
+  const int pp = tid >> 2, cg = (tid & 3) * 16;
+  const int ppy = pp / ST_PW, ppx = pp - ppy * ST_PW;
+  const int py = py0 + ppy, px = px0 + ppx;
+  if (py < PH && px < PW) {
+    f16x8 m0, m1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { m0[e] = (_Float16)0.f; m1[e] = (_Float16)0.f; }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const _Float16* cp = &conv[((2 * ppy + dy) * ST_CW + 2 * ppx + dx) * 64 + cg];
+        const f16x8 a = *reinterpret_cast<const f16x8*>(cp), b = *reinterpret_cast<const f16x8*>(cp + 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { m0[e] = a[e] > m0[e] ? a[e] : m0[e]; m1[e] = b[e] > m1[e] ? b[e] : m1[e]; }
+      }
+    uint4* yp = y + ((((long long)t * PH + py) * PW + px) * 64 + cg) / 8;
+    yp[0] = __builtin_bit_cast(uint4, m0); yp[1] = __builtin_bit_cast(uint4, m1);
+  }
+  __syncthreads();                                                     // the next tile's patch / conv tile overwrite this one's
+  }
+}
+
 }  // namespace
+
+// Stem (7x7 / stride 2 conv with the kernel padded to 7 x 8 taps, FrozenBN folded, ReLU) + 3x3 / stride 2 max pool of a ResNet in one launch:
+// x f32 [T, H, W, 4] (W even), w16 fp16 [64, 7, 8, 4], bias f32 [64] -> y fp16 [T, PH, PW, 64].
+extern "C" int ovis_resnet_stem_pool_f16(const float* x, const void* w16, const float* bias, void* y_f16, int T, int H, int W, ovis_stream_t stream) {
+  OVIS_REQUIRE(x && w16 && bias && y_f16, "resnet_stem_pool: null pointer");
+  OVIS_REQUIRE(T > 0 && H > 0 && W > 0 && W % 2 == 0, "resnet_stem_pool: need an even width (frames are padded to a multiple of 32)");
+  OVIS_REQUIRE((((uintptr_t)x | (uintptr_t)w16 | (uintptr_t)bias | (uintptr_t)y_f16) & 15) == 0, "resnet_stem_pool: 16-byte alignment");
+  const int OH = (H - 1) / 2 + 1, OW = W / 2, PH = (OH - 1) / 2 + 1, PW = (OW - 1) / 2 + 1;
+  const int tiles_x = ovis::cdiv(PW, ST_PW), tiles_y = ovis::cdiv(PH, ST_PH);
+  OVIS_REQUIRE((long long)T * tiles_x * tiles_y < (1ll << 31), "resnet_stem_pool: too many tiles");
+  hipLaunchKernelGGL(stem_pool_kernel, dim3((unsigned)(T * ovis::cdiv(tiles_x, g_stem_xt) * tiles_y)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (const uint4*)w16, bias,
+                     (uint4*)y_f16, T, H, W, OH, OW, PH, PW, tiles_x, tiles_y, g_stem_xt);
+  return ovis::check_launch("resnet_stem_pool");
+}
+
+extern "C" int ovis_stem_tiles(int xt) { g_stem_xt = xt >= 1 ? xt : 2; return OVIS_OK; }   // lab only
 
 extern "C" int ovis_conv_h16(const void* x_f16, const void* w_f16, void* y, int out_f16, int T, int H, int W, int Cin, int Cout, int ksize,
                              int stride, const float* bias, const float* residual, int act, ovis_stream_t stream) {

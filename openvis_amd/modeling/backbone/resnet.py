@@ -39,6 +39,7 @@ class ResNet:
         # to the f32-storage path; the block outputs (the residual stream, and what the pixel decoder reads) stay f32.  The 3x3 convolutions
         # then run on the LDS-DMA kernel of csrc/conv_h16.hip.  False = f32 storage everywhere (rounds 1-3).
         self.h16_storage = True
+        self.fuse_stem = True          # (h16_storage) stem + max pool as one kernel (csrc/conv_h16.hip: stem_pool_kernel)
         self.fuse_shortcut = True      # (h16_storage) conv3 + projection shortcut of a stage's first block as one GEMM (load_state_dict)
         self.w = {}
         self.w16 = {}
@@ -94,8 +95,11 @@ class ResNet:
         f32 accumulation, f32 bias / residual / ReLU; one rounding to fp16 where the f32-storage path rounds while staging."""
         w, w16 = self.w, self.w16
         relu = ops.ACT_RELU
-        x = ops.conv2d_nhwc_o16(x, w16["stem"], 2, 3, w["stem"][1], relu)                      # fp16 [T,H/2,W/2,64]
-        x = ops.maxpool3x3s2(x)                                                                # fp16 [T,H/4,W/4,64]
+        if self.fuse_stem and tuple(w16["stem"].shape) == (64, 7, 8, 4) and x.shape[-1] == 4:
+            x = ops.resnet_stem_pool(x, w16["stem"], w["stem"][1])                             # fp16 [T,H/4,W/4,64], one launch
+        else:
+            x = ops.conv2d_nhwc_o16(x, w16["stem"], 2, 3, w["stem"][1], relu)                  # fp16 [T,H/2,W/2,64]
+            x = ops.maxpool3x3s2(x)                                                            # fp16 [T,H/4,W/4,64]
         feats = {}
         for name, nblocks, first_stride in STAGES[self.depth]:
             for i in range(nblocks):

@@ -568,6 +568,20 @@ def conv1x1_pair_x16(a1, x2, stride, w16, bias=None, act=ACT_NONE):
     return y
 
 
+def resnet_stem_pool(x, w16, bias):
+    """ResNet stem (7x8-tap conv, stride 2, folded FrozenBN, ReLU) + 3x3 / stride 2 max pool in one launch: x f32 [T, H, W, 4] -> fp16
+    [T, PH, PW, 64] (ovis_resnet_stem_pool_f16)."""
+    _chk(x, w16, bias)
+    T, H, W, C = x.shape
+    if C != 4 or tuple(w16.shape) != (64, 7, 8, 4) or w16.dtype != torch.float16:
+        raise _lib.OvisError("resnet_stem_pool: x must be NHWC4 and w16 fp16 [64, 7, 8, 4]")
+    OH, OW = (H - 1) // 2 + 1, W // 2
+    y = torch.empty((T, (OH - 1) // 2 + 1, (OW - 1) // 2 + 1, 64), dtype=torch.float16, device=x.device)
+    with _Prof("stem_pool_kernel", 2.0 * T * OH * OW * 64 * 224):
+        _lib.call("ovis_resnet_stem_pool_f16", x, w16, bias, y, T, H, W, _lib.stream_ptr())
+    return y
+
+
 def conv2d_nhwc_o16(x, w16, stride, pad, bias=None, act=ACT_NONE):
     """conv2d_nhwc with fp16 weights (autocast arithmetic) writing an fp16 map (the ResNet stem of the fp16-storage backbone)."""
     _chk(x, w16, bias)

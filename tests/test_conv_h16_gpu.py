@@ -168,3 +168,29 @@ def test_backbone_fused_shortcut_equals_separate_shortcut_up_to_summation_order(
         d, dm = (new[k] - old[k]).abs().max().item() / scale, (new[k] - old[k]).abs().mean().item() / scale
         print(f"A2 {k}: fused vs separate shortcut, max rel diff {d:.2e}, mean {dm:.2e}")
         assert d < 5e-3 and dm < 3e-4
+
+
+@pytest.mark.parametrize("T,H,W", [(2, 96, 160), (1, 736, 1280), (3, 70, 90), (1, 33, 34)])
+def test_stem_pool_kernel_equals_stem_conv_then_pool(T, H, W):
+    """ovis_resnet_stem_pool_f16 (stem conv + ReLU + max pool in one launch) against the two-launch form (gemm_f16cvt ConvA -> fp16, fp16 pool) and
+    against f64 on the same fp16-rounded operands; sizes that leave partial tiles and odd conv / pool extents."""
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(T, H, W, 4, generator=g)
+    x[..., 3] = 0
+    w = torch.randn(64, 7, 8, 4, generator=g) / 12
+    w[:, :, 7] = 0
+    w[..., 3] = 0
+    b = torch.randn(64, generator=g)
+    xd, w16, bd = x.cuda(), w.half().cuda(), b.cuda()
+    y = ops.resnet_stem_pool(xd, w16, bd)
+    two = ops.maxpool3x3s2(ops.conv2d_nhwc_o16(xd, w16, 2, 3, bd, ops.ACT_RELU))
+    assert y.shape == two.shape and y.dtype == torch.float16
+    ref = F.conv2d(x.half().double().permute(0, 3, 1, 2), w.half().double()[:, :, :7].permute(0, 3, 1, 2), b.double(), stride=2, padding=3).relu()
+    ref = F.max_pool2d(ref, 3, 2, 1).permute(0, 2, 3, 1)
+    scale = ref.abs().max().item()
+    assert (y.double().cpu() - ref).abs().max().item() < 2e-3 * scale          # fp16 rounding of the conv map (2^-11 relative) + f32 order
+    assert (y.float() - two.float()).abs().max().item() < 2e-3 * scale
+    same = (y == two).float().mean().item()
+    print(f"stem + pool {T}x{H}x{W}: identical fp16 values {same:.5f}")
+    assert same > 0.99
