@@ -583,14 +583,18 @@ def clip_text_ensemble(tokens_per_template, W, prefix="clip_adapter.clip_model."
     return e / e.norm(dim=-1, keepdim=True)
 
 
-def clip_encode_image(regions, W, prefix="clip_adapter.clip_model.visual.", resolution=224, heads=12, mask_regions=None,
-                      mask_prompt_depth=0):
-    """adapter.py:140-144; with mask_regions: AdaptedClipAdapter.encode_image (mask_adapted_adapter.py:143-147)."""
+def clip_tower_input(regions, resolution=224):
+    """adapter.py:141-142: `/255`, bicubic resize to the tower's resolution (identity on roi_align's output), CLIP normalisation."""
     image = F.interpolate(regions / 255., (resolution, resolution), mode="bicubic")
     mean = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)
     std = torch.tensor(CLIP_STD).view(1, 3, 1, 1)
-    image = (image - mean) / std
-    feat = clip_visual(image, W, prefix, heads, mask_regions, mask_prompt_depth)
+    return (image - mean) / std
+
+
+def clip_encode_image(regions, W, prefix="clip_adapter.clip_model.visual.", resolution=224, heads=12, mask_regions=None,
+                      mask_prompt_depth=0):
+    """adapter.py:140-144; with mask_regions: AdaptedClipAdapter.encode_image (mask_adapted_adapter.py:143-147)."""
+    feat = clip_visual(clip_tower_input(regions, resolution), W, prefix, heads, mask_regions, mask_prompt_depth)
     return feat / feat.norm(dim=-1, keepdim=True)
 
 
@@ -623,17 +627,25 @@ def open_vocabulary_inference(masks, frames, text_features, W, part_len=5, tempe
         valid_flag.append(valid)
     clip_cls = torch.cat(clip_cls)
     valid_flag = torch.cat(valid_flag)
-    if torch.sum(valid_flag) == 0:
+    probs, vmasks, mean_cls = aggregate_crop_logits(clip_cls, valid_flag, masks)
+    if mean_cls is None:
         return [], [], {}
+    extras = {"crop_logits": clip_cls, "valid": valid_flag, "boxes": torch.cat(boxes) if boxes else None,
+              "query_logits": mean_cls}
+    return probs, vmasks, extras
+
+
+def aggregate_crop_logits(clip_cls, valid_flag, masks):
+    """openvis.py:126-142: crop logits [M,K] in (frame, query) order of `valid_flag` [T,Q] -> per-query mean over the frames with a
+    crop -> softmax over K; the masks of the queries with at least one crop.  ([], [], None) when no crop is valid (:127-128)."""
+    if torch.sum(valid_flag) == 0:
+        return [], [], None
     valid_ids = torch.nonzero(valid_flag)
     valid_query_flag = torch.sum(valid_flag, dim=0) > 0
     valid_query_ids = torch.nonzero(valid_query_flag)[:, 0]
     query_clip_cls = [torch.mean(clip_cls[valid_ids[:, 1] == q], dim=0) for q in valid_query_ids]
     mean_cls = torch.stack(query_clip_cls)
-    probs = mean_cls.softmax(dim=-1)
-    extras = {"crop_logits": clip_cls, "valid": valid_flag, "boxes": torch.cat(boxes) if boxes else None,
-              "query_logits": mean_cls}
-    return probs, masks[valid_query_flag], extras
+    return mean_cls.softmax(dim=-1), masks[valid_query_flag], mean_cls
 
 
 def inference_video(num_queries, num_classes, pred_cls, pred_masks, img_size, out_h, out_w, topk=10):
@@ -1036,14 +1048,25 @@ def san_online_image_outputs(frames, W, text_features, broken_idx=9, merge_ids=(
     return out
 
 
+def temporal_mean_post_processing(pred_logits, pred_masks, image_hw, num_classes):
+    """BriVIS.post_processing (brivis.py:242-265), the same lines inline in SANOnline.forward (san.py:257-273): pred_logits [1,T,Q,C] ->
+    mean over T -> softmax and drop of the last (background) column when C == num_classes + 1; pred_masks [1,Q,T,h,w] -> bilinear to
+    the padded image size.  Returns (probs [Q,K], masks [Q,T,Hp,Wp])."""
+    cls = pred_logits.mean(dim=1)[0]
+    mask_pred = pred_masks[0]
+    if cls.shape[-1] == num_classes + 1:
+        cls = F.softmax(cls, dim=-1)[:, :-1]
+    if tuple(mask_pred.shape[-2:]) != tuple(image_hw):
+        mask_pred = F.interpolate(mask_pred, size=tuple(image_hw), mode="bilinear", align_corners=False)
+    return cls, mask_pred
+
+
 def san_online_forward(frames, W, text_features, out_hw=None, stages=None, **kw):
     """SANOnline.forward, eval (san.py:177-283)."""
     out = san_online_image_outputs(frames, W, text_features, **kw)
     images, (H, Wd) = out["images"], out["image_size"]
     out = minvis_post_processing(out)
-    cls = out["pred_logits"].mean(dim=1)[0]
-    probs = F.softmax(cls, dim=-1)[:, :-1]
-    mask_pred = F.interpolate(out["pred_masks"][0], size=images.shape[-2:], mode="bilinear", align_corners=False)
+    probs, mask_pred = temporal_mean_post_processing(out["pred_logits"], out["pred_masks"], images.shape[-2:], text_features.shape[0])
     oh, ow = out_hw if out_hw is not None else (H, Wd)
     res = inference_video(mask_pred.shape[0], text_features.shape[0], probs, mask_pred, (H, Wd), oh, ow)
     if stages is not None:
@@ -1092,9 +1115,9 @@ def brivis_forward(frames, W, text_features, out_hw=None, stages=None, **kw):
     masks, biases, emb = resampler_heads(x, io["mask_feats"], io["attn_feats"], W)
     sos = san_post_encode_image(io["clip_bk"], biases, W, broken_idx=kw.get("broken_idx", 9), num_sos=num_queries)
     logits = san_cal_sim_logits(io["text_feats"], sos, W)                                # [T,Q,K+1]
-    probs = F.softmax(logits.mean(dim=0), dim=-1)[:, :-1]                                # brivis.py:247-252
     pred_masks = masks.permute(1, 0, 2, 3)                                               # [Q,T,h,w]
-    mask_pred = F.interpolate(pred_masks, size=images.shape[-2:], mode="bilinear", align_corners=False)
+    probs, mask_pred = temporal_mean_post_processing(logits.unsqueeze(0), pred_masks.unsqueeze(0), images.shape[-2:],
+                                                     text_features.shape[0])              # brivis.py:242-265
     oh, ow = out_hw if out_hw is not None else (H, Wd)
     res = inference_video(num_queries, text_features.shape[0], probs, mask_pred, (H, Wd), oh, ow)
     if stages is not None:
