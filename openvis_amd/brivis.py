@@ -103,7 +103,7 @@ class BriVIS(SANOnline):
         # mean over the local frames (kernel) weighted by the shard's share of the clip -> all-reduce = mean over ALL frames
         # -> softmax through the aggregate kernel.  The weighting is one elementwise scale of a [Q,K+1] tensor.
         local = ops.mean_over_dim0(logits.contiguous()) * (float(t) / float(T_total))
-        flag = ops.f16x2_flag() if self.f32_gemm_mode == 3 else None
+        flag = self._forward_flag()
         with D.span("logit_all_reduce", host=True):
             if flag is not None:
                 # fp16x2: every constant-weight GEMM of this forward is queued by now; the range flags of the ranks ride on this all-reduce

@@ -141,7 +141,15 @@ class ResNet:
         if self.w["stem"][0].shape[2] == 8 and x.shape[2] % 2 != 0:
             raise ValueError("ResNet stem with the padded 7x8 kernel needs an even input width (frames are padded to a multiple of 32)")
         if self.precision == "fp16" and self.h16_storage:
-            return self._forward_h16(x)
+            # conv_h16 addresses its fp16 input with 32-bit byte offsets (include/openvis_hip.h: T H W Cin 2 B < 2^31); the largest such
+            # map is conv2's input of res2, [T, H/4, W/4, 64] = T H W / 2 bytes (7.5 MB per 720p frame).  The convolutions are per frame,
+            # so a whole video the reference would hand to the backbone in one piece (openvis.py:64) runs as chunks of the frame axis
+            T, H, W = x.shape[:3]
+            chunk = max(1, self.H16_BYTE_LIMIT // max(1, (H // 4) * (W // 4) * 64 * 2 + (2 * (W // 4) + 2) * 64 * 2))
+            if T <= chunk:
+                return self._forward_h16(x)
+            parts = [self._forward_h16(x[t0:t0 + chunk]) for t0 in range(0, T, chunk)]
+            return {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0]}
         x = self._conv(x, "stem", stride=2, pad=3)
         x = ops.maxpool3x3s2(x)
         feats = {}
@@ -157,6 +165,7 @@ class ResNet:
                 feats[name] = x
         return feats
 
+    H16_BYTE_LIMIT = (1 << 31) - (1 << 20)     # per chunk, below conv_h16's 2^31 guard (tests lower it to exercise the chunking)
     __call__ = forward
 
 

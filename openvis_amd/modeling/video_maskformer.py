@@ -46,6 +46,10 @@ class VideoMaskFormer:
         return self
 
     f32_gemm_mode = None      # MODEL.F32_GEMM_SPLIT resolved by config.build_model (None: leave the library's setting alone)
+    _fwd = __import__("threading").local()     # .flag: the fp16x2 range flag of the forward this host thread is running (or None)
+
+    def _forward_flag(self):
+        return getattr(self._fwd, "flag", None)
 
     def _frames_to_device(self, batched_inputs):
         """list of T uint8 [3,H,W] -> one uint8 [T,3,H,W] device tensor (openvis.py:57-60).  Host frames are copied
@@ -54,10 +58,12 @@ class VideoMaskFormer:
 
         First call of every forward: also (re)applies this model's f32-GEMM split, a process-wide library setting, so that
         a model's results never depend on which model ran before it."""
-        if self.f32_gemm_mode is not None and ops.f32_gemm_mode() != self.f32_gemm_mode:
-            ops.set_f32_gemm_mode(self.f32_gemm_mode)
-        if self.f32_gemm_mode == 3:
-            ops.f16x2_begin(self.device)          # fp16x2: this forward's range flag (read back with the outputs, _range_guard)
+        mode = self.f32_gemm_mode                 # read ONCE: _range_guard may change it from another thread's finish() meanwhile
+        if mode is not None and ops.f32_gemm_mode() != mode:
+            ops.set_f32_gemm_mode(mode)
+        # fp16x2: this forward's range flag (read back with the outputs, _range_guard), kept per host thread next to the library's
+        # per-thread split so that the END of this forward checks the flag its own kernels raise whatever the shared attribute says by then
+        self._fwd.flag = ops.f16x2_begin(self.device) if mode == 3 else None
         frames = [f for video in batched_inputs for f in video["image"]]
         f0 = frames[0]
         if any(f.dtype != torch.uint8 for f in frames):
@@ -111,7 +117,7 @@ class VideoMaskFormer:
         all of them must repeat the clip at the same point of their collective sequence).  n_valid: device int32 [1], the number of
         non-empty masks when the crop list was built on the device (row_ids then names EVERY query): read back with the outputs; 0 means
         what `row_ids is None` means on the host path -- an empty result."""
-        flag = ops.f16x2_flag() if self.f32_gemm_mode == 3 else None
+        flag = self._forward_flag()
         if flag is not None and sync_guard:
             again = self._range_guard(flag.cpu()[0], redo)
             if again is not None:
@@ -139,13 +145,15 @@ class VideoMaskFormer:
             cm = ops.final_masks(pred_masks_lowres, sel_q, padded_hw[0], padded_hw[1], img_size[0], img_size[1],
                                  output_height, output_width, column_major=True)
             counts, n_runs = ops.rle_encode(cm.view(-1, output_height * output_width))
+            # the guard FIRST (as finish() below): an fp16x2 overflow turns the pixel decoder's output into NaN, every mask reads as empty,
+            # and "no valid mask" is exactly the state an overflow produces
+            again = self._range_guard(flag.cpu()[0] if flag is not None else None, redo)
+            if again is not None:
+                return again
             if n_valid is not None and int(n_valid.cpu()[0]) == 0:
                 return {"image_size": (output_height, output_width), "pred_entropys": [], "pred_scores": [], "pred_labels": [], "pred_masks_rle": [],
                         "pred_queries": []}
             labels = [i % K for i in idx.cpu().tolist()]
-            again = self._range_guard(flag.cpu()[0] if flag is not None else None, redo)
-            if again is not None:
-                return again
             return {"image_size": (output_height, output_width), "pred_entropys": ent.cpu().tolist(),
                     "pred_scores": score.cpu().tolist(), "pred_labels": labels,
                     "pred_masks_rle": rle.encode_video_masks(counts, n_runs, topk, T, output_height, output_width),

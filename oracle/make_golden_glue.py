@@ -225,7 +225,7 @@ def gen_glue_functions():
                pp_valid=pvalid.numpy(), pp_regions=regions.numpy(), pp_tower_input=captured["tower_input"].numpy())
 
     # --- batch_index, MinVIS.post_processing, BriVIS.reset_image_output_order + post_processing ---------------------------------
-    T, Q, C, h, w, K = 4, 6, 8, 5, 7, 3
+    T, Q, C, h, w, K = 4, 6, 8, 6, 8, 3                # (stride-4 maps of the model have h w % 4 == 0)
     embeds = torch.randn(1, T, Q, C, generator=g)
     logits = torch.randn(1, T, Q, K + 1, generator=g)
     pmasks = torch.randn(1, Q, T, h, w, generator=g)

@@ -125,6 +125,35 @@ def test_backbone_fp16_storage_equals_f32_storage_up_to_summation_order():
         assert new[k].dtype == torch.float32 and new[k].shape == old[k].shape and d < 5e-3 and dm < 3e-4
 
 
+def test_backbone_chunks_the_frame_axis_beyond_the_32_bit_offset_limit():
+    """conv_h16 addresses its fp16 input with 32-bit byte offsets, so a whole video handed to the backbone in one piece (openvis.py:64: the
+    reference runs the backbone on every frame of the video at once) runs as chunks of the frame axis: the chunked result equals the
+    un-chunked one bit for bit (the convolutions are per frame), and the default limit leaves room below the kernel's 2^31 guard."""
+    import bench
+    from openvis_amd.modeling.backbone.resnet import ResNet
+    model, _, _ = bench.build_model("cuda")
+    bb = model.backbone
+    frames = bench.synth_frames(5, 96, 160, 3, "cuda")
+    images, _, _ = model.preprocess(frames)
+    whole = bb(images)
+    per_frame = (96 // 4) * (160 // 4) * 64 * 2 + (2 * (160 // 4) + 2) * 64 * 2
+    calls = []
+    inner = bb._forward_h16
+    try:
+        bb.H16_BYTE_LIMIT = 2 * per_frame                              # two frames per chunk: 2 + 2 + 1
+        bb._forward_h16 = lambda x: (calls.append(x.shape[0]), inner(x))[1]
+        chunked = bb(images)
+    finally:
+        del bb.H16_BYTE_LIMIT, bb._forward_h16
+    assert calls == [2, 2, 1]
+    for k in whole:
+        assert torch.equal(whole[k], chunked[k]), k
+    # 720p: 7.5 MB per frame -> the default limit admits 284 frames per chunk and stays under the kernel's guard
+    per_720 = (736 // 4) * (1280 // 4) * 64 * 2 + (2 * (1280 // 4) + 2) * 64 * 2
+    n = ResNet.H16_BYTE_LIMIT // per_720
+    assert 250 < n < 300 and n * (736 // 4) * (1280 // 4) * 64 * 2 + (2 * 320 + 2) * 64 * 2 < (1 << 31)
+
+
 def test_two_source_gemms_against_f64_on_the_same_fp16_operands():
     """conv3 + projection shortcut of a bottleneck as one GEMM (ovis_gemm_nt_x16_2a: both sources fp16; ovis_conv1x1_pair_x16: the f32 block
     input read at stride 2 and rounded to fp16 while staged) against f64 on the same fp16-rounded operands: relu([a1 | a2] [w3 | ws]^T + b)."""

@@ -208,6 +208,33 @@ def test_model_falls_back_to_bf16x3_when_an_activation_leaves_the_fp16_range():
         ops.set_f32_gemm_mode(1)
 
 
+def test_rle_output_with_device_crop_list_repeats_the_clip_on_overflow():
+    """The OUTPUT_RLE branch of inference_video with the crop list built on the device: an fp16x2 overflow makes the pixel decoder's output
+    NaN, every mask reads as empty and `n_valid == 0` -- the guard has to come BEFORE the "no valid mask -> empty result" return, or the clip
+    would come back empty without a warning (round-4 review)."""
+    import warnings
+    from openvis_amd import ops
+    from bench import build_model, synth_frames
+    try:
+        model, _, _ = build_model("cuda", f32_split="fp16x2", crop_list="device")
+        ref_model, _, _ = build_model("cuda", f32_split="bf16x3", crop_list="device")
+        for m in (model, ref_model):
+            m.output_rle = True
+        frames = synth_frames(2, 360, 640, 5, "cuda")
+        inp = [{"image": [f for f in frames], "dataset_name": "synthetic_burst_val"}]
+        ref = ref_model(inp)
+        assert len(ref["pred_masks_rle"]) == 10
+        ops._MODE.a_scale = 2.0 ** 14
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            out = model(inp)
+        assert model.f32_gemm_mode == 1 and any("fp16 range" in str(w.message) for w in wlist)
+        assert len(out["pred_masks_rle"]) == 10 and out["pred_labels"] == ref["pred_labels"] and out["pred_masks_rle"] == ref["pred_masks_rle"]
+    finally:
+        ops._MODE.a_scale = 16.0
+        ops.set_f32_gemm_mode(1)
+
+
 @pytest.mark.parametrize("T,S,N2", [(5, 19320, 288), (3, 1001, 288), (2, 4600, 256)])
 def test_dual_gemm_indexing_is_exact_on_small_integers(modes, T, S, N2):
     """ovis_gemm_nt_f32_h2_dual (value_proj + offset / weight projection of an encoder layer as one launch): with small-integer operands

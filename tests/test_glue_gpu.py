@@ -1,0 +1,210 @@
+"""GPU: the HIP path against fixtures produced by the REFERENCE's own meta-architecture glue (oracle/make_golden_glue.py):
+`glue_functions.npz` -- openvis_aggregate vs OpenVIS.open_vocabulary_inference, topk_entropy + final_masks vs
+VideoMaskFormer.postprocess + inference_video, mask_bbox + crop list + clip_crop kernels vs ClipAdapter._preprocess_image +
+encode_image, the linker + batch_index vs MinVIS.post_processing / BriVIS.reset_image_output_order / post_processing;
+`glue_forward.npz` -- the whole model forward (f32 policy) vs the reference's whole eval forward of OpenVIS / OpenVISOnline /
+SANOnline / BriVIS on the same frames and weights.  No oracle function decides pass / fail here: expected values come from the
+fixtures (torch's own F.interpolate is used once, to locate near-zero logits of the output masks)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_oracle_glue import _bits, load_glue_forward
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)            # adapter.py:19-20
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+@pytest.fixture(scope="module")
+def gf():
+    return np.load(os.path.join(GOLDEN, "glue_functions.npz"))
+
+
+def test_openvis_aggregate_vs_reference_open_vocabulary_inference(gf):
+    """openvis.py:126-142: per-query mean of the crop logits over the frames with a crop, softmax -- compacted (host crop list) and
+    un-compacted (device crop list: one logit row per (frame, query), empty masks skipped through slot = -1, their rows filled -1)."""
+    from openvis_amd import ops
+    valid = gf["ovi_valid"]
+    logits = torch.from_numpy(gf["ovi_crop_logits"])
+    T, Q = valid.shape
+    K = logits.shape[1]
+    rows = np.nonzero(valid.any(0))[0]
+    slot = -np.ones((T, Q), np.int32)
+    slot[valid] = np.arange(int(valid.sum()), dtype=np.int32)
+    probs, qv = ops.openvis_aggregate(logits.cuda(), torch.from_numpy(slot).cuda())
+    assert np.array_equal(qv.cpu().numpy().astype(bool), valid.any(0))
+    assert np.abs(probs.cpu().numpy()[rows] - gf["ovi_probs"]).max() < 1e-6
+    full = torch.full((T * Q, K), 1e4)                                       # rows of empty masks hold garbage and must not be read
+    full[torch.from_numpy(valid.reshape(-1))] = logits
+    slot_all = np.where(valid, np.arange(T * Q, dtype=np.int32).reshape(T, Q), -1).astype(np.int32)
+    probs2, _ = ops.openvis_aggregate(full.cuda(), torch.from_numpy(slot_all).cuda(), fill=-1.0)
+    p2 = probs2.cpu().numpy()
+    assert np.abs(p2[rows] - gf["ovi_probs"]).max() < 1e-6
+    assert np.all(p2[~valid.any(0)] == -1.0)
+
+
+def test_topk_entropy_and_final_masks_vs_reference_inference_video(gf):
+    """video_maskformer.py:262-298 on the x4-upsampled masks of :215-229: the ten (row, label) pairs, scores, entropies; the ten
+    output masks (crop to the image size, resize to the output size, > 0) bit for bit except where the output logit is within
+    1e-5 of zero."""
+    from openvis_amd import ops
+    low, cls = torch.from_numpy(gf["iv_lowres"]), torch.from_numpy(gf["iv_cls"])
+    H, W, OH, OW = [int(x) for x in gf["iv_sizes"]]
+    Qv, K = cls.shape
+    h, w = low.shape[-2:]
+    idx, score, ent, sel_q = ops.topk_entropy(cls.cuda(), torch.arange(Qv, dtype=torch.int32).cuda(), 10)
+    idx, score, ent, sel_q = idx.cpu().numpy(), score.cpu().numpy(), ent.cpu().numpy(), sel_q.cpu().numpy()
+    # the reference: scores_per_image, labels = idx % K; rows recovered from the exact scores (distinct in this fixture)
+    ref_rows = np.array([int(np.nonzero(gf["iv_cls"][:, l] == s)[0][0]) for s, l in zip(gf["iv_scores"], gf["iv_labels"])])
+    ref = {(int(r), int(l)): i for i, (r, l) in enumerate(zip(ref_rows, gf["iv_labels"]))}
+    mine = {(int(i // K), int(i % K)): j for j, i in enumerate(idx)}
+    assert set(ref) == set(mine) and len(ref) == 10
+    assert np.array_equal(sel_q, idx // K)
+    for k, i in ref.items():
+        assert score[mine[k]] == gf["iv_scores"][i]
+        assert abs(ent[mine[k]] - gf["iv_entropys"][i]) < 1e-5
+    up = F.interpolate(low, size=(4 * h, 4 * w), mode="bilinear", align_corners=False)
+    for (oh, ow), key in (((OH, OW), "iv_masks"), ((H, W), "iv_masks_same")):
+        ref_masks = _bits(gf[key], gf[key + "_shape"])                        # [10,T,oh,ow] in the reference's top-k order
+        logit = F.interpolate(up[torch.from_numpy(ref_rows)][:, :, :H, :W], size=(oh, ow), mode="bilinear", align_corners=False)
+        assert np.array_equal((logit > 0).numpy(), ref_masks)                 # the located logits are the reference's
+        out = ops.final_masks(low.cuda(), torch.from_numpy(ref_rows.astype(np.int32)).cuda(), 4 * h, 4 * w, H, W, oh, ow).cpu().numpy().astype(bool)
+        diff = out != ref_masks
+        print(f"final_masks {oh}x{ow}: {int(diff.sum())} of {diff.size} bits differ, max |logit| there "
+              f"{float(logit.abs().numpy()[diff].max()) if diff.any() else 0.0:.2e}")
+        assert not diff.any() or float(logit.abs().numpy()[diff].max()) < 1e-5
+
+
+def test_crop_kernels_vs_reference_preprocess_image(gf):
+    """adapter.py:73-116, 140-142 through mask_bbox -> crop list -> clip_crop_patches: valid flags identical, the tower's input
+    (region x mask, /255, CLIP-normalised) of every crop within 2e-4; host-built and device-built crop lists."""
+    from openvis_amd import ops
+    H, W, Hp, Wp, RES = [int(x) for x in gf["pp_sizes"]]
+    frames = torch.from_numpy(gf["pp_frames"]).cuda()
+    low = torch.from_numpy(gf["pp_lowres"]).cuda()                          # [N,T,h,w]
+    valid = gf["pp_valid"]                                                   # [T,N]
+    boxes_d = ops.mask_bbox(low, Hp, Wp)
+    boxes = boxes_d.cpu().numpy()
+    assert np.array_equal(boxes[..., 2] >= 0, valid)
+    tq = np.argwhere(valid)
+    crops = np.concatenate([tq, boxes[valid]], 1).astype(np.int32)
+    PS = 16
+    A = ops.clip_crop_patches(frames, low, torch.from_numpy(crops).cuda(), Hp, Wp, RES, PS, CLIP_MEAN, CLIP_STD).cpu()
+    ref = torch.from_numpy(gf["pp_tower_input"])                             # [M,3,RES,RES]
+    ref_A = ref.unfold(2, PS, PS).unfold(3, PS, PS).permute(0, 2, 3, 1, 4, 5).reshape(-1, 3 * PS * PS)
+    assert A.shape[0] == ref_A.shape[0] and (A[:, :ref_A.shape[1]] - ref_A).abs().max().item() < 2e-4
+    # ... and the blend before normalisation: regions = mask_regions * frame_regions (adapter.py:114), in 0..255
+    mean = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+    regions = (A[:, :3 * PS * PS].reshape(-1, RES // PS, RES // PS, 3, PS, PS).permute(0, 3, 1, 4, 2, 5).reshape(-1, 3, RES, RES) * std + mean) * 255.
+    assert (regions - torch.from_numpy(gf["pp_regions"])).abs().max().item() < 2e-2
+    # the device-built list: one entry per (frame, query); the entries of non-empty masks give the same rows
+    crops_d, slot, counts = ops.crop_list_static(boxes_d, Hp, Wp)
+    assert int(counts.cpu()[0]) == int(valid.sum())
+    assert np.array_equal(slot.cpu().numpy() >= 0, valid)
+    A_all = ops.clip_crop_patches(frames, low, crops_d, Hp, Wp, RES, PS, CLIP_MEAN, CLIP_STD).cpu()
+    G2 = (RES // PS) ** 2
+    keep = torch.from_numpy(valid.reshape(-1)).repeat_interleave(G2)
+    assert torch.equal(A_all[keep], A)
+
+
+def test_linker_and_batch_index_vs_reference_post_processing(gf):
+    """minvis.py:28-72, 320-338 and brivis.py:231-240: the assignment chain on the reference's embeddings, then the re-ordering of
+    logits / masks (pure data movement: exact)."""
+    from openvis_amd.modeling.minvis import batch_video_match_via_embeds
+    embeds = torch.from_numpy(gf["tr_embeds"]).cuda()
+    idx, fe = batch_video_match_via_embeds(embeds)
+    assert np.array_equal(idx.cpu().numpy(), gf["tr_indices"])
+    assert np.array_equal(fe.cpu().numpy(), gf["tr_frame_embeds"])
+    from openvis_amd.modeling.minvis import MinVIS
+    logits, masks = torch.from_numpy(gf["tr_logits"]).cuda(), torch.from_numpy(gf["tr_masks"]).cuda()
+    post = MinVIS.post_processing(None, dict(pred_logits=logits, pred_masks=masks, pred_embeds=embeds))
+    assert np.array_equal(post["pred_logits"].cpu().numpy(), gf["tr_post_logits"])
+    assert np.array_equal(post["pred_masks"].cpu().numpy(), gf["tr_post_masks"])
+    assert np.array_equal(gf["tr_reset_logits"], gf["tr_post_logits"])        # BriVIS.reset_image_output_order: the same re-ordering
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the whole forward against the reference's whole forward
+# ------------------------------------------------------------------------------------------------------------------------------
+ARCH = {"openvis": ("OpenVIS", "VideoMultiScaleMaskedTransformerDecoder"),
+        "openvis_online": ("OpenVISOnline", "FrameMultiScaleMaskedTransformerDecoder"),
+        "san_online": ("SANOnline", "SideAdapterFrameMultiScaleMaskedTransformerDecoder"),
+        "brivis": ("BriVIS", "SideAdapterFrameMultiScaleMaskedTransformerDecoder")}
+VIT = dict(width=256, layers=4, heads=4, patch=16, resolution=64, embed_dim=64)     # tests/_synth.GLUE_CLIP in the product's terms
+
+
+@pytest.mark.parametrize("arch", list(ARCH))
+def test_model_forward_vs_reference_forward(arch):
+    from openvis_amd import config
+    from openvis_amd.catalog import MetadataCatalog
+    from openvis_amd.modeling.clip_adapter.adapter import ClipAdapter
+    from openvis_amd.modeling.clip_adapter.side_adapter import SideAdapter
+    from tests._logits import check_top10
+
+    g, frames, Wd, text, _, out_hw = load_glue_forward(arch)
+    T, H, W, K, Q, OH, OW = [int(x) for x in g["dims"]]
+    cfg = config.get_cfg()
+    cfg.MODEL.META_ARCHITECTURE, cfg.MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME = ARCH[arch]
+    cfg.MODEL.CLIP_ADAPTER.CLIP_NUM_HEADS = 4
+    cfg.MODEL.PRECISION = "fp32"
+    model = config.build_model(cfg)
+    if arch in ("openvis", "openvis_online"):
+        model.clip_adapter = ClipAdapter("tiny", arch=VIT, precision="fp32")
+    else:
+        model.clip_adapter = SideAdapter("tiny", broken_idx=3, merge_ids=[1, 2, 3], num_queries=Q, arch=VIT, precision="fp32")
+    model.load_state_dict(Wd)
+    names = [f"class_{i}" for i in range(K)]
+    MetadataCatalog.get("glue_val").set(thing_classes=names)
+    model.clip_adapter.set_text_features(names, text)
+    st = {}
+    out = model([{"image": [f for f in frames], "dataset_name": "glue_val", "height": OH, "width": OW}], stages=st)
+    torch.cuda.synchronize()
+    out = dict(out.items()) if hasattr(out, "items") else out
+    p = arch + "_"
+    assert tuple(out["image_size"]) == (OH, OW) and len(out["pred_masks"]) == 10
+    ref_probs = g[p + "probs"]
+    probs = st["probs"].cpu().numpy()
+    if arch in ("openvis", "openvis_online"):
+        valid = st["valid"]
+        assert np.array_equal(valid, g[p + "valid"])                          # which (frame, query) masks are non-empty
+        rows_ref = np.nonzero(g[p + "valid"].any(0))[0]
+        lg = st["crop_logits"].cpu().numpy()
+        assert lg.shape == g[p + "crop_logits"].shape
+        print(arch, "crop logits (x100 cosine) max abs err", np.abs(lg - g[p + "crop_logits"]).max())
+        assert np.abs(lg - g[p + "crop_logits"]).max() < 1e-1                 # 1e-3 on the cosine
+        assert np.abs(probs[rows_ref] - ref_probs).max() < 1e-3
+    else:
+        rows_ref = np.arange(Q)
+        assert np.abs(probs - ref_probs).max() < 1e-3
+    if arch != "openvis":                                                     # tracker: the assignment of every frame
+        idx = st["indices"].cpu().numpy().reshape(T, Q)
+        assert np.array_equal(idx, g[p + "indices"])
+    if arch in ("openvis_online", "san_online"):                              # the tracked low-res mask logits (fixture holds fp16)
+        pm = st["pred_masks"].cpu().numpy()
+        ref_pm = g[p + "tracked_masks"].astype(np.float32)
+        clear = np.abs(ref_pm) > 2e-2
+        assert np.array_equal((pm > 0)[clear], (ref_pm > 0)[clear])
+        assert np.abs(pm - ref_pm).max() < 3e-2
+    # top-10: tie-aware (random-init scores of all queries lie within 1e-3 of each other), then the masks of the common entries
+    ref_out = {"rows": [int(r) for r in g[p + "rows"]], "pred_labels": [int(x) for x in g[p + "labels"]],
+               "pred_scores": [float(x) for x in g[p + "scores"]]}
+    n_common, margin = check_top10(out, ref_out, ref_probs, rows_ref=[int(x) for x in rows_ref], tol=1e-3)
+    ref_masks = _bits(g[p + "masks"], (10, T, OH, OW))
+    ref_ent = {(int(rows_ref[r]), int(l)): (float(e), i) for i, (r, l, e) in enumerate(zip(g[p + "rows"], g[p + "labels"], g[p + "entropys"]))}
+    n_bits = n_diff = 0
+    for q, l, e, m in zip(out["pred_queries"], out["pred_labels"], out["pred_entropys"], out["pred_masks"]):
+        if (q, l) in ref_ent:
+            assert abs(e - ref_ent[(q, l)][0]) < 1e-2
+            a, b = m.cpu().numpy().astype(bool), ref_masks[ref_ent[(q, l)][1]]
+            n_bits += a.size
+            n_diff += int((a != b).sum())
+            union = (a | b).sum()
+            assert union == 0 or (a & b).sum() / union > 0.999
+    print(f"{arch}: top-10 common {n_common}/10 (10th - 11th margin {margin:.2e}), output mask bits differing {n_diff} of {n_bits}")
+    assert n_common >= 5
