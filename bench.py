@@ -163,6 +163,63 @@ def cpu_baseline(sd, iters=3):
                       f"timed iterations, median; threads = min(torch default, affinity, cgroup quota, 32)"}
 
 
+def collective_spans(model_fn, inputs, steps=3):
+    """Frame-sharded runs: what every rank spends in the exchange steps, `steps` untimed extra steps.  host=True spans are
+    host wall time around the call (the wait for the side-stream all-gather, the all-reduce, the mask gather: what the rank loses to the
+    collective including the wait for the slowest rank); the others are HIP-event times of replicated work."""
+    from openvis_amd import distributed as D
+    D.SPANS = {}
+    for i in range(steps):
+        o_ = model_fn(inputs[i % len(inputs)])
+        if hasattr(o_, "wait"):
+            o_.wait()
+    torch.cuda.synchronize()
+    mine = D.spans_ms()
+    D.SPANS = None
+    per_rank = D.gather_objects(mine)
+    return {"per_rank": per_rank, "max_over_ranks": {k: max(r.get(k, 0.0) for r in per_rank) for k in per_rank[0]},
+            "note": f"mean of {steps} untimed steps; all_gather_wait / logit_all_reduce / mask_gather = host wall time around the call, "
+                    "linker / temporal_resampler = HIP-event time of the replicated work"}
+
+
+def measure_frame_sharded(device, rank, world, rig, args, sync_all):
+    """north_star's multi-GPU split, measured by the DEFAULT multi-rank command: ONE BriVIS R50 clip of `--sharded-frames` 720p frames
+    (BASELINE.json configs[3]: 36), contiguous frame blocks per rank (36 over 8 ranks: 5,5,5,5,4,4,4,4), one RCCL all-gather of the
+    per-frame query embeddings in front of the replicated Brownian-bridge linker + temporal resampler, an all-reduce of the per-frame logit
+    sums (reference exchange point: modeling/minvis.py:28-72, brivis.py:173-176).  Runs in the process group of the
+    headline, after it; strong scaling: value = frames of the clip / max-over-ranks step time."""
+    from openvis_amd import distributed as D
+    T = args.sharded_frames
+    model, _, _ = build_model(device, clip_precision=args.clip_precision, precision=args.precision, model_name="brivis", f32_split=args.f32_split)
+    fr = D.inference_shard(T, rank, world)
+    kw = {"frame_range": (fr.start, fr.stop)}
+    if args.gather_masks:
+        kw["gather_masks_to"] = 0
+    clips = [synth_frames(T, H720, W720, 1000 + i, "cpu").pin_memory() for i in range(2)]
+    inputs = [[{"image": [f for f in c], "dataset_name": "synthetic_burst_val"}] for c in clips]
+    fn = lambda inp: model(inp, **kw)
+    D.warm_up(device if not rig else "cpu")                  # the first all-gather / all-reduce / gather of the communicator: untimed
+    n = max(2, min(20, args.steps // 5))
+    for i in range(2):
+        fn(inputs[i % 2])
+    sync_all()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(n):
+        out = fn(inputs[i % 2])
+    sync_all()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, "cpu" if rig else device)
+    if out is not None and hasattr(out, "wait"):
+        out.wait()
+    spans = collective_spans(fn, inputs)
+    return {"value": round(T * n / elapsed, 3), "unit": "frames/s", "ms_per_step": round(elapsed / n * 1e3, 3), "steps": n, "scaling": "strong",
+            "frames_per_rank": [len(D.inference_shard(T, r, world)) for r in range(world)], "world_size_seen": D.world_size(),
+            "collective_ms": spans,
+            "workload": f"brivis R50 720p, ONE {T}-frame clip frame-sharded x{world}, RCCL all-gather of [t,100,256] query embeddings + "
+                        f"replicated linker / resampler + logit all-reduce" + (" + mask gather to rank 0" if args.gather_masks else ""),
+            "note": "BASELINE.json configs[3] (north_star's split) in the same process group as the clip-replica headline; not the headline"}
+
+
 def _respawn_ranks(args):
     """`python bench.py --gpus N` without torchrun: start the N ranks as CHILD processes (torch.distributed.run) before
     anything touches the GPU, and exit with their code.  (Never exec: the GPU boxes refuse an exec after GPU init.)"""
@@ -200,6 +257,9 @@ def main():
     ap.add_argument("--gather-masks", action="store_true",
                     help="frame-sharded runs: gather the ten output masks of all frames on rank 0 (the reference's single video_output); "
                          "default: every rank keeps the masks of its own frames for a sharded evaluator (SURVEY.md 8e (3))")
+    ap.add_argument("--sharded-frames", type=int, default=36,
+                    help="N > 1 with the default model: frames of the ONE BriVIS clip that is additionally run frame-sharded over the ranks "
+                         "(`frame_sharded` on the JSON line; BASELINE.json configs[3]: 36); 0 skips it")
     ap.add_argument("--precision", default="mixed", choices=["mixed", "fp32"],
                     help="dense-path policy: mixed = the reference's autocast policy, fp32 = exact f32 everywhere")
     ap.add_argument("--f32-split", default="auto", choices=["auto", "fp16x2", "bf16x3", "bf16x2", "f32"],
@@ -335,22 +395,14 @@ def main():
         torch.cuda.synchronize()
 
     # ---- frame-sharded runs: what every rank spends in the exchange steps, untimed extra steps --------------------
-    # host=True spans are host wall time around the call (the wait for the side-stream all-gather, the all-reduce, the mask gather:
-    # what the rank loses to the collective including the wait for the slowest rank); the others are HIP-event times of replicated work
-    collective_ms = None
-    if frame_sharded:
-        D.SPANS = {}
-        for i in range(3):
-            o_ = model(inputs[i % len(inputs)])
-            if hasattr(o_, "wait"):
-                o_.wait()
-        torch.cuda.synchronize()
-        mine = D.spans_ms()
-        D.SPANS = None
-        per_rank = D.gather_objects(mine)
-        collective_ms = {"per_rank": per_rank, "max_over_ranks": {k: max(r.get(k, 0.0) for r in per_rank) for k in per_rank[0]},
-                         "note": "mean of 3 untimed steps; all_gather_wait / logit_all_reduce / mask_gather = host wall time around the call, "
-                                 "linker / temporal_resampler = HIP-event time of the replicated work"}
+    collective_ms = collective_spans(model, inputs) if frame_sharded else None
+
+    # ---- N > 1, default model: north_star's own multi-GPU split next to the clip-replica headline ---------------------------------
+    # The OpenVIS offline decoder attends over all frames of a clip, so the headline shards by CLIP and its only collective is the
+    # timing's scalar.  The frame-sharded BriVIS pass (configs[3]) is what moves data over RCCL / xGMI: one command measures both.
+    frame_sharded_side = None
+    if world > 1 and not frame_sharded and args.model == "openvis" and args.sharded_frames > 0:
+        frame_sharded_side = measure_frame_sharded(device, rank, world, rig, args, sync_all)
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream -----------
     # Per-launch events around every GEMM / K1 launch (ops.PROFILE).  Two untimed passes:
@@ -554,7 +606,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "f32_split": f32_split, "f32_split_f32_grade": f32_split != "bf16x2",
             "f32_split_fell_back_to_bf16x3": bool(fell_back),
             "crop_list": getattr(getattr(_model, "clip_adapter", None), "crop_list", None), "alt_f32_split": alt, "alt_f32_splits": alts,
-            "two_clips_in_flight": in_flight2,
+            "two_clips_in_flight": in_flight2, "frame_sharded": frame_sharded_side,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if frame_sharded else "weak",
             "vs_baseline": None, "dtype": "f16" if "fp16" in (bb_prec, _model.clip_adapter.precision) else "f32", "data": "synthetic",

@@ -259,7 +259,7 @@ class ClipAdapter:
     mask_prompt_fwd = False
     crop_list = "auto"               # MODEL.CLIP_ADAPTER.CROP_LIST (config.py)
     _valid_frac = None               # share of non-empty masks of the most recent clip whose count is known (auto mode)
-    _pending_count = None            # (event, pinned host int32 [1], T*Q) of a device-list forward whose count is still on its way
+    _pending_counts = ()             # (event, pinned host int32 [1], T*Q) of the device-list forwards whose counts are still on their way, oldest first
 
     def __init__(self, clip_model_name="ViT-B/16", text_templates="vild", arch=None, precision="fp16"):
         self.clip_model_name = clip_model_name
@@ -319,10 +319,14 @@ class ClipAdapter:
         """MODEL.CLIP_ADAPTER.CROP_LIST resolved for this forward; "auto" looks at the newest known share of non-empty masks."""
         if self.crop_list != "auto":
             return self.crop_list == "device"
-        pend = self._pending_count
-        if pend is not None and pend[0].query():                 # the count of an earlier device-list forward has arrived (never waits)
-            self._valid_frac = float(pend[1][0]) / float(pend[2])
-            self._pending_count = None
+        # Deterministic: clip n looks at the count of clip n - 2, never at "whatever has arrived" (an event.query() made the choice -- and with
+        # it the GEMM shapes: M compacted or T Q -- depend on host timing).  That copy was queued two forwards ago behind clip n - 2's mask
+        # kernel; the launch window (_lib.LAUNCH_WINDOW) keeps the host less than a clip ahead, so the synchronize returns at once.
+        if len(self._pending_counts) >= 2:
+            ev, host, n = self._pending_counts[0]
+            ev.synchronize()
+            self._valid_frac = float(host[0]) / float(n)
+            self._pending_counts = self._pending_counts[1:]
         return self._valid_frac is not None and self._valid_frac >= 0.9
 
     def forward(self, frames, text, masks_lowres, padded_hw):
@@ -343,7 +347,7 @@ class ClipAdapter:
                     ev = torch.cuda.Event()
                     ev.record(side)
                 counts.record_stream(side)
-                self._pending_count = (ev, host, slot.numel())
+                self._pending_counts = tuple(self._pending_counts) + ((ev, host, slot.numel()),)
             M = crops_d.shape[0]
             if self.mask_prompt_fwd:
                 A, patch_open = ops.clip_crop_patches_masked(frames, masks_lowres, crops_d, Hp, Wp, self.input_resolution, self.arch["patch"],
@@ -357,6 +361,7 @@ class ClipAdapter:
             return ops.gemm_nt(feat, self.encode_text(text)), dc, crops_d
         valid, crops = self.preprocess_boxes(masks_lowres, Hp, Wp)
         self._valid_frac = float(valid.mean()) if valid.size else 0.0
+        self._pending_counts = ()                                 # this clip's own share is newer than any count still on its way
         if crops.shape[0] == 0:
             return None, valid, crops
         crops_d = ops.to_device_async(crops, self.device)

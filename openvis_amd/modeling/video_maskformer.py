@@ -106,6 +106,16 @@ class VideoMaskFormer:
         out = redo()
         return dict(out.items()) if hasattr(out, "items") else out
 
+    @staticmethod
+    def _check_selected_rows(scores, topk, K):
+        """Device crop list: EVERY query row takes part in the top-k and rows without a crop hold -1.  A selected -1 means fewer than `topk`
+        (valid query, class) pairs exist -- where the reference's `scores.flatten(0, 1).topk(10)` raises (video_maskformer.py:269) and the
+        host crop-list path raises inside ovis_topk_entropy; never hand out the filler rows as detections."""
+        if scores and min(scores) < 0:
+            n = sum(1 for v in scores if v >= 0)
+            raise RuntimeError(f"inference_video: top-{topk} over {n // max(K, 1)} valid queries x {K} classes: selected index k out of range "
+                               "(fewer (query, class) pairs than topk; video_maskformer.py:269)")
+
     output_rle = False        # MODEL.MASK_FORMER.TEST.OUTPUT_RLE (not a reference key): RLE hand-off instead of dense masks
     mask_gather = None        # frame-sharded runs: callable(device masks [n,t_local,H,W]) -> masks of all frames on the output rank / None
 
@@ -154,8 +164,10 @@ class VideoMaskFormer:
                 return {"image_size": (output_height, output_width), "pred_entropys": [], "pred_scores": [], "pred_labels": [], "pred_masks_rle": [],
                         "pred_queries": []}
             labels = [i % K for i in idx.cpu().tolist()]
+            scores = score.cpu().tolist()
+            self._check_selected_rows(scores, topk, K)
             return {"image_size": (output_height, output_width), "pred_entropys": ent.cpu().tolist(),
-                    "pred_scores": score.cpu().tolist(), "pred_labels": labels,
+                    "pred_scores": scores, "pred_labels": labels,
                     "pred_masks_rle": rle.encode_video_masks(counts, n_runs, topk, T, output_height, output_width),
                     "pred_queries": sel_q.cpu().tolist()}
         masks = ops.final_masks(pred_masks_lowres, sel_q, padded_hw[0], padded_hw[1], img_size[0], img_size[1],
@@ -203,6 +215,7 @@ class VideoMaskFormer:
             if nv_host is not None and int(nv_host[0]) == 0:                  # no mask had a positive pixel (openvis.py:127-128)
                 return {"pred_entropys": [], "pred_scores": [], "pred_labels": [], "pred_masks": [], "pred_queries": []}
             i_, s_, e_, q_ = (h_.tolist() for h_ in small)
+            self._check_selected_rows(s_, topk, K)
             return {"pred_entropys": e_, "pred_scores": s_, "pred_labels": [i % K for i in i_],      # video_maskformer.py:269-270
                     "pred_masks": [m for m in host.view(torch.bool)], "pred_queries": q_}
         return VideoOutput({"image_size": (output_height, output_width)}, done, finish)

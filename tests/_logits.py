@@ -53,3 +53,16 @@ def check_top10(out_gpu, ref, ref_probs, rows_ref=None, tol=1e-3):
         assert q in row_of and p[row_of[q], l] >= s10 - 2 * tol, ("GPU top-10 entry is not a reference top-10 candidate", q, l, s)
         assert abs(p[row_of[q], l] - s) <= tol, ((q, l), s, p[row_of[q], l])
     return len(set(sg) & set(sr)), s10 - s11
+
+
+def differing_bits_outside_ambiguous(got, ref, gold):
+    """"Masks match bit-exact" as the workload goldens state it (oracle/make_golden_workload.py `ambiguous`): next to the oracle's sign
+    bits the fixture holds, for each eps of `ambig_eps`, the bitmap of the pixels whose ORACLE logit lies within eps of zero.
+    got / ref: bool arrays [..., h, w].  Returns (n_differing, {eps: number of differing bits OUTSIDE the eps set})."""
+    diff = got != ref
+    out = {}
+    for i, eps in enumerate(gold["ambig_eps"]):
+        amb = np.unpackbits(gold[f"ambig_bits_{i}"], axis=-1)[..., : ref.shape[-1]].astype(bool)
+        assert amb.shape == ref.shape
+        out[float(eps)] = int((diff & ~amb).sum())
+    return int(diff.sum()), out

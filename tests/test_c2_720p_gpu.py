@@ -79,8 +79,8 @@ def test_c2_720p_clip_under_the_bench_policy_matches_oracle():
     assert min(ious) > 0.999, ious
 
 
-@pytest.mark.parametrize("split", ["auto", "bf16x3", "bf16x2"])
-def test_c2_full_size_5_frames_against_the_oracle_golden(split):
+@pytest.mark.parametrize("split,backbone", [("auto", "auto"), ("bf16x3", "auto"), ("bf16x2", "auto"), ("auto", "fp32"), ("bf16x3", "fp32")])
+def test_c2_full_size_5_frames_against_the_oracle_golden(split, backbone):
     """configs[1] at FULL size -- the very clip bench.py times first (5 frames of 720x1280, seed 1000, 100 queries, 482 classes) -- against
     the f32 CPU oracle's outputs committed as tests/golden/c2_openvis_720p_5f.npz (oracle/make_golden_workload.py c2; the oracle needs
     minutes for it).  Under the timed policy (auto = fp16x2), the f32-grade bf16x3 and the 16-bit bf16x2; the exact-bit rate of the mask
@@ -95,7 +95,9 @@ def test_c2_full_size_5_frames_against_the_oracle_golden(split):
     sd = weights.random_init(weights.openvis_spec("r50", None, 100), seed=42)
     cfg = config.get_cfg()
     cfg.MODEL.F32_GEMM_SPLIT = split
+    cfg.MODEL.BACKBONE_PRECISION = backbone
     model = config.build_model(cfg)
+    assert model.backbone.precision == ("fp16" if backbone == "auto" else "fp32")
     model.load_state_dict(sd)
     names = [f"class_{i}" for i in range(K)]
     MetadataCatalog.get("synthetic_c2").set(thing_classes=names)
@@ -110,11 +112,20 @@ def test_c2_full_size_5_frames_against_the_oracle_golden(split):
     assert got.shape == ref.shape == (100, T, 184, 320)
     inter, union = (got & ref).sum(axis=(1, 2, 3)).astype(np.float64), (got | ref).sum(axis=(1, 2, 3)).astype(np.float64)
     iq = np.where(union > 0, inter / np.maximum(union, 1), 1.0)
-    print("C2 full size [%s]: exact bit match rate %.6f (%d of %d bits differ), per-query IoU min %.5f median %.5f, %d of 100 query masks bit-identical"
-          % (split, (got == ref).mean(), int((got != ref).sum()), got.size, iq.min(), np.median(iq), int((got == ref).all(axis=(1, 2, 3)).sum())))
+    print("C2 full size [%s, backbone %s]: exact bit match rate %.6f (%d of %d bits differ), per-query IoU min %.5f median %.5f, %d of 100 query masks bit-identical"
+          % (split, backbone, (got == ref).mean(), int((got != ref).sum()), got.size, iq.min(), np.median(iq), int((got == ref).all(axis=(1, 2, 3)).sum())))
     assert iq.min() >= 0.999, (iq.min(), int((iq < 0.999).sum()))
+    from tests._logits import differing_bits_outside_ambiguous
+    n_diff, outside = differing_bits_outside_ambiguous(got, ref, g)
+    print("C2 full size [%s, backbone %s]: %d differing bits; outside the |oracle logit| < eps sets: %s" % (split, backbone, n_diff, outside))
+    if backbone == "fp32" and split != "bf16x2":
+        assert outside[1e-4] == 0, outside          # f32-class everywhere: bit-exact outside |oracle logit| < 1e-4
+    else:
+        assert outside[3e-2] == 0, outside          # fp16-operand backbone (reference autocast) / 16-bit bf16x2 split
     vg, vr = st["valid"], g["valid"].astype(bool)
     assert (vg == vr).mean() > 0.99
+    if backbone == "fp32":
+        assert np.array_equal(vg, vr)               # ... and with them every valid flag
     # cosine logits on the crops whose box is identical on both sides
     lg = st["crop_logits"].cpu().numpy()
     gb = {(int(c[0]), int(c[1])): (i, c[2:]) for i, c in enumerate(st["crops"])}

@@ -74,7 +74,7 @@ def test_device_crop_list_equals_host_crop_list(kind):
 
 def test_auto_mode_switches_to_the_device_list_after_a_clip_with_mostly_valid_masks():
     """auto: the first clip reads the boxes back (and learns the share of non-empty masks); from then on the list is built on the device
-    while that share stays >= 90 % -- the count of a device-list clip rides back with its outputs and is consulted without waiting."""
+    while that share stays >= 90 % -- the count of a device-list clip rides back with its outputs and decides two clips later."""
     import bench
     model, names = _model("auto")
     ad = model.clip_adapter
@@ -91,7 +91,34 @@ def test_auto_mode_switches_to_the_device_list_after_a_clip_with_mostly_valid_ma
     assert ("device_crops" in st2) == (frac >= 0.9)
     assert o1["pred_labels"] == o2["pred_labels"] and o1["pred_scores"] == o2["pred_scores"]
     assert all(torch.equal(a, b) for a, b in zip(o1["pred_masks"], o2["pred_masks"]))
-    torch.cuda.synchronize()
-    ad._use_device_list()                                                                      # picks up the count that rode back
     if frac >= 0.9:
-        assert ad._pending_count is None and abs(ad._valid_frac - frac) < 1e-6
+        # the count of a device-list clip is consulted TWO clips later, deterministically (never "whatever has arrived by now")
+        assert len(ad._pending_counts) == 1
+        ad._valid_frac = -1.0
+        assert ad._use_device_list() is False and len(ad._pending_counts) == 1                 # clip n - 1's count is not looked at
+        ad._valid_frac = frac
+        o3 = model(inp)
+        o3.wait()
+        assert len(ad._pending_counts) == 2
+        assert ad._use_device_list() and len(ad._pending_counts) == 1 and abs(ad._valid_frac - frac) < 1e-6
+
+
+def test_device_list_raises_when_fewer_pairs_than_topk_exist():
+    """Device crop list: every query row takes part in the top-k and rows without a crop hold -1.  With fewer (valid query, class) pairs
+    than topk the reference's `topk(10)` raises (video_maskformer.py:269) and so does the host-list path; the device-list path must not
+    hand out the -1 filler rows as detections (round-4 review)."""
+    model, names = _model("device")
+    Q, K, T, h, w = 100, 3, 2, 24, 32
+    probs = torch.full((Q, K), -1.0, device="cuda")
+    probs[[5, 17]] = torch.tensor([[0.2, 0.3, 0.5], [0.6, 0.3, 0.1]], device="cuda")      # 2 valid queries x 3 classes = 6 pairs < 10
+    rid = torch.arange(Q, dtype=torch.int32, device="cuda")
+    masks = torch.randn(Q, T, h, w, device="cuda")
+    nv = torch.tensor([3], dtype=torch.int32, device="cuda")
+    out = model.inference_video(Q, K, probs, rid, masks, (4 * h, 4 * w), (90, 120), 90, 120, n_valid=nv)
+    with pytest.raises(RuntimeError, match="out of range"):
+        out.wait() if hasattr(out, "wait") else None
+        out["pred_scores"]
+    # ... and with at least topk pairs the same call returns them
+    probs[[1, 2]] = torch.tensor([[0.1, 0.2, 0.7], [0.3, 0.3, 0.4]], device="cuda")       # 4 x 3 = 12 pairs
+    out = model.inference_video(Q, K, probs, rid, masks, (4 * h, 4 * w), (90, 120), 90, 120, n_valid=nv)
+    assert len(out["pred_scores"]) == 10 and min(out["pred_scores"]) > 0 and set(out["pred_queries"]) <= {1, 2, 5, 17}

@@ -54,7 +54,8 @@ def test_bench_multi_rank_control_flow(model, scaling, tmp_path):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="29651",
                    OVIS_BENCH_TEST_RIG="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                                       "--model", model, "--frames", "6" if model == "brivis" else "0"] + (["--gather-masks"] if model == "brivis" else []), env=env,
+                                       "--model", model, "--frames", "6" if model == "brivis" else "0", "--sharded-frames", "6"]
+                                      + (["--gather-masks"] if model == "brivis" else []), env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
@@ -70,8 +71,16 @@ def test_bench_multi_rank_control_flow(model, scaling, tmp_path):
         assert len(cm["per_rank"]) == 2 and all(set(r) >= {"all_gather_wait", "linker", "temporal_resampler", "logit_all_reduce", "mask_gather"}
                                                 for r in cm["per_rank"][:1])
         assert {"all_gather_wait", "linker", "logit_all_reduce"} <= set(cm["per_rank"][1]) and all(v >= 0 for v in cm["max_over_ranks"].values())
+        assert d["frame_sharded"] is None
     else:
+        # the default multi-rank command also measures north_star's split: ONE BriVIS clip frame-sharded over the same ranks
         assert d["collective_ms"] is None
+        fs = d["frame_sharded"]
+        assert fs["value"] > 0 and fs["unit"] == "frames/s" and fs["scaling"] == "strong" and fs["ms_per_step"] > 0
+        assert fs["frames_per_rank"] == [3, 3] and fs["world_size_seen"] == 2
+        cm = fs["collective_ms"]
+        assert len(cm["per_rank"]) == 2 and all({"all_gather_wait", "linker", "temporal_resampler", "logit_all_reduce"} <= set(r) for r in cm["per_rank"])
+        assert all(v >= 0 for v in cm["max_over_ranks"].values())
 
 
 def test_rccl_collectives_of_the_frame_sharded_path():
