@@ -30,6 +30,20 @@ PEAK_F16_MFMA_TFLOPS = 2500.0     # same guide: Peak BF16/FP16 MFMA, dense (~2.5
 PEAK_HBM_GBS = 8000.0
 
 
+def csrc_digest():
+    """sha256 over the kernel sources (openvis_amd/csrc: *.hip, *.h, *.cpp, Makefile, torch_ext/*), in sorted path order.  tools/pmc_traffic.py
+    stores it with the PMC traffic summary; the bench line only quotes a summary whose digest matches the sources it runs on."""
+    import glob
+    import hashlib
+    base = os.path.join(ROOT, "openvis_amd", "csrc")
+    files = sorted(f for pat in ("*.hip", "*.h", "*.cpp", "Makefile", "torch_ext/*.cpp", "torch_ext/*.h") for f in glob.glob(os.path.join(base, pat)))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.relpath(f, base).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def synth_frames(T, H, W, seed, device):
     g = torch.Generator().manual_seed(seed)
     base = torch.rand(T, 3, H, W, generator=g) * 255
@@ -471,16 +485,23 @@ def main():
     def _norm(k):
         return k.replace("(anonymous namespace)::", "").replace("void ", "").replace(" ", "")
 
-    pmc, pmc_src = {}, None
+    pmc, pmc_src, pmc_stale = {}, None, None
     import glob
+    digest = csrc_digest()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_bench.json")), reverse=True):
         try:
             d = json.load(open(f))
-            pmc = {_norm(k): v for k, v in d["kernels"].items()}
-            pmc_src = {"file": os.path.relpath(f, ROOT), "commit": d.get("commit"), "static": True}
-            break
         except Exception:
             continue
+        if d.get("csrc_sha256") != digest:
+            # counters of OTHER kernel sources say nothing about the kernels timed here: traffic stays null, with the reason on the line
+            pmc_stale = {"file": os.path.relpath(f, ROOT), "commit": d.get("commit"),
+                         "reason": "openvis_amd/csrc changed since these PMC passes were collected (csrc_sha256 differs): re-run tools/final_verify.sh"}
+            break
+        pmc = {_norm(k): v for k, v in d["kernels"].items()}
+        pmc_src = {"file": os.path.relpath(f, ROOT), "commit": d.get("commit"), "csrc_sha256": digest[:16], "static": True,
+                   "note": "PMC passes of this same command on the same kernel sources (digest verified at run time)"}
+        break
 
     def _pmc_lookup(name):
         fh = name.endswith(",FH>")                            # fp16x2 instantiations: the template's LAST argument is true
@@ -533,7 +554,7 @@ def main():
     traffic = tv["hbm_bytes_per_launch"] if tv else None
     roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "peak_note": peak_note, "traffic": traffic,
-                "traffic_source": pmc_src if traffic is not None else None,
+                "traffic_source": pmc_src if traffic is not None else pmc_stale,
                 "traffic_split": ({"fetch": tv["fetch_bytes_per_launch"], "write": tv["write_bytes_per_launch"]} if tv else None),
                 "measured": (f"HIP events per launch, in situ: {args.steps} clips with {args.streams} in flight (launches of "
                              "different clips share the GPU)" if pipelined else "HIP events per launch, one clip on one stream"),
@@ -596,6 +617,15 @@ def main():
                        "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": ktraffic, "launches_per_step": kn // n_situ,
                        "avg_launch_ms": round(ksecs / kn * 1e3, 4), "algorithmic_mb_per_launch": round(kbytes / kn / 1e6, 2),
                        "isolated": {"achieved": round(kiso[1] / kiso[2] / 1e9, 1), "avg_launch_ms": round(kiso[2] / kiso[0] * 1e3, 4)}}
+        # The roof that BINDS K1 is not HBM (the value tensor of a frame level is L2 / Infinity-Cache resident): every (query, head, level, point)
+        # pulls four 128-byte tap segments through the CU's L1 -- 48 taps x 128 B x 8 heads per token.  MI355X_MICROARCH.md, "Indexed rows: gather
+        # into LDS": rows served from the XCD's L2 arrive at 66-73 GB/s per CU = 16.8-18.8 TB/s chip-wide (profiles/r05/k1_tiled_sweep.txt).
+        tokens = kbytes / kn / 3200.0                                # algorithmic bytes per launch = 3 200 B per token
+        gathered = tokens * 8 * 48 * 128
+        roofline_k1["gather"] = {"bound": "L2 -> CU gather path", "gathered_bytes_per_launch": int(gathered),
+                                 "achieved": round(gathered / (ksecs / kn) / 1e12, 2), "peak": 18.8, "unit": "TB/s",
+                                 "frac": round(gathered / (ksecs / kn) / 1e12 / 18.8, 3),
+                                 "peak_note": "16.8-18.8 TB/s: the guide's measured rate for rows gathered from the XCD's L2 (66-73 GB/s per CU)"}
     if rank == 0:
         frames_total = T * args.steps * (1 if frame_sharded else world)
         n_valid = int(st["valid"].sum()) if "valid" in st else 0

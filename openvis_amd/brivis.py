@@ -15,6 +15,7 @@ from .config import resampler_precision
 from . import distributed as D
 from .modeling.minvis import batch_video_match_via_embeds
 from .modeling.resampler import TemporalInstanceResampler
+from .modeling.video_maskformer import retry_if_oom
 from .registry import META_ARCH_REGISTRY
 from .san import SANOnline
 
@@ -38,6 +39,7 @@ class BriVIS(SANOnline):
         self.resampler.load_state_dict(sd, "resampler.", self.device)
         return self
 
+    @retry_if_oom
     def forward(self, batched_inputs, stages=None, frame_range=None, gather_masks_to=None):
         """frame_range=(begin, end): this rank's contiguous frame block of the clip (frame-sharded mode; requires an
         initialised process group). Default: all frames on this rank.  gather_masks_to=r: the selected output masks of all

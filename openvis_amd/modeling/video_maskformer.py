@@ -6,6 +6,44 @@ from .. import ops
 from ..registry import META_ARCH_REGISTRY, BACKBONE_REGISTRY, SEM_SEG_HEADS_REGISTRY
 
 
+def retry_if_oom(forward):
+    """The reference wraps its big eval stages in detectron2's `retry_if_cuda_oom` (openvis.py:108, video_maskformer.py:205 / 213,
+    brivis.py:201 / 211): run; on a CUDA out-of-memory error empty the caching allocator and run again; then run with the inputs moved to
+    the CPU.  Here the same ladder sits around the whole eval forward (the stages the reference protects -- the x4 mask upsample and the
+    output masks -- are never materialised by this implementation, so what can run out is a whole-video activation set):
+      1. run;  2. OutOfMemoryError -> synchronize, torch.cuda.empty_cache(), run again;
+      3. still out of memory -> the per-frame (online) models run once more as WINDOWS of MODEL.MASK_FORMER.TEST.WINDOW_SIZE frames
+         (minvis.py:340-362: same outputs, activation memory bounded by the window) -- there is no CPU path to fall back to, by design;
+         the offline models (decoder joint over all frames) and frame-sharded runs (every rank must take the same path through the
+         collectives) re-raise."""
+    import functools
+    import warnings
+
+    @functools.wraps(forward)
+    def wrapped(self, batched_inputs, *args, **kwargs):
+        try:
+            return forward(self, batched_inputs, *args, **kwargs)
+        except torch.OutOfMemoryError:
+            pass
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        try:
+            return forward(self, batched_inputs, *args, **kwargs)
+        except torch.OutOfMemoryError:
+            sharded = kwargs.get("frame_range") is not None or (len(args) >= 2 and args[1] is not None)     # BriVIS.forward(.., stages, frame_range)
+            if sharded or not hasattr(self, "window_inference") or self.window_inference:
+                raise
+        warnings.warn(f"{type(self).__name__}: out of device memory on a whole clip; repeating it as windows of {self.window_size} frames")
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        self.window_inference = True
+        try:
+            return forward(self, batched_inputs, *args, **kwargs)
+        finally:
+            self.window_inference = False
+    return wrapped
+
+
 def build_backbone(cfg):
     return BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg)
 

@@ -10,7 +10,7 @@ import torch
 from . import ops
 from .catalog import MetadataCatalog
 from .modeling.clip_adapter import build_clip_adapter
-from .modeling.video_maskformer import VideoMaskFormer
+from .modeling.video_maskformer import VideoMaskFormer, retry_if_oom
 from .registry import META_ARCH_REGISTRY
 
 
@@ -36,6 +36,7 @@ class OpenVIS(VideoMaskFormer):
     def get_class_name_list(self, dataset_name):
         return [c.strip() for c in MetadataCatalog.get(dataset_name).thing_classes]
 
+    @retry_if_oom
     def forward(self, batched_inputs, stages=None):
         dataset_name = list(set(x["dataset_name"] for x in batched_inputs))[0]
         class_names = self.get_class_name_list(dataset_name)
@@ -132,6 +133,7 @@ class OpenVISOnline(OpenVIS):
         args["window"] = (cfg.MODEL.MASK_FORMER.TEST.WINDOW_INFERENCE, cfg.MODEL.MASK_FORMER.TEST.WINDOW_SIZE)
         return args
 
+    @retry_if_oom
     def forward(self, batched_inputs, stages=None):
         dataset_name = batched_inputs[0]["dataset_name"]
         class_names = self.get_class_name_list(dataset_name)

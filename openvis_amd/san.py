@@ -10,7 +10,7 @@ from . import ops
 from .catalog import MetadataCatalog
 from .modeling.clip_adapter.side_adapter import SideAdapter
 from .modeling.minvis import MinVIS
-from .modeling.video_maskformer import VideoMaskFormer
+from .modeling.video_maskformer import VideoMaskFormer, retry_if_oom
 from .registry import META_ARCH_REGISTRY
 
 
@@ -54,6 +54,7 @@ class SAN(VideoMaskFormer):
     def get_class_name_list(self, dataset_name):
         return [c.strip() for c in MetadataCatalog.get(dataset_name).thing_classes]
 
+    @retry_if_oom
     def forward(self, batched_inputs, stages=None):
         dataset_name = list(set(x["dataset_name"] for x in batched_inputs))[0]
         class_names = self.get_class_name_list(dataset_name)
@@ -128,6 +129,7 @@ class SANOnline(MinVIS):
         """mean over frames, softmax, drop the background column (san.py:257,264-265) -> probs [Q,K]."""
         return _classify(pred_logits)
 
+    @retry_if_oom
     def forward(self, batched_inputs, stages=None):
         dataset_name = list(set(x["dataset_name"] for x in batched_inputs))[0]
         class_names = self.get_class_name_list(dataset_name)

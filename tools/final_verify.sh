@@ -17,7 +17,7 @@ cd $ROOTD
 python tools/trace_by_shape.py $R/stats $R/kernel_by_shape.csv 23
 python tools/pmc_traffic.py $R/pmc_fetch $R/pmc_write $R/pmc_traffic_bench.json "${GIT_HEAD:-unknown}"
 python tools/pmc_mfma.py $R/pmc_mfma $R/pmc_mfma_bench.json
-mkdir -p profiles/${ROUND:-r04} && cp $R/pmc_traffic_bench.json profiles/${ROUND:-r04}/pmc_traffic_bench.json   # so that the bench line below reads THIS build's traffic
+mkdir -p profiles/${ROUND:-r05} && cp $R/pmc_traffic_bench.json profiles/${ROUND:-r05}/pmc_traffic_bench.json   # so that the bench line below reads THIS build's traffic
 python bench.py > $R/bench_default.json 2> $R/bench_default.err
 if [ "${1:-}" != "quick" ]; then
   for m in openvis_online san_online brivis brivis_swinl openvis_swinl; do python bench.py --model $m --steps 10 --warmup 2 2>> $R/bench_models.err | tail -1 >> $R/bench_all_models.jsonl; done

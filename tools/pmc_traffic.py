@@ -86,6 +86,9 @@ if __name__ == "__main__":
         wb = 1024 * sum(w) / max(len(w), 1)
         res[short(k)] = {"launches": max(len(f), len(w)), "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
                          "hbm_bytes_per_launch": round(fb + wb)}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_digest                              # hash of the kernel sources these counters were collected on
     json.dump({"note": "FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes, "
-                       "average per launch; separate --pmc passes", "commit": commit, "kernels": res}, open(out, "w"), indent=1)
+                       "average per launch; separate --pmc passes", "commit": commit, "csrc_sha256": csrc_digest(), "kernels": res},
+              open(out, "w"), indent=1)
     print("wrote", out, len(res), "kernels")
