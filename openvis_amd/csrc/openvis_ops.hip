@@ -1194,11 +1194,32 @@ topk_entropy_kernel(const float* __restrict__ probs, const int* __restrict__ row
 
 // A16 (masks): for the selected queries: x4 bilinear upsample to the padded size, crop to [H,W], bilinear resize to
 // (OH,OW), threshold > 0 (openvis.py:87-96; video_maskformer.py:273-278). out uint8 [n_sel,T,OH,OW].
+// One output pixel: the same expressions in the same order as the reference's two interpolations (identical bits whatever the launch shape).
+__device__ __forceinline__ unsigned final_mask_bit(const float* __restrict__ mp, int oy, int ox, int h, int w, float usy, float usx, int H, int W,
+                                                   int OH, int OW) {
+  if (OH == H && OW == W)
+    // output size == image size (the usual case): the second resize is the identity (its taps are (oy, weight 1) and a weight-0
+    // neighbour), so one bilinear evaluation gives the same bits as the four below
+    return bilerp(mp, w, make_tap(oy, usy, h), make_tap(ox, usx, w)) > 0.f ? 1u : 0u;
+  const Tap oyT = make_tap(oy, (float)H / (float)OH, H), oxT = make_tap(ox, (float)W / (float)OW, W);
+  const Tap ty0 = make_tap(oyT.i0, usy, h), ty1 = make_tap(oyT.i1, usy, h);
+  const Tap tx0 = make_tap(oxT.i0, usx, w), tx1 = make_tap(oxT.i1, usx, w);
+  const float a = bilerp(mp, w, ty0, tx0), b = bilerp(mp, w, ty0, tx1);
+  const float c = bilerp(mp, w, ty1, tx0), d = bilerp(mp, w, ty1, tx1);
+  const float v = oyT.l0 * (oxT.l0 * a + oxT.l1 * b) + oyT.l1 * (oxT.l0 * c + oxT.l1 * d);
+  return v > 0.f ? 1u : 0u;
+}
+
+// VEC consecutive output pixels of the fast axis per thread, stored as ONE word of VEC bytes (VEC = 1: any size; VEC = 4 / 16 when the
+// fast axis is a multiple of it).  One byte per thread -- round 4's form -- is store-issue bound: 64-byte wave stores and three 64-bit
+// divisions per pixel (214 us for ten 5 x 720 x 1280 masks, 46 MB; VEC = 16: one 1-KB store per wavefront, the divisions once per 16 pixels).
+template <int VEC>
 __global__ void __launch_bounds__(256)
 final_masks_kernel(const float* __restrict__ masks, const int* __restrict__ sel_q, uint8_t* __restrict__ out, int n_sel,
                    int Q, int T, int h, int w, int Hp, int Wp, int H, int W, int OH, int OW, int column_major) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)n_sel * T * OH * OW;
+  const long long i = g * VEC;
   if (i >= total) return;
   // row-major [.., OH, OW] (the reference's tensor) or column-major [.., OW, OH] (the order COCO RLE scans a mask in)
   int ox, oy;
@@ -1209,19 +1230,80 @@ final_masks_kernel(const float* __restrict__ masks, const int* __restrict__ sel_
   const int j = (int)(r / T);
   const float* mp = masks + ((long long)sel_q[j] * T + t) * h * w;
   const float usy = (float)h / (float)Hp, usx = (float)w / (float)Wp;
-  if (OH == H && OW == W) {
-    // output size == image size (the usual case): the second resize is the identity (its taps are (oy, weight 1) and a weight-0
-    // neighbour), so one bilinear evaluation gives the same bits as the four below
-    out[i] = bilerp(mp, w, make_tap(oy, usy, h), make_tap(ox, usx, w)) > 0.f ? 1 : 0;
-    return;
+  if constexpr (VEC == 1) {
+    out[i] = (uint8_t)final_mask_bit(mp, oy, ox, h, w, usy, usx, H, W, OH, OW);
+  } else {
+    unsigned wd[VEC / 4];
+#pragma unroll
+    for (int k = 0; k < VEC / 4; ++k) {
+      unsigned v = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int o = 4 * k + e;
+        v |= final_mask_bit(mp, column_major ? oy + o : oy, column_major ? ox : ox + o, h, w, usy, usx, H, W, OH, OW) << (8 * e);
+      }
+      wd[k] = v;
+    }
+    if constexpr (VEC == 4) *reinterpret_cast<unsigned*>(out + i) = wd[0];
+    else *reinterpret_cast<uint4*>(out + i) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
   }
-  const Tap oyT = make_tap(oy, (float)H / (float)OH, H), oxT = make_tap(ox, (float)W / (float)OW, W);
-  const Tap ty0 = make_tap(oyT.i0, usy, h), ty1 = make_tap(oyT.i1, usy, h);
-  const Tap tx0 = make_tap(oxT.i0, usx, w), tx1 = make_tap(oxT.i1, usx, w);
-  const float a = bilerp(mp, w, ty0, tx0), b = bilerp(mp, w, ty0, tx1);
-  const float c = bilerp(mp, w, ty1, tx0), d = bilerp(mp, w, ty1, tx1);
-  const float v = oyT.l0 * (oxT.l0 * a + oxT.l1 * b) + oyT.l1 * (oxT.l0 * c + oxT.l1 * d);
-  out[i] = v > 0.f ? 1 : 0;
+}
+
+// Exact x4 case (Hp == 4 h, Wp == 4 w: every model of the path) with output size == image size: one thread = one low-resolution cell = a
+// 4 x 4 block of output pixels.  The 16 pixels draw their taps from the cell's 3 x 3 neighbourhood, loaded once (9 loads instead of 64,
+// no 64-bit index arithmetic per tap); every pixel still evaluates make_tap() and bilerp()'s expression on its own four values, so the
+// bits are those of final_masks_kernel<1>.  W % 4 == 0 (row-major: a block row is one aligned 4-byte store) or H % 4 == 0 (column-major).
+template <bool CM>
+__global__ void __launch_bounds__(256)
+final_masks_cell_kernel(const float* __restrict__ masks, const int* __restrict__ sel_q, uint8_t* __restrict__ out, int n_sel, int T, int h,
+                        int w, int H, int W) {
+  const int cw = (W + 3) >> 2, ch = (H + 3) >> 2;                    // cells that hold at least one output pixel
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (long long)n_sel * T * ch * cw) return;
+  const int cx = (int)(g % cw);
+  long long r = g / cw;
+  const int cy = (int)(r % ch);
+  r /= ch;
+  const int t = (int)(r % T), j = (int)(r / T);
+  const float* mp = masks + ((long long)sel_q[j] * T + t) * h * w;
+  const int R[3] = {max(cy - 1, 0), cy, min(cy + 1, h - 1)}, C[3] = {max(cx - 1, 0), cx, min(cx + 1, w - 1)};
+  float v[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) v[a][b] = mp[R[a] * w + C[b]];
+  Tap ty[4], tx[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { ty[e] = make_tap(4 * cy + e, 0.25f, h); tx[e] = make_tap(4 * cx + e, 0.25f, w); }
+  auto pick = [&](int i_row, int i_col) {                            // value of low-res pixel (i_row, i_col): both within one of the cell
+    const int a = i_row - cy + 1, b = i_col - cx + 1;                // (make_tap: i0, i1 in {c - 1, c, c + 1}, clamped like R / C)
+    const float r0 = b == 0 ? v[0][0] : (b == 1 ? v[0][1] : v[0][2]);
+    const float r1 = b == 0 ? v[1][0] : (b == 1 ? v[1][1] : v[1][2]);
+    const float r2 = b == 0 ? v[2][0] : (b == 1 ? v[2][1] : v[2][2]);
+    return a == 0 ? r0 : (a == 1 ? r1 : r2);
+  };
+  unsigned bits[4][4];
+#pragma unroll
+  for (int ey = 0; ey < 4; ++ey)
+#pragma unroll
+    for (int ex = 0; ex < 4; ++ex) {
+      const float a = pick(ty[ey].i0, tx[ex].i0), b = pick(ty[ey].i0, tx[ex].i1);
+      const float c = pick(ty[ey].i1, tx[ex].i0), d = pick(ty[ey].i1, tx[ex].i1);
+      const float u = ty[ey].l0 * (tx[ex].l0 * a + tx[ex].l1 * b) + ty[ey].l1 * (tx[ex].l0 * c + tx[ex].l1 * d);   // == bilerp()
+      bits[ey][ex] = u > 0.f ? 1u : 0u;
+    }
+  uint8_t* ob = out + ((long long)j * T + t) * H * W;
+  if constexpr (!CM) {
+#pragma unroll
+    for (int ey = 0; ey < 4; ++ey)
+      if (4 * cy + ey < H)
+        *reinterpret_cast<unsigned*>(ob + (long long)(4 * cy + ey) * W + 4 * cx) = bits[ey][0] | (bits[ey][1] << 8) | (bits[ey][2] << 16) | (bits[ey][3] << 24);
+  } else {
+#pragma unroll
+    for (int ex = 0; ex < 4; ++ex)
+      if (4 * cx + ex < W)
+        *reinterpret_cast<unsigned*>(ob + (long long)(4 * cx + ex) * H + 4 * cy) = bits[0][ex] | (bits[1][ex] << 8) | (bits[2][ex] << 16) | (bits[3][ex] << 24);
+  }
 }
 
 }  // namespace
@@ -1497,12 +1579,34 @@ extern "C" int ovis_topk_entropy_f32(const float* probs, const int* row_ids, int
   return ovis::check_launch("topk_entropy");
 }
 
+static int g_final_cells = 1;     // lab / tests: 0 = the per-pixel kernels for every shape
+extern "C" int ovis_final_masks_set_cells(int on) { g_final_cells = on ? 1 : 0; return OVIS_OK; }
+
 extern "C" int ovis_final_masks_u8(const float* masks, const int* sel_q, uint8_t* out, int n_sel, int Q, int T, int h, int w,
                                    int Hp, int Wp, int H, int W, int OH, int OW, int column_major, ovis_stream_t stream) {
   OVIS_REQUIRE(masks && sel_q && out, "final_masks: null pointer");
   OVIS_REQUIRE(n_sel > 0 && T > 0 && H <= Hp && W <= Wp && OH > 0 && OW > 0, "final_masks: bad sizes");
   const long long total = (long long)n_sel * T * OH * OW;
-  hipLaunchKernelGGL(final_masks_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, masks, sel_q, out, n_sel,
-                     Q, T, h, w, Hp, Wp, H, W, OH, OW, column_major);
+  // a thread's VEC pixels must not cross a row (column) of the output: the fast axis has to be a multiple of VEC (out is a fresh
+  // allocation: 16-byte aligned, and i = g VEC keeps every store aligned to its width)
+  const int fast = column_major ? OH : OW;
+  const bool a16 = (((uintptr_t)out) & 15) == 0;
+  if (g_final_cells && OH == H && OW == W && Hp == 4 * h && Wp == 4 * w && fast % 4 == 0 && a16 && (long long)h * w < (1ll << 31)) {
+    const long long cells = (long long)n_sel * T * ((H + 3) / 4) * ((W + 3) / 4);
+    if (column_major)
+      hipLaunchKernelGGL(final_masks_cell_kernel<true>, dim3(ovis::cdiv(cells, 256)), dim3(256), 0, (hipStream_t)stream, masks, sel_q, out, n_sel, T, h, w, H, W);
+    else
+      hipLaunchKernelGGL(final_masks_cell_kernel<false>, dim3(ovis::cdiv(cells, 256)), dim3(256), 0, (hipStream_t)stream, masks, sel_q, out, n_sel, T, h, w, H, W);
+    return ovis::check_launch("final_masks (cells)");
+  }
+  if (fast % 16 == 0 && a16)
+    hipLaunchKernelGGL(final_masks_kernel<16>, dim3(ovis::cdiv(total / 16, 256)), dim3(256), 0, (hipStream_t)stream, masks, sel_q, out, n_sel,
+                       Q, T, h, w, Hp, Wp, H, W, OH, OW, column_major);
+  else if (fast % 4 == 0 && a16)
+    hipLaunchKernelGGL(final_masks_kernel<4>, dim3(ovis::cdiv(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, masks, sel_q, out, n_sel,
+                       Q, T, h, w, Hp, Wp, H, W, OH, OW, column_major);
+  else
+    hipLaunchKernelGGL(final_masks_kernel<1>, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, masks, sel_q, out, n_sel,
+                       Q, T, h, w, Hp, Wp, H, W, OH, OW, column_major);
   return ovis::check_launch("final_masks");
 }

@@ -889,6 +889,11 @@ def topk_entropy(probs, row_ids, topk):
     return _mi().topk_entropy(probs, row_ids, int(topk))
 
 
+def final_masks_set_cells(on):
+    """lab / tests: False = the per-pixel kernels for every shape (the 4 x 4-cell kernel is bit-identical to them)"""
+    _lib.call("ovis_final_masks_set_cells", int(bool(on)))
+
+
 def final_masks(masks, sel_q, Hp, Wp, H, W, OH, OW, column_major=False):
     """-> uint8 [n,T,OH,OW] (or [n,T,OW,OH] column-major, the scan order of COCO RLE)."""
     _chk(masks, sel_q)

@@ -286,6 +286,28 @@ def test_mask_bbox_crop_and_final_masks_vs_oracle():
         assert (out == ref).float().mean() > 0.9995
 
 
+@pytest.mark.parametrize("H,W,cm", [(720, 1280, False), (720, 1280, True), (90, 120, False), (88, 118, True), (45, 60, False), (3, 4, False), (4, 3, True)])
+def test_final_masks_cell_kernel_is_bit_identical_to_the_per_pixel_kernel(H, W, cm):
+    """final_masks_cell_kernel (one thread per low-resolution cell: 3 x 3 neighbourhood -> a 4 x 4 block of output pixels by the same
+    make_tap / bilerp expressions) against final_masks_kernel<1>: output == image size, exact x4 padded maps, ragged last block rows /
+    columns (H or W not a multiple of 4 on the slow axis), clamped borders, row- and column-major."""
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(H * 7 + W)
+    Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
+    m = (torch.randn(6, 2, Hp // 4, Wp // 4, generator=g) * (1e-3 if H == 90 else 2.0)).cuda()     # one case with logits near the threshold
+    sel = torch.tensor([5, 0, 3], dtype=torch.int32).cuda()
+    try:
+        ops.final_masks_set_cells(False)
+        ref = ops.final_masks(m, sel, Hp, Wp, H, W, H, W, column_major=cm)
+        ops.final_masks_set_cells(True)
+        out = ops.final_masks(m, sel, Hp, Wp, H, W, H, W, column_major=cm)
+    finally:
+        ops.final_masks_set_cells(True)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape and torch.equal(out, ref)
+    assert 0 < int(ref.sum()) < ref.numel()
+
+
 def test_aggregate_topk():
     from openvis_amd import ops
     g = torch.Generator().manual_seed(9)
