@@ -189,7 +189,11 @@ flash_attn_f16_kernel(AttnH a) {
 // (batch, head), one wavefront = one tile of 32 queries; K and V of the head are staged ONCE in LDS (the tiled kernel
 // above re-stages them for every group of 4 query tiles and synchronises twice per key tile), then every wavefront
 // walks the key tiles on its own with the online-softmax recurrence -- no barrier inside the loop.
-template <int KT>
+// G = 8-key groups of the LAST key tile that hold a valid key (Nk - 32 (KT - 1) <= 8 G).  The score registers of a lane cover the tile's
+// keys in groups of 8 (register r: key (r & 3) + 8 (r >> 2) + 4 h), so with G < 4 the max / exp / sum work of the padded groups and the
+// P V products of the padded 16-key halves are skipped outright instead of being computed on -inf scores (197 tokens = 6 tiles + 5 keys:
+// G = 1 drops 3/4 of the last tile's softmax work and half of its P V MFMAs; same values, the skipped terms were exact zeros).
+template <int KT, int G = 4>
 __global__ void __launch_bounds__(64 * KT, 4)          // <= 128 VGPRs: two 7-wavefront workgroups per CU (their LDS: 2 x 75 KB)
 flash_attn_f16_seq_kernel(AttnH a) {
   constexpr int D = 64;
@@ -248,7 +252,7 @@ flash_attn_f16_seq_kernel(AttnH a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  const int nkt = (a.Nk + 31) / 32;
+  constexpr int nkt = KT;                                        // the dispatch picks KT = ceil(Nk / 32)
   // Key tiles are walked in PAIRS (64 keys per online-softmax step; a single tile closes an odd count): one running-max update, one
   // alpha and one rescale of the 32 output registers per 64 keys instead of per 32 -- the loop is VALU-bound (softmax), not MFMA-bound.
   auto step = [&](auto nt_tag, int kt0) {
@@ -272,9 +276,12 @@ flash_attn_f16_seq_kernel(AttnH a) {
     }
     // scores stay unscaled: the running max is tracked on the raw dot products (scale > 0 keeps the order) and the scale
     // is folded into the exponent's fma; only the last key tile can hold keys >= Nk, so only it is masked
-    if (kt0 + NT == nkt) {
+    const bool last = kt0 + NT == nkt;                             // (nkt == KT by the dispatch: decided when the loop below is unrolled)
+    auto nreg = [&](int u) { return (last && u == NT - 1) ? 4 * G : 16; };   // score registers of tile u that can hold a valid key
+    if (last) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+        if (r >= 4 * G) continue;
         const int key = (kt0 + NT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         s[NT - 1][r] = key < a.Nk ? s[NT - 1][r] : -INFINITY;
       }
@@ -283,7 +290,8 @@ flash_attn_f16_seq_kernel(AttnH a) {
 #pragma unroll
     for (int u = 0; u < NT; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[u][r]);
+      for (int r = 0; r < 16; ++r)
+        if (r < nreg(u)) mt = fmaxf(mt, s[u][r]);
     mt = max_xor32(mt);
     const float m_new = fmaxf(m_run, mt);                        // finite: every key tile holds at least one valid key
     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
@@ -293,9 +301,13 @@ flash_attn_f16_seq_kernel(AttnH a) {
     for (int u = 0; u < NT; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], sl2, moff));
-        s[u][r] = p;
-        ps += p;
+        if (r < nreg(u)) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], sl2, moff));
+          s[u][r] = p;
+          ps += p;
+        } else {
+          s[u][r] = 0.f;                                           // a padded group: exp2(-inf) = 0 exactly
+        }
       }
     ps = sum_xor32(ps);
     l_run = l_run * alpha + ps;
@@ -308,6 +320,7 @@ flash_attn_f16_seq_kernel(AttnH a) {
     for (int u = 0; u < NT; ++u)
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
+        if (8 * sp >= nreg(u)) continue;                           // a 16-key half of padded keys only: P = 0, nothing to add
         using f32x2 = __attribute__((ext_vector_type(2))) float;
         using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
         f16x8 pb;
@@ -349,17 +362,17 @@ flash_attn_f16_seq_kernel(AttnH a) {
     }
 }
 
-template <int KT>
+template <int KT, int G = 4>
 int launch_seq(const AttnH& a, hipStream_t stream) {
   const size_t shmem = (size_t)32 * KT * ((64 + 8) + (64 + 32)) * sizeof(_Float16);
   static bool attr_set = false;
   if (shmem > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_f16_seq_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_f16_seq_kernel<KT, G>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)shmem) != hipSuccess)
       return ovis::fail(OVIS_EINVAL, "attention_f16: cannot raise the dynamic LDS limit");
     attr_set = true;
   }
-  hipLaunchKernelGGL((flash_attn_f16_seq_kernel<KT>), dim3(a.H, a.B), dim3(64 * KT), shmem, stream, a);
+  hipLaunchKernelGGL((flash_attn_f16_seq_kernel<KT, G>), dim3(a.H, a.B), dim3(64 * KT), shmem, stream, a);
   return ovis::check_launch("attention_f16 (whole sequence)");
 }
 
@@ -393,7 +406,13 @@ extern "C" int ovis_attention_f16(const void* q, long long q_bs, int q_ld, const
       case 4: return launch_seq<4>(a, (hipStream_t)stream);
       case 5: return launch_seq<5>(a, (hipStream_t)stream);
       case 6: return launch_seq<6>(a, (hipStream_t)stream);
-      default: return launch_seq<7>(a, (hipStream_t)stream);
+      default:                                        // 7 tiles: the 197 tokens of ViT-B/16 @224 leave 5 keys in the last one
+        switch (ovis::cdiv(Nk - 192, 8)) {
+          case 1: return launch_seq<7, 1>(a, (hipStream_t)stream);
+          case 2: return launch_seq<7, 2>(a, (hipStream_t)stream);
+          case 3: return launch_seq<7, 3>(a, (hipStream_t)stream);
+          default: return launch_seq<7, 4>(a, (hipStream_t)stream);
+        }
     }
   }
   hipLaunchKernelGGL(flash_attn_f16_kernel, dim3(ovis::cdiv(Nq, 128), B * H), dim3(256), 0, (hipStream_t)stream, a);

@@ -110,7 +110,7 @@ def test_attention(B, H, Nq, Nk, D, nsplit, masked):
         assert out16.dtype == torch.float16 and _rel(out16, ref) < 2e-3
 
 
-@pytest.mark.parametrize("B,H,N", [(3, 12, 197), (2, 4, 64), (1, 16, 577), (5, 2, 33)])
+@pytest.mark.parametrize("B,H,N", [(3, 12, 197), (2, 4, 64), (1, 16, 577), (5, 2, 33), (2, 3, 193), (2, 3, 205), (2, 3, 215), (2, 3, 224), (2, 2, 208)])
 def test_attention_f16(B, H, N):
     from openvis_amd import ops
     g = torch.Generator().manual_seed(N)

@@ -5,7 +5,7 @@ import torch
 from openvis_amd import ops
 
 from openvis_amd import _lib
-for (B, H, L), dbg in [((475, 12, 197), 0), ((475, 12, 197), 1), ((475, 12, 197), 2), ((180, 16, 577), 0)]:
+for (B, H, L), dbg in [((500, 12, 197), 0), ((500, 12, 197), 0), ((500, 12, 197), 1), ((500, 12, 197), 2), ((180, 16, 577), 0)]:
     _lib.call("ovis_attention_f16_debug", dbg)
     D, C = 64, H * 64
     qkv = torch.randn(B * L, 3 * C, device="cuda").half()
