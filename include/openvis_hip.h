@@ -86,7 +86,9 @@ int ovis_conv2d_nhwc_f32_w3(const float* x, const float* w, const void* w3, long
 
 /* "fp16x2" (round 4): f32-grade large GEMMs / convolutions at the MFMA cost of bf16x2.  Every f32 operand is carried as fp16 hi + fp16 lo
  * (hi = fp16(x), lo = fp16(x - hi): 11 + 11 significand bits) and the three products hi hi + hi lo + lo hi run on v_mfma_f32_*_f16 with f32
- * accumulation: every term down to 2^-22 |a b|.  fp16's narrow range is met by power-of-two scales (exact): constant weights are split ONCE
+ * accumulation: every term down to 2^-22 |a b| WHERE lo is a normal fp16 number; an activation below ~1e-3 (a_scale 16) keeps an ABSOLUTE
+ * error of 2^-29 instead (fp16 subnormal spacing / a_scale), i.e. the guarantee is f32-grade against the row's scale |A||W| + |b| + |R|, not a
+ * relative 2^-22 per element.  fp16's narrow range is met by power-of-two scales (exact): constant weights are split ONCE
  * into two fp16 planes of w * w_scale (ovis_split_f32_to_f16x2; callers pick w_scale = 2^k with max |w| w_scale in [2^14, 2^15)), activations are
  * multiplied by a_scale while they are split in registers (ovis_set_f16x2, default 16: |a| < 4 094, absolute floor 2^-29), the accumulators
  * carry a_scale * w_scale and are scaled back before bias-free epilogue work.  An activation beyond the range makes the result non-finite; the

@@ -80,11 +80,16 @@ def get_cfg():
             #              finer than autocast's fp16 operands, 32 x finer than the TF32 the reference's f32 convolutions get
             #              from cuDNN by default), products and sums in f32, half the MFMA work;
             #   "f32"    = the native f32 MFMA (an fmaf chain) for every size;
-            #   "fp16x2" = (round 4) three products hi hi + hi lo + lo hi of the fp16 split (11 + 11 significand bits per operand: every
-            #              term down to 2^-22 |a b|, the f32 grade) on the FP16 MFMA at the cost of bf16x2, for the constant-weight layers;
-            #              operands are moved to the top of fp16's range by power-of-two scales (include/openvis_hip.h).  An activation
-            #              beyond 65 504 / 16 raises a device flag and the clip is repeated under bf16x3 (VideoMaskFormer._range_guard);
-            #              GEMMs between two activations stay on bf16x3;
+            #   "fp16x2" = (round 4) three products hi hi + hi lo + lo hi of the fp16 split (11 + 11 significand bits per operand) on the FP16
+            #              MFMA at the cost of bf16x2, for the constant-weight layers; operands are moved to the top of fp16's range by
+            #              power-of-two scales (include/openvis_hip.h).  The bound is ABSOLUTE + relative, not purely relative: an
+            #              activation a is carried with error <= max(2^-22 |a|, 2^-29) (a_scale = 16: below |a| ~ 1e-3 the lo plane runs
+            #              into fp16's subnormal spacing 2^-24 / a_scale and a keeps 16-19 significant bits; below 4e-6 hi is subnormal
+            #              too), weights with 2^-22 |w| (they sit at the top of the range).  Against a row's own scale -- the measure of
+            #              tests/test_fp16x2_gpu.py, max |C - C64| / (|A||W| + |b| + |R|) -- this is the f32 grade (2.0-3.0e-7 measured,
+            #              native f32 MFMA 3.6-4.5e-7); it is NOT a 2^-22 relative bound on an element whose row is all tiny.  An
+            #              activation beyond 65 504 / 16 raises a device flag and the clip is repeated under bf16x3
+            #              (VideoMaskFormer._range_guard); GEMMs between two activations stay on bf16x3;
             #   "auto"   = "fp16x2" under MODEL.PRECISION "mixed" (the reference keeps these layers in f32, msdeformattn.py:329: the
             #              timed policy is f32-grade), "bf16x3" under "fp32".  "bf16x2" is an explicit opt-in (16 significand bits per
             #              operand; measured at 720p against the f32 oracle, profiles/r02/bf16x2.txt: per-query mask IoU min 0.99928).

@@ -154,6 +154,7 @@ class VideoMaskFormer:
             raise RuntimeError(f"inference_video: top-{topk} over {n // max(K, 1)} valid queries x {K} classes: selected index k out of range "
                                "(fewer (query, class) pairs than topk; video_maskformer.py:269)")
 
+    sticky_range_flag = None  # optional device int32 [1]: OR of the fp16x2 range flags of every forward since it was set (never read by the model)
     output_rle = False        # MODEL.MASK_FORMER.TEST.OUTPUT_RLE (not a reference key): RLE hand-off instead of dense masks
     mask_gather = None        # frame-sharded runs: callable(device masks [n,t_local,H,W]) -> masks of all frames on the output rank / None
 
@@ -166,6 +167,8 @@ class VideoMaskFormer:
         non-empty masks when the crop list was built on the device (row_ids then names EVERY query): read back with the outputs; 0 means
         what `row_ids is None` means on the host path -- an empty result."""
         flag = self._forward_flag()
+        if flag is not None and self.sticky_range_flag is not None:
+            self.sticky_range_flag.bitwise_or_(flag)          # callers that drop outputs unread (bench.py's timed loop) still learn of an overflow
         if flag is not None and sync_guard:
             again = self._range_guard(flag.cpu()[0], redo)
             if again is not None:
