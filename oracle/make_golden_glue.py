@@ -10,8 +10,9 @@ Two files:
   VideoMaskFormer.postprocess + inference_video (video_maskformer.py:215-229, 262-298), ClipAdapter._preprocess_image +
   encode_image up to the tower's input (adapter.py:73-116, 140-142), BriVIS.reset_image_output_order + post_processing
   (brivis.py:231-265), MinVIS.post_processing (minvis.py:320-338), batch_index (utils/index.py:4-18).
-* tests/golden/glue_forward.npz -- the reference's whole eval `forward` of OpenVIS, OpenVISOnline, SANOnline and BriVIS
-  (openvis.py:47-108, 177-242; san.py:177-283; brivis.py:105-211) called as unbound methods on a stub whose sem_seg_head is the
+* tests/golden/glue_forward.npz -- the reference's whole eval `forward` of OpenVIS, OpenVISOnline, SAN, SANOnline and BriVIS
+  (openvis.py:47-108, 177-242; san.py:84-144, 177-283; brivis.py:105-211; OpenVIS also with the reference's AdaptedClipAdapter,
+  mask_adapted_adapter.py:58-148) called as unbound methods on a stub whose sem_seg_head is the
   reference's own pixel decoder + decoder, whose clip_adapter is the reference's own ClipAdapter / SideAdapter over the vendored
   CLIP at a tiny size, whose resampler is the reference's TemporalInstanceResampler.
 
@@ -297,6 +298,9 @@ def gen_glue_forward():
     fd = R.ref("openvis.modeling.transformer_decoder.frame_mask2former_transformer_decoder")
     vd = R.ref("openvis.modeling.transformer_decoder.video_mask2former_transformer_decoder")
     sfd = R.ref("openvis.modeling.transformer_decoder.side_adapter_frame_mask2former_transformer_decoder")
+    svd = R.ref("openvis.modeling.transformer_decoder.side_adapter_video_mask2former_transformer_decoder")
+    maa = R.ref("openvis.modeling.clip_adapter.mask_adapted_adapter")
+    maa.BitMasks, maa.roi_align = _BitMasks, TR.roi_align
     rs = R.ref("openvis.modeling.resampler")
     Q, T, K = GLUE_Q, GLUE_T, GLUE_K
     names = [f"class_{i}" for i in range(K)]
@@ -313,10 +317,15 @@ def gen_glue_forward():
     spec_fdec = _load_synth(fdec, 414)
     sdec = sfd.SideAdapterFrameMultiScaleMaskedTransformerDecoder(clip_heads=4, **dkw).eval()
     spec_sdec = _load_synth(sdec, 415)
+    svdec = svd.SideAdapterVideoMultiScaleMaskedTransformerDecoder(clip_heads=4, **dkw).eval()
+    spec_svdec = _load_synth(svdec, 4151)
     M.ad.build_clip_model = lambda name: M.mac.CLIP(**GLUE_CLIP)            # clip.load() needs the network
     M.sa.build_clip_model = lambda name: M.mac.CLIP(**GLUE_CLIP)
     cad = M.ad.ClipAdapter("tiny", text_templates=["{}"]).eval()
     spec_cad = _load_synth(cad, 416)
+    maa.build_mask_adapted_clip_model = lambda name, depth: M.mac.CLIP(**{**GLUE_CLIP, "mask_prompt_depth": depth})
+    acad = maa.AdaptedClipAdapter("tiny", 3, True, text_templates=["{}"]).eval()           # mask_prompt_depth 3, mask_prompt_fwd True
+    spec_acad = _load_synth(acad, 4161)
     sad = M.sa.SideAdapter("tiny", out_dims=256, broken_idx=3, merge_ids=[1, 2, 3], num_queries=Q, text_templates=["{}"]).eval()
     spec_sad = _load_synth(sad, 417)
     LOGIT_SCALE = float(np.log(1 / 0.07))                                   # CLIP's own initial value (model.py: logit_scale); the synthetic
@@ -325,10 +334,12 @@ def gen_glue_forward():
     spec_res = _load_synth(res, 418)
     text = glue_text(419, GLUE_CLIP["embed_dim"])
     cad.text_cache = dict(zip(names, text))                                 # encode_text (adapter.py:121-138): every word cached
+    acad.text_cache = dict(zip(names, text))
     sad.text_cache = dict(zip([n.replace("_", " ") for n in names], text))   # side_adapter.py:214 strips "()_" before the lookup
     out = dict(spec_bb=_spec_arrays(spec_bb), spec_pd=_spec_arrays(spec_pd), spec_vdec=_spec_arrays(spec_vdec),
                spec_fdec=_spec_arrays(spec_fdec), spec_sdec=_spec_arrays(spec_sdec), spec_cad=_spec_arrays(spec_cad),
-               spec_sad=_spec_arrays(spec_sad), spec_res=_spec_arrays(spec_res), seeds=np.array([411, 412, 413, 414, 415, 416, 417, 418, 419]),
+               spec_sad=_spec_arrays(spec_sad), spec_res=_spec_arrays(spec_res), spec_svdec=_spec_arrays(spec_svdec), spec_acad=_spec_arrays(spec_acad),
+               seeds=np.array([411, 412, 413, 414, 415, 416, 417, 418, 419]), seeds_more=np.array([4151, 4161]),
                dims=np.array([T, GLUE_H, GLUE_W, K, Q, *GLUE_OUT_HW]), side_logit_scale=np.array([LOGIT_SCALE], np.float32))
 
     def W_of(dec_spec, dec_seed, ad_spec, ad_seed, with_res=False):
@@ -355,11 +366,28 @@ def gen_glue_forward():
         frames = glue_frames(seed)
         inp = [{"image": [f for f in frames], "dataset_name": "glue_val", "height": GLUE_OUT_HW[0], "width": GLUE_OUT_HW[1]}]
         rec = {}
-        if arch in ("openvis", "openvis_online"):
-            cls = M.ov.OpenVIS if arch == "openvis" else M.ov.OpenVISOnline
-            stub = _stub(M, Wbb, _Head(pd, vdec if arch == "openvis" else fdec), cad, names)
+        if arch == "san":                                                     # SAN.forward (san.py:84-144): offline side-adapter decoder, no tracker
+            stub = _stub(M, Wbb, _Head(pd, svdec), sad, names)
+            stub.postprocess = types.MethodType(M.vm.VideoMaskFormer.postprocess, stub)
+            stub.inference_video = M.vm.VideoMaskFormer.inference_video
+            W = W_of(spec_svdec, 4151, spec_sad, 417)
+            iv = stub.inference_video
+
+            def iv_rec(*a):
+                rec["iv_probs"] = [x for x in a if torch.is_tensor(x) and x.dim() == 2][0]
+                return iv(*a)
+            stub.inference_video = iv_rec
+            with torch.no_grad(), _cpu_f32():
+                vo = M.san.SAN.forward(stub, inp)
+                st = {}
+                mine = TR.san_forward(frames, W, text, out_hw=GLUE_OUT_HW, stages=st, broken_idx=3, merge_ids=(1, 2, 3),
+                                      resolution=GLUE_CLIP["image_resolution"], clip_heads=4, num_queries=Q)
+            return vo, rec, mine, st
+        if arch in ("openvis", "openvis_online", "openvis_adapted"):
+            cls = M.ov.OpenVISOnline if arch == "openvis_online" else M.ov.OpenVIS
+            stub = _stub(M, Wbb, _Head(pd, fdec if arch == "openvis_online" else vdec), acad if arch == "openvis_adapted" else cad, names)
             stub.open_vocabulary_inference = types.MethodType(cls.open_vocabulary_inference, stub)
-            if arch == "openvis":
+            if arch != "openvis_online":
                 stub.inference_video = M.vm.VideoMaskFormer.inference_video
             else:
                 stub.inference_video = types.MethodType(M.mv.MinVIS.inference_video, stub)
@@ -368,9 +396,12 @@ def gen_glue_forward():
             real = stub.clip_adapter
             stub.clip_adapter = lambda *a: rec.setdefault("clip", []).append(real(*a)) or rec["clip"][-1]
             record(stub, "open_vocabulary_inference", rec)
-            W = W_of(spec_vdec if arch == "openvis" else spec_fdec, 413 if arch == "openvis" else 414, spec_cad, 416)
-            oracle_fn = TR.openvis_forward if arch == "openvis" else TR.openvis_online_forward
+            W = W_of(spec_fdec if arch == "openvis_online" else spec_vdec, 414 if arch == "openvis_online" else 413,
+                     spec_acad if arch == "openvis_adapted" else spec_cad, 4161 if arch == "openvis_adapted" else 416)
+            oracle_fn = TR.openvis_online_forward if arch == "openvis_online" else TR.openvis_forward
             okw = dict(clip_heads=GLUE_CLIP["vision_width"] // 64, clip_resolution=GLUE_CLIP["image_resolution"])
+            if arch == "openvis_adapted":
+                okw.update(mask_prompt_depth=3, mask_prompt_fwd=True)
         else:
             cls = M.san.SANOnline if arch == "san_online" else M.bv.BriVIS
             stub = _stub(M, Wbb, _Head(pd, sdec), sad, names)
@@ -421,7 +452,7 @@ def gen_glue_forward():
         b = {(r, l): (s, m) for r, l, s, m in zip(mine["rows"], mine["pred_labels"], mine["pred_scores"], mine["pred_masks"])}
         if len(a) != 10 or set(a) != set(b) or any(not torch.equal(a[k][1], b[k][1]) or abs(a[k][0] - b[k][0]) > 1e-4 for k in a):
             return False
-        if arch in ("openvis", "openvis_online"):
+        if arch in ("openvis", "openvis_online", "openvis_adapted"):
             v = torch.cat([c[1] for c in rec["clip"]])
             if not torch.equal(v, st["valid"]):
                 return False
@@ -432,7 +463,7 @@ def gen_glue_forward():
         rec["rows"] = rows
         return True
 
-    for arch, seed0 in (("openvis", 421), ("openvis_online", 521), ("san_online", 621), ("brivis", 721)):
+    for arch, seed0 in (("openvis", 421), ("openvis_online", 521), ("san_online", 621), ("brivis", 721), ("san", 821), ("openvis_adapted", 921)):
         for seed in range(seed0, seed0 + 100, 10):
             vo, rec, mine, st = run(arch, seed)
             if stable(arch, vo, rec, mine, st):
@@ -448,7 +479,7 @@ def gen_glue_forward():
                     p + "scores": np.array(vo["pred_scores"], np.float32),
                     p + "labels": np.array(vo["pred_labels"], np.int64), p + "entropys": np.array(vo["pred_entropys"], np.float32),
                     p + "masks": _pack(masks.numpy())})
-        if arch in ("openvis", "openvis_online"):
+        if arch in ("openvis", "openvis_online", "openvis_adapted"):
             probs, vmasks = rec["open_vocabulary_inference"][0]
             out.update({p + "valid": torch.cat([c[1] for c in rec["clip"]]).numpy(),
                         p + "crop_logits": torch.cat([c[0] for c in rec["clip"] if c[0] is not None]).numpy()})
@@ -459,7 +490,7 @@ def gen_glue_forward():
                 out.update({p + "tracked_logits": post["pred_logits"].numpy(), p + "tracked_masks": post["pred_masks"].numpy().astype(np.float16)})
             else:                                                            # BriVIS.post_processing: (class probabilities, upsampled masks)
                 out.update({p + "cls": post[0].numpy()})
-        if arch != "openvis":
+        if arch in ("openvis_online", "san_online", "brivis"):
             out[p + "indices"] = st["indices"].numpy()                      # the tracker's assignment (stable(): the outputs built on it agree)
     np.savez_compressed(os.path.join(GOLD, "glue_forward.npz"), **out)
     print("wrote glue_forward.npz", {k: v.shape for k, v in out.items() if not k.startswith("spec")})

@@ -2,8 +2,8 @@
 `glue_functions.npz` -- openvis_aggregate vs OpenVIS.open_vocabulary_inference, topk_entropy + final_masks vs
 VideoMaskFormer.postprocess + inference_video, mask_bbox + crop list + clip_crop kernels vs ClipAdapter._preprocess_image +
 encode_image, the linker + batch_index vs MinVIS.post_processing / BriVIS.reset_image_output_order / post_processing;
-`glue_forward.npz` -- the whole model forward (f32 policy) vs the reference's whole eval forward of OpenVIS / OpenVISOnline /
-SANOnline / BriVIS on the same frames and weights.  No oracle function decides pass / fail here: expected values come from the
+`glue_forward.npz` -- the whole model forward (f32 policy) vs the reference's whole eval forward of OpenVIS (ClipAdapter and
+AdaptedClipAdapter) / OpenVISOnline / SAN / SANOnline / BriVIS on the same frames and weights.  No oracle function decides pass / fail here: expected values come from the
 fixtures (torch's own F.interpolate is used once, to locate near-zero logits of the output masks)."""
 import os
 
@@ -135,7 +135,9 @@ def test_linker_and_batch_index_vs_reference_post_processing(gf):
 ARCH = {"openvis": ("OpenVIS", "VideoMultiScaleMaskedTransformerDecoder"),
         "openvis_online": ("OpenVISOnline", "FrameMultiScaleMaskedTransformerDecoder"),
         "san_online": ("SANOnline", "SideAdapterFrameMultiScaleMaskedTransformerDecoder"),
-        "brivis": ("BriVIS", "SideAdapterFrameMultiScaleMaskedTransformerDecoder")}
+        "brivis": ("BriVIS", "SideAdapterFrameMultiScaleMaskedTransformerDecoder"),
+        "san": ("SAN", "SideAdapterVideoMultiScaleMaskedTransformerDecoder"),
+        "openvis_adapted": ("OpenVIS", "VideoMultiScaleMaskedTransformerDecoder")}          # with AdaptedClipAdapter (mask prompt depth 3, fwd)
 VIT = dict(width=256, layers=4, heads=4, patch=16, resolution=64, embed_dim=64)     # tests/_synth.GLUE_CLIP in the product's terms
 
 
@@ -143,7 +145,7 @@ VIT = dict(width=256, layers=4, heads=4, patch=16, resolution=64, embed_dim=64) 
 def test_model_forward_vs_reference_forward(arch):
     from openvis_amd import config
     from openvis_amd.catalog import MetadataCatalog
-    from openvis_amd.modeling.clip_adapter.adapter import ClipAdapter
+    from openvis_amd.modeling.clip_adapter.adapter import AdaptedClipAdapter, ClipAdapter
     from openvis_amd.modeling.clip_adapter.side_adapter import SideAdapter
     from tests._logits import check_top10
 
@@ -154,7 +156,9 @@ def test_model_forward_vs_reference_forward(arch):
     cfg.MODEL.CLIP_ADAPTER.CLIP_NUM_HEADS = 4
     cfg.MODEL.PRECISION = "fp32"
     model = config.build_model(cfg)
-    if arch in ("openvis", "openvis_online"):
+    if arch == "openvis_adapted":
+        model.clip_adapter = AdaptedClipAdapter("tiny", 3, True, arch=VIT, precision="fp32")
+    elif arch in ("openvis", "openvis_online"):
         model.clip_adapter = ClipAdapter("tiny", arch=VIT, precision="fp32")
     else:
         model.clip_adapter = SideAdapter("tiny", broken_idx=3, merge_ids=[1, 2, 3], num_queries=Q, arch=VIT, precision="fp32")
@@ -170,7 +174,7 @@ def test_model_forward_vs_reference_forward(arch):
     assert tuple(out["image_size"]) == (OH, OW) and len(out["pred_masks"]) == 10
     ref_probs = g[p + "probs"]
     probs = st["probs"].cpu().numpy()
-    if arch in ("openvis", "openvis_online"):
+    if arch in ("openvis", "openvis_online", "openvis_adapted"):
         valid = st["valid"]
         assert np.array_equal(valid, g[p + "valid"])                          # which (frame, query) masks are non-empty
         rows_ref = np.nonzero(g[p + "valid"].any(0))[0]
@@ -182,7 +186,7 @@ def test_model_forward_vs_reference_forward(arch):
     else:
         rows_ref = np.arange(Q)
         assert np.abs(probs - ref_probs).max() < 1e-3
-    if arch != "openvis":                                                     # tracker: the assignment of every frame
+    if arch in ("openvis_online", "san_online", "brivis"):                    # tracker: the assignment of every frame
         idx = st["indices"].cpu().numpy().reshape(T, Q)
         assert np.array_equal(idx, g[p + "indices"])
     if arch in ("openvis_online", "san_online"):                              # the tracked low-res mask logits (fixture holds fp16)

@@ -2,7 +2,7 @@
 (oracle/make_golden_glue.py -> tests/golden/glue_functions.npz, glue_forward.npz): OpenVIS.open_vocabulary_inference,
 VideoMaskFormer.postprocess / inference_video, ClipAdapter._preprocess_image / encode_image, MinVIS.post_processing,
 BriVIS.reset_image_output_order / post_processing, batch_index -- alone on crafted inputs, and inside the reference's whole eval
-`forward` of OpenVIS / OpenVISOnline / SANOnline / BriVIS.  The end-to-end config tests (C1-C5) compare the HIP path with these
+`forward` of OpenVIS (with ClipAdapter and with AdaptedClipAdapter) / OpenVISOnline / SAN / SANOnline / BriVIS.  The end-to-end config tests (C1-C5) compare the HIP path with these
 oracle functions; this file is what ties them to the reference."""
 import json
 import os
@@ -113,11 +113,18 @@ def load_glue_forward(arch):
     T, H, W, K, Q, OH, OW = [int(x) for x in g["dims"]]
     Wd = synth_weights(_spec(g["spec_bb"]), s[0], "backbone.")
     Wd.update(synth_weights(_spec(g["spec_pd"]), s[1], "sem_seg_head.pixel_decoder."))
-    dec = {"openvis": ("spec_vdec", s[2]), "openvis_online": ("spec_fdec", s[3])}.get(arch, ("spec_sdec", s[4]))
+    more = [int(x) for x in g["seeds_more"]]                                  # side-adapter VIDEO decoder, AdaptedClipAdapter
+    dec = {"openvis": ("spec_vdec", s[2]), "openvis_adapted": ("spec_vdec", s[2]), "openvis_online": ("spec_fdec", s[3]),
+           "san": ("spec_svdec", more[0])}.get(arch, ("spec_sdec", s[4]))
     Wd.update(synth_weights(_spec(g[dec[0]]), dec[1], "sem_seg_head.predictor."))
-    if arch in ("openvis", "openvis_online"):
-        Wd.update(synth_weights(_spec(g["spec_cad"]), s[5], "clip_adapter."))
+    if arch in ("openvis", "openvis_online", "openvis_adapted"):
+        if arch == "openvis_adapted":
+            Wd.update(synth_weights(_spec(g["spec_acad"]), more[1], "clip_adapter."))
+        else:
+            Wd.update(synth_weights(_spec(g["spec_cad"]), s[5], "clip_adapter."))
         kw = dict(clip_heads=GLUE_CLIP["vision_width"] // 64, clip_resolution=GLUE_CLIP["image_resolution"])
+        if arch == "openvis_adapted":
+            kw.update(mask_prompt_depth=3, mask_prompt_fwd=True)
     else:
         Wd.update(synth_weights(_spec(g["spec_sad"]), s[6], "clip_adapter."))
         Wd["clip_adapter.clip_model.logit_scale"] = torch.tensor(float(g["side_logit_scale"][0]))
@@ -130,10 +137,10 @@ def load_glue_forward(arch):
 
 
 ORACLE_FORWARD = {"openvis": TR.openvis_forward, "openvis_online": TR.openvis_online_forward, "san_online": TR.san_online_forward,
-                  "brivis": TR.brivis_forward}
+                  "brivis": TR.brivis_forward, "san": TR.san_forward, "openvis_adapted": TR.openvis_forward}
 
 
-@pytest.mark.parametrize("arch", ["openvis", "openvis_online", "san_online", "brivis"])
+@pytest.mark.parametrize("arch", ["openvis", "openvis_online", "san_online", "brivis", "san", "openvis_adapted"])
 def test_oracle_forward_equals_the_reference_forward(arch):
     """The reference's eval `forward` (openvis.py:47-108 / 177-242, san.py:177-283, brivis.py:105-211), run on a stub whose head /
     adapter / resampler are the reference's own modules, against the oracle's forward on the same frames and weights: the class
@@ -155,7 +162,7 @@ def test_oracle_forward_equals_the_reference_forward(arch):
         assert abs(out["pred_scores"][j] - float(g[p + "scores"][i])) < 1e-5
         assert abs(out["pred_entropys"][j] - float(g[p + "entropys"][i])) < 1e-4
         assert np.array_equal(out["pred_masks"][j].numpy(), ref_masks[i])
-    if arch in ("openvis", "openvis_online"):
+    if arch in ("openvis", "openvis_online", "openvis_adapted"):
         assert np.array_equal(st["valid"].numpy(), g[p + "valid"])
         assert np.abs(st["crop_logits"].numpy() - g[p + "crop_logits"]).max() < 1e-3          # x100 cosine logits
     if arch in ("openvis_online", "san_online"):
