@@ -36,7 +36,8 @@ class MinVIS(VideoMaskFormer):
         concatenate the per-frame outputs along time.  Every tensor up to the tracker is per-frame, so the result equals
         the un-windowed one; the windows only bound the activation memory of long videos (the reference additionally parks
         the masks on the CPU, minvis.py:358 -- with 288 GB of HBM they stay on the device)."""
-        if not self.window_inference or T <= self.window_size:
+        windows = self.window_inference or getattr(self._fwd, "force_windows", False)     # (retry_if_oom: this host thread's forward only)
+        if not windows or T <= self.window_size:
             return fn(0, T)
         parts = [fn(b, min(b + self.window_size, T)) for b in range(0, T, self.window_size)]
         out = dict(parts[0])

@@ -36,11 +36,11 @@ def retry_if_oom(forward):
         warnings.warn(f"{type(self).__name__}: out of device memory on a whole clip; repeating it as windows of {self.window_size} frames")
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
-        self.window_inference = True
+        self._fwd.force_windows = True          # per host thread (like the range flag): other threads' forwards on this model are not touched
         try:
             return forward(self, batched_inputs, *args, **kwargs)
         finally:
-            self.window_inference = False
+            self._fwd.force_windows = False
     return wrapped
 
 

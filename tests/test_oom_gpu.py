@@ -63,7 +63,7 @@ def test_online_model_falls_back_to_windows():
             warnings.simplefilter("always")
             out = model(inp)
         assert calls == [5, 5, 2, 2, 1]                                        # run, run again, then windows 2 + 2 + 1
-        assert any("windows" in str(w.message) for w in wl) and model.window_inference is False
+        assert any("windows" in str(w.message) for w in wl) and model.window_inference is False and model._fwd.force_windows is False
         assert out["pred_labels"] == ref["pred_labels"]
         assert all(abs(a - b) < 1e-4 for a, b in zip(out["pred_scores"], ref["pred_scores"]))
     finally:
