@@ -141,7 +141,8 @@ class SANOnline(MinVIS):
         masks_lowres = outputs["pred_masks"][0]
         if stages is not None:
             stages.update(dict(images=images, pred_masks=outputs["pred_masks"], pred_logits=outputs["pred_logits"],
-                               indices=outputs["indices"], probs=probs, class_attn_biases=outputs["class_attn_biases"]))
+                               indices=outputs["indices"], probs=probs, class_attn_biases=outputs["class_attn_biases"],
+                               pred_embeds=outputs["pred_embeds"]))
         inp = batched_inputs[0]
         row_ids = np.arange(self.num_queries, dtype=np.int32)
         return self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,

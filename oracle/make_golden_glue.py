@@ -362,7 +362,16 @@ def gen_glue_forward():
             return r
         setattr(stub, key, wrapped)
 
+    rois_seen = []
+
+    def roi_rec(inp, rois, output_size, **kw):                        # every roi_align call of the reference: rois [M, 5] = (index, x0, y0, x1, y1)
+        rois_seen.append((tuple(inp.shape), rois.clone()))
+        return TR.roi_align(inp, rois, output_size, **kw)
+    M.ad.roi_align = roi_rec
+    maa.roi_align = roi_rec
+
     def run(arch, seed):
+        rois_seen.clear()
         frames = glue_frames(seed)
         inp = [{"image": [f for f in frames], "dataset_name": "glue_val", "height": GLUE_OUT_HW[0], "width": GLUE_OUT_HW[1]}]
         rec = {}
@@ -480,14 +489,17 @@ def gen_glue_forward():
                     p + "labels": np.array(vo["pred_labels"], np.int64), p + "entropys": np.array(vo["pred_entropys"], np.float32),
                     p + "masks": _pack(masks.numpy())})
         if arch in ("openvis", "openvis_online", "openvis_adapted"):
+            # the square crop boxes the reference handed to roi_align for the FRAME crops (adapter.py:97-108): [M, 4] in (frame, query) order
+            out[p + "boxes"] = torch.cat([r[:, 1:] for shp, r in rois_seen if shp[1] == 3]).numpy().astype(np.float32)
             probs, vmasks = rec["open_vocabulary_inference"][0]
             out.update({p + "valid": torch.cat([c[1] for c in rec["clip"]]).numpy(),
                         p + "crop_logits": torch.cat([c[0] for c in rec["clip"] if c[0] is not None]).numpy()})
             assert torch.equal(probs, rec["iv_probs"])
         if "post_processing" in rec:
             post = rec["post_processing"][0]
-            if isinstance(post, dict):                                       # MinVIS.post_processing: tracked logits / masks (low-res)
-                out.update({p + "tracked_logits": post["pred_logits"].numpy(), p + "tracked_masks": post["pred_masks"].numpy().astype(np.float16)})
+            if isinstance(post, dict):                                       # MinVIS.post_processing: tracked logits / masks (low-res), the per-frame query embeddings it matched on
+                out.update({p + "tracked_logits": post["pred_logits"].numpy(), p + "tracked_masks": post["pred_masks"].numpy().astype(np.float16),
+                            p + "pred_embeds": post["pred_embeds"].numpy()})
             else:                                                            # BriVIS.post_processing: (class probabilities, upsampled masks)
                 out.update({p + "cls": post[0].numpy()})
         if arch in ("openvis_online", "san_online", "brivis"):

@@ -1070,7 +1070,8 @@ def san_online_forward(frames, W, text_features, out_hw=None, stages=None, **kw)
     oh, ow = out_hw if out_hw is not None else (H, Wd)
     res = inference_video(mask_pred.shape[0], text_features.shape[0], probs, mask_pred, (H, Wd), oh, ow)
     if stages is not None:
-        stages.update(dict(pred_masks=out["pred_masks"], pred_logits=out["pred_logits"], indices=out["indices"], probs=probs))
+        stages.update(dict(pred_masks=out["pred_masks"], pred_logits=out["pred_logits"], indices=out["indices"], probs=probs,
+                           pred_embeds=out["pred_embeds"]))
     return res
 
 

@@ -183,6 +183,12 @@ def test_model_forward_vs_reference_forward(arch):
         print(arch, "crop logits (x100 cosine) max abs err", np.abs(lg - g[p + "crop_logits"]).max())
         assert np.abs(lg - g[p + "crop_logits"]).max() < 1e-1                 # 1e-3 on the cosine
         assert np.abs(probs[rows_ref] - ref_probs).max() < 1e-3
+        # the crop boxes: the product keeps (t, q, x0, y0, x1, y1) inclusive, the reference hands roi_align the square (x0, y0, x0+s, y0+s)
+        crops = np.asarray(st["crops"])
+        assert [(int(c[0]), int(c[1])) for c in crops] == [(int(t), int(q)) for t, q in np.argwhere(g[p + "valid"])]
+        side = np.maximum(crops[:, 4] + 1 - crops[:, 2], crops[:, 5] + 1 - crops[:, 3])
+        mine = np.stack([crops[:, 2], crops[:, 3], crops[:, 2] + side, crops[:, 3] + side], 1).astype(np.float32)
+        assert np.array_equal(mine, g[p + "boxes"])
     else:
         rows_ref = np.arange(Q)
         assert np.abs(probs - ref_probs).max() < 1e-3
@@ -195,6 +201,9 @@ def test_model_forward_vs_reference_forward(arch):
         clear = np.abs(ref_pm) > 2e-2
         assert np.array_equal((pm > 0)[clear], (ref_pm > 0)[clear])
         assert np.abs(pm - ref_pm).max() < 3e-2
+        pe = st["pred_embeds"].float().cpu().numpy().reshape(g[p + "pred_embeds"].shape)
+        print(arch, "pred_embeds (the tracker's input) max abs err", np.abs(pe - g[p + "pred_embeds"]).max())
+        assert np.abs(pe - g[p + "pred_embeds"]).max() < 2e-3
     # top-10: tie-aware (random-init scores of all queries lie within 1e-3 of each other), then the masks of the common entries
     ref_out = {"rows": [int(r) for r in g[p + "rows"]], "pred_labels": [int(x) for x in g[p + "labels"]],
                "pred_scores": [float(x) for x in g[p + "scores"]]}

@@ -165,9 +165,11 @@ def test_oracle_forward_equals_the_reference_forward(arch):
     if arch in ("openvis", "openvis_online", "openvis_adapted"):
         assert np.array_equal(st["valid"].numpy(), g[p + "valid"])
         assert np.abs(st["crop_logits"].numpy() - g[p + "crop_logits"]).max() < 1e-3          # x100 cosine logits
+        assert np.array_equal(st["boxes"].numpy().astype(np.float32), g[p + "boxes"])        # the square crop boxes handed to roi_align
     if arch in ("openvis_online", "san_online"):
         assert np.array_equal(st["indices"].numpy(), g[p + "indices"])
         assert np.abs(st["pred_masks"].numpy() - g[p + "tracked_masks"].astype(np.float32)).max() < 2e-2   # stored as fp16
+        assert np.abs(st["pred_embeds"].numpy() - g[p + "pred_embeds"]).max() < 1e-4         # per-frame query embeddings, the tracker's input
     if arch == "brivis":
         assert np.array_equal(st["indices"].numpy(), g[p + "indices"])
         assert np.abs(st["probs"].numpy() - g[p + "cls"]).max() < 1e-5
