@@ -1,5 +1,5 @@
-"""The masked-attention decoder (A7-A8) of the headline workload alone: 30 forwards on fixed pixel-decoder outputs.
-   cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python3 $GRAFT_REPO_ROOT/tools/prof_decoder.py"""
+"""The pixel decoder (A3-A6) of the headline workload alone: N forwards on fixed backbone features.
+   cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python3 $GRAFT_REPO_ROOT/tools/prof_pixel_decoder.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,14 +11,13 @@ ops.set_f32_gemm_mode(model.f32_gemm_mode)      # a forward sets it in _frames_t
 frames = bench.synth_frames(5, 720, 1280, 1000, "cuda")
 images, _, _ = model.preprocess(frames)
 feats = model.backbone(images)
-mf, _, ms = model.sem_seg_head.pixel_decoder.forward_features(feats)
-dec = model.sem_seg_head.predictor
+pd = model.sem_seg_head.pixel_decoder
 for _ in range(3):
-    out = dec(ms, mf)
+    out = pd.forward_features(feats)
 torch.cuda.synchronize()
 n = int(os.environ.get("N", "30"))
 t0 = time.perf_counter()
 for _ in range(n):
-    out = dec(ms, mf)
+    out = pd.forward_features(feats)
 torch.cuda.synchronize()
-print(f"decoder forward: {(time.perf_counter() - t0) / n * 1e3:.3f} ms per clip (wall, {n} runs)")
+print(f"pixel decoder forward: {(time.perf_counter() - t0) / n * 1e3:.3f} ms per clip (wall, {n} runs)")
