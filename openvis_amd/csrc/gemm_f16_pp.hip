@@ -325,34 +325,51 @@ gemm_f16_pp_kernel(const PPArgs p) {
   // ---- fragment read addresses -----------------------------------------------------------------------------
   const unsigned rd0 = FA ? (unsigned)(l15 * 128 + (((2 * q) ^ sw) << 4))      // floats 8q .. 8q+3 of the row; 8q+4 .. 8q+7 = ^ 16
                           : (unsigned)(l15 * 128 + ((q ^ sw) << 4));            // k block 0; k block 1 = ^ 64
-  const unsigned a_rd = rd0 + wr * 64 * 128;
+  const unsigned a_rd = (FH ? (unsigned)(l15 * 128 + ((q ^ sw) << 4)) : rd0) + wr * 64 * 128;   // FH: the converted image (convert_a) reads like an fp16 tile
   const unsigned b_rd = FA ? (unsigned)(wc * 2 * 2048 + l15 * 64 + q * 16)      // + e * 2048 + plane * 1024
                            : rd0 + wc * 32 * 128;                               // callers add the B0 slot (2 * PP_HT)
 
   f32x4 acc[8][4];
   f16x8 af[4][2], bf0[2][2], bf1[2][2];                            // FA: second index = bf16 plane (0 hi, 1 lo) instead of k block
+  // FH (round 5): the f32 rows of an A half-tile are split into fp16 hi | lo ONCE, in place, by the wavefront whose DMA wrote them
+  // (convert_a below) -- before that every wavefront split its whole 128 x 32 fragment itself, i.e. each element four times per tile (once
+  // per wavefront column) on the vector pipe the partner wavefront's MFMAs issue on.  Same expressions, same values: bit-identical results.
+  // Wavefront w owns LDS rows 16 w .. 16 w + 15 of every half-tile (its two DMA instructions); lane -> row lane >> 2, floats 8 j .. 8 j + 7
+  // (j = lane & 3 = source chunks 2 j, 2 j + 1 at slots (2 j) ^ s, (2 j + 1) ^ s, s = (row >> 1) & 7).  The 8 hi halfs go to slot j ^ s, the
+  // 8 lo halfs to slot j ^ s ^ 4: a row then reads [hi k 0..31 | lo k 0..31] under the fp16 kernel's swizzle -- k block 0 / 1 of read_a.
+  // hi = fp16(s v), lo = fp16(s v - hi) (s v is exact, s v - hi too: one rounding each); the arithmetic is plain C between the two asm blocks
+  // (round 4 lost a day to v_fma_mix in inline asm sunk next to MFMAs: profiles/r04/fp16x2_asm_hazard.txt); the reads / writes are asm so that
+  // hipcc does not drain the DMA queue in front of them (see tile_entry).  Issuing the conversion's reads ahead of the phase's own fragment
+  // reads and DMA issue (wait first, two fewer younger operations) was measured: no faster (profiles/r05/fp16x2_convert_once.txt).
+  // In place is safe: a wavefront's reads complete (lgkmcnt) before its writes, and no other wavefront touches these rows between the
+  // vmcnt wait that lands them and the barrier that publishes them (the barrier the DMA'd rows were published by before).
+  auto convert_a = [&](unsigned buf, int h) {
+    if constexpr (FH) {
+      const int r = lane >> 2, j = lane & 3, s_ = (r >> 1) & 7;
+      const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(lds) + buf + h * PP_HT + wave * 2048 + r * 128;
+      const unsigned s0 = base + (((2 * j) ^ s_) << 4), s1 = base + (((2 * j + 1) ^ s_) << 4);
+      const unsigned d0 = base + ((j ^ s_) << 4), d1 = base + ((j ^ s_ ^ 4) << 4);
+      f32x4 x0, x1;
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x0), "=&v"(x1) : "v"(s0), "v"(s1) : "memory");
+      f16x8 h0, h1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = e < 4 ? x0[e & 3] : x1[e & 3];
+        const _Float16 a0 = (_Float16)(v * p.a_scale);
+        h0[e] = a0; h1[e] = (_Float16)__builtin_fmaf(v, p.a_scale, -(float)a0);
+      }
+      asm volatile("ds_write_b128 %0, %2\n\tds_write_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" :: "v"(d0), "v"(d1), "v"(h0), "v"(h1) : "memory");
+    }
+  };
   auto read_a = [&](unsigned buf, int i) {
-    if constexpr (FA) {
+    if constexpr (FA && !FH) {
       using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
         if (i == 1 && mb < MB1_LO) continue;                         // TM = 192: only the upper two row blocks of half-tile 1
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(lds + buf + i * PP_HT + mb * 2048 + a_rd);
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(lds + buf + i * PP_HT + mb * 2048 + (a_rd ^ 16));
-        if constexpr (FH) {
-          // hi = fp16(s v), lo = fp16(s v - hi) (s v is exact, s v - hi too: one rounding each).  Plain C on purpose: as inline v_fma_mix asm
-          // the conversions were two instructions per element, but the optimiser sank the (pure) asm statements past the s_barrier into the
-          // MFMA segment, where a VALU write -> MFMA read needs wait states only the compiler's hazard recogniser inserts -- and it does not
-          // look into inline asm: stale lo fragments, 1e-4 errors that changed from run to run (profiles/r04/fp16x2_asm_hazard.txt).
-          f16x8 h0, h1;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float v = e < 4 ? x0[e & 3] : x1[e & 3];
-            const _Float16 a0 = (_Float16)(v * p.a_scale);
-            h0[e] = a0; h1[e] = (_Float16)__builtin_fmaf(v, p.a_scale, -(float)a0);
-          }
-          af[mb][0] = h0; af[mb][1] = h1;
-        } else {
+        {
         bf16x8 h0, h1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -837,6 +854,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
   issue_a0(0); issue_b0(0); advance2(); issue_b1(0); issue_a1(0); advance1();
   issue_a0(PP_BUF); issue_b0(PP_BUF); advance2(); issue_b1(PP_BUF); issue_a1(PP_BUF); advance1();
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                 // A0, B0 of K step 0
+  convert_a(0, 0);
   if (wr == 1) PP_BARRIER();                                       // wavefronts 4-7 (G1) run one slot behind wavefronts 0-3 (G0)
   PP_BARRIER();
   // read segment of phase 1 of the first K step
@@ -879,6 +897,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
       read_b(cur + 2 * PP_HT, 1, bf1);
       if (kt) issue_a1(oth);
       if (kt < 2) PP_WAIT(8, 8 + NS1); else PP_VMCNT(8);
+      convert_a(cur, 1);                                             // FH: A1 of this K step has landed (the wait above): own rows f32 -> fp16 hi | lo
       PP_BARRIER();
       mma(0, 1, bf1);
       if (kt) advance1();
@@ -892,6 +911,7 @@ gemm_f16_pp_kernel(const PPArgs p) {
       // ---- phase 4: quadrant (1,0), no LDS reads ----
       issue_b0(cur);
       if (kt == 0) PP_WAIT(8, 8 + NS1); else PP_VMCNT(8);
+      convert_a(oth, 0);                                             // FH: A0 of the NEXT K step (of this or the next tile) has landed
       PP_BARRIER();
       mma(1, 0, bf0);
       advance2();
