@@ -251,6 +251,8 @@ def main():
                     help="timed steps (default 100 = 5 s of GPU work: long enough for the driver's 5 s GPU-busy sampling)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-splits", action="store_true",
+                    help="skip the passes under the other f32-GEMM splits (`alt_f32_splits`): profiling runs that want one policy's kernels only")
     ap.add_argument("--no-in-flight", action="store_true",
                     help="skip the `two_clips_in_flight` side measurement (profiling runs: its overlapping launches would mix into rocprofv3's "
                          "per-kernel averages, which are meant to be compared with the sequential per-launch times of `roofline`)")
@@ -371,7 +373,7 @@ def main():
     # mixed), as the f32-grade bf16x3 (6 bf16 products) or as bf16x2 (3 bf16 products, 16 significand bits per operand: NOT f32-grade,
     # listed for comparison only).  Whichever the headline uses, the others stand beside it in `alt_f32_splits`.
     alts = []
-    if not (args.streams > 1 and not frame_sharded) and f32_split != "f32":
+    if not (args.streams > 1 and not frame_sharded) and f32_split != "f32" and not args.no_alt_splits:
         from openvis_amd.config import F32_GEMM_SPLITS
         keep_mode = _model.f32_gemm_mode
         for alt_name in [n for n in ("fp16x2", "bf16x3", "bf16x2") if n != f32_split]:

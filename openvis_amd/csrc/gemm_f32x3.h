@@ -272,6 +272,11 @@ template <typename LoaderA>
 inline void launch_gemm_f16x2_h2(LoaderA la, const void* H2, long long ldb, long long plane, float* C, long long ldc, int M, int N,
                                  int K, const float* bias, const float* R, long long ldr, int act, hipStream_t stream, F16x2 fh) {
   const int tm = cdiv(M, 128), tn = cdiv(N, 128);
+  if (N <= 64) {   // 64-column tiles (round 5): the 64-channel convolutions of an f32-class ResNet (stem, res2) computed half a 128-column tile of zeros
+    hipLaunchKernelGGL((gemm_f32x3_kernel<128, 64, LoaderA, PlanesB, 2, true>), dim3(tm, 1), dim3(256), 0, stream, la,
+                       PlanesB{(const __bf16*)H2, ldb, plane, N, K}, C, ldc, M, N, K, bias, R, ldr, act, 1, 0ll, 0ll, 0ll, fh);
+    return;
+  }
   hipLaunchKernelGGL((gemm_f32x3_kernel<128, 128, LoaderA, PlanesB, 2, true>), dim3(tm * tn, 1), dim3(256), 0, stream, la,
                      PlanesB{(const __bf16*)H2, ldb, plane, N, K}, C, ldc, M, N, K, bias, R, ldr, act, tn, 0ll, 0ll, 0ll, fh);
 }

@@ -59,6 +59,9 @@ class ResNet:
         if self.precision == "fp16":
             sw = torch.nn.functional.pad(sw, (0, 0, 0, 1)).contiguous()              # [64, 7, 7, 4] -> [64, 7, 8, 4]
         self.w["stem"] = (d(sw), d(sb))
+        # (f32-class policy, SAN / BriVIS: the stem stays on the native-f32 convolution, 4.2 ms per 36-frame 720p clip.  The padded 7x8 kernel
+        # under the fp16x2 split runs 1.6 ms and is f32-grade, but its different rounding in the FIRST layer moved 3 mask bits of C3 outside
+        # the |logit| < 1e-3 set the parity statement allows (52 instead of 30 differing bits of 29.4 M; round 5): not taken.)
         for name, nblocks, _ in STAGES[self.depth]:
             for i in range(nblocks):
                 p = f"{prefix}{name}.{i}"

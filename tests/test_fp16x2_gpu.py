@@ -154,7 +154,9 @@ def test_1x1_and_strided_convs_under_fp16x2(modes):
     """input_proj 1x1 convolutions (msdeformattn.py:227-235) and a stride-2 3x3 (f32-class backbone of SAN / BriVIS) on fp16 products."""
     ops = modes
     g = torch.Generator().manual_seed(21)
-    for (N, H, W, Cin, Cout, k, s, p) in [(5, 46, 80, 1024, 256, 1, 1, 0), (5, 92, 160, 128, 256, 3, 2, 1)]:
+    # ... and the 64-channel layers of that backbone (64-column tiles): res2's 3x3, a 256 -> 64 1x1 with odd sizes, the stem's padded 7x8 kernel
+    for (N, H, W, Cin, Cout, k, s, p) in [(5, 46, 80, 1024, 256, 1, 1, 0), (5, 92, 160, 128, 256, 3, 2, 1), (5, 184, 320, 64, 64, 3, 1, 1),
+                                           (3, 91, 157, 256, 64, 1, 1, 0), (2, 93, 161, 64, 48, 3, 1, 1)]:
         x = torch.randn(N, H, W, Cin, generator=g).relu().cuda()
         w = (torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).cuda()
         b = torch.randn(Cout, generator=g).cuda()

@@ -15,7 +15,7 @@ agg = defaultdict(lambda: [0, 0])
 for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = demangle(r["Kernel_Name"]).replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:110]
-        key = (name, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")), r.get("LDS_Block_Size", ""))
+        key = (name, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", "") + ("x" + r["Grid_Size_Z"] if r.get("Grid_Size_Z", "1") not in ("", "1") else ""), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")), r.get("LDS_Block_Size", ""))
         a = agg[key]
         a[0] += 1
         a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
