@@ -378,6 +378,113 @@ onewave_persist_kernel(const OWArgs p) {
   }
 }
 
+// =====================================================================================================================================
+// v3 (late round 5): the v1 K loop on v_mfma_f32_16x16x32_f16 instead of 32x32x16.  MI355X_MICROARCH.md (DVFS item 7): on random operands the
+// 16x16x32 loop delivers ~1.12-1.15x the FLOP/s of the 32x32x16 loop at equal cycles (the chip holds a higher clock), and the shipped
+// ping-pong kernel as well as hipBLASLt's assembly kernel (profiles/r05/gemm_vs_hipblaslt.txt) use that shape.  Same LDS image, same DMA;
+// a K step = two 32-deep slices of 64 MFMAs (8 x 8 accumulator tiles of 16 x 16, 256 registers); the fragments of the next slice (16
+// ds_read_b128) are read behind MFMAs 0..15, the 16 DMA instructions of K step s + 2 behind every third MFMA of slice (s, 1); step s is
+// closed (lgkmcnt(0), vmcnt(0), barrier) after slice (s, 0), when all its fragments are in registers.
+// =====================================================================================================================================
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+template <int VARIANT>
+__global__ void __launch_bounds__(256, 1)
+onewave16_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ B, _Float16* __restrict__ C, int M, int N, int K,
+                 unsigned long long* __restrict__ stamps) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[OW_LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_n = N / 256;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int nk = K / 64;
+  const int dr = lane >> 3, slot = lane & 7;
+  unsigned voA[8], voB[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int row = 64 * wave + 8 * g + dr;
+    const int c = slot ^ ((row >> 1) & 7);
+    voA[g] = (unsigned)(((long long)(tm * 256 + row) * K) * 2 + c * 16);
+    voB[g] = (unsigned)(((long long)(tn * 256 + row) * K) * 2 + c * 16);
+  }
+  const char* Ab = reinterpret_cast<const char*>(A);
+  const char* Bb = reinterpret_cast<const char*>(B);
+  unsigned char* dstA = lds + wave * 8192;
+  unsigned char* dstB = lds + OW_HT + wave * 8192;
+  auto dma_a = [&](int step, int g) { OW_GLDS(Ab + voA[g] + step * 128, dstA + (step & 1) * OW_BUF + g * 1024); };
+  auto dma_b = [&](int step, int g) { OW_GLDS(Bb + voB[g] + step * 128, dstB + (step & 1) * OW_BUF + g * 1024); };
+  // fragment of mfma_f32_16x16x32_f16: per lane 8 consecutive k of row (lane & 15): k = 32 ks + 8 (lane >> 4)
+  const int r16 = lane & 15, kq = lane >> 4;
+  auto frag = [&](int buf, int operand, int rb, int ks) {
+    const int row = 128 * (operand ? wc : wr) + 16 * rb + r16;
+    const int c = (4 * ks + kq) ^ ((row >> 1) & 7);
+    return *reinterpret_cast<const f16x8*>(lds + buf * OW_BUF + operand * OW_HT + row * 128 + c * 16);
+  };
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 8; ++g) { dma_a(0, g); dma_b(0, g); }
+  if (nk > 1) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) { dma_a(1, g); dma_b(1, g); }
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  OW_FENCE();
+  unsigned long long t0 = 0;
+  if (stamps && tid == 0) t0 = __builtin_amdgcn_s_memrealtime();
+  f16x8 af[2][8], bf[2][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { af[0][i] = frag(0, 0, i, 0); bf[0][i] = frag(0, 1, i, 0); }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  OW_FENCE();
+  for (int s = 0; s < nk; ++s) {
+    const int buf = VARIANT == 1 ? 0 : (s & 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int cur = ks, nxt = ks ^ 1;
+      const bool more = ks < 1 || s + 1 < nk;
+      const int nbuf = ks < 1 ? buf : (VARIANT == 1 ? 0 : (buf ^ 1)), nks = ks ^ 1;
+      const bool dma_on = VARIANT != 1 && ks == 1 && s + 2 < nk;
+#pragma unroll
+      for (int t = 0; t < 64; ++t) {
+        const int i = t >> 3, j = t & 7;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+        if (t < 16) {
+          if (more) {
+            if (t < 8) af[nxt][t] = frag(nbuf, 0, t, nks);
+            else bf[nxt][t - 8] = frag(nbuf, 1, t - 8, nks);
+          }
+        } else if (dma_on && (t - 16) % 3 == 0) {
+          const int u = (t - 16) / 3, g = u >> 1;                     // u = 0 .. 15
+          if ((u & 1) == 0) dma_a(s + 2, g); else dma_b(s + 2, g);
+        }
+        OW_FENCE();
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (ks == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      OW_FENCE();
+    }
+  }
+  if (stamps && tid == 0) { stamps[2 * blockIdx.x] = t0; stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); }
+  // epilogue (plain): lane holds column n = 16 j + r16, rows m = 16 i + 4 kq + r
+  _Float16* cp = C + (long long)(tm * 256 + 128 * wr) * N + tn * 256 + 128 * wc;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cp[(long long)(16 * i + 4 * kq + r) * N + 16 * j + r16] = (_Float16)acc[i][j][r];
+}
+
 __device__ inline unsigned hash32(unsigned x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
 __global__ void fill_f16(_Float16* p, long long n, unsigned seed, int kind) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -444,6 +551,45 @@ int main() {
       const float med = t[v][t[v].size() / 2], mn = t[v][0];
       printf("time  %-18s %-50s median %.4f ms (%4.0f TF)  min %.4f ms (%4.0f TF)\n", sh.name, names[v], med, flop / med / 1e9, mn, flop / mn / 1e9);
     }
+    // ---- v3: the one-wave K loop on 16x16x32 MFMAs ----
+    {
+      fill_f16<<<2048, 256, 0, s>>>(A, MK, 11u, 1); fill_f16<<<2048, 256, 0, s>>>(B, NK, 13u, 1);
+      HIP_OK(hipMemsetAsync(C, 0xff, MN * 2, s)); HIP_OK(hipMemsetAsync(d_bad, 0, 8, s));
+      hipLaunchKernelGGL((onewave16_kernel<0>), dim3((sh.M / 256) * (sh.N / 256)), dim3(256), 0, s, A, B, C, sh.M, sh.N, sh.K, (unsigned long long*)nullptr);
+      ref_check<<<(unsigned)((MN / stride + 255) / 256), 256, 0, s>>>(A, B, C, sh.M, sh.N, sh.K, d_bad, stride);
+      HIP_OK(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
+      printf("check %-18s one-wave kernel on 16x16x32 MFMAs: %llu wrong %s\n", sh.name, bad, bad ? "FAIL" : "OK");
+      fill_f16<<<2048, 256, 0, s>>>(A, MK, 3u, 0); fill_f16<<<2048, 256, 0, s>>>(B, NK, 5u, 0);
+      std::vector<float> t3[4];
+      for (int round = 0; round < 12; ++round)
+        for (int v = 0; v < 4; ++v) {
+          HIP_OK(hipEventRecord(e0, s));
+          if (v == 0) hipLaunchKernelGGL((onewave16_kernel<0>), dim3((sh.M / 256) * (sh.N / 256)), dim3(256), 0, s, A, B, C, sh.M, sh.N, sh.K, (unsigned long long*)nullptr);
+          else if (v == 1) hipLaunchKernelGGL((onewave16_kernel<1>), dim3((sh.M / 256) * (sh.N / 256)), dim3(256), 0, s, A, B, C, sh.M, sh.N, sh.K, (unsigned long long*)nullptr);
+          else if (v == 2) launch<0>(A, B, C, sh.M, sh.N, sh.K, nullptr, s);
+          else OVIS_OKAY(ovis_gemm_nt_f16(A, sh.K, B, sh.K, C2, sh.N, sh.M, sh.N, sh.K, nullptr, nullptr, 0, 0, 1, s));
+          HIP_OK(hipEventRecord(e1, s)); HIP_OK(hipEventSynchronize(e1));
+          float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+          if (round >= 2) t3[v].push_back(ms);
+        }
+      const char* n3[4] = {"one wave / SIMD on 16x16x32 MFMAs", "  ... without the DMA (step-0 operands)", "one wave / SIMD on 32x32x16 MFMAs (v1)", "shipped ping-pong kernel (ovis_gemm_nt_f16)"};
+      for (int v = 0; v < 4; ++v) {
+        std::sort(t3[v].begin(), t3[v].end());
+        const float med = t3[v][t3[v].size() / 2], mn = t3[v][0];
+        printf("time3 %-18s %-50s median %.4f ms (%4.0f TF)  min %.4f ms (%4.0f TF)\n", sh.name, n3[v], med, flop / med / 1e9, mn, flop / mn / 1e9);
+      }
+      const int nt3 = (sh.M / 256) * (sh.N / 256);
+      if (nt3 <= 65536) {
+        hipLaunchKernelGGL((onewave16_kernel<0>), dim3(nt3), dim3(256), 0, s, A, B, C, sh.M, sh.N, sh.K, d_st);
+        std::vector<unsigned long long> st(2 * nt3);
+        HIP_OK(hipMemcpyAsync(st.data(), d_st, 16ull * nt3, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
+        std::vector<double> span;
+        for (int i = 0; i < nt3; ++i) span.push_back((st[2 * i + 1] - st[2 * i]) * 0.01 / (sh.K / 64));
+        std::sort(span.begin(), span.end());
+        printf("trace3 %-17s K loop per 64-deep step on 16x16x32 MFMAs (in-kernel, median over %d tiles): %.3f us (p10 %.3f, p90 %.3f)\n", sh.name, nt3, span[nt3 / 2], span[nt3 / 10], span[nt3 * 9 / 10]);
+      }
+    }
+    if (getenv("OW_ONLY_V3")) { HIP_OK(hipFree(A)); HIP_OK(hipFree(B)); HIP_OK(hipFree(C)); HIP_OK(hipFree(C2)); continue; }
     // ---- v2: persistent, overlapped epilogue ----
     {
       OWArgs a; a.A = A; a.B = B; a.C = C; a.M = sh.M; a.N = sh.N; a.K = sh.K; a.tiles_m = sh.M / 256; a.tiles_n = sh.N / 256; a.n_tiles = a.tiles_m * a.tiles_n;
