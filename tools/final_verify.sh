@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/pmc_fetch --
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/pmc_write -- python3 $ROOTD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-in-flight --no-alt-splits > /dev/null 2> $R/pmc_write.err
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/pmc_mfma -- python3 $ROOTD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-in-flight --no-alt-splits > /dev/null 2> $R/pmc_mfma.err
 cd $ROOTD
-python tools/trace_by_shape.py $R/stats $R/kernel_by_shape.csv 24
+python tools/trace_by_shape.py $R/stats $R/kernel_by_shape.csv 26
 python tools/pmc_traffic.py $R/pmc_fetch $R/pmc_write $R/pmc_traffic_bench.json "${GIT_HEAD:-unknown}"
 python tools/pmc_mfma.py $R/pmc_mfma $R/pmc_mfma_bench.json
 mkdir -p profiles/${ROUND:-r05} && cp $R/pmc_traffic_bench.json profiles/${ROUND:-r05}/pmc_traffic_bench.json   # so that the bench line below reads THIS build's traffic
