@@ -267,6 +267,23 @@ gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int HW,
   for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) atomicAdd(&stats[(long long)n * 2 * G + i], sh[i]);
 }
 
+// (mean, rstd) of every (n, g) from the f64 sums, once (round 5: every thread of gn_apply recomputed them -- two f64 divisions and a
+// square root per channel quad): the float pair overwrites the first of the two doubles it was computed from.  Same expressions: same values.
+__global__ void __launch_bounds__(256)
+gn_finalize_kernel(double* __restrict__ stats, int NG, double cnt, float eps) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= NG) return;
+  const double sum = stats[2 * k], sq = stats[2 * k + 1];
+  const double mean_d = sum / cnt;
+  const double var_d = sq / cnt - mean_d * mean_d;
+  const float mean = (float)mean_d;
+  const float rstd = 1.f / sqrtf((float)var_d + eps);
+  reinterpret_cast<float2*>(stats + 2 * k)[0] = make_float2(mean, rstd);
+}
+
+// IDX: int when the (padded) map has fewer than 2^31 channel quads (every 720p / 1080p clip): the index arithmetic below is six integer
+// divisions per thread, 64-bit ones cost several times the 32-bit ones
+template <typename IDX>
 __global__ void __launch_bounds__(256)
 gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats, const float* __restrict__ gamma,
                 const float* __restrict__ beta, float* __restrict__ y, int N, int H, int W, int C, int G,
@@ -274,30 +291,27 @@ gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats, c
   // pad = 1: y is [N][H+2][W+2][C] with a ring of zeros (the input layout of ovis_conv3x3_padded_f32_w3): one thread per channel quad of
   // the PADDED map, the ring threads store zeros -- no memset pass, no state between calls
   const int c4n = C >> 2;
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long oidx = i;
+  IDX i = (IDX)blockIdx.x * (IDX)blockDim.x + (IDX)threadIdx.x;
+  IDX oidx = i;
   if (pad) {
-    const long long totalp = (long long)N * (H + 2) * (W + 2) * c4n;
+    const IDX totalp = (IDX)N * (H + 2) * (W + 2) * c4n;
     if (i >= totalp) return;
     const int cqp = (int)(i % c4n);
-    const long long pp = i / c4n;
+    const IDX pp = i / c4n;
     const int xx = (int)(pp % (W + 2));
-    const long long rr = pp / (W + 2);
+    const IDX rr = pp / (W + 2);
     const int yy = (int)(rr % (H + 2)), nn = (int)(rr / (H + 2));
     if (xx == 0 || yy == 0 || xx == W + 1 || yy == H + 1) { reinterpret_cast<float4*>(y)[i] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
-    i = (((long long)nn * H + (yy - 1)) * W + (xx - 1)) * c4n + cqp;
+    i = (((IDX)nn * H + (yy - 1)) * W + (xx - 1)) * c4n + cqp;
   }
-  const long long total = (long long)N * H * W * c4n;
+  const IDX total = (IDX)N * H * W * c4n;
   if (i >= total) return;
   const int cq = (int)(i % c4n);
-  const long long pix = i / c4n;
-  const int n = (int)(pix / ((long long)H * W));
+  const IDX pix = i / c4n;
+  const int n = (int)(pix / ((IDX)H * W));
   const int g = (cq * 4) / (C / G);
-  const double cnt = (double)H * W * (C / G);
-  const double mean_d = stats[((long long)n * G + g) * 2] / cnt;
-  const double var_d = stats[((long long)n * G + g) * 2 + 1] / cnt - mean_d * mean_d;
-  const float mean = (float)mean_d;
-  const float rstd = 1.f / sqrtf((float)var_d + eps);
+  const float2 mr = reinterpret_cast<const float2*>(stats + ((long long)n * G + g) * 2)[0];      // gn_finalize_kernel
+  const float mean = mr.x, rstd = mr.y;
   const float4 v = reinterpret_cast<const float4*>(x)[i];
   const float4 ga = reinterpret_cast<const float4*>(gamma)[cq], be = reinterpret_cast<const float4*>(beta)[cq];
   float4 o;
@@ -307,7 +321,7 @@ gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats, c
   o.w = (v.w - mean) * rstd * ga.w + be.w;
   if (up) {
     // F.interpolate(up, size=(H,W), mode="bilinear", align_corners=False) added to the normalised map
-    const int rem = (int)(pix % ((long long)H * W));
+    const int rem = (int)(pix % ((IDX)H * W));
     const int oy = rem / W, ox = rem % W;
     const float sy = fmaxf(((float)oy + 0.5f) * ((float)UH / (float)H) - 0.5f, 0.f);
     const float sx = fmaxf(((float)ox + 0.5f) * ((float)UW / (float)W) - 0.5f, 0.f);
@@ -589,9 +603,14 @@ static int groupnorm_impl(int pad, const float* x, float* y, const float* gamma,
   const int pix_per_blk = 128;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(ovis::cdiv(HW, pix_per_blk), N), dim3(threads), sizeof(double) * 2 * G, s, x,
                      stats_ws, HW, C, G, pix_per_blk);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(ovis::cdiv(N * G, 256)), dim3(256), 0, s, stats_ws, N * G, (double)H * W * (C / G), eps);
   const long long total = pad ? (long long)N * (H + 2) * (W + 2) * c4n : (long long)N * HW * c4n;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, s, x, stats_ws, gamma, beta, y, N, H,
-                     W, C, G, eps, relu, up_add, UH, UW, pad);
+  if ((long long)N * (H + 2) * (W + 2) * c4n < (1ll << 31) - 256)
+    hipLaunchKernelGGL(gn_apply_kernel<int>, dim3(ovis::cdiv(total, 256)), dim3(256), 0, s, x, stats_ws, gamma, beta, y, N, H,
+                       W, C, G, eps, relu, up_add, UH, UW, pad);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<long long>, dim3(ovis::cdiv(total, 256)), dim3(256), 0, s, x, stats_ws, gamma, beta, y, N, H,
+                       W, C, G, eps, relu, up_add, UH, UW, pad);
   return ovis::check_launch("groupnorm");
 }
 
