@@ -9,9 +9,10 @@ from openvis_amd import _lib
 name = sys.argv[1] if len(sys.argv) > 1 else "brivis"
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 T = 36 if name.startswith("brivis") else 5
+RES = (1080, 1920) if name.endswith("swinl") else (720, 1280)
 model, sd, text = bench.build_model("cuda", model_name=name)
-frames = bench.synth_frames(T, 720, 1280, 1000, "cuda")
-inp = [{"image": [f for f in frames.cpu()], "dataset_name": "synthetic_burst_val", "height": 720, "width": 1280}]
+frames = bench.synth_frames(T, RES[0], RES[1], 1000, "cuda")
+inp = [{"image": [f for f in frames.cpu()], "dataset_name": "synthetic_burst_val", "height": RES[0], "width": RES[1]}]
 for _ in range(2):
     model(inp)
 torch.cuda.synchronize()
