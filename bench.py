@@ -65,6 +65,103 @@ def synth_text(K, dim, seed=1, spread=0.05):
     return torch.nn.functional.normalize(base + spread * torch.randn(K, dim, generator=g), dim=-1)
 
 
+def _aggregate(prof):
+    """ops.PROFILE entries -> ({kernel: [launches, flops, seconds]}, {kernel: [launches, bytes, seconds]}) (HIP events per launch)."""
+    agg, hbm = {}, {}
+    for name, work, e0, e1 in prof:
+        a = (hbm if name.startswith("hbm:") else agg).setdefault(name.replace("hbm:", ""), [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += work
+        a[2] += e0.elapsed_time(e1) * 1e-3
+    return agg, hbm
+
+
+def _family_of(k):
+    # the ping-pong kernel's f32-A instantiations (<.., X3=false, FA=true>: bf16x2, three bf16 products per f32 product) are a
+    # family of their own: their flops are f32-equivalent and their ceiling is the bf16 peak / 3, not the fp16 peak
+    base = k.split("<")[0]
+    targs = k[len(base) + 1:-1].split(",") if "<" in k else []          # <OUT, ACT, HAS_R, X3, FA, R16>
+    return base + "[f32A]" if base == "gemm_f16_pp_kernel" and len(targs) >= 5 and targs[4] == "true" else base
+
+
+def _families(a):
+    """"The dominant kernel" = the kernel TEMPLATE with the largest summed launch time (rocprofv3 lists every instantiation as its own row
+    -- <out dtype, activation, residual> for the fp16 GEMM --, but it is one piece of code)."""
+    fam = {}
+    for k, v in a.items():
+        f = fam.setdefault(_family_of(k), [0, 0.0, 0.0, {}])
+        f[0] += v[0]; f[1] += v[1]; f[2] += v[2]; f[3][k] = v
+    return fam
+
+
+def _family_peak(kbase, f32_split):
+    """(peak TFLOP/s, note) of a GEMM kernel family: one f32 product = 6 (bf16x3) or 3 (bf16x2 / fp16x2) 16-bit MFMA products."""
+    if "f32x3" in kbase or "[f32A]" in kbase:
+        nprod = 3 if (f32_split in ("bf16x2", "fp16x2") or "[f32A]" in kbase) else 6
+        return round(PEAK_F16_MFMA_TFLOPS / nprod, 1), (f"{'fp16' if f32_split == 'fp16x2' else 'bf16'} dense MFMA peak / {nprod} "
+                                                         f"({f32_split}: {nprod} 16-bit products per f32 product)")
+    if "f16" in kbase:
+        return PEAK_F16_MFMA_TFLOPS, "fp16 dense MFMA peak"
+    return PEAK_F32_MFMA_TFLOPS, "f32 MFMA peak"
+
+
+def _family_label(kbase, members):
+    return kbase.replace("[f32A]", "") + ("<*,FA=true>" if "[f32A]" in kbase else "<*>") if len(members) > 1 else next(iter(members))
+
+
+def measure_other_config(name, device, args, f32_split):
+    """One of BASELINE.json's other single-GPU-runnable configs (configs[2] san_online, [3] brivis 36 frames, [4] brivis Swin-L 1080p) on the
+    DEFAULT command's line: built, warmed, timed like the headline (barrier-free: N = 1), then one extra pass under per-launch HIP events
+    for the roofline of ITS dominant GEMM family.  The model is dropped afterwards (weights + activations of Swin-L / ViT-L: ~6 GB)."""
+    from openvis_amd import ops
+    T = 36 if name.startswith("brivis") else T_CLIP
+    res = 1080 if name.endswith("_swinl") else 720
+    FH, FW = res, res * 16 // 9
+    steps = {"san_online": 20, "brivis": 6, "brivis_swinl": 2}.get(name, 4)
+    m, _, _ = build_model(device, clip_precision=args.clip_precision, precision=args.precision, model_name=name, f32_split=args.f32_split)
+    clips = [synth_frames(T, FH, FW, 1000 + i, "cpu").pin_memory() for i in range(2)]
+    inputs = [[{"image": [f for f in c], "dataset_name": "synthetic_burst_val"}] for c in clips]
+    out = None
+    for i in range(2):
+        out = m(inputs[i % 2])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = m(inputs[i % 2])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if out is not None and hasattr(out, "wait"):
+        out.wait()
+    ops.PROFILE = []
+    m(inputs[0])
+    torch.cuda.synchronize()
+    prof, ops.PROFILE = ops.PROFILE, None
+    agg, hbm = _aggregate(prof)
+    fam = _families(agg)
+    kbase, (n_launch, flops, secs, members) = max(fam.items(), key=lambda kv: kv[1][2])
+    peak, peak_note = _family_peak(kbase, f32_split)
+    roof = {"kernel": _family_label(kbase, members), "bound": "mfma", "achieved": round(flops / secs / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(flops / secs / 1e12 / peak, 4), "peak_note": peak_note, "launches_per_step": n_launch,
+            "ms_per_step_in_kernel": round(secs * 1e3, 3)}
+    k1 = None
+    if hbm:
+        kname, (kn, kbytes, ksecs) = max(hbm.items(), key=lambda kv: kv[1][2])
+        k1 = {"kernel": kname, "bound": "hbm", "achieved": round(kbytes / ksecs / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+              "frac": round(kbytes / ksecs / 1e9 / PEAK_HBM_GBS, 4), "launches_per_step": kn}
+    bb = {"r50": "R50", "swin_l": "Swin-L"}[MODELS[name].get("backbone", "r50")]
+    line = {"workload": f"{name} {bb} {res}p, {T}-frame clips, {MODELS[name].get('clip', 'ViT-B/16')}, 100 queries, 482 classes",
+            "baseline_config": {"san_online": "configs[2]", "brivis": "configs[3] (one GPU: all 36 frames on this rank)",
+                                "brivis_swinl": "configs[4] (one GPU: all 36 frames on this rank)"}.get(name),
+            "value": round(T * steps / elapsed, 3), "unit": "frames/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": 2,
+            "frames_per_step": T, "dtype": "f16" if "fp16" in (m.backbone.precision, m.clip_adapter.precision) else "f32 (fp16x2 on the 16-bit MFMA)"
+            if f32_split == "fp16x2" else "f32", "roofline": roof, "roofline_k1": k1}
+    del m, out, clips, inputs
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return line
+
+
 MODELS = {   # --model: META_ARCHITECTURE, decoder, weight spec, backbone, CLIP tower, queries
     "openvis": dict(arch="OpenVIS", decoder="VideoMultiScaleMaskedTransformerDecoder", spec="openvis_spec"),
     "openvis_online": dict(arch="OpenVISOnline", decoder="FrameMultiScaleMaskedTransformerDecoder", spec="openvis_spec"),
@@ -256,6 +353,8 @@ def main():
     ap.add_argument("--no-in-flight", action="store_true",
                     help="skip the `two_clips_in_flight` side measurement (profiling runs: its overlapping launches would mix into rocprofv3's "
                          "per-kernel averages, which are meant to be compared with the sequential per-launch times of `roofline`)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip `other_configs` (short timed runs of san_online / brivis / brivis_swinl = BASELINE.json configs[2..4] after the headline)")
     ap.add_argument("--streams", type=int, default=1,
                     help="clips in flight per GPU (openvis_amd.runtime.ClipPipeline: one HIP stream + host thread each); "
                          "the default 1 keeps every launch alone on the GPU, which is what the roofline figures describe -- "
@@ -276,6 +375,10 @@ def main():
     ap.add_argument("--sharded-frames", type=int, default=36,
                     help="N > 1 with the default model: frames of the ONE BriVIS clip that is additionally run frame-sharded over the ranks "
                          "(`frame_sharded` on the JSON line; BASELINE.json configs[3]: 36); 0 skips it")
+    ap.add_argument("--process-group", action="store_true",
+                    help="N = 1: create a ONE-rank RCCL process group anyway and (online models) run the frame-sharded control flow over it -- "
+                         "the all-gather on the side stream, the logit all-reduce, the mask gather -- so that the RCCL code path executes on a "
+                         "one-GPU box (tests/test_sharded_gpu.py)")
     ap.add_argument("--precision", default="mixed", choices=["mixed", "fp32"],
                     help="dense-path policy: mixed = the reference's autocast policy, fp32 = exact f32 everywhere")
     ap.add_argument("--f32-split", default="auto", choices=["auto", "fp16x2", "bf16x3", "bf16x2", "f32"],
@@ -294,14 +397,14 @@ def main():
     # one-GPU box; the driver's multi-GPU runs use one GPU per rank over RCCL
     rig = os.environ.get("OVIS_BENCH_TEST_RIG") == "1"
     torch.cuda.set_device(0 if rig else int(os.environ.get("LOCAL_RANK", "0")))
-    rank, world, local_rank = D.init_from_env("gloo" if rig else "nccl")   # "nccl" is RCCL on ROCm
+    rank, world, local_rank = D.init_from_env("gloo" if rig else "nccl", force=args.process_group)   # "nccl" is RCCL on ROCm
     device = torch.device("cuda", 0 if rig else local_rank)
 
     from openvis_amd import ops
     f32_split = args.f32_split if args.f32_split != "auto" else ("bf16x3" if args.precision == "fp32" else "fp16x2")
     model, sd, text = build_model(device, clip_precision=args.clip_precision, precision=args.precision, model_name=args.model, f32_split=args.f32_split,
                                   crop_list=args.crop_list)
-    frame_sharded = args.model.startswith("brivis") and world > 1
+    frame_sharded = args.model.startswith("brivis") and (world > 1 or args.process_group)
     T = args.frames or (36 if args.model.startswith("brivis") else T_CLIP)
     res = args.resolution or (1080 if args.model.endswith("_swinl") else 720)
     FH, FW = res, res * 16 // 9                          # frame size of this run
@@ -330,7 +433,7 @@ def main():
 
     # frames every rank processes per step (frame-sharded: its block of the clip; clip replicas: whole clips)
     frames_per_rank = ([len(D.inference_shard(T, r, world)) for r in range(world)] if frame_sharded else [T] * world)
-    if world > 1:
+    if world > 1 or args.process_group:
         # RCCL builds its rings / channels at the first collective of every kind, so the first ones run OUTSIDE the timed region:
         # clip replicas only ever use the scalar all-reduce of the timing; the frame-sharded path also its all-gather / all-reduce /
         # gather (distributed.warm_up; the warm-up steps then repeat them through the model)
@@ -340,7 +443,8 @@ def main():
 
     if f32_split == "fp16x2":
         # the timed loop drops its outputs unread (only the last one is waited for), so the range flags of ALL forwards are OR-ed on the device
-        _model.sticky_range_flag = torch.zeros((1,), dtype=torch.int32, device=device)
+        from openvis_amd.modeling.video_maskformer import StickyFlag
+        _model.sticky_range_flag = StickyFlag(device)          # one device word per host thread (clips in flight), OR-ed at readout
     out = None
     if args.streams > 1 and not frame_sharded:
         # K steps = K clips, `--streams` of them in flight (independent clips; results identical to the sequential loop)
@@ -395,6 +499,35 @@ def main():
         torch.cuda.synchronize()
     alt = alts[0] if alts else None
 
+    # ---- the same clips with an f32-class BACKBONE (the parity-grade policy), timed the same way ---------------------------------
+    # The headline's ResNet runs fp16 MFMA operands with f32 accumulation (the reference's autocast, train_net.py:241), which moves mask
+    # logits by up to 2e-2: on C2 its masks differ from the f32 oracle in ~14 k of 29.4 M bits, all inside |logit| < 3e-2.  With the
+    # backbone under MODEL.BACKBONE_PRECISION = fp32 (large convs on the f32-grade split like the pixel decoder) the same clip differs in
+    # ~120 bits, <= 5 of them beyond |logit| 1e-3 (tests/test_c2_720p_gpu.py, profiles/r06/parity_summary.txt).  That policy's frames/s
+    # stands here, driver-timed, next to the headline.
+    alt_bb = None
+    if (args.model == "openvis" and _model.backbone.precision == "fp16" and not (args.streams > 1) and not args.no_alt_splits
+            and hasattr(_model.backbone, "h16_storage")):
+        from openvis_amd.modeling.backbone.resnet import ResNet
+        keep_bb = _model.backbone
+        _model.backbone = ResNet(keep_bb.depth, keep_bb.out_features, precision="fp32").load_state_dict(sd, "backbone.", device)
+        n_alt = max(args.steps // 2, 1)
+        for i in range(2):
+            model(inputs[i % len(inputs)])
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(n_alt):
+            model(inputs[i % len(inputs)])
+        sync_all()
+        e_alt = D.max_over_ranks(time.perf_counter() - t0, "cpu" if rig else device)
+        alt_bb = {"backbone": f"f32-class ({f32_split} on the 16-bit MFMA, native f32 for the small layers)", "value": round(T * n_alt * world / e_alt, 3),
+                  "unit": "frames/s", "ms_per_step": round(e_alt / n_alt * 1e3, 3), "steps": n_alt,
+                  "parity": "C2 full size: <= 16 mask bits beyond |oracle logit| 1e-3 (asserted; measured 5), 0 beyond 3e-2; headline policy: 0 beyond 3e-2"}
+        _model.backbone = keep_bb
+        del keep_bb
+        out = model(inputs[0])
+        torch.cuda.synchronize()
+
     # ---- the same clips with TWO in flight (openvis_amd.runtime.ClipPipeline: one HIP stream + host thread per slot) --------------------
     # What a serving process would run: the tails of the persistent GEMMs and the latency-bound decoder of one clip fill with the other
     # clip's kernels.  Reported BESIDE the headline, not as it: per-launch HIP-event times of overlapping clips include each other's kernels,
@@ -422,22 +555,18 @@ def main():
     # timing's scalar.  The frame-sharded BriVIS pass (configs[3]) is what moves data over RCCL / xGMI: one command measures both.
     frame_sharded_side = None
     if world > 1 and not frame_sharded and args.model == "openvis" and args.sharded_frames > 0:
-        frame_sharded_side = measure_frame_sharded(device, rank, world, rig, args, sync_all)
+        if world > args.sharded_frames:
+            # more ranks than frames: inference_shard() would hand some ranks an EMPTY frame block and they would fall out of the collective
+            # sequence (frames[0] of an empty list) -- skipped on every rank alike, with the reason on the line
+            frame_sharded_side = {"skipped": f"--sharded-frames {args.sharded_frames} < world size {world}: a rank would own no frame"}
+        else:
+            frame_sharded_side = measure_frame_sharded(device, rank, world, rig, args, sync_all)
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream -----------
     # Per-launch events around every GEMM / K1 launch (ops.PROFILE).  Two untimed passes:
     #   in situ : the K clips again exactly as in the timed region (with `--streams` > 1 the kernels of different clips
     #             share the GPU, so a launch lasts longer than alone -- this is what rocprofv3 sees for this command);
     #   isolated: one clip alone on one stream (the kernel's own rate; also fills the per-stage tensors `st`).
-    def _aggregate(prof):
-        agg, hbm = {}, {}
-        for name, work, e0, e1 in prof:
-            a = (hbm if name.startswith("hbm:") else agg).setdefault(name.replace("hbm:", ""), [0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += work
-            a[2] += e0.elapsed_time(e1) * 1e-3
-        return agg, hbm
-
     pipelined = args.streams > 1 and not frame_sharded
     agg_situ = hbm_situ = None
     if pipelined:
@@ -458,33 +587,12 @@ def main():
     # "The dominant kernel" = the kernel TEMPLATE with the largest summed launch time (rocprofv3 lists every instantiation as
     # its own row -- <out dtype, activation, residual> for the fp16 GEMM --, but it is one piece of code); the line carries
     # the aggregate over its instantiations and every instantiation's own row for the cross-check against rocprofv3.
-    def _family_of(k):
-        # the ping-pong kernel's f32-A instantiations (<.., X3=false, FA=true>: bf16x2, three bf16 products per f32 product) are a
-        # family of their own: their flops are f32-equivalent and their ceiling is the bf16 peak / 3, not the fp16 peak
-        base = k.split("<")[0]
-        targs = k[len(base) + 1:-1].split(",") if "<" in k else []          # <OUT, ACT, HAS_R, X3, FA, R16>
-        return base + "[f32A]" if base == "gemm_f16_pp_kernel" and len(targs) >= 5 and targs[4] == "true" else base
-
-    def _families(a):
-        fam = {}
-        for k, v in a.items():
-            f = fam.setdefault(_family_of(k), [0, 0.0, 0.0, {}])
-            f[0] += v[0]; f[1] += v[1]; f[2] += v[2]; f[3][k] = v
-        return fam
-
     fam_situ, fam_iso = _families(agg_situ), _families(agg)
     kbase, (n_launch, flops, secs, members) = max(fam_situ.items(), key=lambda kv: kv[1][2])
-    dom = (kbase.replace("[f32A]", "") + ("<*,FA=true>" if "[f32A]" in kbase else "<*>") if len(members) > 1 else next(iter(members)), None)
+    dom = (_family_label(kbase, members), None)
     achieved = flops / secs / 1e12
     iso = fam_iso.get(kbase, (n_launch, flops, secs))
-    if "f32x3" in kbase or "[f32A]" in kbase:      # one f32 product = 6 (bf16x3) or 3 (bf16x2) bf16 MFMA products: ceiling = bf16 peak / that
-        nprod = 3 if (f32_split in ("bf16x2", "fp16x2") or "[f32A]" in kbase) else 6
-        peak, peak_note = round(PEAK_F16_MFMA_TFLOPS / nprod, 1), (f"{'fp16' if f32_split == 'fp16x2' else 'bf16'} dense MFMA peak / {nprod} "
-                                                                   f"({f32_split}: {nprod} 16-bit products per f32 product)")
-    elif "f16" in kbase:
-        peak, peak_note = PEAK_F16_MFMA_TFLOPS, "fp16 dense MFMA peak"
-    else:
-        peak, peak_note = PEAK_F32_MFMA_TFLOPS, "f32 MFMA peak"
+    peak, peak_note = _family_peak(kbase, f32_split)
     # HBM traffic of that kernel: PMC passes of this same command (tools/pmc_traffic.py: FETCH_SIZE x2 gfx950 correction +
     # WRITE_SIZE, separate --pmc runs) committed under profiles/rNN/ -- a STATIC figure (bench.py cannot run rocprofv3 on
     # itself), tagged with the file and the commit it was collected at; null if no summary has this kernel
@@ -626,8 +734,13 @@ def main():
         # The roof that BINDS K1 is not HBM (the value tensor of a frame level is L2 / Infinity-Cache resident): every (query, head, level, point)
         # pulls four 128-byte tap segments through the CU's L1 -- 48 taps x 128 B x 8 heads per token.  MI355X_MICROARCH.md, "Indexed rows: gather
         # into LDS": rows served from the XCD's L2 arrive at 66-73 GB/s per CU = 16.8-18.8 TB/s chip-wide (profiles/r05/k1_tiled_sweep.txt).
-        tokens = kbytes / kn / 3200.0                                # algorithmic bytes per launch = 3 200 B per token
-        gathered = tokens * 8 * 48 * 128
+        # constants from the model's own deformable attention (d_model C, heads M, levels L, points P), not hard-wired: algorithmic bytes per
+        # token = 4 (2 C + 3 M L P) (f32 value row + output row + offsets / logits: 3 200 B for 256 / 8 / 3 / 4); a (query,
+        # head, level, point) gathers four taps of C / M f32 channels
+        sa = _model.sem_seg_head.pixel_decoder.layers[0].self_attn
+        Cm, Mh, Ll, Pp = sa.d_model, sa.n_heads, sa.n_levels, sa.n_points
+        tokens = kbytes / kn / (4.0 * (2 * Cm + 3 * Mh * Ll * Pp))
+        gathered = tokens * Mh * (Ll * Pp * 4) * (Cm // Mh * 4)
         roofline_k1["gather"] = {"bound": "L2 -> CU gather path", "gathered_bytes_per_launch": int(gathered),
                                  "achieved": round(gathered / (ksecs / kn) / 1e12, 2), "peak": 18.8, "unit": "TB/s",
                                  "frac": round(gathered / (ksecs / kn) / 1e12 / 18.8, 3),
@@ -639,6 +752,7 @@ def main():
             "metric": ("frames/sec (whole node) OpenVIS R50 720p inference" if args.model == "openvis" and res == 720 else
                        f"frames/sec (whole node) {args.model} {bb_name} {res}p inference"), "value": round(frames_total / elapsed, 3),
             "unit": "frames/s", "n_gpus": world, "world_size_seen": D.world_size(), "frames_per_rank": frames_per_rank,
+            "process_group": D.backend_name(),
             "steps": args.steps, "warmup": args.warmup, "f32_split": f32_split, "f32_split_f32_grade": f32_split != "bf16x2",
             "f32_split_bound": {"fp16x2": "error <= max(2^-22 |a|, 2^-29) per activation (absolute floor of the fp16 lo plane at a_scale 16) and 2^-22 |w| per weight: "
                                           "f32-grade against the row scale |A||W| + |b| + |R| (2.0-3.0e-7 measured, native f32 MFMA 3.6-4.5e-7), not a relative bound per element",
@@ -646,7 +760,7 @@ def main():
                                 "f32": "native f32 MFMA"}.get(f32_split),
             "f32_split_fell_back_to_bf16x3": bool(fell_back),
             "crop_list": getattr(getattr(_model, "clip_adapter", None), "crop_list", None), "alt_f32_split": alt, "alt_f32_splits": alts,
-            "two_clips_in_flight": in_flight2, "frame_sharded": frame_sharded_side,
+            "alt_backbone_f32": alt_bb, "two_clips_in_flight": in_flight2, "frame_sharded": frame_sharded_side,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if frame_sharded else "weak",
             "vs_baseline": None, "dtype": "f16" if "fp16" in (bb_prec, _model.clip_adapter.precision) else "f32", "data": "synthetic",
@@ -668,10 +782,21 @@ def main():
             "roofline": roofline, "roofline_k1": roofline_k1, "stage_ms": stage_ms, "collective_ms": collective_ms,
             "stage_ms_note": "one clip alone, device sync after every stage (clips in flight overlap these stages)",
         }
+        if (world == 1 and args.model == "openvis" and res == 720 and not args.no_other_configs and args.streams == 1
+                and D.backend_name() is None):
+            # BASELINE.json configs[2], [3], [4] on the driver's line: short runs after the headline, each with its own dominant-kernel roofline
+            del out, st
+            _model = model = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            line["other_configs"] = [measure_other_config(n, device, args, f32_split) for n in ("san_online", "brivis", "brivis_swinl")]
+            line["other_configs_note"] = ("N = 1 runs of the other BASELINE.json configs, same timing rules as the headline (warm-up, then `steps` "
+                                          "steps between device synchronisations, H2D of the frames and D2H of the masks included); not the headline")
         if not args.no_cpu_baseline and world == 1 and args.model == "openvis":
             line["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(line))
-    if world > 1:
+    if D.backend_name() is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -13,14 +13,17 @@ import os
 import torch
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=False):
     """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* (torch.distributed.run). Returns
-    (rank, world, local_rank); a no-op for world == 1."""
+    (rank, world, local_rank); a no-op for world == 1 unless `force` (or OVIS_FORCE_PROCESS_GROUP=1): a ONE-rank group is legal, and on
+    a one-GPU box a 1-rank "nccl" group is the only way to execute the RCCL branches of this module (async all_gather_into_tensor on the
+    side stream, device all-reduce, dist.gather of device tensors) before the first multi-GPU run does."""
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = force or os.environ.get("OVIS_FORCE_PROCESS_GROUP") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
@@ -65,6 +68,12 @@ def world_size():
     """World size the process group actually has (1 without one) -- bench.py prints it next to --gpus."""
     import torch.distributed as dist
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def backend_name():
+    """"nccl" (= RCCL) / "gloo" of the default process group, None without one."""
+    import torch.distributed as dist
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
 
 
 # ---- per-rank timing of the exchange steps (bench.py --model brivis --gpus N prints them as `collective_ms`) ---------------------------

@@ -144,11 +144,13 @@ class ResNet:
         if self.w["stem"][0].shape[2] == 8 and x.shape[2] % 2 != 0:
             raise ValueError("ResNet stem with the padded 7x8 kernel needs an even input width (frames are padded to a multiple of 32)")
         if self.precision == "fp16" and self.h16_storage:
-            # conv_h16 addresses its fp16 input with 32-bit byte offsets (include/openvis_hip.h: T H W Cin 2 B < 2^31); the largest such
-            # map is conv2's input of res2, [T, H/4, W/4, 64] = T H W / 2 bytes (7.5 MB per 720p frame).  The convolutions are per frame,
-            # so a whole video the reference would hand to the backbone in one piece (openvis.py:64) runs as chunks of the frame axis
+            # conv_h16 addresses its fp16 input with 32-bit byte offsets (include/openvis_hip.h: T H W Cin 2 B < 2^31).  The largest such map
+            # is NOT res2's: res3.0 runs conv1 at the full H/4 resolution and puts the stride on conv2 (STRIDE_IN_1X1 False), so its conv2
+            # reads [T, H/4, W/4, 128] -- twice res2's bytes (15 MB per 720p frame) -- h16_bytes_per_frame() takes the maximum over every
+            # conv_h16 call of _forward_h16.  The convolutions are per frame, so a whole video the reference would hand to the backbone in
+            # one piece (openvis.py:64) runs as chunks of the frame axis
             T, H, W = x.shape[:3]
-            chunk = max(1, self.H16_BYTE_LIMIT // max(1, (H // 4) * (W // 4) * 64 * 2 + (2 * (W // 4) + 2) * 64 * 2))
+            chunk = max(1, (self.H16_BYTE_LIMIT - self.h16_guard_slack(H, W)) // self.h16_bytes_per_frame(H, W))
             if T <= chunk:
                 return self._forward_h16(x)
             parts = [self._forward_h16(x[t0:t0 + chunk]) for t0 in range(0, T, chunk)]
@@ -167,6 +169,27 @@ class ResNet:
             if name in self.out_features:
                 feats[name] = x
         return feats
+
+    def h16_conv_inputs(self, H, W):
+        """[(block, H_in, W_in, Cin)] of every ops.conv_h16 call of _forward_h16 on padded [T, H, W, 4] frames: conv2 of a bottleneck reads
+        conv1's output, which has the block INPUT's resolution (the stride sits on conv2) and the block's bottleneck width."""
+        h, w = ((H + 1) // 2 + 1) // 2, ((W + 1) // 2 + 1) // 2         # stem 7x7 / s2 (pad 3), max pool 3x3 / s2 (pad 1)
+        out = []
+        for name, nblocks, first_stride in STAGES[self.depth]:
+            mid = self.w[f"{name}.0.conv2"][0].shape[3] if f"{name}.0.conv2" in self.w else {"res2": 64, "res3": 128, "res4": 256, "res5": 512}[name]
+            for i in range(nblocks):
+                out.append((f"{name}.{i}", h, w, mid))
+                if i == 0 and first_stride == 2:
+                    h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        return out
+
+    def h16_bytes_per_frame(self, H, W):
+        """Bytes of the largest fp16 map one frame hands to conv_h16 (720p: res3.0.conv2's [184, 320, 128] = 15.1 MB)."""
+        return max(h * w * c * 2 for _, h, w, c in self.h16_conv_inputs(H, W))
+
+    def h16_guard_slack(self, H, W):
+        """The frame-independent term of conv_h16's guard, (2 W + 2) Cin 2 bytes, at its largest."""
+        return max((2 * w + 2) * c * 2 for _, h, w, c in self.h16_conv_inputs(H, W))
 
     H16_BYTE_LIMIT = (1 << 31) - (1 << 20)     # per chunk, below conv_h16's 2^31 guard (tests lower it to exercise the chunking)
     __call__ = forward

@@ -258,8 +258,15 @@ class ClipAdapter:
     mask_prompt_depth = 0            # AdaptedClipAdapter: > 0 (the tower owns a mask_embedding)
     mask_prompt_fwd = False
     crop_list = "auto"               # MODEL.CLIP_ADAPTER.CROP_LIST (config.py)
-    _valid_frac = None               # share of non-empty masks of the most recent clip whose count is known (auto mode)
-    _pending_counts = ()             # (event, pinned host int32 [1], T*Q) of the device-list forwards whose counts are still on their way, oldest first
+    # auto mode, PER HOST THREAD (ClipPipeline / --streams run several forwards of one model at once: a shared queue would be an unguarded
+    # read-modify-write, and a dropped or duplicated entry makes the host / device choice -- and the GEMM shapes -- timing-dependent again):
+    #   _valid_frac     share of non-empty masks of the most recent clip of THIS thread whose count is known
+    #   _pending_counts (event, pinned host int32 [1], T*Q) of this thread's device-list forwards whose counts are still on their way
+    _auto = __import__("threading").local()
+    _valid_frac = property(lambda self: getattr(self._auto, "frac", {}).get(id(self)),
+                           lambda self, v: self._auto.__dict__.setdefault("frac", {}).__setitem__(id(self), v))
+    _pending_counts = property(lambda self: getattr(self._auto, "pend", {}).get(id(self), ()),
+                               lambda self, v: self._auto.__dict__.setdefault("pend", {}).__setitem__(id(self), v))
 
     def __init__(self, clip_model_name="ViT-B/16", text_templates="vild", arch=None, precision="fp16"):
         self.clip_model_name = clip_model_name
@@ -321,7 +328,8 @@ class ClipAdapter:
             return self.crop_list == "device"
         # Deterministic: clip n looks at the count of clip n - 2, never at "whatever has arrived" (an event.query() made the choice -- and with
         # it the GEMM shapes: M compacted or T Q -- depend on host timing).  That copy was queued two forwards ago behind clip n - 2's mask
-        # kernel; the launch window (_lib.LAUNCH_WINDOW) keeps the host less than a clip ahead, so the synchronize returns at once.
+        # kernel; the launch window (_lib.LAUNCH_WINDOW) keeps the host less than a clip ahead, so the synchronize normally returns at once
+        # (it IS a host wait in the launch path if the host ever runs two clips ahead: bounded by one clip's GPU time).
         if len(self._pending_counts) >= 2:
             ev, host, n = self._pending_counts[0]
             ev.synchronize()

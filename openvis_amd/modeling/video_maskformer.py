@@ -14,24 +14,28 @@ def retry_if_oom(forward):
       1. run;  2. OutOfMemoryError -> synchronize, torch.cuda.empty_cache(), run again;
       3. still out of memory -> the per-frame (online) models run once more as WINDOWS of MODEL.MASK_FORMER.TEST.WINDOW_SIZE frames
          (minvis.py:340-362: same outputs, activation memory bounded by the window) -- there is no CPU path to fall back to, by design;
-         the offline models (decoder joint over all frames) and frame-sharded runs (every rank must take the same path through the
-         collectives) re-raise."""
+         the offline models (decoder joint over all frames) re-raise.
+    Frame-sharded runs (every rank must take the same path through the collectives) re-raise at the FIRST out-of-memory error."""
     import functools
     import warnings
 
     @functools.wraps(forward)
     def wrapped(self, batched_inputs, *args, **kwargs):
+        sharded = kwargs.get("frame_range") is not None or (len(args) >= 2 and args[1] is not None)     # BriVIS.forward(.., stages, frame_range)
         try:
             return forward(self, batched_inputs, *args, **kwargs)
         except torch.OutOfMemoryError:
-            pass
+            # frame-sharded: NO local retry at all.  The forward's `on_embeds` hook has launched the all-gather as soon as the decoder output
+            # existed; a rank that runs out of memory behind it and repeats the forward would issue a second all-gather while its peers have
+            # moved on to the logit all-reduce / mask gather -- mismatched collective sequences hang or exchange garbage instead of failing.
+            if sharded:
+                raise
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         try:
             return forward(self, batched_inputs, *args, **kwargs)
         except torch.OutOfMemoryError:
-            sharded = kwargs.get("frame_range") is not None or (len(args) >= 2 and args[1] is not None)     # BriVIS.forward(.., stages, frame_range)
-            if sharded or not hasattr(self, "window_inference") or self.window_inference:
+            if not hasattr(self, "window_inference") or self.window_inference:
                 raise
         warnings.warn(f"{type(self).__name__}: out of device memory on a whole clip; repeating it as windows of {self.window_size} frames")
         torch.cuda.synchronize()
@@ -42,6 +46,33 @@ def retry_if_oom(forward):
         finally:
             self._fwd.force_windows = False
     return wrapped
+
+
+class StickyFlag:
+    """OR of the fp16x2 range flags of every forward since it was made, for callers that drop outputs unread.  `bitwise_or_` on ONE device
+    word is a read-modify-write queued from each host thread's own stream: with several clips in flight (ClipPipeline, --streams > 1) two
+    forwards can race and lose a bit.  So: one device word per host thread (each only ever touched from that thread's stream), OR-ed at
+    readout after a device synchronize."""
+
+    def __init__(self, device):
+        import threading
+        self.device, self._lock, self._words = torch.device(device), threading.Lock(), {}
+
+    def or_(self, flag):
+        import threading
+        tid = threading.get_ident()
+        w = self._words.get(tid)
+        if w is None:
+            w = torch.zeros((1,), dtype=torch.int32, device=self.device)
+            with self._lock:
+                self._words[tid] = w
+        w.bitwise_or_(flag)
+
+    def item(self):
+        torch.cuda.synchronize(self.device)
+        with self._lock:
+            words = list(self._words.values())
+        return int(any(int(w.item()) != 0 for w in words))
 
 
 def build_backbone(cfg):
@@ -154,7 +185,7 @@ class VideoMaskFormer:
             raise RuntimeError(f"inference_video: top-{topk} over {n // max(K, 1)} valid queries x {K} classes: selected index k out of range "
                                "(fewer (query, class) pairs than topk; video_maskformer.py:269)")
 
-    sticky_range_flag = None  # optional device int32 [1]: OR of the fp16x2 range flags of every forward since it was set (never read by the model)
+    sticky_range_flag = None  # optional StickyFlag: OR of the fp16x2 range flags of every forward since it was set (never read by the model)
     output_rle = False        # MODEL.MASK_FORMER.TEST.OUTPUT_RLE (not a reference key): RLE hand-off instead of dense masks
     mask_gather = None        # frame-sharded runs: callable(device masks [n,t_local,H,W]) -> masks of all frames on the output rank / None
 
@@ -168,7 +199,7 @@ class VideoMaskFormer:
         what `row_ids is None` means on the host path -- an empty result."""
         flag = self._forward_flag()
         if flag is not None and self.sticky_range_flag is not None:
-            self.sticky_range_flag.bitwise_or_(flag)          # callers that drop outputs unread (bench.py's timed loop) still learn of an overflow
+            self.sticky_range_flag.or_(flag)                  # callers that drop outputs unread (bench.py's timed loop) still learn of an overflow
         if flag is not None and sync_guard:
             again = self._range_guard(flag.cpu()[0], redo)
             if again is not None:
@@ -219,8 +250,10 @@ class VideoMaskFormer:
                 again = self._range_guard(flag.cpu()[0] if flag is not None else None, redo)
                 if again is not None:
                     return again
+                scores = score.cpu().tolist()
+                self._check_selected_rows(scores, topk, K)                    # every rank raises where the output rank raises
                 return {"image_size": (output_height, output_width), "pred_entropys": ent.cpu().tolist(),
-                        "pred_scores": score.cpu().tolist(), "pred_labels": [i % K for i in idx.cpu().tolist()],
+                        "pred_scores": scores, "pred_labels": [i % K for i in idx.cpu().tolist()],
                         "pred_masks": [], "pred_queries": sel_q.cpu().tolist()}
         # D2H of the 10 output masks and of the top-10 scalars (video_maskformer.py:267-283): pinned staging buffers from torch's
         # caching host allocator, async copies on the hand-off side stream behind the last kernel; uint8 {0,1} is re-viewed as

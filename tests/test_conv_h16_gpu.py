@@ -136,11 +136,25 @@ def test_backbone_chunks_the_frame_axis_beyond_the_32_bit_offset_limit():
     frames = bench.synth_frames(5, 96, 160, 3, "cuda")
     images, _, _ = model.preprocess(frames)
     whole = bb(images)
-    per_frame = (96 // 4) * (160 // 4) * 64 * 2 + (2 * (160 // 4) + 2) * 64 * 2
+    # the derived per-frame table against the shapes ops.conv_h16 really receives (res3.0.conv2 reads [T, H/4, W/4, 128],
+    # twice res2's bytes -- sizing the chunk from res2 let 143-281 frame 720p videos through to the kernel's guard)
+    from openvis_amd import ops
+    seen = []
+    real = ops.conv_h16
+    try:
+        ops.conv_h16 = lambda x, *a, **k: (seen.append(tuple(x.shape)), real(x, *a, **k))[1]
+        bb(images)
+    finally:
+        ops.conv_h16 = real
+    Hp, Wp = images.shape[1:3]
+    table = bb.h16_conv_inputs(Hp, Wp)
+    assert [(h, w, c) for _, h, w, c in table] == [s[1:] for s in seen], (table, seen)
+    per_frame = bb.h16_bytes_per_frame(Hp, Wp)
+    assert per_frame == max(s[1] * s[2] * s[3] * 2 for s in seen) == (Hp // 4) * (Wp // 4) * 128 * 2
     calls = []
     inner = bb._forward_h16
     try:
-        bb.H16_BYTE_LIMIT = 2 * per_frame                              # two frames per chunk: 2 + 2 + 1
+        bb.H16_BYTE_LIMIT = 2 * per_frame + bb.h16_guard_slack(Hp, Wp)   # two frames per chunk: 2 + 2 + 1
         bb._forward_h16 = lambda x: (calls.append(x.shape[0]), inner(x))[1]
         chunked = bb(images)
     finally:
@@ -148,10 +162,31 @@ def test_backbone_chunks_the_frame_axis_beyond_the_32_bit_offset_limit():
     assert calls == [2, 2, 1]
     for k in whole:
         assert torch.equal(whole[k], chunked[k]), k
-    # 720p: 7.5 MB per frame -> the default limit admits 284 frames per chunk and stays under the kernel's guard
-    per_720 = (736 // 4) * (1280 // 4) * 64 * 2 + (2 * (1280 // 4) + 2) * 64 * 2
-    n = ResNet.H16_BYTE_LIMIT // per_720
-    assert 250 < n < 300 and n * (736 // 4) * (1280 // 4) * 64 * 2 + (2 * 320 + 2) * 64 * 2 < (1 << 31)
+    # 720p: 15.1 MB per frame (res3.0.conv2) -> the default limit admits 142 frames per chunk, and EVERY conv_h16 call of such a chunk
+    # satisfies the kernel's guard T H W Cin 2 + (2 W + 2) Cin 2 < 2^31 (csrc/conv_h16.hip: ovis_conv_h16)
+    n = (ResNet.H16_BYTE_LIMIT - bb.h16_guard_slack(736, 1280)) // bb.h16_bytes_per_frame(736, 1280)
+    assert n == 142
+    for _, h, w, c in bb.h16_conv_inputs(736, 1280):
+        assert n * h * w * c * 2 + (2 * w + 2) * c * 2 < (1 << 31)
+    assert (n + 1) * 184 * 320 * 128 * 2 + (2 * 320 + 2) * 128 * 2 >= (1 << 31)      # and one more frame would not
+
+
+@pytest.mark.gpu
+def test_conv_h16_guard_accepts_the_largest_chunk_the_backbone_builds():
+    """The 720p case the advisor could not run: res3.0.conv2 on a 142-frame chunk [142, 184, 320, 128] fp16 (2.14 GB in, 0.54 GB out)
+    passes the kernel's guard and equals the same convolution run on two halves."""
+    from openvis_amd import ops
+    from openvis_amd.modeling.backbone.resnet import ResNet
+    g = torch.Generator().manual_seed(5)
+    n = 142
+    x = (torch.randn(2, 184, 320, 128, generator=g).half().cuda()).repeat(n // 2, 1, 1, 1).contiguous()
+    w = (torch.randn(128, 3, 3, 128, generator=g) / 34).half().cuda()
+    b = torch.randn(128, generator=g).cuda()
+    y = ops.conv_h16(x, w, 3, 2, b, None, ops.ACT_RELU, out_f16=True)
+    y0 = ops.conv_h16(x[:2].contiguous(), w, 3, 2, b, None, ops.ACT_RELU, out_f16=True)
+    assert torch.equal(y[:2], y0) and torch.equal(y[-2:], y0)
+    with pytest.raises(Exception, match="too large"):
+        ops.conv_h16(torch.cat([x, x[:1]]), w, 3, 2, b, None, ops.ACT_RELU, out_f16=True)
 
 
 def test_two_source_gemms_against_f64_on_the_same_fp16_operands():

@@ -98,3 +98,34 @@ def test_rccl_collectives_of_the_frame_sharded_path():
                         "127.0.0.1", "--master-port", "29671", os.path.join(ROOT, "tests", "_rccl_worker.py")], env=env,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and f"RCCL_OK world={world}" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+def test_one_rank_rccl_group_runs_the_frame_sharded_path(tmp_path):
+    """A ONE-rank "nccl" (= RCCL) process group on the box's single GPU, created in a fresh child process before anything touches the GPU:
+    the async all_gather_into_tensor on the side stream, the device all-reduce (with the fp16x2 range flag riding on it) and dist.gather of
+    device tensors -- the branches no gloo rig takes -- run under BriVIS(frame_range=(0, T), gather_masks_to=0) and give the un-sharded
+    forward's outputs; an out-of-memory error behind the all-gather re-raises without a second collective (tests/_rccl_one_rank_worker.py)."""
+    out = str(tmp_path / "rccl1.json")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29678")
+    for k in ("OVIS_BENCH_TEST_RIG", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_one_rank_worker.py"), out], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "RCCL1_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+    r = json.load(open(out))
+    assert r["ok"] and r["backend"] == "nccl" and r["world"] == 1 and r["librccl"], r
+
+
+def test_bench_brivis_under_a_one_rank_rccl_group():
+    """`bench.py --model brivis --process-group` : the frame-sharded bench control flow (warm_up, all-gather on the side stream, logit
+    all-reduce, mask gather, collective_ms) over a 1-rank RCCL group -- what `--gpus 8` runs, minus the peers."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29679")
+    for k in ("OVIS_BENCH_TEST_RIG", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "brivis", "--process-group", "--frames", "6", "--steps", "2", "--warmup", "1",
+                        "--gather-masks", "--no-alt-splits", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["world_size_seen"] == 1 and line["process_group"] == "nccl" and line["scaling"] == "strong"
+    cm = line["collective_ms"]
+    assert {"all_gather_wait", "linker", "temporal_resampler", "logit_all_reduce", "mask_gather"} <= set(cm["per_rank"][0])
+    assert line["value"] > 0 and line["frames_per_rank"] == [6]
