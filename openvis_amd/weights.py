@@ -266,6 +266,22 @@ def random_init(spec, seed=42):
     return sd
 
 
+def sharpen_clip_attention(sd, gain=4.0, prefix="clip_adapter.clip_model.visual."):
+    """SYNTHETIC checkpoints only (parity fixtures; never applied to a loaded checkpoint).  random_init() gives a CLIP tower whose attention
+    is nearly uniform: every crop's CLS token averages its patches, the crop embeddings of one clip differ by 0.3-1 % (centred singular values
+    0.03, 0.003, 0.002, ...), every query scores alike and a classification test cannot fail.  Multiplying the q and k rows of every
+    `attn.in_proj_weight / in_proj_bias` of the tower by `gain` (attention logits x gain^2: the peaked attention a trained tower has) spreads
+    the embeddings over many directions (gain 4: centred singular values 1.3, 0.9, 0.7, ...), so that class scores differ between queries.
+    Returns a NEW dict; everything outside `prefix` is shared."""
+    out = dict(sd)
+    for k, v in sd.items():
+        if k.startswith(prefix) and (k.endswith("attn.in_proj_weight") or k.endswith("attn.in_proj_bias")):
+            w = v.clone()
+            w[: 2 * (v.shape[0] // 3)] *= gain
+            out[k] = w
+    return out
+
+
 class _ArrayUnpickler(__import__("pickle").Unpickler):
     """Unpickler for detectron2 model-zoo `.pkl` files that resolves only what such a file needs (numpy array
     reconstruction, OrderedDict, builtin containers): a MODEL.WEIGHTS path must not be able to run arbitrary code."""

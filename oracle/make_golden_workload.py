@@ -3,6 +3,8 @@ the f32 CPU oracle (oracle/torch_ref.py, pinned against the reference's own modu
 ONCE in the build container on seeded synthetic inputs, and what the GPU tests compare against is committed as data:
 
   tests/golden/c2_openvis_720p_5f.npz    OpenVIS R50 + ClipAdapter ViT-B/16, the bench workload at full size: 5 frames of 720x1280, 482 classes
+  tests/golden/c2_sharp_classes.npz      the same clip, synthetic CLIP tower with peaked attention + a label space built from the oracle's own
+                                         crop embeddings: a classification result that can differ (`c2s`; oracle/fixtures.py)
   tests/golden/c3_san_online_720p.npz    SANOnline R50 + SideAdapter ViT-B/16, 5 frames of 720x1280 (the config's T)
   tests/golden/c4_brivis_720p_36f.npz    BriVIS R50, ONE 36-frame 720p clip (linker over all 36 frames, resampler, heads)
   tests/golden/c5_brivis_swinl_1080p.npz BriVIS Swin-L (embed 192, depths 2/2/18/2, window 12) + SideAdapter ViT-L/14@336,
@@ -109,6 +111,34 @@ def c2():
          mask_counts=(pm > 0).sum(dim=(-1, -2)).numpy().astype(np.int32), **ambiguous(pm), **topk_arrays(res))
 
 
+def c2s():
+    """C2 again with a label space on which the classification can FAIL (oracle/fixtures.py): the synthetic tower gets peaked attention
+    (weights.sharpen_clip_attention: crop embeddings differ between queries; masks are those of c2 -- the CLIP weights do not reach them),
+    the text rows are built from the oracle's own per-query embeddings.  Stored: the parts of the text, the oracle's crop embeddings
+    [500, 512] (expected logits = 100 E text^T), class probabilities, the top-10 and the pixel counts of its ten output masks."""
+    from oracle import fixtures as FX
+    T, K2 = 5, 482
+    sd = weights.sharpen_clip_attention(weights.random_init(weights.openvis_spec("r50", None, Q), seed=42))
+    frames = bench.synth_frames(T, 720, 1280, 1000, "cpu")
+    st = {}
+    with torch.no_grad():
+        TR.openvis_forward(frames, sd, bench.synth_text(K2, 512, spread=0.25), stages=st)
+        E, valid = st["crop_embeds"], st["valid"]
+        rows, Mq = FX.per_query_mean(E, valid)
+        parts, rep = FX.sharp_parts(Mq, K2)
+        text = FX.text_from_parts(parts, K2)
+        crop_logits = 100.0 * E @ text.T
+        mask_pred = F.interpolate(st["pred_masks"][0], size=st["images"].shape[-2:], mode="bilinear", align_corners=False)
+        probs, vmasks, _ = TR.aggregate_crop_logits(crop_logits, valid, mask_pred)
+        res = TR.inference_video(Q, K2, probs, vmasks, (720, 1280), 720, 1280)
+    print("  label space:", rep, flush=True)
+    assert rep["margin"] >= 1e-2 and rep["distinct_labels"] >= 5
+    assert sorted((r, l) for r, l in zip(res["rows"], res["pred_labels"])) == rep["top"]
+    save("c2_sharp_classes.npz", crop_embeds=E.numpy().astype(np.float32), valid=valid.numpy().astype(np.uint8), boxes=st["boxes"].numpy().astype(np.int32),
+         probs=probs.numpy(), rows=np.asarray(rows, np.int32), margin=np.asarray([rep["margin"]]),
+         top_mask_counts=np.asarray([int(m.sum()) for m in res["pred_masks"]], np.int64), **FX.parts_arrays(parts), **topk_arrays(res))
+
+
 def c3():
     T = 5
     sd = weights.random_init(weights.san_spec("r50", None, Q), seed=42)
@@ -181,5 +211,5 @@ if __name__ == "__main__":
     for case in sys.argv[1:] or ["c3", "c4", "c5"]:
         t0 = time.time()
         print(f"== {case}", flush=True)
-        {"c2": c2, "c3": c3, "c4": c4, "c5": c5, "c5f": c5f}[case]()
+        {"c2": c2, "c2s": c2s, "c3": c3, "c4": c4, "c5": c5, "c5f": c5f}[case]()
         print(f"== {case} done in {time.time() - t0:.0f} s", flush=True)

@@ -608,7 +608,7 @@ def open_vocabulary_inference(masks, frames, text_features, W, part_len=5, tempe
     whose tower sees the mask regions when mask_prompt_fwd.
     Returns (probs [Qv,K], masks[valid_query], extras)."""
     T = frames.shape[0]
-    clip_cls, valid_flag, boxes = [], [], []
+    clip_cls, valid_flag, boxes, embeds = [], [], [], []
     for idx in range(0, T, part_len):
         part_frames = frames[idx:idx + part_len]
         part_masks = masks[:, idx:idx + part_len].sigmoid().transpose(0, 1).contiguous()
@@ -623,6 +623,7 @@ def open_vocabulary_inference(masks, frames, text_features, W, part_len=5, tempe
                 feat = clip_encode_image(regions, W, resolution=clip_resolution, heads=clip_heads)
             logits = temperature * feat @ text_features.T                     # adapter.py:146-147
             boxes.append(sb)
+            embeds.append(feat)
         clip_cls.append(logits)
         valid_flag.append(valid)
     clip_cls = torch.cat(clip_cls)
@@ -631,7 +632,7 @@ def open_vocabulary_inference(masks, frames, text_features, W, part_len=5, tempe
     if mean_cls is None:
         return [], [], {}
     extras = {"crop_logits": clip_cls, "valid": valid_flag, "boxes": torch.cat(boxes) if boxes else None,
-              "query_logits": mean_cls}
+              "query_logits": mean_cls, "crop_embeds": torch.cat(embeds) if embeds else None}     # unit rows [M, E]: what `feat` is at adapter.py:144-145
     return probs, vmasks, extras
 
 

@@ -64,8 +64,8 @@ def test_c2_720p_clip_under_the_bench_policy_matches_oracle():
     rows_ref = ref_st["valid"].any(0).nonzero()[:, 0].tolist()
     from tests._logits import check_top10
     n_common, margin = check_top10(out, ref, ref_st["probs"].numpy(), rows_ref, tol=1e-3)
-    print("C2 top-10: %d of 10 (query, label) pairs in common, reference margin 10th - 11th score %.2e" % (n_common, margin))
-    assert n_common == 10 or margin <= 2e-3, (n_common, margin)
+    print("C2 top-10 on bench.synth_text (every query scores alike): %d of 10 (query, label) pairs in common, reference margin 10th - 11th score "
+          "%.2e -- tie-aware check only; the classification that can FAIL is asserted below" % (n_common, margin))
     sg = {(q, l): i for i, (q, l) in enumerate(zip(out["pred_queries"], out["pred_labels"]))}
     sr = {(rows_ref[q], l): i for i, (q, l) in enumerate(zip(ref["rows"], ref["pred_labels"]))}
     ious = []
@@ -77,6 +77,42 @@ def test_c2_720p_clip_under_the_bench_policy_matches_oracle():
     # north-star IoU; with an fp16-operand decoder two of the ten dip to 0.9984 (tools/exp_policy_mix.py)
     print("C2 per-mask IoU:", [round(float(v), 5) for v in ious])
     assert min(ious) > 0.999, ious
+
+    # ---- classification on a SEPARATED label space, same clip, same masks -------------------------------------------------------------
+    # the synthetic tower with peaked attention (crop embeddings differ between queries) on both sides; text rows built from the ORACLE's
+    # per-query embeddings: ten (query, label) pairs, >= 5 distinct labels, graded scores, 11th candidate >= 1e-2 behind (oracle/fixtures.py).
+    # The product (fp16 tower operands, the bench policy) must return exactly that set.
+    from oracle import fixtures as FX
+    import torch.nn.functional as F
+    sd2 = weights.sharpen_clip_attention(sd)
+    with torch.no_grad():
+        mask_pred = F.interpolate(ref_st["pred_masks"][0], size=ref_st["images"].shape[-2:], mode="bilinear", align_corners=False)
+        regions, valid_o, _ = TR.clip_crops(frames, mask_pred.sigmoid().transpose(0, 1).contiguous(), 224)
+        assert torch.equal(valid_o, ref_st["valid"])
+        E = TR.clip_encode_image(regions, sd2)
+        rows2, Mq = FX.per_query_mean(E, valid_o)
+        parts, rep = FX.sharp_parts(Mq, K)
+        text2 = FX.text_from_parts(parts, K)
+        logits2 = 100.0 * E @ text2.T
+        probs2, vmasks2, _ = TR.aggregate_crop_logits(logits2, valid_o, mask_pred)
+        ref2 = TR.inference_video(100, K, probs2, vmasks2, (720, 1280), 720, 1280)
+    print("C2 label space: top-10 %s scores %s margin %.3f, %d distinct labels" % (rep["top"], np.round(rep["scores"][:10], 3).tolist(), rep["margin"], rep["distinct_labels"]))
+    assert rep["margin"] >= 1e-2 and rep["distinct_labels"] >= 5
+    model.clip_adapter.load_state_dict(sd2, device=model.device)
+    model.clip_adapter.set_text_features(names, text2)
+    st2 = {}
+    out2 = model([{"image": [f for f in frames], "dataset_name": "synthetic_c2"}], stages=st2)
+    torch.cuda.synchronize()
+    d2_same, d2_diff = logit_errors_by_box(st2, dict(ref_st, crop_logits=logits2))
+    print("C2 sharpened tower: %d crops with identical boxes, max logit err %.4f (x100 scale)" % (len(d2_same), d2_same.max()))
+    assert d2_same.max() <= 1e-1                                               # 1e-3 on the cosine, fp16 operands, peaked attention
+    sg = {(q, l): s for q, l, s in zip(out2["pred_queries"], out2["pred_labels"], out2["pred_scores"])}
+    sr = {(rows_ref[r], l): s for r, l, s in zip(ref2["rows"], ref2["pred_labels"], ref2["pred_scores"])}
+    assert set(sg) == set(sr) and len({l for _, l in sg}) >= 5, (sorted(sg), sorted(sr))          # EXACT (query, label) set
+    ds = max(abs(sg[k] - sr[k]) for k in sg)
+    dp = np.abs(st2["probs"].cpu().numpy()[rows_ref] - probs2.numpy()).max()
+    print("C2 separated label space: top-10 sets equal, max score diff %.2e, max class-probability diff %.2e" % (ds, dp))
+    assert ds <= 5e-3 and dp <= 5e-3          # d p <= p (1 - p) d logit: 1e-1 on the x100 logits allows 2.5e-2; measured ~1e-3 under fp16 operands
 
 
 @pytest.mark.parametrize("split,backbone", [("auto", "auto"), ("bf16x3", "auto"), ("bf16x2", "auto"), ("auto", "fp32"), ("bf16x3", "fp32")])
@@ -146,6 +182,67 @@ def test_c2_full_size_5_frames_against_the_oracle_golden(split, backbone):
     rows_ref = np.nonzero(vr.any(axis=0))[0].tolist()
     refd = {"rows": g["top_rows"].tolist(), "pred_labels": g["top_labels"].tolist(), "pred_scores": g["top_scores"].tolist()}
     n_common, margin = check_top10(out, refd, g["probs"], rows_ref, tol=1e-3)
-    print("C2 full size [%s] top-10: %d of 10 (query, label) pairs in common, reference margin 10th - 11th %.2e" % (split, n_common, margin))
-    assert n_common == 10 or margin <= 2e-3
+    print("C2 full size [%s] top-10 on bench.synth_text: %d of 10 pairs in common, reference margin 10th - 11th %.2e (tie-aware check only; the "
+          "separated label space is test_c2_full_size_classification_on_a_separated_label_space)" % (split, n_common, margin))
     assert len(out["pred_masks"]) == 10 and tuple(out["pred_masks"][0].shape) == (T, 720, 1280)
+
+
+@pytest.mark.parametrize("clip_precision", ["fp16", "fp32"])
+def test_c2_full_size_classification_on_a_separated_label_space(clip_precision):
+    """The classification half of configs[1] at full size on a label space where it can FAIL (tests/golden/c2_sharp_classes.npz, oracle/
+    make_golden_workload.py c2s): synthetic tower with peaked attention, text rows built from the oracle's own per-query embeddings -- ten
+    winners with >= 5 distinct labels, graded scores, the 11th candidate >= 1e-2 behind.  Asserted: cosine logits within 1e-3 on every crop
+    with the oracle's box, the EXACT top-10 (query, label) set, scores, class probabilities."""
+    import os
+    import bench
+    from openvis_amd import config, weights
+    from openvis_amd.catalog import MetadataCatalog
+    from oracle import fixtures as FX
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c2_sharp_classes.npz"))
+    K, T = 482, 5
+    assert float(g["margin"][0]) >= 1e-2 and len(set(g["top_labels"].tolist())) >= 5
+    sd = weights.sharpen_clip_attention(weights.random_init(weights.openvis_spec("r50", None, 100), seed=42))
+    cfg = config.get_cfg()
+    cfg.MODEL.CLIP_ADAPTER.PRECISION = clip_precision
+    model = config.build_model(cfg)
+    model.load_state_dict(sd)
+    names = [f"class_{i}" for i in range(K)]
+    MetadataCatalog.get("synthetic_c2").set(thing_classes=names)
+    text = FX.text_from_parts(FX.parts_from_arrays(g), K)
+    model.clip_adapter.set_text_features(names, text)
+    frames = bench.synth_frames(T, 720, 1280, 1000, "cpu")
+    st = {}
+    out = model([{"image": [f for f in frames], "dataset_name": "synthetic_c2"}], stages=st)
+    out.wait()
+    vr = g["valid"].astype(bool)
+    assert (st["valid"] == vr).mean() > 0.99
+    ref_logits = 100.0 * g["crop_embeds"] @ text.numpy().T
+    lg = st["crop_logits"].cpu().numpy()
+    gb = {(int(c[0]), int(c[1])): (i, c[2:]) for i, c in enumerate(st["crops"])}
+    same, moved = [], 0
+    for i, (t, q) in enumerate(np.argwhere(vr)):
+        hit = gb.get((int(t), int(q)))
+        if hit is None:
+            continue
+        j, (x0, y0, x1, y1) = hit
+        side = max(x1 + 1 - x0, y1 + 1 - y0)
+        b = g["boxes"][i]
+        if b[0] == x0 and b[1] == y0 and b[2] == x0 + side and b[3] == y0 + side:
+            same.append(float(np.abs(lg[j] - ref_logits[i]).max()))
+        else:
+            moved += 1
+    same = np.array(same)
+    print("C2 separated [%s tower]: %d crops with identical boxes, max logit err %.4f (x100 scale), %d moved" % (clip_precision, len(same), same.max(), moved))
+    assert len(same) >= 0.95 * (len(same) + moved) and same.max() <= 1e-1
+    rows = g["rows"].tolist()
+    sr = {(rows[r], int(l)): float(s) for r, l, s in zip(g["top_rows"], g["top_labels"], g["top_scores"])}
+    sg = {(q, l): s for q, l, s in zip(out["pred_queries"], out["pred_labels"], out["pred_scores"])}
+    assert set(sg) == set(sr), (sorted(sg), sorted(sr))                         # EXACT (query, label) set, >= 5 distinct labels
+    ds = max(abs(sg[k] - sr[k]) for k in sg)
+    dp = np.abs(st["probs"].cpu().numpy()[rows] - g["probs"]).max()
+    counts = {(q, l): int(m.sum()) for q, l, m in zip(out["pred_queries"], out["pred_labels"], out["pred_masks"])}
+    ref_counts = {(rows[r], int(l)): int(n) for r, l, n in zip(g["top_rows"], g["top_labels"], g["top_mask_counts"])}
+    dc = max(abs(counts[k] - ref_counts[k]) / max(ref_counts[k], 1) for k in sg)
+    print("C2 separated [%s tower]: top-10 sets equal (labels %s), max score diff %.2e, max probability diff %.2e, output-mask pixel counts within %.2e"
+          % (clip_precision, sorted({l for _, l in sg}), ds, dp, dc))
+    assert ds <= (5e-3 if clip_precision == "fp16" else 1e-3) and dp <= (5e-3 if clip_precision == "fp16" else 1e-3) and dc <= 2e-3
