@@ -5,6 +5,8 @@ ONCE in the build container on seeded synthetic inputs, and what the GPU tests c
   tests/golden/c2_openvis_720p_5f.npz    OpenVIS R50 + ClipAdapter ViT-B/16, the bench workload at full size: 5 frames of 720x1280, 482 classes
   tests/golden/c2_sharp_classes.npz      the same clip, synthetic CLIP tower with peaked attention + a label space built from the oracle's own
                                          crop embeddings: a classification result that can differ (`c2s`; oracle/fixtures.py)
+  tests/golden/c2_autocast_backbone.npz  the same clip's mask sign bits with the backbone in the reference's GPU arithmetic (autocast: every op's
+                                         output rounded to fp16; `c2a`), and their distance to the f32 oracle's
   tests/golden/c3_san_online_720p.npz    SANOnline R50 + SideAdapter ViT-B/16, 5 frames of 720x1280 (the config's T)
   tests/golden/c4_brivis_720p_36f.npz    BriVIS R50, ONE 36-frame 720p clip (linker over all 36 frames, resampler, heads)
   tests/golden/c5_brivis_swinl_1080p.npz BriVIS Swin-L (embed 192, depths 2/2/18/2, window 12) + SideAdapter ViT-L/14@336,
@@ -139,6 +141,36 @@ def c2s():
          top_mask_counts=np.asarray([int(m.sum()) for m in res["pred_masks"]], np.int64), **FX.parts_arrays(parts), **topk_arrays(res))
 
 
+def c2a():
+    """C2's masks with the backbone in the reference's own GPU arithmetic (TR.resnet50_autocast: every conv / BN / add output rounded to
+    fp16, as `autocast` does at train_net.py:241), everything behind it f32 as in c2.  Stored: the sign bits of the mask logits, and how
+    many of them differ from the f32 oracle's (c2_openvis_720p_5f.npz) in total and outside its |logit| < eps sets -- the envelope the
+    reference's own arithmetic has against f32, which the product's fp16-operand backbone is measured against (tests/test_c2_720p_gpu.py)."""
+    T = 5
+    sd = weights.random_init(weights.openvis_spec("r50", None, Q), seed=42)
+    frames = bench.synth_frames(T, 720, 1280, 1000, "cpu")
+    with torch.no_grad():
+        images, _ = TR.preprocess([f for f in frames])
+        feats = TR.resnet50_autocast(images, sd)
+        mask_features, _, ms = TR.pixel_decoder(feats, sd)
+        _, pred_masks = TR.video_decoder(ms, mask_features, sd)
+    pm = pred_masks[0]
+    g = np.load(os.path.join(GOLDEN, "c2_openvis_720p_5f.npz"))
+    ref = np.unpackbits(g["mask_bits"], axis=-1)[..., : int(g["mask_shape"][-1])].astype(bool)
+    got = (pm > 0).numpy()
+    diff = got != ref
+    outside = []
+    for i, eps in enumerate(g["ambig_eps"]):
+        amb = np.unpackbits(g[f"ambig_bits_{i}"], axis=-1)[..., : ref.shape[-1]].astype(bool)
+        outside.append(int((diff & ~amb).sum()))
+    inter, union = (got & ref).sum(axis=(1, 2, 3)).astype(np.float64), (got | ref).sum(axis=(1, 2, 3)).astype(np.float64)
+    iq = np.where(union > 0, inter / np.maximum(union, 1), 1.0)
+    print(f"  autocast-arithmetic backbone vs f32 oracle: {int(diff.sum())} of {diff.size} mask bits differ, outside the |logit| < "
+          f"{g['ambig_eps'].tolist()} sets: {outside}; per-query IoU min {iq.min():.5f}; {int((~diff).all(axis=(1, 2, 3)).sum())} of {Q} masks bit-identical", flush=True)
+    save("c2_autocast_backbone.npz", mask_bits=pack(pm), mask_shape=np.array(pm.shape), n_diff_vs_f32=np.asarray([int(diff.sum())], np.int64),
+         outside_vs_f32=np.asarray(outside, np.int64), ambig_eps=g["ambig_eps"], iou_min_vs_f32=np.asarray([iq.min()]))
+
+
 def c3():
     T = 5
     sd = weights.random_init(weights.san_spec("r50", None, Q), seed=42)
@@ -211,5 +243,5 @@ if __name__ == "__main__":
     for case in sys.argv[1:] or ["c3", "c4", "c5"]:
         t0 = time.time()
         print(f"== {case}", flush=True)
-        {"c2": c2, "c2s": c2s, "c3": c3, "c4": c4, "c5": c5, "c5f": c5f}[case]()
+        {"c2": c2, "c2s": c2s, "c2a": c2a, "c3": c3, "c4": c4, "c5": c5, "c5f": c5f}[case]()
         print(f"== {case} done in {time.time() - t0:.0f} s", flush=True)

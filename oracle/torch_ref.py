@@ -145,6 +145,44 @@ def swin(x, W, embed_dim, depths, num_heads, ws, prefix="backbone.", patch_norm=
     return outs
 
 
+def _h(x):
+    """one fp16 rounding (what a half tensor holds), carried in f32 so that the CPU convolutions accumulate in f32 like the GPU's fp16 kernels"""
+    return x.half().float()
+
+
+def _conv_bn_autocast(x, W, prefix, stride=1, padding=0, eps=1e-5):
+    """conv + FrozenBatchNorm2d as the reference's GPU eval runs them under `torch.cuda.amp.autocast` (train_net.py:241): conv2d is on
+    autocast's fp16 list -- operands cast to fp16, f32 accumulation, fp16 result -- and detectron2 v0.6 FrozenBatchNorm2d.forward (eval
+    branch) then computes `x * scale.to(x.dtype) + bias.to(x.dtype)` on that fp16 tensor: scale and bias rounded to fp16, the product
+    rounded to fp16, the sum rounded to fp16.  x arrives holding fp16 values (or the f32 images: autocast casts them)."""
+    y = _h(F.conv2d(_h(x), _h(W[prefix + ".weight"]), None, stride=stride, padding=padding))
+    scale = W[prefix + ".norm.weight"] * (W[prefix + ".norm.running_var"] + eps).rsqrt()
+    bias = W[prefix + ".norm.bias"] - W[prefix + ".norm.running_mean"] * scale
+    return _h(_h(y * _h(scale).reshape(1, -1, 1, 1)) + _h(bias).reshape(1, -1, 1, 1))
+
+
+def resnet50_autocast(x, W, prefix="backbone."):
+    """resnet50() in the arithmetic of the reference's own GPU run: EVERY tensor between two ops is fp16 (conv outputs, BN outputs, ReLU,
+    max pool, the residual sums `out += shortcut`), res2..res5 leave as fp16 values and the pixel decoder (autocast disabled,
+    msdeformattn.py:329) converts them with .float().  This is the arithmetic the product's fp16 backbone policy stands in for; the product
+    itself rounds LESS (BN folded into the fp16 weights, f32 accumulators carry bias / residual / ReLU, the block outputs stay f32) --
+    oracle/make_golden_workload.py c2a measures all three against each other."""
+    x = F.relu(_conv_bn_autocast(x, W, prefix + "stem.conv1", stride=2, padding=3))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    feats = {}
+    for name, nblocks, first_stride in RESNET50_STAGES:
+        for i in range(nblocks):
+            p = f"{prefix}{name}.{i}"
+            stride = first_stride if i == 0 else 1
+            sc = _conv_bn_autocast(x, W, p + ".shortcut", stride=stride) if (p + ".shortcut.weight") in W else x
+            out = F.relu(_conv_bn_autocast(x, W, p + ".conv1", stride=1))
+            out = F.relu(_conv_bn_autocast(out, W, p + ".conv2", stride=stride, padding=1))
+            out = _conv_bn_autocast(out, W, p + ".conv3")
+            x = F.relu(_h(out + sc))                                          # `out += shortcut` on fp16 tensors
+        feats[name] = x
+    return feats
+
+
 def resnet50(x, W, prefix="backbone."):
     x = F.relu(_conv_bn(x, W, prefix + "stem.conv1", stride=2, padding=3))
     x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
