@@ -410,6 +410,15 @@ int ovis_clip_crop_patches_masked(const uint8_t* frames, const float* masks, con
                                   unsigned char* patch_open, int out_f16, int M, int Q, int T, int H, int W, int h, int w,
                                   int Hp, int Wp, int resolution, int patch, long long lda, const float* mean3_host,
                                   const float* std3_host, ovis_stream_t stream);
+/* Both of the above with a caller-provided device workspace of >= ovis_clip_crop_workspace_bytes(M, resolution) bytes (16-byte aligned;
+ *   patch_open may be NULL = ovis_clip_crop_patches).  The frame half of a crop -- roi_align of the RGB planes, adapter.py:104-108 -- depends
+ *   on (frame, box) only: with the workspace, crops of one frame that share a box compute it once (a leader pass that keeps the bins' frame
+ *   averages, a follower pass that evaluates the mask half only); bit-identical to the one-pass entry points, whatever the boxes are.
+ *   ws == NULL: the one-pass kernel. */
+long long ovis_clip_crop_workspace_bytes(int M, int resolution);
+int ovis_clip_crop_patches_ws(const uint8_t* frames, const float* masks, const int* crops, void* A, unsigned char* patch_open, int out_f16,
+                              int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int resolution, int patch, long long lda,
+                              const float* mean3_host, const float* std3_host, void* ws, long long ws_bytes, ovis_stream_t stream);
 /* Mask prompt of the mask-adapted CLIP ViT (third_parties/mask_adapted_clip/mask_adapted_clip/model.py:334-338 before
  *   the class token, :349-352 after block d < mask_prompt_depth): in place,
  *   x[m, first_token + l, :] = patch_open[m*L + l] ? x[m, first_token + l, :] : mask_embedding[emb_rows == 1 ? 0 : l, :];

@@ -739,20 +739,45 @@ constexpr int CROP_GMAX = 8;       // samples per bin and axis the tiled kernel 
 constexpr int CROP_WMAX = CROP_GMAX + 2;   // source pixels one bin can touch along an axis
 struct AxisW { short fbase, mbase, fn, mn; float fw[CROP_WMAX], mw[CROP_WMAX]; };
 
-template <int TY, int TX>
+// MODE 1 (round 6): the frame half of a crop -- roi_align of the RGB planes -- depends on (frame, box) only, not on the query; crops of one
+// frame that share a box (every query of a degenerate clip whose masks all span the frame: the random-init worst case, 100 per frame) share
+// it.  crop_dedupe_kernel names every crop's LEADER (the first crop of its frame with the same box), counts followers and writes ONE work list
+// of all M crops, leaders from the front, followers from the back; the ONE launch walks that list (workgroups are dispatched in blockIdx
+// order, so a leader's tile normally starts -- and finishes -- long before a follower's):
+//   leader with followers: the fused path; its bins' (f0, f1, f2) AFTER the division by the sample count go to F[m][3][R][R] and the
+//                          tile's flag is released (agent scope);
+//   follower:              reads the flag of its leader's tile ONCE (acquire).  Set: mask half only (no frame gathers, no frame taps),
+//                          f0..f2 from F -- the final expression ((mk f) / 255 - mean) / std sees the same operands.  Not set yet: the
+//                          fused path like anybody else -- nobody ever waits, so no dispatch order can deadlock it.
+// Every path computes the same bits as MODE 0 (one fused pass, no workspace); with all boxes distinct MODE 1 costs the dedupe kernel.
+template <int TY, int TX, int MODE = 0>
 __global__ void __launch_bounds__(TY * TX)
 clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ masks, const int* __restrict__ crops,
                        void* __restrict__ Av, unsigned char* __restrict__ patch_open, int out_f16, int M, int Q, int T, int H,
                        int W, int h, int w, int Hp, int Wp, int R, int ps, long long lda, int PRmax, int PWmax, float m0,
-                       float m1, float m2, float s0, float s1, float s2, int split_taps) {
+                       float m1, float m2, float s0, float s1, float s2, int split_taps, int* __restrict__ dd = nullptr,
+                       float* __restrict__ F = nullptr) {
   extern __shared__ uint2 patch[];                      // [PR][PW]: .x = r | g<<8 | b<<16, .y = bits of the soft mask
   __shared__ AxisW xtab[TX], ytab[TY];
+  __shared__ int s_ready;
   const int tiles_x = R / TX, tiles_y = R / TY;
   const int tid = threadIdx.x;
   const int tx_i = blockIdx.x % tiles_x, ty_i = (blockIdx.x / tiles_x) % tiles_y;
-  const int m = blockIdx.x / (tiles_x * tiles_y);
-  const int px = tx_i * TX + tid % TX, py = ty_i * TY + tid / TX;
+  int m = blockIdx.x / (tiles_x * tiles_y);
+  int leader = m, n_follow = 0;
+  int* flag = nullptr;
   const int* cr = crops + m * 6;
+  if constexpr (MODE == 1) {
+    // dd = the dedupe kernel's output: counters[4] | work list[Mi][12] | tile flags[Mi tiles].  A work-list record holds everything the
+    // workgroup needs -- (crop, leader, followers, pad, t, q, x0, y0, x1, y1) -- so that its start is ONE (scalar) load deep, like MODE 0's
+    const int Mi = ((M + 3) >> 2) << 2;
+    const int* rec = dd + 4 + m * 12;
+    m = rec[0]; leader = rec[1]; n_follow = rec[2];
+    cr = rec + 4;
+    flag = dd + 4 + 12 * Mi + leader * (tiles_x * tiles_y) + ty_i * tiles_x + tx_i;
+  }
+  bool follow_rt = false;                               // wave-uniform: this tile takes its frame half from the leader's F
+  const int px = tx_i * TX + tid % TX, py = ty_i * TY + tid / TX;
   const int t = cr[0], q = cr[1];
   const float bx0 = (float)cr[2], by0 = (float)cr[3];
   const float bw = (float)(cr[4] + 1 - cr[2]), bh = (float)(cr[5] + 1 - cr[3]);
@@ -792,6 +817,17 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
     }
     return;
   }
+  if constexpr (MODE == 1) {
+    if (leader != m) {
+      if (tid == 0) s_ready = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      follow_rt = s_ready != 0;
+    }
+  }
+  // the two paths are two INSTANTIATIONS of the body (a runtime flag inside the staging loop costs its software pipeline: the counted waits
+  // the compiler derives rely on every load being issued unconditionally -- measured 2.10 -> 2.62 ms with a runtime branch there)
+  auto body = [&](auto follow_tag) {
+  constexpr bool follow = decltype(follow_tag)::value;
   const int PR = min(max(yhi - ylo + 1, 1), PRmax), PW = min(max(xhi - xlo + 1, 1), PWmax);
   // odd row stride (in 8-byte elements): the 4 bin rows a wavefront covers read 4 different patch rows at similar
   // columns; with an even stride those rows alias to the same LDS banks (4-way conflicts on every tap read)
@@ -826,11 +862,14 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         L.a[m] = r0[txs[m].i0]; L.b[m] = r0[txs[m].i1]; L.c[m] = r1[txs[m].i0]; L.d[m] = r1[txs[m].i1];
+        if constexpr (follow) { L.r[m] = L.g[m] = L.bl[m] = 0u; }          // followers: the frame half comes from the leader's F
+        else {
         const int x = xlo + lane + 64 * m;
         const bool in = yin && x < W;
         const int xc = in ? x : 0;
         const unsigned v0 = frow[xc], v1 = frow[plane + xc], v2 = frow[2 * plane + xc];
         L.r[m] = in ? v0 : 0u; L.g[m] = in ? v1 : 0u; L.bl[m] = in ? v2 : 0u;
+        }
       }
     };
     auto consume = [&](const RowLoads& L, int r) {
@@ -907,7 +946,7 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
     const AxisW& ey = ytab[tid / TX];
     const int fnx = ex.fn, fny = ey.fn, mnx = ex.mn, mny = ey.mn;
     const uint2* fbase = patch + ey.fbase * PWs + ex.fbase;
-    if (!split_taps && ex.fbase == ex.mbase && ey.fbase == ey.mbase && fnx == mnx && fny == mny) {
+    if (!follow && !split_taps && ex.fbase == ex.mbase && ey.fbase == ey.mbase && fnx == mnx && fny == mny) {
       // interior bins: frame and mask taps are the same source pixels -- one LDS read per tap instead of two (each accumulator
       // sees the same sequence of operations as in the two loops below: bit-identical)
       for (int r = 0; r < fny; ++r) {
@@ -924,6 +963,7 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
         mk += ey.mw[r] * a;
       }
     } else {
+    if constexpr (!follow)
     for (int r = 0; r < fny; ++r) {
       const uint2* row = fbase + r * PWs;
       float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -945,6 +985,17 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
     }
   }
   f0 /= count; f1 /= count; f2 /= count; mk /= count;
+  if constexpr (MODE == 1) {
+    if constexpr (follow) {
+      const float* fi = F + ((long long)leader * 3 * R + py) * R + px;
+      f0 = fi[0]; f1 = fi[(long long)R * R]; f2 = fi[2ll * R * R];
+    } else if (leader == m && n_follow > 0) {                        // (wave-uniform) somebody shares this box: keep the frame half
+      float* fo = F + ((long long)m * 3 * R + py) * R + px;
+      fo[0] = f0; fo[(long long)R * R] = f1; fo[2ll * R * R] = f2;
+      __syncthreads();                                               // (workgroup-scope release: every thread's F stores are performed)
+      if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   const float r0 = ((mk * f0) / 255.f - m0) / s0;
   const float r1 = ((mk * f1) / 255.f - m1) / s1;
   const float r2 = ((mk * f2) / 255.f - m2) / s2;
@@ -963,6 +1014,51 @@ clip_crop_tiled_kernel(const uint8_t* __restrict__ frames, const float* __restri
     float* ap = reinterpret_cast<float*>(Av) + row * lda + col;
     ap[0] = r0; ap[ps * ps] = r1; ap[2 * ps * ps] = r2;
   }
+  };
+  if (MODE == 1 && follow_rt) body(std::true_type{}); else body(std::false_type{});
+}
+
+// Leaders and followers of the crop list (see clip_crop_tiled_kernel, MODE 1): uid[m] = the first crop of m's frame with m's box (m itself:
+// a leader), nfollow[m] = how many later crops of the frame share a leader's box.  Crops of one frame are contiguous in both crop lists
+// ((t, q) lexicographic); one thread per crop walks its frame's entries (Q <= a few hundred).
+__global__ void __launch_bounds__(1024)
+crop_dedupe_kernel(const int* __restrict__ crops, int* __restrict__ ws, int M, int n_flags) {
+  // ONE workgroup: the two list cursors live in LDS (no counters to clear beforehand) and the same launch clears the tile flags.  The crop
+  // list is staged in LDS first: the scans below stop at a frame boundary, i.e. every step depends on the entry it has just read -- from
+  // global memory that chain cost ~65 us for 475 crops (a memory round trip per step), from LDS it is a few
+  extern __shared__ int4 sbox[];                                             // [M] boxes, then [M] frame ids
+  int* sfr = reinterpret_cast<int*>(sbox + M);
+  __shared__ int cnt[2];
+  if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+  for (int m = threadIdx.x; m < M; m += blockDim.x) {
+    const int* c = crops + (long long)m * 6;
+    sbox[m] = make_int4(c[2], c[3], c[4], c[5]);
+    sfr[m] = c[0];
+  }
+  __syncthreads();
+  int* list = ws + 4;                                                        // ONE work list of all M crops: leaders from the front, followers from the back
+  for (int m = threadIdx.x; m < M; m += blockDim.x) {
+    const int4 b = sbox[m];
+    const int t = sfr[m];
+    int first = m, n = 0;
+    for (int j = m - 1; j >= 0 && sfr[j] == t; --j) {
+      const int4 d = sbox[j];
+      if (d.x == b.x && d.y == b.y && d.z == b.z && d.w == b.w) first = j;
+    }
+    if (first == m)
+      for (int j = m + 1; j < M && sfr[j] == t; ++j) {
+        const int4 d = sbox[j];
+        n += d.x == b.x && d.y == b.y && d.z == b.z && d.w == b.w;
+      }
+    const int fol = first != m;
+    const int pos = atomicAdd(&cnt[fol], 1);                                // (the order inside either group only affects scheduling, never a result)
+    int4* rec = reinterpret_cast<int4*>(list + (long long)(fol ? M - 1 - pos : pos) * 12);
+    rec[0] = make_int4(m, first, n, 0);
+    rec[1] = make_int4(t, crops[(long long)m * 6 + 1], b.x, b.y);
+    rec[2] = make_int4(b.z, b.w, 0, 0);
+  }
+  int4* fl = reinterpret_cast<int4*>(ws + 4 + (long long)(((M + 3) >> 2) << 2) * 12);
+  for (int i = threadIdx.x; i < n_flags / 4; i += blockDim.x) fl[i] = make_int4(0, 0, 0, 0);
 }
 
 // ViT token assembly + ln_pre (model.py:341-343): tok[m,0] = cls + pos[0]; tok[m,1+p] = patch[m,p] + pos[1+p]; LN.
@@ -1459,11 +1555,19 @@ extern "C" int ovis_crop_list_static(const int* boxes, int* crops, int* slot, in
   return ovis::check_launch("crop_list_static");
 }
 
-extern "C" int ovis_crop_tile(int t) { g_crop_tile = t; return OVIS_OK; }
+extern "C" int ovis_crop_tile(int t) { g_crop_tile = t; return OVIS_OK; }   // lab / tests: 8 = 8x8 tiles, 16 = separate tap loops, 32 = ignore the workspace (one fused pass)
+
+extern "C" long long ovis_clip_crop_workspace_bytes(int M, int resolution) {
+  if (M <= 0 || resolution <= 0) return 0;
+  const long long mi = (((long long)M + 3) / 4) * 4;
+  const long long tiles = (long long)((resolution + 15) / 16) * ((resolution + 15) / 16);
+  return 16 + 12 * mi * 4 + mi * tiles * 4 + (long long)M * 3 * resolution * resolution * 4;
+}
 
 static int clip_crop_impl(const uint8_t* frames, const float* masks, const int* crops, void* A, unsigned char* patch_open,
                           int out_f16, int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int resolution,
-                          int patch, long long lda, const float* mean3_host, const float* std3_host, ovis_stream_t stream) {
+                          int patch, long long lda, const float* mean3_host, const float* std3_host, ovis_stream_t stream,
+                          void* ws = nullptr, long long ws_bytes = 0) {
   OVIS_REQUIRE(frames && masks && crops && A && mean3_host && std3_host, "clip_crop: null pointer");
   OVIS_REQUIRE(M > 0 && resolution > 0 && patch > 0 && resolution % patch == 0, "clip_crop: bad sizes");
   OVIS_REQUIRE(lda >= 3ll * patch * patch, "clip_crop: lda smaller than a patch row (3*patch*patch)");
@@ -1484,13 +1588,34 @@ static int clip_crop_impl(const uint8_t* frames, const float* masks, const int* 
                    "clip_crop: cannot raise the dynamic LDS limit");
       attr_set[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((clip_crop_tiled_kernel<16, 16>), dim3((unsigned)((long long)M * (resolution / 16) * (resolution / 16))), dim3(256),
-                       (size_t)p16 * (p16 + 1) * 8, (hipStream_t)stream, frames, masks, crops, A, patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
-                       resolution, patch, lda, p16, p16, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2], (g_crop_tile >> 4) & 1);
+    const dim3 grid16((unsigned)((long long)M * (resolution / 16) * (resolution / 16)));
+    const size_t lds16 = (size_t)p16 * (p16 + 1) * 8;
+    if (ws && !(g_crop_tile & 32) && (size_t)M * 20 <= 60 * 1024) {         // (the dedupe kernel stages the crop list in LDS: M <= 3 072)
+      // leaders / followers (MODE 1 above): the frame half of crops that share (frame, box) is computed once
+      OVIS_REQUIRE(ws_bytes >= ovis_clip_crop_workspace_bytes(M, resolution) && ((uintptr_t)ws & 15) == 0, "clip_crop: workspace too small (ovis_clip_crop_workspace_bytes) or misaligned");
+      static std::atomic<bool> attr12[64];
+      if (!attr12[dev].load(std::memory_order_acquire)) {
+        OVIS_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&clip_crop_tiled_kernel<16, 16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 76 * 1024) == hipSuccess,
+                     "clip_crop: cannot raise the dynamic LDS limit");
+        attr12[dev].store(true, std::memory_order_release);
+      }
+      const long long Mi = (((long long)M + 3) / 4) * 4, tiles = (long long)(resolution / 16) * (resolution / 16);
+      int* dd = reinterpret_cast<int*>(ws);                             // counters[4] | work list [Mi][12] | tile flags [Mi tiles] | F
+      float* Fw = reinterpret_cast<float*>(dd + 4 + 12 * Mi + Mi * tiles);
+      hipLaunchKernelGGL(crop_dedupe_kernel, dim3(1), dim3(1024), (size_t)M * 20, (hipStream_t)stream, crops, dd, M, (int)(Mi * tiles));
+      hipLaunchKernelGGL((clip_crop_tiled_kernel<16, 16, 1>), grid16, dim3(256), lds16, (hipStream_t)stream, frames, masks, crops, A, patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
+                         resolution, patch, lda, p16, p16, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2], (g_crop_tile >> 4) & 1, dd, Fw);
+      return ovis::check_launch("clip_crop (leaders / followers)");
+    }
+    hipLaunchKernelGGL((clip_crop_tiled_kernel<16, 16>), grid16, dim3(256),
+                       lds16, (hipStream_t)stream, frames, masks, crops, A, patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
+                       resolution, patch, lda, p16, p16, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2], (g_crop_tile >> 4) & 1,
+                       (int*)nullptr, (float*)nullptr);
   } else if (grid_ok && resolution % 8 == 0 && (size_t)p8 * (p8 + 1) * 8 <= 64 * 1024) {
     hipLaunchKernelGGL((clip_crop_tiled_kernel<8, 8>), dim3((unsigned)((long long)M * (resolution / 8) * (resolution / 8))), dim3(64),
                        (size_t)p8 * (p8 + 1) * 8, (hipStream_t)stream, frames, masks, crops, A, patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp,
-                       resolution, patch, lda, p8, p8, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2], (g_crop_tile >> 4) & 1);
+                       resolution, patch, lda, p8, p8, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2], (g_crop_tile >> 4) & 1,
+                       (int*)nullptr, (float*)nullptr);
   } else {
     const long long total = (long long)M * resolution * resolution;
     hipLaunchKernelGGL(clip_crop_kernel, dim3(ovis::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, frames, masks, crops, A,
@@ -1506,6 +1631,16 @@ extern "C" int ovis_clip_crop_patches(const uint8_t* frames, const float* masks,
                                       ovis_stream_t stream) {
   return clip_crop_impl(frames, masks, crops, A, nullptr, out_f16, M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, lda,
                         mean3_host, std3_host, stream);
+}
+
+extern "C" int ovis_clip_crop_patches_ws(const uint8_t* frames, const float* masks, const int* crops, void* A, unsigned char* patch_open, int out_f16,
+                                         int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int resolution, int patch, long long lda,
+                                         const float* mean3_host, const float* std3_host, void* ws, long long ws_bytes, ovis_stream_t stream) {
+  const long long G = resolution > 0 && patch > 0 ? resolution / patch : 0;
+  if (patch_open && M > 0 && G > 0)
+    OVIS_REQUIRE(hipMemsetAsync(patch_open, 0, (size_t)M * G * G, (hipStream_t)stream) == hipSuccess, "clip_crop_ws: memset failed");
+  return clip_crop_impl(frames, masks, crops, A, patch_open, out_f16, M, Q, T, H, W, h, w, Hp, Wp, resolution, patch, lda, mean3_host, std3_host, stream,
+                        ws, ws_bytes);
 }
 
 extern "C" int ovis_clip_crop_patches_masked(const uint8_t* frames, const float* masks, const int* crops, void* A,

@@ -197,10 +197,14 @@ at::Tensor clip_crop_patches(const at::Tensor& frames, const at::Tensor& masks, 
   const auto opt = masks.options().dtype(out_f16 ? at::kHalf : at::kFloat);
   at::Tensor A = ld == 3 * patch * patch ? at::empty({M * G * G, ld}, opt) : at::zeros({M * G * G, ld}, opt);   // pad columns stay zero
   const float m3[3] = {(float)mean[0], (float)mean[1], (float)mean[2]}, s3[3] = {(float)std_[0], (float)std_[1], (float)std_[2]};
-  const int rc = ovis_clip_crop_patches(frames.data_ptr<uint8_t>(), masks.data_ptr<float>(), crops.data_ptr<int>(), A.data_ptr(), out_f16 ? 1 : 0,
-                                        (int)M, (int)masks.size(0), (int)frames.size(0), (int)frames.size(2), (int)frames.size(3),
-                                        (int)masks.size(2), (int)masks.size(3), (int)Hp, (int)Wp, (int)resolution, (int)patch, ld, m3, s3,
-                                        cur_stream());
+  // workspace of the leader / follower passes (crops of a frame that share a box compute the frame half once): from torch's caching
+  // allocator, so that forwards on different streams never share it
+  const int64_t wsb = ovis_clip_crop_workspace_bytes((int)M, (int)resolution);
+  at::Tensor ws = at::empty({(wsb + 3) / 4}, masks.options());
+  const int rc = ovis_clip_crop_patches_ws(frames.data_ptr<uint8_t>(), masks.data_ptr<float>(), crops.data_ptr<int>(), A.data_ptr(), nullptr, out_f16 ? 1 : 0,
+                                           (int)M, (int)masks.size(0), (int)frames.size(0), (int)frames.size(2), (int)frames.size(3),
+                                           (int)masks.size(2), (int)masks.size(3), (int)Hp, (int)Wp, (int)resolution, (int)patch, ld, m3, s3,
+                                           ws.data_ptr(), wsb, cur_stream());
   TORCH_CHECK(rc == OVIS_OK, "clip_crop_patches: ", ovis_last_error());
   return A;
 }

@@ -836,8 +836,10 @@ def clip_crop_patches_masked(frames, masks, crops, Hp, Wp, resolution, patch, me
     G = resolution // patch
     A = _patch_matrix(M * G * G, patch, out_f16, frames.device)
     patch_open = torch.empty((M, G * G), dtype=torch.uint8, device=frames.device)
-    _lib.call("ovis_clip_crop_patches_masked", frames, masks, crops, A, patch_open, int(out_f16), M, Q, T, H, W, h, w, Hp, Wp,
-              resolution, patch, _ll(A.shape[1]), _f3(mean), _f3(std), _lib.stream_ptr())
+    wsb = int(_lib.lib().ovis_clip_crop_workspace_bytes(M, resolution))
+    ws = torch.empty(((wsb + 3) // 4,), dtype=torch.float32, device=frames.device)       # leader / follower passes (csrc/openvis_ops.hip)
+    _lib.call("ovis_clip_crop_patches_ws", frames, masks, crops, A, patch_open, int(out_f16), M, Q, T, H, W, h, w, Hp, Wp,
+              resolution, patch, _ll(A.shape[1]), _f3(mean), _f3(std), ws, _ll(wsb), _lib.stream_ptr())
     return A, patch_open
 
 

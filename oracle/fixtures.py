@@ -38,19 +38,25 @@ def sharp_parts(M, K, seed=0, n_pick=10, n_labels=7, scale=100.0):
         mc = (Mn @ Mn[picked].T).max(dim=1).values
         mc[picked] = 2.0
         picked.append(int(torch.argmin(mc)))
-    labels = torch.randperm(K, generator=g)[:n_labels].tolist()
-    lab = [labels[i % n_labels] for i in range(n_pick)]
-    designed = torch.stack([torch.nn.functional.normalize(sum(Mn[p] for p, pl in zip(picked, lab) if pl == l), dim=0) for l in labels])
+    perm = torch.randperm(K, generator=g).tolist()
     best = None
-    for beta in np.linspace(0.05, 1.0, 39):
-        parts = dict(c=c, designed=designed, labels=labels, beta=float(beta), seed=int(seed))
-        text = text_from_parts(parts, K).double()
-        P = (scale * M @ text.T).softmax(-1)
-        fl = P.flatten().sort(descending=True)
-        top = sorted((int(i) // K, int(i) % K) for i in fl.indices[:10])
-        margin = float(fl.values[9] - fl.values[10])
-        if len({l for _, l in top}) >= 5 and float(fl.values[0]) < 0.97 and (best is None or margin > best[1]["margin"]):
-            best = (parts, dict(top=top, scores=fl.values[:11].tolist(), margin=margin, distinct_labels=len({l for _, l in top})))
+    # candidates: 7 or 10 labels (3 or 0 of them shared by two rows); designed rows from the raw embeddings or from the CENTRED ones (the part of
+    # an embedding that is not the common direction separates neighbours better when the per-query means of several frames lie close together)
+    for nl in (n_labels, n_pick):
+        labels = perm[:nl]
+        lab = [labels[i % nl] for i in range(n_pick)]
+        for centred in (False, True):
+            src = torch.nn.functional.normalize(Mn - c, dim=-1) if centred else Mn
+            designed = torch.stack([torch.nn.functional.normalize(sum(src[p] for p, pl in zip(picked, lab) if pl == l), dim=0) for l in labels])
+            for beta in np.linspace(0.02, 1.0, 50):
+                parts = dict(c=c, designed=designed, labels=labels, beta=float(beta), seed=int(seed))
+                text = text_from_parts(parts, K).double()
+                P = (scale * M @ text.T).softmax(-1)
+                fl = P.flatten().sort(descending=True)
+                top = sorted((int(i) // K, int(i) % K) for i in fl.indices[:10])
+                margin = float(fl.values[9] - fl.values[10])
+                if len({l for _, l in top}) >= 5 and float(fl.values[0]) < 0.97 and (best is None or margin > best[1]["margin"]):
+                    best = (parts, dict(top=top, scores=fl.values[:11].tolist(), margin=margin, distinct_labels=len({l for _, l in top})))
     if best is None:
         raise RuntimeError("sharp_parts: no blend gives >= 5 distinct labels in the top-10")
     return best

@@ -474,6 +474,41 @@ def test_crop_kernel_merged_taps_and_out_of_frame_tiles():
     assert torch.equal(P[3, :, 4:], zero.expand(14, 10, 3, 16, 16)) and not torch.equal(P[3, :, 3], P[3, :, 4])
 
 
+@pytest.mark.parametrize("masked", [False, True])
+def test_crop_leader_follower_passes_are_bit_identical_to_the_fused_pass(masked):
+    """Round 6: crops of one frame that share a box compute the frame half (roi_align of the RGB planes, adapter.py:104-108) ONCE -- a
+    leader pass that keeps the bins' frame averages and a follower pass that evaluates the mask half only (csrc/openvis_ops.hip,
+    clip_crop_tiled_kernel MODE 1 / 2 + crop_dedupe_kernel).  Against the one-pass kernel (lab switch ovis_crop_tile(32)) on a crop list
+    with duplicates inside a frame, the same box on ANOTHER frame (not a duplicate), unique boxes, a far-away (empty-mask) box twice and a
+    leader that is not the first crop of its frame: every output bit equal, fp16 and f32, and patch_open of the masked variant too."""
+    from openvis_amd import ops
+    from openvis_amd import _lib
+    T, Q, H, W, Hp, Wp = 3, 8, 360, 640, 384, 640
+    g = torch.Generator().manual_seed(13)
+    frames = (torch.rand(T, 3, H, W, generator=g) * 255).to(torch.uint8).cuda()
+    masks = (torch.randn(Q, T, Hp // 4, Wp // 4, generator=g) * 2).cuda()
+    full, far = [0, 0, Wp - 1, Hp - 1], [4 * Wp + 4096, 4 * Hp + 4096, 4 * Wp + 4096, 4 * Hp + 4096]
+    boxes = [[0, 0] + full, [0, 1, 5, 7, 604, 100], [0, 2] + full, [0, 3, 5, 7, 604, 100], [0, 4] + full, [0, 5] + far, [0, 6] + far, [0, 7, 50, 60, 90, 95],
+             [1, 0, 50, 60, 90, 95], [1, 1] + full, [1, 2, 0, 0, W - 1, H - 1], [1, 3] + full, [1, 5, 0, 0, W - 1, H - 1],
+             [2, 0, 560, 3, 600, 350], [2, 4, 560, 3, 600, 350], [2, 7, 560, 3, 600, 351]]
+    cr = torch.tensor(boxes, dtype=torch.int32).cuda()
+    mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+    fn = ops.clip_crop_patches_masked if masked else ops.clip_crop_patches
+    for f16 in (False, True):
+        try:
+            two = fn(frames, masks, cr, Hp, Wp, 224, 16, mean, std, out_f16=f16)
+            _lib.call("ovis_crop_tile", 32)
+            one = fn(frames, masks, cr, Hp, Wp, 224, 16, mean, std, out_f16=f16)
+        finally:
+            _lib.call("ovis_crop_tile", 0)
+        if masked:
+            assert torch.equal(two[1], one[1]) and 0 < int(one[1].sum()) < one[1].numel()
+            two, one = two[0], one[0]
+        assert torch.equal(two, one)
+        P = one.view(len(boxes), 14 * 14, -1)
+        assert not torch.equal(P[0], P[2]) and not torch.equal(P[0], P[9])          # same box, other query / other frame: different crops
+
+
 def test_preprocess_whole_video_beyond_65535_rows():
     """A1 on a whole video (openvis.py:57-62 runs before the windowing, :109): T * Hp = 720 * 96 = 69 120 rows > 65 535, the y limit of a HIP
     grid -- the rows sit on gridDim.x.  Bit-exact against the oracle's arithmetic ((x - mean) / std in f32, zero pad)."""

@@ -23,3 +23,9 @@ for name, side in (("full-frame boxes", None), ("200px boxes", 200)):
         ms = timeit(lambda: ops.clip_crop_patches(frames, masks, cr, Hp, Wp, 224, 16, mean, std, out_f16=True), n=10)
         print(name, len(crops), "crops", f"{tile}x{tile}-bin tiles", round(ms, 3), "ms")
     _lib.call("ovis_crop_tile", 0)
+    # round 6: leader / follower passes (crops of a frame that share a box compute the frame half once) against the one fused pass
+    for name2, sw in (("leader/follower passes (ships)", 0), ("one fused pass", 32)):
+        _lib.call("ovis_crop_tile", sw)
+        ms = timeit(lambda: ops.clip_crop_patches(frames, masks, cr, Hp, Wp, 224, 16, mean, std, out_f16=True), n=10)
+        print(name, len(crops), "crops", name2, round(ms, 3), "ms")
+    _lib.call("ovis_crop_tile", 0)
