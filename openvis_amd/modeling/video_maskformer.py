@@ -140,12 +140,15 @@ class VideoMaskFormer:
         if any(f.shape != f0.shape for f in frames):
             raise ValueError("all frames of a clip must have the same size (ImageList.from_tensors pads, openvis.py:62; "
                              "the dataset mapper resizes every frame of a video identically)")
+        nb = f0.numel()
+        one_buffer = all(f.is_contiguous() and f.untyped_storage().data_ptr() == f0.untyped_storage().data_ptr()
+                         and f.storage_offset() == f0.storage_offset() + i * nb for i, f in enumerate(frames))
         if all(f.is_cuda for f in frames):
+            if one_buffer and f0.device == self.device:       # a clip already resident in HBM as one [T,3,H,W] tensor: a view, no copy
+                return torch.empty(0, dtype=torch.uint8, device=self.device).set_(f0.untyped_storage(), f0.storage_offset(), (len(frames),) + tuple(f0.shape))
             return torch.stack(frames).to(self.device).contiguous()
         x = torch.empty((len(frames),) + tuple(f0.shape), dtype=torch.uint8, device=self.device)
-        nb = f0.numel()
-        if (not f0.is_cuda and all(f.is_contiguous() and f.untyped_storage().data_ptr() == f0.untyped_storage().data_ptr()
-                                   and f.storage_offset() == f0.storage_offset() + i * nb for i, f in enumerate(frames))):
+        if not f0.is_cuda and one_buffer:
             # the frames are consecutive slices of ONE host buffer (a collated / stacked clip): one copy instead of T -- every
             # async copy costs the host ~0.1 ms of launch latency during which the GPU has nothing queued (tools/trace_gaps.py)
             whole = torch.empty(0, dtype=torch.uint8).set_(f0.untyped_storage(), f0.storage_offset(), x.shape)

@@ -23,12 +23,13 @@ def per_query_mean(embeds, valid):
     return rows.tolist(), torch.stack([e[ids[:, 1] == q].mean(0) for q in rows])
 
 
-def sharp_parts(M, K, seed=0, n_pick=10, n_labels=7, scale=100.0):
+def sharp_parts(M, K, seed=0, n_pick=10, n_labels=7, scale=100.0, extra_rows=None):
     """M [R, E] per-query mean embeddings (oracle).  Picks `n_pick` rows far from each other (farthest-point on the cosine), gives them
     `n_labels` distinct labels (n_pick - n_labels labels are shared by two rows: text row = their normalised sum), blends every designed row
     with the common direction c by the beta that maximises the 10th - 11th score margin while the best score stays below 0.97.
     Returns dict(c [E], designed [n_labels, E] (unit, un-blended), labels [n_labels], beta, seed) -- the parts the fixture stores -- and the
-    report (top-10 (row, label) pairs, their scores, margin)."""
+    report (top-10 (row, label) pairs, their scores, margin).  extra_rows [X, E]: rows appended to the text for the softmax's denominator only
+    (the SideAdapter's non-object embedding: side_adapter.py cal_sim_logits over K + 1 rows, brivis.py:247-252 drops the last column)."""
     g = torch.Generator().manual_seed(int(seed))
     M = torch.as_tensor(np.asarray(M)).double()
     Mn = torch.nn.functional.normalize(M, dim=-1)
@@ -42,7 +43,7 @@ def sharp_parts(M, K, seed=0, n_pick=10, n_labels=7, scale=100.0):
     best = None
     # candidates: 7 or 10 labels (3 or 0 of them shared by two rows); designed rows from the raw embeddings or from the CENTRED ones (the part of
     # an embedding that is not the common direction separates neighbours better when the per-query means of several frames lie close together)
-    for nl in (n_labels, n_pick):
+    for nl in sorted({min(n_labels, K), min(n_pick, K)}):
         labels = perm[:nl]
         lab = [labels[i % nl] for i in range(n_pick)]
         for centred in (False, True):
@@ -51,7 +52,9 @@ def sharp_parts(M, K, seed=0, n_pick=10, n_labels=7, scale=100.0):
             for beta in np.linspace(0.02, 1.0, 50):
                 parts = dict(c=c, designed=designed, labels=labels, beta=float(beta), seed=int(seed))
                 text = text_from_parts(parts, K).double()
-                P = (scale * M @ text.T).softmax(-1)
+                if extra_rows is not None:
+                    text = torch.cat([text, torch.as_tensor(np.asarray(extra_rows)).double().reshape(-1, text.shape[1])])
+                P = (scale * M @ text.T).softmax(-1)[:, :K]
                 fl = P.flatten().sort(descending=True)
                 top = sorted((int(i) // K, int(i) % K) for i in fl.indices[:10])
                 margin = float(fl.values[9] - fl.values[10])

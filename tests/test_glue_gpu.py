@@ -220,4 +220,17 @@ def test_model_forward_vs_reference_forward(arch):
             union = (a | b).sum()
             assert union == 0 or (a & b).sum() / union > 0.999
     print(f"{arch}: top-10 common {n_common}/10 (10th - 11th margin {margin:.2e}), output mask bits differing {n_diff} of {n_bits}")
-    assert n_common >= 5
+    from tests.test_oracle_glue import GLUE_SHARP
+    if arch in GLUE_SHARP:
+        # a SEPARATED label space (oracle/make_golden_glue.py: text rows built from the reference's own crop embeddings: >= 5 labels among the ten
+        # winners, the 11th candidate >= 1e-2 behind): the EXACT (query, label) set, every score, and every output-mask bit
+        sg = {(q, l): s_ for q, l, s_ in zip(out["pred_queries"], out["pred_labels"], out["pred_scores"])}
+        sr = {(int(rows_ref[r]), int(l)): float(s_) for r, l, s_ in zip(g[p + "rows"], g[p + "labels"], g[p + "scores"])}
+        assert margin >= 1e-2 and len({l for _, l in sr}) >= 5
+        assert set(sg) == set(sr), (sorted(sg), sorted(sr))
+        assert max(abs(sg[k] - sr[k]) for k in sg) <= 1e-3
+        assert n_diff == 0 and n_bits == 10 * T * OH * OW
+    else:
+        # random-init side adapters score every query alike (margins ~1e-6): the tie-aware check above is all the top-10 can state there --
+        # what IS asserted: the class probabilities (1e-3, above), the tracker's assignment, and every bit of every output mask both sides picked
+        assert n_common >= 5 and n_diff == 0

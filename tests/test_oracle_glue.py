@@ -131,9 +131,21 @@ def load_glue_forward(arch):
         kw = dict(broken_idx=3, merge_ids=(1, 2, 3), resolution=GLUE_CLIP["image_resolution"], clip_heads=4, num_queries=Q)
         if arch == "brivis":
             Wd.update(synth_weights(_spec(g["spec_res"]), s[7], "resampler."))
+    # round 6 (oracle/make_golden_glue.py): the ClipAdapter towers carry peaked attention, the offline OpenVIS decoder a mask-logit gain, and
+    # the two OpenVIS architectures run on a label space built from the reference's own crop embeddings (stored per architecture)
+    if arch in ("openvis", "openvis_online", "openvis_adapted"):
+        from openvis_amd.weights import sharpen_clip_attention
+        Wd = sharpen_clip_attention(Wd, float(g["clip_qk_gain"][0]))
+    if dec[0] == "spec_vdec":
+        for k_ in ("weight", "bias"):
+            Wd[f"sem_seg_head.predictor.mask_embed.layers.2.{k_}"] = Wd[f"sem_seg_head.predictor.mask_embed.layers.2.{k_}"] * float(g["mask_gain"][0])
     frames = glue_frames(int(g[arch + "_frame_seed"][0]))
-    text = glue_text(s[8], GLUE_CLIP["embed_dim"], K)
+    text = torch.from_numpy(g[arch + "_text"])
+    assert arch in GLUE_SHARP or torch.equal(text, glue_text(s[8], GLUE_CLIP["embed_dim"], K))
     return g, frames, Wd, text, kw, (OH, OW)
+
+
+GLUE_SHARP = ("openvis", "openvis_adapted")     # forwards whose fixture holds a SEPARATED label space: ten winners, >= 5 labels, margin >= 1e-2
 
 
 ORACLE_FORWARD = {"openvis": TR.openvis_forward, "openvis_online": TR.openvis_online_forward, "san_online": TR.san_online_forward,
@@ -151,15 +163,18 @@ def test_oracle_forward_equals_the_reference_forward(arch):
         out = ORACLE_FORWARD[arch](frames, Wd, text, out_hw=out_hw, stages=st, **kw)
     p = arch + "_"
     assert out["image_size"] == out_hw
-    assert np.abs(st["probs"].numpy() - g[p + "probs"]).max() < 1e-5
+    assert np.abs(st["probs"].numpy() - g[p + "probs"]).max() < (1e-4 if arch in GLUE_SHARP else 1e-5)     # (an un-saturated softmax moves more per logit ulp)
     ref = {(int(r), int(l)): i for i, (r, l) in enumerate(zip(g[p + "rows"], g[p + "labels"]))}
     mine = {(int(r), int(l)): i for i, (r, l) in enumerate(zip(out["rows"], out["pred_labels"]))}
     assert set(ref) == set(mine) and len(ref) == 10
+    if arch in GLUE_SHARP:                       # ... on a label space where that is a statement: >= 5 labels among the winners, the 11th candidate >= 1e-2 behind
+        fl = np.sort(g[p + "probs"].reshape(-1))[::-1]
+        assert len({l for _, l in ref}) >= 5 and fl[9] - fl[10] >= 1e-2 and fl[0] < 0.985 and abs(float(g[p + "margin"][0]) - (fl[9] - fl[10])) < 1e-6
     T, OH, OW = frames.shape[0], out_hw[0], out_hw[1]
     ref_masks = _bits(g[p + "masks"], (10, T, OH, OW))
     for k, i in ref.items():
         j = mine[k]
-        assert abs(out["pred_scores"][j] - float(g[p + "scores"][i])) < 1e-5
+        assert abs(out["pred_scores"][j] - float(g[p + "scores"][i])) < (1e-4 if arch in GLUE_SHARP else 1e-5)
         assert abs(out["pred_entropys"][j] - float(g[p + "entropys"][i])) < 1e-4
         assert np.array_equal(out["pred_masks"][j].numpy(), ref_masks[i])
     if arch in ("openvis", "openvis_online", "openvis_adapted"):
