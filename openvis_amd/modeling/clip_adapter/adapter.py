@@ -43,7 +43,7 @@ class ClipVisual:
 
     def load_state_dict(self, sd, prefix, device):
         g = lambda k: sd[prefix + k].float().contiguous().to(device)
-        w = self.w
+        w = self.w = {}                                             # (a second load must not meet the first one's folded operands: _fold caches in w)
         cw = g("conv1.weight")
         cw = cw.view(cw.shape[0], -1)
         w["conv1"] = torch.nn.functional.pad(cw, (0, ops.patch_row_len(self.patch) - cw.shape[1])).contiguous()   # zero pad columns

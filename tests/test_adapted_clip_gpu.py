@@ -275,3 +275,27 @@ def test_layernorm_folded_tower_agrees_with_the_layernorm_kernels(arch):
     assert d_fold < 4e-3 and d_plain < 4e-3, (d_fold, d_plain)
     assert (c_fold - c32).abs().mean().item() <= 1.1 * (c_plain - c32).abs().mean().item()      # the fold skips one fp16 rounding: not worse
     assert (y_fold.float() - y_plain.float()).abs().max().item() / y32.abs().max().item() < 4e-3
+
+
+def test_second_load_state_dict_replaces_the_folded_operands():
+    """ClipVisual caches LayerNorm-folded operands (ops.fold_layernorm) at first use.  A second load_state_dict on the same adapter must not
+    meet the first checkpoint's folds (round 6: it did -- the cache lived in the weight dict, which load_state_dict kept): after reloading,
+    the adapter equals a freshly built one on the new weights, bit for bit."""
+    import bench
+    from openvis_amd import weights
+    from openvis_amd.modeling.clip_adapter.adapter import ClipAdapter
+    arch = dict(width=256, layers=2, heads=4, patch=16, resolution=64, embed_dim=64)
+    spec = [(k, s) for k, s in weights.openvis_spec("r50", arch, 100) if k.startswith("clip_adapter.")]
+    sd_a, sd_b = weights.random_init(spec, seed=1), weights.random_init(spec, seed=2)
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(6 * 16, 768, generator=g).half().cuda()
+    outs = []
+    for first in (sd_a, None):
+        ad = ClipAdapter("tiny", arch=arch, precision="fp16")
+        ad.visual.stream16 = True
+        if first is not None:
+            ad.load_state_dict(first)
+            ad.visual.forward_patches(A, 6)                         # builds the folds of checkpoint A
+        ad.load_state_dict(sd_b)
+        outs.append(ad.visual.forward_patches(A, 6).float().cpu())
+    assert torch.equal(outs[0], outs[1])
