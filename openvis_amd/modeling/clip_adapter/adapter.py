@@ -262,11 +262,15 @@ class ClipAdapter:
     # read-modify-write, and a dropped or duplicated entry makes the host / device choice -- and the GEMM shapes -- timing-dependent again):
     #   _valid_frac     share of non-empty masks of the most recent clip of THIS thread whose count is known
     #   _pending_counts (event, pinned host int32 [1], T*Q) of this thread's device-list forwards whose counts are still on their way
-    _auto = __import__("threading").local()
-    _valid_frac = property(lambda self: getattr(self._auto, "frac", {}).get(id(self)),
-                           lambda self, v: self._auto.__dict__.setdefault("frac", {}).__setitem__(id(self), v))
-    _pending_counts = property(lambda self: getattr(self._auto, "pend", {}).get(id(self), ()),
-                               lambda self, v: self._auto.__dict__.setdefault("pend", {}).__setitem__(id(self), v))
+    def _auto(self):
+        """this adapter's per-host-thread state (created on first use; dict.setdefault is atomic, so two threads agree on one object)"""
+        return self.__dict__.setdefault("_auto_local", __import__("threading").local())
+
+    # a thread that has no share of its own yet (the slot threads of a ClipPipeline.run are new every call) starts from the newest share ANY
+    # thread of this adapter has published: one float, written whole -- the queue of pending counts is what must not be shared
+    _valid_frac = property(lambda self: getattr(self._auto(), "frac", self.__dict__.get("_last_frac")),
+                           lambda self, v: (setattr(self._auto(), "frac", v), self.__dict__.__setitem__("_last_frac", v))[0])
+    _pending_counts = property(lambda self: getattr(self._auto(), "pend", ()), lambda self, v: setattr(self._auto(), "pend", v))
 
     def __init__(self, clip_model_name="ViT-B/16", text_templates="vild", arch=None, precision="fp16"):
         self.clip_model_name = clip_model_name
