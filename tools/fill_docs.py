@@ -23,6 +23,14 @@ for a in head.get("alt_f32_splits") or ([head["alt_f32_split"]] if head.get("alt
     vals[key], vals[key + "MS"] = f"{a['value']:.1f}", f"{a['ms_per_step']:.1f}"
 if head.get("two_clips_in_flight"):
     vals["S2I"] = f"{head['two_clips_in_flight']['value']:.1f}"
+if head.get("host_inputs"):
+    vals["HOSTIN"], vals["HOSTINMS"] = f"{head['host_inputs']['value']:.1f}", f"{head['host_inputs']['ms_per_step']:.1f}"
+if head.get("alt_backbone_f32"):
+    vals["ALTBB"], vals["ALTBBMS"] = f"{head['alt_backbone_f32']['value']:.1f}", f"{head['alt_backbone_f32']['ms_per_step']:.1f}"
+for o in head.get("other_configs") or []:
+    key = {"san_online": "OCSAN", "brivis": "OCBRIVIS", "brivis_swinl": "OCBSWIN"}.get(o["workload"].split()[0])
+    if key:
+        vals[key], vals[key + "FRAC"] = f"{o['value']:.1f}", f"{o['roofline']['frac']:.2f}"
 if head.get("stage_ms"):
     st = head["stage_ms"]
     vals.update({"A2": f"{st['A2_backbone']:.2f}", "A36": f"{st['A3-A6_pixel_decoder']:.2f}", "A78": f"{st['A7-A8_decoder']:.2f}",

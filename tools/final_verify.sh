@@ -9,15 +9,15 @@ rm -rf $R; mkdir -p $R
 cd $ROOTD
 python -m pytest tests -q -m gpu -x 2>&1 | tail -5 > $R/pytest_gpu.txt
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/stats -- python3 $ROOTD/bench.py --steps $STEPS_PROF --warmup 3 --no-cpu-baseline --no-in-flight --no-alt-splits > $R/bench_under_rocprof.json 2> $R/rocprof_stats.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/pmc_fetch -- python3 $ROOTD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-in-flight --no-alt-splits > /dev/null 2> $R/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/pmc_write -- python3 $ROOTD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-in-flight --no-alt-splits > /dev/null 2> $R/pmc_write.err
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/pmc_mfma -- python3 $ROOTD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-in-flight --no-alt-splits > /dev/null 2> $R/pmc_mfma.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/stats -- python3 $ROOTD/bench.py --steps $STEPS_PROF --warmup 3 --no-cpu-baseline --no-in-flight --no-alt-splits --no-other-configs > $R/bench_under_rocprof.json 2> $R/rocprof_stats.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/pmc_fetch -- python3 $ROOTD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-in-flight --no-alt-splits --no-other-configs > /dev/null 2> $R/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/pmc_write -- python3 $ROOTD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-in-flight --no-alt-splits --no-other-configs > /dev/null 2> $R/pmc_write.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/pmc_mfma -- python3 $ROOTD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-in-flight --no-alt-splits --no-other-configs > /dev/null 2> $R/pmc_mfma.err
 cd $ROOTD
 python tools/trace_by_shape.py $R/stats $R/kernel_by_shape.csv 26
 python tools/pmc_traffic.py $R/pmc_fetch $R/pmc_write $R/pmc_traffic_bench.json "${GIT_HEAD:-unknown}"
 python tools/pmc_mfma.py $R/pmc_mfma $R/pmc_mfma_bench.json
-mkdir -p profiles/${ROUND:-r05} && cp $R/pmc_traffic_bench.json profiles/${ROUND:-r05}/pmc_traffic_bench.json   # so that the bench line below reads THIS build's traffic
+mkdir -p profiles/${ROUND:-r06} && cp $R/pmc_traffic_bench.json profiles/${ROUND:-r06}/pmc_traffic_bench.json   # so that the bench line below reads THIS build's traffic
 python bench.py > $R/bench_default.json 2> $R/bench_default.err
 if [ "${1:-}" != "quick" ]; then
   for m in openvis_online san_online brivis brivis_swinl openvis_swinl; do python bench.py --model $m --steps 10 --warmup 2 2>> $R/bench_models.err | tail -1 >> $R/bench_all_models.jsonl; done
