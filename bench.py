@@ -822,7 +822,7 @@ def main():
             torch.cuda.empty_cache()
             line["other_configs"] = [measure_other_config(n, device, args, f32_split) for n in ("san_online", "brivis", "brivis_swinl")]
             line["other_configs_note"] = ("N = 1 runs of the other BASELINE.json configs, same timing rules as the headline (warm-up, then `steps` "
-                                          "steps between device synchronisations, H2D of the frames and D2H of the masks included); not the headline")
+                                          "steps between device synchronisations, clips resident in HBM, D2H of the masks included); not the headline")
         if not args.no_cpu_baseline and world == 1 and args.model == "openvis":
             line["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(line))

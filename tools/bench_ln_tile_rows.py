@@ -1,6 +1,7 @@
 """LayerNorm-folded fp16 GEMMs of the CLIP tower (in_proj, c_fc + QuickGELU) on 256-row against 192-row tiles (round 6: the folded
 instantiations take 192-row tiles; lab switch ovis_pp_tile_rows), M = 500 crops x 197 tokens.  Equality of the two outputs is checked
-(the same dot products per element in the same order: tile height does not enter the arithmetic)."""
+(the same dot products per element in the same order: tile height does not enter the arithmetic).
+Needs the LAB build described in profiles/r06/tile_rows.txt: the shipped launcher keeps the folded instantiations on 256-row tiles."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
