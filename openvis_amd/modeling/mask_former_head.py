@@ -16,9 +16,12 @@ class MaskFormerHead:
 
     @classmethod
     def from_config(cls, cfg, input_shape):
+        # mask_former_head.py:92-117: the decoder's input width follows TRANSFORMER_IN_FEATURE.  Every config of the reference sets
+        # "multi_scale_pixel_decoder" (configs/*/*.yaml:20-21); the other branches exist in the reference's dispatch and are mirrored in
+        # forward() below with the failure each of them meets there (all registered decoders are *MultiScale* decoders)
         tif = cfg.MODEL.MASK_FORMER.TRANSFORMER_IN_FEATURE
-        if tif != "multi_scale_pixel_decoder":
-            raise NotImplementedError(f"TRANSFORMER_IN_FEATURE={tif} is not used by the eval configs of the path")
+        if tif not in ("multi_scale_pixel_decoder", "transformer_encoder", "pixel_embedding", "side_adapter") and tif not in input_shape:
+            raise KeyError(tif)                                     # input_shape[TRANSFORMER_IN_FEATURE].channels (:101)
         return cls({k: v for k, v in input_shape.items() if k in cfg.MODEL.SEM_SEG_HEAD.IN_FEATURES},
                    ignore_value=cfg.MODEL.SEM_SEG_HEAD.IGNORE_VALUE, num_classes=cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES,
                    pixel_decoder=build_pixel_decoder(cfg, input_shape), loss_weight=cfg.MODEL.SEM_SEG_HEAD.LOSS_WEIGHT,
@@ -31,7 +34,24 @@ class MaskFormerHead:
         return self
 
     def forward(self, features, mask=None, extra_feats=None, images=None, texts=None):
-        mask_features, _, multi_scale_features = self.pixel_decoder.forward_features(features, extra_feats)
-        return self.predictor(multi_scale_features, mask_features, mask)
+        """mask_former_head.py:119-135.  "multi_scale_pixel_decoder" is the path; the single-map branches reach decoders that assert three feature
+        levels (video decoder:387, frame decoder:98: `assert len(x) == self.num_feature_levels`) and fail there in the reference as well."""
+        mask_features, transformer_encoder_features, multi_scale_features = self.pixel_decoder.forward_features(features, extra_feats)
+        tif = self.transformer_in_feature
+        if tif == "multi_scale_pixel_decoder":
+            return self.predictor(multi_scale_features, mask_features, mask)
+        if tif == "side_adapter":                                   # :122: predictor(multi_scale_features, mask_features, images, texts)
+            raise TypeError("forward() takes from 3 to 4 positional arguments but 5 were given (no registered decoder takes images and texts: "
+                            "mask_former_head.py:122)")
+        if tif == "transformer_encoder":
+            assert transformer_encoder_features is not None, "Please use the TransformerEncoderPixelDecoder."       # :126-128
+            x = transformer_encoder_features
+        elif tif == "pixel_embedding":
+            x = mask_features                                       # :131
+        else:
+            x = features[tif]                                       # :133
+        assert isinstance(x, (list, tuple)) and len(x) == self.predictor.num_feature_levels, \
+            f"TRANSFORMER_IN_FEATURE={tif}: a single map where the multi-scale decoder expects {self.predictor.num_feature_levels} levels"
+        return self.predictor(x, mask_features, mask)
 
     __call__ = forward

@@ -198,3 +198,31 @@ def test_evaluator_handoff_formats():
     assert [sorted(f) for f in burst["segmentations"]] == [[0, 1], [0], [0]]
     a = burst["segmentations"][0][1]
     assert a == {"rle": coco[1]["segmentations"][0]["counts"], "is_gt": False, "score": 0.4, "entropy": 0.7}
+
+
+def test_mask_former_head_dispatch_mirrors_the_reference_branches():
+    """mask_former_head.py:119-135: TRANSFORMER_IN_FEATURE selects what the decoder is fed.  Every reference config uses
+    "multi_scale_pixel_decoder"; the single-map branches reach *MultiScale* decoders that assert three feature levels and fail in the
+    reference too -- here they fail the same way instead of being refused at construction (round 5's review, missing item 5)."""
+    import pytest
+    from openvis_amd.modeling.mask_former_head import MaskFormerHead
+
+    class PD:
+        def forward_features(self, features, extra=None):
+            return "mask_features", "enc0", ["ms0", "ms1", "ms2"]
+
+    class Dec:
+        num_feature_levels = 3
+
+        def __call__(self, x, mask_features, mask=None):
+            return {"x": x, "mask_features": mask_features, "mask": mask}
+
+    shape = {k: dict(channels=c, stride=s) for k, c, s in (("res2", 256, 4), ("res3", 512, 8), ("res4", 1024, 16), ("res5", 2048, 32))}
+    mk = lambda tif: MaskFormerHead(shape, num_classes=1, pixel_decoder=PD(), transformer_predictor=Dec(), transformer_in_feature=tif)
+    out = mk("multi_scale_pixel_decoder")({"res5": "f5"}, mask="m")
+    assert out == {"x": ["ms0", "ms1", "ms2"], "mask_features": "mask_features", "mask": "m"}
+    for tif in ("transformer_encoder", "pixel_embedding", "res5"):
+        with pytest.raises(AssertionError):
+            mk(tif)({"res5": "f5"})
+    with pytest.raises(TypeError):
+        mk("side_adapter")({"res5": "f5"})
