@@ -414,7 +414,8 @@ int ovis_clip_crop_patches_masked(const uint8_t* frames, const float* masks, con
  *   patch_open may be NULL = ovis_clip_crop_patches).  The frame half of a crop -- roi_align of the RGB planes, adapter.py:104-108 -- depends
  *   on (frame, box) only: with the workspace, crops of one frame that share a box compute it once (a leader pass that keeps the bins' frame
  *   averages, a follower pass that evaluates the mask half only); bit-identical to the one-pass entry points, whatever the boxes are.
- *   ws == NULL: the one-pass kernel. */
+ *   ws == NULL: the one-pass kernel.  ovis_clip_crop_workspace_bytes returns 0 where the launcher would not use a workspace (M > 3 072: the
+ *   dedupe kernel stages the crop list in LDS). */
 long long ovis_clip_crop_workspace_bytes(int M, int resolution);
 int ovis_clip_crop_patches_ws(const uint8_t* frames, const float* masks, const int* crops, void* A, unsigned char* patch_open, int out_f16,
                               int M, int Q, int T, int H, int W, int h, int w, int Hp, int Wp, int resolution, int patch, long long lda,

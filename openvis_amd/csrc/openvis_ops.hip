@@ -1558,7 +1558,7 @@ extern "C" int ovis_crop_list_static(const int* boxes, int* crops, int* slot, in
 extern "C" int ovis_crop_tile(int t) { g_crop_tile = t; return OVIS_OK; }   // lab / tests: 8 = 8x8 tiles, 16 = separate tap loops, 32 = ignore the workspace (one fused pass)
 
 extern "C" long long ovis_clip_crop_workspace_bytes(int M, int resolution) {
-  if (M <= 0 || resolution <= 0) return 0;
+  if (M <= 0 || resolution <= 0 || (long long)M * 20 > 60 * 1024) return 0;      // beyond 3 072 crops the launcher takes the one-pass kernel: no workspace
   const long long mi = (((long long)M + 3) / 4) * 4;
   const long long tiles = (long long)((resolution + 15) / 16) * ((resolution + 15) / 16);
   return 16 + 12 * mi * 4 + mi * tiles * 4 + (long long)M * 3 * resolution * resolution * 4;
