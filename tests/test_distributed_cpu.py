@@ -166,3 +166,33 @@ def test_rccl_worker_logic_on_gloo(tmp_path):
                         "--master-port", str(_free_port()), os.path.join(root, "tests", "_rccl_worker.py")], env=env, capture_output=True,
                        text=True, timeout=300)
     assert p.returncode == 0 and "RCCL_OK world=3" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+def _forced_one_rank(port, q):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from openvis_amd import distributed as D
+    assert D.init_from_env("gloo") == (0, 1, 0) and not dist.is_initialized()           # world 1: a no-op ...
+    assert D.backend_name() is None
+    assert D.init_from_env("gloo", force=True) == (0, 1, 0) and dist.is_initialized()   # ... unless forced (round 6: the 1-rank RCCL group)
+    assert D.backend_name() == "gloo" and D.world_size() == 1
+    x = torch.arange(7 * 4 * 8, dtype=torch.float32).view(7, 4, 8)
+    assert torch.equal(D.all_gather_frames(x, 7), x)
+    assert torch.equal(D.all_reduce_sum(torch.ones(5)), torch.ones(5))
+    m = (torch.arange(2 * 7 * 3 * 3) % 2).to(torch.uint8).view(2, 7, 3, 3)
+    assert torch.equal(D.gather_frame_masks(m, 7, dst=0), m)
+    assert D.max_over_ranks(1.5) == 1.5
+    D.warm_up("cpu")
+    dist.destroy_process_group()
+    q.put("ok")
+
+
+def test_forced_one_rank_process_group():
+    """distributed.init_from_env(force=True): a ONE-rank group (what the GPU suite uses to run the RCCL branches on a single device) -- here on
+    gloo: every helper of the frame-sharded path is the identity at world 1, and without `force` no group is created."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    p = ctx.Process(target=_forced_one_rank, args=(port, q))
+    p.start(); p.join(120)
+    assert p.exitcode == 0 and q.get(timeout=5) == "ok"
