@@ -522,6 +522,12 @@ int ovis_rle_encode_u8(const uint8_t* masks, int n_masks, long long len, int* co
 int ovis_pil_resize_u8_hwc_to_chw(const uint8_t* src, int H, int W, uint8_t* tmp, uint8_t* dst, int OH, int OW,
                                   const int* xbounds, const int* xk, int xksize, const int* ybounds, const int* yk, int yksize,
                                   ovis_stream_t stream);
+/* The same resize whose vertical pass ALSO writes what ovis_preprocess_u8_nhwc4 would compute from dst (resize + normalise + pad
+ * fused): img f32 [Hp,Wp,4] = ((dst - mean) / std, 0) zero padded (openvis.py:57-62), Hp >= OH, Wp >= OW; dst is still written (the CLIP crops
+ * read the resized uint8 frame, adapter.py:96-108).  Both outputs bit-identical to the two separate calls. */
+int ovis_pil_resize_preprocess_u8(const uint8_t* src, int H, int W, uint8_t* tmp, uint8_t* dst, float* img_nhwc4, int OH, int OW, int Hp,
+                                  int Wp, const int* xbounds, const int* xk, int xksize, const int* ybounds, const int* yk, int yksize,
+                                  const float* mean3_host, const float* std3_host, ovis_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,35 @@ def resize_frame(frame_hwc_u8, out_hw):
     return dst
 
 
+def resize_and_preprocess(frames_hwc_u8, min_size, max_size=1333, size_divisibility=32, pixel_mean=(123.675, 116.28, 103.53),
+                          pixel_std=(58.395, 57.12, 57.375), device="cuda"):
+    """SURVEY.md 8f-2, fused: list of decoded uint8 [H,W,3] frames of ONE video -> (frames uint8 [T,3,OH,OW] -- one device tensor, what the model's
+    `image` list slices --, images f32 [T,Hp,Wp,4] = the model's A1 output for them, original (H, W)).  The vertical pass of the resize writes both
+    (csrc/resize.hip: resize_vertical_preprocess_kernel); hand `images` to the forward as batched_inputs[0]["images_nhwc4"] and A1 is skipped.
+    Bit-identical to resize_frame() + VideoMaskFormer.preprocess()."""
+    fs = [torch.as_tensor(np.ascontiguousarray(f)) if not torch.is_tensor(f) else f for f in frames_hwc_u8]
+    H, W, _ = fs[0].shape
+    OH, OW = shortest_edge_size(H, W, min_size, max_size)
+    d = size_divisibility
+    Hp, Wp = ((OH + d - 1) // d * d, (OW + d - 1) // d * d) if d > 1 else (OH, OW)
+    xb, xk, xks = pil_bilinear_coeffs(W, OW)
+    yb, yk, yks = pil_bilinear_coeffs(H, OH)
+    t = lambda a: torch.from_numpy(a).to(device)
+    xb, xk, yb, yk = t(xb), t(xk), t(yb), t(yk)
+    T = len(fs)
+    frames = torch.empty((T, 3, OH, OW), dtype=torch.uint8, device=device)
+    images = torch.empty((T, Hp, Wp, 4), dtype=torch.float32, device=device)
+    tmp = torch.empty((H, OW, 3), dtype=torch.uint8, device=device)
+    from .ops import _f3
+    for i, f in enumerate(fs):
+        if tuple(f.shape) != (H, W, 3) or f.dtype != torch.uint8:
+            raise _lib.OvisError("resize_and_preprocess: all frames of a video are uint8 [H,W,3] of one size")
+        src = f.to(device, non_blocking=True).contiguous()
+        _lib.call("ovis_pil_resize_preprocess_u8", src, H, W, tmp, frames[i], images[i], OH, OW, Hp, Wp, xb, xk, xks, yb, yk, yks,
+                  _f3(pixel_mean), _f3(pixel_std), _lib.stream_ptr())
+    return frames, images, (H, W)
+
+
 def load_and_resize(frames_hwc_u8, min_size, max_size=1333, device="cuda"):
     """list of decoded uint8 [H,W,3] arrays/tensors -> (list of uint8 [3,OH,OW] device tensors, original (H, W))."""
     out = []
