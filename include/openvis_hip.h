@@ -361,6 +361,27 @@ int ovis_attention_f32(const float* q, long long q_bs, int q_ld, const float* k,
                        long long bias_bs, long long bias_hs, int bias_ld, int B, int H, int Nq, int Nk, int D,
                        float scale, int nsplit, float* workspace, ovis_stream_t stream);
 
+/* ---- One clip's masked cross-attention with the KEYS split over several GPUs (OpenVIS row: "split-KV") --------------
+ *   The offline video decoder attends over the keys of all T frames at once (video decoder:397-403, 417-426).  With the frames of ONE clip
+ *   sharded over GPUs every GPU holds the K / V rows of its own frames; per decoder layer it runs
+ *     ovis_attention_partial_f32  -> this GPU's un-normalised flash partial, packed as
+ *                                    [B*H*Nq*D weighted V | B*H*Nq*2 (row max in log2 units, row sum) | B*Nq "had an open key here"]
+ *                                    = ovis_attention_partial_floats(B,H,Nq,D) floats (100 queries x 8 heads x 32: 109 200 B),
+ *     one all-gather of that block over the GPUs (RCCL; the caller's job -- this library knows no communicator),
+ *     ovis_attention_merge_f32    -> out[b,q,h*D:(h+1)*D] from the R gathered blocks (block r at parts + r*stride floats).
+ *   mask / row_open cover THIS GPU's keys only.  A row that is blocked on every key of the clip attends to all keys (video decoder:419):
+ *   the flash kernel runs locally-closed rows unmasked and the merge keeps those partials only if the row is closed on every GPU.
+ *   R = 1 reproduces ovis_attention_f32 with the same nsplit (same partials, same merge arithmetic).
+ *   workspace: ovis_attention_partial_workspace_bytes(B,H,Nq,D,nsplit) bytes (needed for every nsplit >= 1). */
+long long ovis_attention_partial_floats(int B, int H, int Nq, int D);
+long long ovis_attention_partial_workspace_bytes(int B, int H, int Nq, int D, int nsplit);
+int ovis_attention_partial_f32(const float* q, long long q_bs, int q_ld, const float* k, long long k_bs, int k_ld,
+                               const float* v, long long v_bs, int v_ld, const uint8_t* mask, long long mask_ld,
+                               long long mask_bs, const int* row_open, int B, int H, int Nq, int Nk, int D, float scale,
+                               int nsplit, float* workspace, float* partial, ovis_stream_t stream);
+int ovis_attention_merge_f32(const float* parts, int R, long long stride, float* out, long long o_bs, int o_ld, int B, int H,
+                             int Nq, int D, ovis_stream_t stream);
+
 /* fp16-operand variant for the CLIP ViT tower (no mask, no split): q/k/v/out fp16, f32 softmax + accumulation, D = 64.
  *   element (b,row,h,d) at ptr[b*bs + row*ld + h*D + d] (strides in halfs, multiples of 8). */
 int ovis_attention_f16(const void* q, long long q_bs, int q_ld, const void* k, long long k_bs, int k_ld, const void* v,

@@ -39,7 +39,8 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ovis_last_error.restype = ctypes.c_char_p
         _lib.ovis_abi_version.restype = ctypes.c_int
-        for fn in ("ovis_attention_workspace_bytes", "ovis_hungarian_link_workspace_bytes", "ovis_clip_crop_workspace_bytes"):
+        for fn in ("ovis_attention_workspace_bytes", "ovis_hungarian_link_workspace_bytes", "ovis_clip_crop_workspace_bytes",
+                   "ovis_attention_partial_floats", "ovis_attention_partial_workspace_bytes"):
             if hasattr(_lib, fn):
                 getattr(_lib, fn).restype = ctypes.c_longlong
     return _lib

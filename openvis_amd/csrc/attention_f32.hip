@@ -246,10 +246,15 @@ flash_attn_f32_kernel(AttnArgs a) {
 // every G-th split (G = 256 / D groups), the groups' (max, sum, weighted V) are merged through LDS.  (Round 2 ran the nsplit
 // -- up to 250 for the 73 600-key level -- partials of a row as ONE serial loop per (bh, q, d) thread: 30 us of dependent loads
 // per launch, 9 launches per clip.)
-template <int D>
+// RAW (the cross-GPU split of ONE clip, ovis_attention_partial_f32): the merged (weighted V, max, sum) of THIS GPU's keys is kept
+// un-normalised -- out = packed partial [B*H*Nq*D | B*H*Nq*2 | B*Nq]: the last block holds, per query row, whether any of this GPU's keys
+// was open (row_open > 0; rows without an open key were run unmasked by the flash kernel, video decoder:419, and the merge over GPUs
+// needs to know which of the two a partial is).
+template <int D, bool RAW = false>
 __global__ void __launch_bounds__(256)
 attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, float* __restrict__ out,
-                    long long o_bs, int o_ld, int B, int H, int Nq, int nsplit) {
+                    long long o_bs, int o_ld, int B, int H, int Nq, int nsplit, const int* __restrict__ row_open = nullptr,
+                    long long open_bs = 0) {
   constexpr int G = 256 / D;
   __shared__ float gm[G], gl[G][D], ga[G][D];
   const int d = threadIdx.x % D, grp = threadIdx.x / D;
@@ -278,8 +283,53 @@ attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ 
   if (grp == 0) {
 #pragma unroll
     for (int g = 1; g < G; ++g) { l += gl[g][d]; acc += ga[g][d]; }
-    out[b * o_bs + (long long)q * o_ld + head * D + d] = l > 0.f ? acc / l : 0.f;
+    if constexpr (RAW) {
+      out[row * D + d] = acc;
+      if (d == 0) {
+        float* ml = out + BHQ * D + row * 2;
+        ml[0] = mall; ml[1] = l;
+        if (head == 0) out[BHQ * (D + 2) + (long long)b * Nq + q] = (!row_open || row_open[(long long)b * open_bs + q] > 0) ? 1.f : 0.f;
+      }
+    } else {
+      out[b * o_bs + (long long)q * o_ld + head * D + d] = l > 0.f ? acc / l : 0.f;
+    }
   }
+}
+
+// merge the packed partials of R GPUs (attn_combine_kernel<D, true>, all-gathered: GPU r's block at parts + r * stride) into the attention
+// output.  One 64-thread workgroup per (bh, q); R is the number of GPUs of one node (<= 8 here), a serial loop.  A query row that has an
+// open key on ANY GPU takes only the partials of the GPUs where it has one (the others ran the row unmasked); a row closed everywhere takes
+// all of them -- together exactly "rows whose mask blocks every key of the clip attend to everything" (video decoder:419).
+template <int D>
+__global__ void __launch_bounds__(64)
+attn_merge_ranks_kernel(const float* __restrict__ parts, int R, long long stride, float* __restrict__ out, long long o_bs, int o_ld,
+                        int B, int H, int Nq) {
+  const int d = threadIdx.x;
+  if (d >= D) return;
+  const long long row = blockIdx.x;
+  const int q = (int)(row % Nq);
+  const int bh = (int)(row / Nq);
+  const int b = bh / H, head = bh % H;
+  const long long BHQ = (long long)B * H * Nq;
+  const long long flag_at = BHQ * (D + 2) + (long long)b * Nq + q;
+  bool any_open = false;
+  for (int r = 0; r < R; ++r) any_open |= parts[r * stride + flag_at] > 0.f;
+  float m = -INFINITY;
+  for (int r = 0; r < R; ++r) {
+    const float* p = parts + r * stride;
+    if (any_open && !(p[flag_at] > 0.f)) continue;
+    m = fmaxf(m, p[BHQ * D + row * 2]);
+  }
+  float l = 0.f, acc = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const float* p = parts + r * stride;
+    if (any_open && !(p[flag_at] > 0.f)) continue;
+    const float mr = p[BHQ * D + row * 2];
+    const float w = mr == -INFINITY ? 0.f : exp2f(mr - m);
+    l += p[BHQ * D + row * 2 + 1] * w;
+    acc += p[row * D + d] * w;
+  }
+  out[b * o_bs + (long long)q * o_ld + head * D + d] = l > 0.f ? acc / l : 0.f;
 }
 
 }  // namespace
@@ -289,12 +339,15 @@ extern "C" long long ovis_attention_workspace_bytes(int B, int H, int Nq, int D,
   return (long long)nsplit * B * H * Nq * (D + 2) * sizeof(float);
 }
 
-extern "C" int ovis_attention_f32(const float* q, long long q_bs, int q_ld, const float* k, long long k_bs, int k_ld,
-                                  const float* v, long long v_bs, int v_ld, void* out, long long o_bs, int o_ld,
-                                  int out_f16, const uint8_t* mask, long long mask_ld, long long mask_bs,
-                                  const int* row_open, const float* bias, long long bias_bs, long long bias_hs,
-                                  int bias_ld, int B, int H, int Nq, int Nk, int D, float scale, int nsplit,
-                                  float* workspace, ovis_stream_t stream) {
+// `partial` != null: the cross-GPU form -- the flash kernel always writes split partials (AttnArgs.nsplit = 0 stands for "one split, kept
+// raw": the kernel normalises in place only when the field is 1) and the RAW combine packs this GPU's merged partial into `partial`.
+static int attention_launch(const float* q, long long q_bs, int q_ld, const float* k, long long k_bs, int k_ld,
+                            const float* v, long long v_bs, int v_ld, void* out, long long o_bs, int o_ld,
+                            int out_f16, const uint8_t* mask, long long mask_ld, long long mask_bs,
+                            const int* row_open, const float* bias, long long bias_bs, long long bias_hs,
+                            int bias_ld, int B, int H, int Nq, int Nk, int D, float scale, int nsplit,
+                            float* workspace, float* partial, ovis_stream_t stream) {
+  if (partial) out = partial;
   OVIS_REQUIRE(q && k && v && out, "attention: null pointer");
   OVIS_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "attention: non-positive size");
   OVIS_REQUIRE(D == 32 || D == 64, "attention: head dim %d not supported (32 or 64)", D);
@@ -302,7 +355,7 @@ extern "C" int ovis_attention_f32(const float* q, long long q_bs, int q_ld, cons
                    v_bs % 4 == 0 && o_bs % 4 == 0,
                "attention: strides must be multiples of 4 floats");
   OVIS_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, "attention: 16-byte alignment");
-  OVIS_REQUIRE(nsplit >= 1 && (nsplit == 1 || workspace), "attention: nsplit > 1 needs a workspace");
+  OVIS_REQUIRE(nsplit >= 1 && ((nsplit == 1 && !partial) || workspace), "attention: nsplit > 1 (and every partial launch) needs a workspace");
   OVIS_REQUIRE(!(out_f16 && nsplit > 1), "attention: fp16 output is only supported with nsplit == 1");
   OVIS_REQUIRE(!mask || mask_ld >= Nk, "attention: mask_ld < Nk");
   OVIS_REQUIRE(!bias || (bias_ld % 4 == 0 && bias_ld >= (Nk + 3) / 4 * 4 && bias_bs % 4 == 0 && bias_hs % 4 == 0 &&
@@ -315,7 +368,7 @@ extern "C" int ovis_attention_f32(const float* q, long long q_bs, int q_ld, cons
   a.q = q; a.q_bs = q_bs; a.q_ld = q_ld; a.k = k; a.k_bs = k_bs; a.k_ld = k_ld; a.v = v; a.v_bs = v_bs; a.v_ld = v_ld;
   a.out = out; a.o_bs = o_bs; a.o_ld = o_ld; a.out_f16 = out_f16; a.mask = mask; a.mask_ld = mask_ld; a.mask_bs = mask_bs; a.row_open = row_open;
   a.bias = bias; a.bias_bs = bias_bs; a.bias_hs = bias_hs; a.bias_ld = bias_ld;
-  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.nsplit = nsplit; a.keys_per_split = keys_per_split; a.scale = scale;
+  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.nsplit = (partial && nsplit == 1) ? 0 : nsplit; a.keys_per_split = keys_per_split; a.scale = scale;
   a.part_o = workspace;
   a.part_ml = workspace ? workspace + (long long)nsplit * B * H * Nq * D : nullptr;
   const bool five = Nq > 128 && Nq <= 160;                          // one 160-query workgroup instead of 128 + a nearly empty one
@@ -328,11 +381,57 @@ extern "C" int ovis_attention_f32(const float* q, long long q_bs, int q_ld, cons
   else hipLaunchKernelGGL(flash_attn_f32_kernel<64>, grid, dim3(256), 0, s, a);
   int rc = ovis::check_launch("attention");
   if (rc) return rc;
-  if (nsplit > 1) {
-    const unsigned rows = (unsigned)((long long)B * H * Nq);
+  const unsigned rows = (unsigned)((long long)B * H * Nq);
+  if (partial) {
+    const long long open_bs = mask_bs ? Nq : 0;
+    if (D == 32) hipLaunchKernelGGL((attn_combine_kernel<32, true>), dim3(rows), dim3(256), 0, s, a.part_o, a.part_ml, partial, 0LL, 0, B, H, Nq, nsplit, row_open, open_bs);
+    else hipLaunchKernelGGL((attn_combine_kernel<64, true>), dim3(rows), dim3(256), 0, s, a.part_o, a.part_ml, partial, 0LL, 0, B, H, Nq, nsplit, row_open, open_bs);
+    rc = ovis::check_launch("attention combine (partial)");
+  } else if (nsplit > 1) {
     if (D == 32) hipLaunchKernelGGL(attn_combine_kernel<32>, dim3(rows), dim3(256), 0, s, a.part_o, a.part_ml, (float*)out, o_bs, o_ld, B, H, Nq, nsplit);
     else hipLaunchKernelGGL(attn_combine_kernel<64>, dim3(rows), dim3(256), 0, s, a.part_o, a.part_ml, (float*)out, o_bs, o_ld, B, H, Nq, nsplit);
     rc = ovis::check_launch("attention combine");
   }
   return rc;
+}
+
+extern "C" int ovis_attention_f32(const float* q, long long q_bs, int q_ld, const float* k, long long k_bs, int k_ld,
+                                  const float* v, long long v_bs, int v_ld, void* out, long long o_bs, int o_ld,
+                                  int out_f16, const uint8_t* mask, long long mask_ld, long long mask_bs,
+                                  const int* row_open, const float* bias, long long bias_bs, long long bias_hs,
+                                  int bias_ld, int B, int H, int Nq, int Nk, int D, float scale, int nsplit,
+                                  float* workspace, ovis_stream_t stream) {
+  return attention_launch(q, q_bs, q_ld, k, k_bs, k_ld, v, v_bs, v_ld, out, o_bs, o_ld, out_f16, mask, mask_ld, mask_bs, row_open, bias,
+                          bias_bs, bias_hs, bias_ld, B, H, Nq, Nk, D, scale, nsplit, workspace, nullptr, stream);
+}
+
+extern "C" long long ovis_attention_partial_floats(int B, int H, int Nq, int D) {
+  return (long long)B * H * Nq * (D + 2) + (long long)B * Nq;
+}
+
+extern "C" long long ovis_attention_partial_workspace_bytes(int B, int H, int Nq, int D, int nsplit) {
+  return (long long)(nsplit < 1 ? 1 : nsplit) * B * H * Nq * (D + 2) * sizeof(float);
+}
+
+extern "C" int ovis_attention_partial_f32(const float* q, long long q_bs, int q_ld, const float* k, long long k_bs, int k_ld,
+                                          const float* v, long long v_bs, int v_ld, const uint8_t* mask, long long mask_ld,
+                                          long long mask_bs, const int* row_open, int B, int H, int Nq, int Nk, int D, float scale,
+                                          int nsplit, float* workspace, float* partial, ovis_stream_t stream) {
+  OVIS_REQUIRE(partial && workspace, "attention partial: null pointer");
+  OVIS_REQUIRE((((uintptr_t)partial) & 15) == 0, "attention partial: 16-byte alignment");
+  return attention_launch(q, q_bs, q_ld, k, k_bs, k_ld, v, v_bs, v_ld, nullptr, 4, 4, 0, mask, mask_ld, mask_bs, row_open, nullptr, 0, 0, 0,
+                          B, H, Nq, Nk, D, scale, nsplit, workspace, partial, stream);
+}
+
+extern "C" int ovis_attention_merge_f32(const float* parts, int R, long long stride, float* out, long long o_bs, int o_ld, int B, int H,
+                                        int Nq, int D, ovis_stream_t stream) {
+  OVIS_REQUIRE(parts && out, "attention merge: null pointer");
+  OVIS_REQUIRE(R >= 1 && B > 0 && H > 0 && Nq > 0, "attention merge: non-positive size");
+  OVIS_REQUIRE(D == 32 || D == 64, "attention merge: head dim %d not supported (32 or 64)", D);
+  OVIS_REQUIRE(stride >= (long long)B * H * Nq * (D + 2) + (long long)B * Nq, "attention merge: stride smaller than one partial");
+  const unsigned rows = (unsigned)((long long)B * H * Nq);
+  hipStream_t s = (hipStream_t)stream;
+  if (D == 32) hipLaunchKernelGGL(attn_merge_ranks_kernel<32>, dim3(rows), dim3(64), 0, s, parts, R, stride, out, o_bs, o_ld, B, H, Nq);
+  else hipLaunchKernelGGL(attn_merge_ranks_kernel<64>, dim3(rows), dim3(64), 0, s, parts, R, stride, out, o_bs, o_ld, B, H, Nq);
+  return ovis::check_launch("attention merge");
 }

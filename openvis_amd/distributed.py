@@ -218,6 +218,25 @@ def gather_frame_masks(masks, total_frames, dst=0):
     return full.transpose(0, 1).contiguous().to(dev)
 
 
+def all_gather_rows(t):
+    """Equal-sized flat blocks, one per rank -> [world, n] in rank order (the per-layer exchange of the split-KV video decoder: one
+    109 KB flash partial per rank).  On RCCL the collective is queued behind the producer on the caller's stream and the
+    consumer (ops.attention_merge) behind it: nothing overlaps it by construction -- the next kernel needs the merged rows -- so there
+    is no side stream here.  Without a process group: t[None]."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return t.reshape(1, -1)
+    world = dist.get_world_size()
+    flat = t.reshape(-1).contiguous()
+    if dist.get_backend() == "gloo":                            # CPU tests / one-GPU test rigs: staged through the host
+        out = torch.empty((world * flat.numel(),), dtype=flat.dtype)
+        dist.all_gather_into_tensor(out, flat.detach().cpu())
+        return out.view(world, -1).to(t.device)
+    out = flat.new_empty((world * flat.numel(),))
+    dist.all_gather_into_tensor(out, flat)
+    return out.view(world, -1)
+
+
 def all_reduce_sum(t):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
@@ -244,6 +263,7 @@ def warm_up(device):
     g = all_gather_frames(x, 2 * world + 1)
     assert g.shape[0] == 2 * world + 1
     all_reduce_sum(torch.ones(16, device=dev))
+    assert all_gather_rows(torch.full((32,), float(dist.get_rank()), device=dev)).shape == (world, 32)
     gather_frame_masks(torch.zeros((2, t_local, 4, 4), dtype=torch.uint8, device=dev), 2 * world + 1)
     max_over_ranks(0.0, "cpu" if dist.get_backend() == "gloo" else dev)
     if dev.type == "cuda":

@@ -33,12 +33,14 @@ class MaskFormerHead:
         self.predictor.load_state_dict(sd, prefix + "predictor.", device)
         return self
 
-    def forward(self, features, mask=None, extra_feats=None, images=None, texts=None):
+    def forward(self, features, mask=None, extra_feats=None, images=None, texts=None, shard=None):
         """mask_former_head.py:119-135.  "multi_scale_pixel_decoder" is the path; the single-map branches reach decoders that assert three feature
         levels (video decoder:387, frame decoder:98: `assert len(x) == self.num_feature_levels`) and fail there in the reference as well."""
         mask_features, transformer_encoder_features, multi_scale_features = self.pixel_decoder.forward_features(features, extra_feats)
         tif = self.transformer_in_feature
         if tif == "multi_scale_pixel_decoder":
+            if shard is not None:                                   # one clip's frames over several GPUs: the offline video decoder's split-KV form
+                return self.predictor(multi_scale_features, mask_features, mask, shard=shard)
             return self.predictor(multi_scale_features, mask_features, mask)
         if tif == "side_adapter":                                   # :122: predictor(multi_scale_features, mask_features, images, texts)
             raise TypeError("forward() takes from 3 to 4 positional arguments but 5 were given (no registered decoder takes images and texts: "

@@ -151,9 +151,14 @@ class VideoMultiScaleMaskedTransformerDecoder:
     def _nsplit(nk):
         return max(1, min(64, nk // 256))        # x 8 heads: >= 128 workgroups from 4 600 keys on (nk // 1024 left the 18 400-key level on 136)
 
-    def forward(self, x, mask_features, mask=None):
+    def forward(self, x, mask_features, mask=None, shard=None):
         """x: 3 maps [T,H_l,W_l,C] (res5,res4,res3 scale); mask_features [T,h,w,C] (NHWC).
-        Returns {'pred_logits': [1,Q,C+1], 'pred_masks': [1,Q,T,h,w]} (eval: bs = 1, t = T; :381-383)."""
+        Returns {'pred_logits': [1,Q,C+1], 'pred_masks': [1,Q,T,h,w]} (eval: bs = 1, t = T; :381-383).
+
+        shard = (T_total, b0, exchange): the clip's frames are split over GPUs (OpenVIS row "split-KV") and x / mask_features
+        hold the frames [b0, b0 + T) of T_total.  The queries are replicated; the cross-attention's keys are this GPU's frames, its flash
+        partial is exchanged once per layer (`exchange`: packed f32 [n] -> [R, n], an all-gather) and merged (ops.attention_merge); the
+        prediction heads' masks are per-frame products of the replicated mask embedding, so pred_masks covers the local frames only."""
         w = self.w
         T, hm, wm, C = mask_features.shape
         Q, H8 = self.num_queries, self.num_heads
@@ -164,7 +169,11 @@ class VideoMultiScaleMaskedTransformerDecoder:
             sizes.append((H, W))
             s = ops.add_bcast(x[i].reshape(T * H * W, C), w["level_embed.weight"][i].contiguous())   # :401
             src.append(s)
-            kin.append(ops.add_bcast(s, self._pos(T, H, W)))                                           # memory + pos
+            if shard is None:
+                pos = self._pos(T, H, W)
+            else:                                                   # the 3-D sine embedding normalises z by the CLIP's length: slice the clip's table
+                pos = self._pos(shard[0], H, W)[shard[1] * H * W:(shard[1] + T) * H * W]
+            kin.append(ops.add_bcast(s, pos))                                                          # memory + pos
             sc = hm // H
             pooled.append(ops.center_pool(mask_features, sc).view(T * H * W, C) if sc > 1 else mask_features.view(-1, C))
         f16 = self.precision == "fp16"
@@ -196,7 +205,11 @@ class VideoMultiScaleMaskedTransformerDecoder:
                 kp = self._mm(kin[li], f"ca{i}.wk", f"ca{i}.bk")
                 vp = self._mm(src[li], f"ca{i}.wv", f"ca{i}.bv")
                 ldkv = C
-            att = ops.attention(qp, kp, vp, 1, H8, Q, Nk, D, 0, C, 0, ldkv, 0, ldkv, amask, row_open, self._nsplit(Nk))
+            if shard is None:
+                att = ops.attention(qp, kp, vp, 1, H8, Q, Nk, D, 0, C, 0, ldkv, 0, ldkv, amask, row_open, self._nsplit(Nk))
+            else:
+                part = ops.attention_partial(qp, kp, vp, 1, H8, Q, Nk, D, 0, C, 0, ldkv, 0, ldkv, amask, row_open, self._nsplit(Nk))
+                att = ops.attention_merge(shard[2](part), 1, H8, Q, D)
             y = self._mm(att.view(Q, C), f"ca{i}.wo", f"ca{i}.bo", output)
             output = ops.layernorm(y, w[f"ca{i}.nw"], w[f"ca{i}.nb"])
             # self-attention (:428-432, SelfAttentionLayer.forward_post :52-62)

@@ -259,6 +259,9 @@ class VideoMaskFormer:
                 again = self._range_guard(flag.cpu()[0] if flag is not None else None, redo)
                 if again is not None:
                     return again
+                if n_valid is not None and int(n_valid.cpu()[0]) == 0:        # the output rank returns the empty result (finish() below)
+                    return {"image_size": (output_height, output_width), "pred_entropys": [], "pred_scores": [], "pred_labels": [],
+                            "pred_masks": [], "pred_queries": []}
                 scores = score.cpu().tolist()
                 self._check_selected_rows(scores, topk, K)                    # every rank raises where the output rank raises
                 return {"image_size": (output_height, output_width), "pred_entropys": ent.cpu().tolist(),

@@ -37,10 +37,17 @@ class OpenVIS(VideoMaskFormer):
         return [c.strip() for c in MetadataCatalog.get(dataset_name).thing_classes]
 
     @retry_if_oom
-    def forward(self, batched_inputs, stages=None):
+    def forward(self, batched_inputs, stages=None, frame_range=None, gather_masks_to=None):
+        """frame_range=(begin, end): this rank's contiguous frame block of the clip -- ONE clip over several GPUs (OpenVIS row:
+        backbone, pixel decoder and CLIP crops per frame; the offline decoder's cross-attention as split-KV, one all-gather of flash partials
+        per layer).  Needs an initialised process group whose ranks hold the blocks of `distributed.inference_shard`, every rank with at
+        least one frame.  gather_masks_to=r: the selected masks of all frames end up on rank r (the others return `pred_masks: []`);
+        None: every rank keeps the masks of its own frames (`pred_masks_frames`).  Default: the whole clip on this GPU."""
         dataset_name = list(set(x["dataset_name"] for x in batched_inputs))[0]
         class_names = self.get_class_name_list(dataset_name)
         self.sem_seg_head.num_classes = len(class_names)
+        if frame_range is not None:
+            return self._forward_split(batched_inputs, class_names, stages, frame_range, gather_masks_to)
 
         frames = self._frames_to_device(batched_inputs)                       # uint8 [T,3,H,W]
         images, image_size, padded = self.preprocess(frames)                  # A1
@@ -62,6 +69,89 @@ class OpenVIS(VideoMaskFormer):
                                     height, width, redo=lambda: self.forward(batched_inputs, stages), n_valid=dc.counts if dc is not None else None)
 
     __call__ = forward
+
+    def _forward_split(self, batched_inputs, class_names, stages, frame_range, gather_masks_to):
+        from . import distributed as D
+        all_frames = [f for video in batched_inputs for f in video["image"]]
+        T_total = len(all_frames)
+        b0, b1 = frame_range
+        if not (0 <= b0 < b1 <= T_total):
+            raise ValueError(f"frame_range {frame_range} of a {T_total}-frame clip: every rank of a split clip needs at least one frame")
+        frames = self._frames_to_device([{"image": all_frames[b0:b1]}])
+        images, image_size, padded = self.preprocess(frames)
+        features = self.backbone(images)
+
+        def exchange(part):
+            with D.span("partial_all_gather", host=True):
+                return D.all_gather_rows(part)
+
+        outputs = self.sem_seg_head(features, shard=(T_total, b0, exchange))
+        masks_lowres = outputs["pred_masks"][0]                               # [Q, t_local, h, w]
+        probs, row_ids, n_valid, extras = self._classify_split(masks_lowres, frames, class_names, padded, T_total)
+        if stages is not None:
+            stages.update(dict(images=images, features=features, pred_masks=outputs["pred_masks"], pred_logits=outputs["pred_logits"],
+                               probs=probs, row_ids=row_ids, **extras))
+        inp = batched_inputs[0]
+        self.mask_gather = None
+        if gather_masks_to is not None:
+            def _mg(m):
+                with D.span("mask_gather", host=True):
+                    return D.gather_frame_masks(m, T_total, gather_masks_to)
+            self.mask_gather = _mg
+        try:
+            out = self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
+                                       inp.get("height", image_size[0]), inp.get("width", image_size[1]),
+                                       redo=lambda: self.forward(batched_inputs, stages, frame_range, gather_masks_to), sync_guard=True,
+                                       n_valid=n_valid)
+        finally:
+            self.mask_gather = None
+        if gather_masks_to is None:
+            out["pred_masks_frames"] = (b0, b1)
+        return out
+
+    def _classify_split(self, masks_lowres, frames, class_names, padded_hw, T_total):
+        """openvis.py:110-147 with the clip's frames on several GPUs.  The crops of a frame need that frame only; the per-query mean over
+        the frames with a non-empty mask (:130-138) needs all of them: every rank lays its crop logits out as [t_local, Q, K | valid] and
+        ONE all-gather (distributed.all_gather_frames: ragged blocks padded) gives every rank the clip's [T, Q, K] -- the aggregate kernel
+        then runs on exactly the rows, in exactly the order, of the one-GPU path, so every rank holds the same probabilities and picks the
+        same top-10.  (T x Q x (K + 1) f32: 80 KB for 5 frames x 40 classes, 17 MB for 36 x 1196.)"""
+        from . import distributed as D
+        from .modeling.clip_adapter.adapter import DeviceCrops
+        logits, valid, crops = self.clip_adapter(frames, class_names, masks_lowres, padded_hw)
+        K = len(class_names)
+        Q, t = masks_lowres.shape[0], masks_lowres.shape[1]
+        dev = masks_lowres.device
+        if logits is not None and logits.shape[1] != K:
+            raise ValueError(f"{type(self.clip_adapter).__name__} returns {logits.shape[1]} logits for {K} classes; OpenVIS needs "
+                             "ClipAdapter or AdaptedClipAdapter")
+        packed = torch.zeros((t, Q, K + 1), dtype=torch.float32, device=dev)
+        if isinstance(valid, DeviceCrops):
+            ok = valid.slot >= 0                                              # [t, Q]; logit row of (t, q) = slot
+            rows = logits[valid.slot.clamp(min=0).reshape(-1).long()].view(t, Q, K)
+            packed[..., :K] = torch.where(ok.unsqueeze(-1), rows, torch.zeros((), device=dev))
+            packed[..., K] = ok.float()
+            extras = {"device_crops": valid, "crop_logits_all": logits}
+        else:
+            ok = ops.to_device_async(np.ascontiguousarray(valid.astype(np.uint8)), dev).bool()
+            if logits is not None:
+                full = packed[..., :K]
+                full[ok] = logits                                             # (t, q) lexicographic = the adapter's row order
+            packed[..., K] = ok.float()
+            extras = {"valid": valid, "crops": crops, "crop_logits": logits}
+        flag = self._forward_flag()
+        with D.span("logit_all_gather", host=True):
+            every = D.all_gather_frames(packed, T_total)                       # [T, Q, K + 1]
+            if flag is not None:          # fp16x2: all ranks must agree on whether the clip is repeated under bf16x3 (inference_video, sync_guard)
+                flag.copy_((D.all_reduce_sum(flag.to(torch.float32)) > 0).to(torch.int32))
+        ok_all = every[..., K] > 0
+        slot = torch.where(ok_all, torch.arange(T_total * Q, device=dev, dtype=torch.int32).view(T_total, Q),
+                           torch.full((), -1, dtype=torch.int32, device=dev)).contiguous()
+        probs, _ = ops.openvis_aggregate(every[..., :K].reshape(T_total * Q, K).contiguous(), slot, fill=-1.0)
+        n_valid = ok_all.sum().to(torch.int32).reshape(1)
+        rid = self._all_rows.get((Q, str(dev)))
+        if rid is None:
+            rid = self._all_rows[(Q, str(dev))] = torch.arange(Q, dtype=torch.int32, device=dev)
+        return probs, rid, n_valid, extras
 
     @staticmethod
     def _host_view_of_crops(extras):

@@ -737,6 +737,32 @@ def attention(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, mask
     return out
 
 
+def attention_partial(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, mask=None, row_open=None, nsplit=1, mask_per_batch=False):
+    """This GPU's share of an attention whose KEYS are split over GPUs (include/openvis_hip.h: ovis_attention_partial_f32): the packed
+    un-normalised partial, f32 [ovis_attention_partial_floats(B,H,Nq,D)].  All-gather the blocks, then attention_merge."""
+    for t in (q, k, v):
+        if not t.is_cuda:
+            raise _lib.OvisError("attention needs HIP tensors")
+    L = _lib.lib()
+    part = torch.empty((L.ovis_attention_partial_floats(B, H, Nq, D),), dtype=torch.float32, device=q.device)
+    ws = torch.empty((L.ovis_attention_partial_workspace_bytes(B, H, Nq, D, nsplit) // 4,), dtype=torch.float32, device=q.device)
+    mask_ld = mask.shape[-1] if mask is not None else 0
+    mask_bs = Nq * mask_ld if (mask is not None and mask_per_batch) else 0
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.call("ovis_attention_partial_f32", vp(q), _ll(q_bs), q_ld, vp(k), _ll(k_bs), k_ld, vp(v), _ll(v_bs), v_ld, mask, _ll(mask_ld),
+              _ll(mask_bs), row_open, B, H, Nq, Nk, D, float(D) ** -0.5, nsplit, ws, part, _lib.stream_ptr())
+    return part
+
+
+def attention_merge(parts, B, H, Nq, D):
+    """parts f32 [R, n] (n >= ovis_attention_partial_floats): the gathered blocks of R GPUs -> out [B, Nq, H*D]."""
+    _chk(parts)
+    R, n = parts.shape
+    out = torch.empty((B, Nq, H * D), dtype=torch.float32, device=parts.device)
+    _lib.call("ovis_attention_merge_f32", parts, R, _ll(n), out, _ll(Nq * H * D), H * D, B, H, Nq, D, _lib.stream_ptr())
+    return out
+
+
 def attention_f16(q, k, v, B, H, Nq, Nk, D, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld):
     """fp16 q/k/v views (element (b,row,h,d) at data_ptr + (b*bs + row*ld + h*D + d)*2) -> fp16 out [B,Nq,H*D]."""
     for t in (q, k, v):

@@ -45,6 +45,9 @@ def main():
     g = D.gather_frame_masks(masks, T, dst=0)
     assert g.is_cuda and torch.equal(g, masks)
     assert D.max_over_ranks(2.5, dev) == 2.5
+    blk = torch.arange(27300, dtype=torch.float32, device=dev)       # the split-KV decoder's per-layer exchange (one packed flash partial)
+    rows = D.all_gather_rows(blk)
+    assert rows.is_cuda and rows.shape == (1, 27300) and torch.equal(rows[0], blk) and rows.data_ptr() != blk.data_ptr()
 
     # (2) BriVIS frame-"sharded" over the 1-rank RCCL group == the un-sharded forward
     import bench

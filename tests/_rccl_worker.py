@@ -41,6 +41,10 @@ def main():
         assert out.shape == (10, T, 8, 16) and all(int(out[:, t].min()) == int(out[:, t].max()) == t % 251 for t in range(T)), "mask gather"
     else:
         assert out is None
+    # the per-layer exchange of the split-KV video decoder: one equal-sized packed block per rank, stacked in rank order
+    rows = D.all_gather_rows(torch.arange(27300, dtype=torch.float32, device=dev) + 1e5 * rank)
+    assert rows.shape == (world, 27300) and rows.device.type == dev.type
+    assert all(torch.equal(rows[r].cpu(), torch.arange(27300, dtype=torch.float32) + 1e5 * r) for r in range(world)), "all_gather_rows"
     assert D.max_over_ranks(float(rank), dev) == float(world - 1)
     D.barrier()
     if rank == 0:

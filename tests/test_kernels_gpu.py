@@ -110,6 +110,48 @@ def test_attention(B, H, Nq, Nk, D, nsplit, masked):
         assert out16.dtype == torch.float16 and _rel(out16, ref) < 2e-3
 
 
+@pytest.mark.parametrize("H,Nq,D,blocks,nsplit", [(8, 100, 32, (2300, 1500), 8), (8, 100, 32, (920, 920, 920, 460), 3), (4, 37, 64, (65, 31, 200), 1),
+                                                  (8, 100, 32, (18400,), 64)])
+def test_attention_keys_split_over_gpus(H, Nq, D, blocks, nsplit):
+    """ovis_attention_partial_f32 + ovis_attention_merge_f32 (the split-KV form of the offline video decoder): the key range cut
+    into contiguous blocks as the frames of a clip are over GPUs; each block's packed partial, stacked as an all-gather would, merged.
+    Rows: 3 is blocked on EVERY key (attends to all), 7 is blocked on the whole first block only (that block's partial must be dropped),
+    11 is open on the first block only."""
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(Nq + sum(blocks))
+    C, Nk = H * D, sum(blocks)
+    q = torch.randn(1, Nq, C, generator=g)
+    kv = torch.randn(1, Nk, 2 * C, generator=g)
+    logits = torch.randn(Nq, Nk, generator=g) + 1.0
+    logits[3] = -5.0
+    logits[7, : blocks[0]] = -5.0
+    logits[11, blocks[0]:] = -5.0
+    mask = torch.sigmoid(logits) < 0.5
+    ref = _attn_ref(q.view(1, Nq, H, D), kv[..., :C].reshape(1, Nk, H, D), kv[..., C:].reshape(1, Nk, H, D), mask)
+    qd = q.cuda()
+    parts, k0 = [], 0
+    for n in blocks:
+        kvb = kv[:, k0:k0 + n].contiguous().cuda()
+        md, ro = ops.attn_mask_from_logits(logits[:, k0:k0 + n].contiguous().cuda())
+        parts.append(ops.attention_partial(qd, kvb, kvb[..., C:], 1, H, Nq, n, D, Nq * C, C, n * 2 * C, 2 * C, n * 2 * C, 2 * C, md, ro, nsplit))
+        k0 += n
+    out = ops.attention_merge(torch.stack(parts).contiguous(), 1, H, Nq, D)
+    assert _rel(out, ref) < 2e-5
+    if len(blocks) == 1:            # one GPU: the same partials merged by the same arithmetic as ovis_attention_f32 -- bit for bit
+        kvd = kv.cuda()
+        md, ro = ops.attn_mask_from_logits(logits.cuda())
+        whole = ops.attention(qd, kvd, kvd[..., C:], 1, H, Nq, Nk, D, Nq * C, C, Nk * 2 * C, 2 * C, Nk * 2 * C, 2 * C, md, ro, nsplit)
+        assert torch.equal(out, whole)
+    # without a mask (row_open NULL): every block counts as open
+    parts, k0 = [], 0
+    for n in blocks:
+        kvb = kv[:, k0:k0 + n].contiguous().cuda()
+        parts.append(ops.attention_partial(qd, kvb, kvb[..., C:], 1, H, Nq, n, D, Nq * C, C, n * 2 * C, 2 * C, n * 2 * C, 2 * C, None, None, nsplit))
+        k0 += n
+    ref0 = _attn_ref(q.view(1, Nq, H, D), kv[..., :C].reshape(1, Nk, H, D), kv[..., C:].reshape(1, Nk, H, D))
+    assert _rel(ops.attention_merge(torch.stack(parts).contiguous(), 1, H, Nq, D), ref0) < 2e-5
+
+
 @pytest.mark.parametrize("B,H,N", [(3, 12, 197), (2, 4, 64), (1, 16, 577), (5, 2, 33), (2, 3, 193), (2, 3, 205), (2, 3, 215), (2, 3, 224), (2, 2, 208)])
 def test_attention_f16(B, H, N):
     from openvis_amd import ops
