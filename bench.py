@@ -332,6 +332,59 @@ def measure_frame_sharded(device, rank, world, rig, args, sync_all):
             "note": "BASELINE.json configs[3] (north_star's split) in the same process group as the clip-replica headline; not the headline"}
 
 
+def measure_split_clip(model, device, rank, world, rig, args, sync_all):
+    """The OpenVIS row of SURVEY.md 8(e): ONE clip of `--split-frames` 720p frames over the ranks -- backbone, pixel decoder and CLIP crops on the
+    rank's own frames, the offline decoder's cross-attention (joint over all frames: video decoder:397-403, 417-426) as split-KV: per layer
+    every rank's flash partial over its own keys (109 KB) is all-gathered over RCCL and merged; the crop logits are all-gathered once for the
+    per-query mean.  Strong scaling: value = frames of the clip / max-over-ranks step time.  Rank 0 then runs the same clip un-split, alone,
+    as the in-run one-GPU reference.  Uses the headline's model (same weights, same policy)."""
+    from openvis_amd import distributed as D
+    T = max(args.split_frames, world)
+    fr = D.inference_shard(T, rank, world)
+    kw = {"frame_range": (fr.start, fr.stop)}
+    if args.gather_masks:
+        kw["gather_masks_to"] = 0
+    clips = [synth_frames(T, H720, W720, 2000 + i, "cpu").to(device) if args.inputs == "device" else synth_frames(T, H720, W720, 2000 + i, "cpu").pin_memory()
+             for i in range(2)]
+    inputs = [[{"image": [f for f in c], "dataset_name": "synthetic_burst_val"}] for c in clips]
+    fn = lambda inp: model(inp, **kw)
+    D.warm_up(device if not rig else "cpu")
+    n = max(2, min(20, args.steps // 5))
+    for i in range(2):
+        fn(inputs[i % 2])
+    sync_all()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(n):
+        out = fn(inputs[i % 2])
+    sync_all()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, "cpu" if rig else device)
+    if out is not None and hasattr(out, "wait"):
+        out.wait()
+    spans = collective_spans(fn, inputs)
+    alone = None
+    if rank == 0:                                            # the other ranks wait at sync_all's barrier
+        for i in range(2):
+            model(inputs[i % 2])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            o_ = model(inputs[i % 2])
+        torch.cuda.synchronize()
+        alone = (time.perf_counter() - t0) / n
+        if hasattr(o_, "wait"):
+            o_.wait()
+    sync_all()
+    return {"value": round(T * n / elapsed, 3), "unit": "frames/s", "ms_per_step": round(elapsed / n * 1e3, 3), "steps": n, "scaling": "strong",
+            "frames_per_rank": [len(D.inference_shard(T, r, world)) for r in range(world)], "world_size_seen": D.world_size(),
+            "unsplit_on_one_gpu": ({"ms_per_step": round(alone * 1e3, 3), "value": round(T / alone, 3), "unit": "frames/s"} if alone else None),
+            "collective_ms": spans,
+            "workload": f"openvis R50 720p, ONE {T}-frame clip over {world} rank(s): per-frame stages local, 9 x all-gather of the decoder's "
+                        f"[100 x 8 x (32 + 2) + 100] f32 flash partials + 1 x all-gather of the [t,100,483] crop logits"
+                        + (" + mask gather to rank 0" if args.gather_masks else ""),
+            "note": "SURVEY.md 8(e), OpenVIS row (optional split-KV) in the process group of the clip-replica headline; not the headline"}
+
+
 def _respawn_ranks(args):
     """`python bench.py --gpus N` without torchrun: start the N ranks as CHILD processes (torch.distributed.run) before
     anything touches the GPU, and exit with their code.  (Never exec: the GPU boxes refuse an exec after GPU init.)"""
@@ -379,6 +432,9 @@ def main():
     ap.add_argument("--sharded-frames", type=int, default=36,
                     help="N > 1 with the default model: frames of the ONE BriVIS clip that is additionally run frame-sharded over the ranks "
                          "(`frame_sharded` on the JSON line; BASELINE.json configs[3]: 36); 0 skips it")
+    ap.add_argument("--split-frames", type=int, default=8,
+                    help="N > 1 (or --process-group) with the default model: frames of the ONE OpenVIS clip that is additionally run split over the "
+                         "ranks, split-KV offline decoder (`split_clip` on the JSON line; at least one frame per rank); 0 skips it")
     ap.add_argument("--process-group", action="store_true",
                     help="N = 1: create a ONE-rank RCCL process group anyway and (online models) run the frame-sharded control flow over it -- "
                          "the all-gather on the side stream, the logit all-reduce, the mask gather -- so that the RCCL code path executes on a "
@@ -401,6 +457,13 @@ def main():
     # one-GPU box; the driver's multi-GPU runs use one GPU per rank over RCCL
     rig = os.environ.get("OVIS_BENCH_TEST_RIG") == "1"
     torch.cuda.set_device(0 if rig else int(os.environ.get("LOCAL_RANK", "0")))
+    if env_world > 1 or args.process_group:
+        # RCCL prints a version banner ("RCCL version : ...", five lines) to the C stdout when its first communicator comes up.  stdout of this
+        # command is ONE JSON line: file descriptor 1 is pointed at stderr for every native library, python's print keeps the real stdout
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
+        sys.stdout = os.fdopen(real_stdout, "w", buffering=1)
     rank, world, local_rank = D.init_from_env("gloo" if rig else "nccl", force=args.process_group)   # "nccl" is RCCL on ROCm
     device = torch.device("cuda", 0 if rig else local_rank)
 
@@ -589,6 +652,10 @@ def main():
             frame_sharded_side = {"skipped": f"--sharded-frames {args.sharded_frames} < world size {world}: a rank would own no frame"}
         else:
             frame_sharded_side = measure_frame_sharded(device, rank, world, rig, args, sync_all)
+
+    split_clip_side = None
+    if (world > 1 or args.process_group) and not frame_sharded and args.model == "openvis" and args.split_frames > 0 and args.streams == 1:
+        split_clip_side = measure_split_clip(_model, device, rank, world, rig, args, sync_all)
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream -----------
     # Per-launch events around every GEMM / K1 launch (ops.PROFILE).  Two untimed passes:
@@ -790,7 +857,7 @@ def main():
             "crop_list": getattr(getattr(_model, "clip_adapter", None), "crop_list", None), "alt_f32_split": alt, "alt_f32_splits": alts,
             "inputs": ("resident in HBM (uint8 [T,3,H,W] device tensors) when the timed region starts" if args.inputs == "device" else
                        "pinned host memory: every step uploads its frames (PCIe-inclusive)"), "host_inputs": host_inputs,
-            "alt_backbone_f32": alt_bb, "two_clips_in_flight": in_flight2, "frame_sharded": frame_sharded_side,
+            "alt_backbone_f32": alt_bb, "two_clips_in_flight": in_flight2, "frame_sharded": frame_sharded_side, "split_clip": split_clip_side,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if frame_sharded else "weak",
             "vs_baseline": None, "dtype": "f16" if "fp16" in (bb_prec, _model.clip_adapter.precision) else "f32", "data": "synthetic",

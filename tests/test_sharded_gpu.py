@@ -54,7 +54,7 @@ def test_bench_multi_rank_control_flow(model, scaling, tmp_path):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="29651",
                    OVIS_BENCH_TEST_RIG="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                                       "--model", model, "--frames", "6" if model == "brivis" else "0", "--sharded-frames", "6"]
+                                       "--model", model, "--frames", "6" if model == "brivis" else "0", "--sharded-frames", "6", "--split-frames", "3"]
                                       + (["--gather-masks"] if model == "brivis" else []), env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
@@ -78,6 +78,10 @@ def test_bench_multi_rank_control_flow(model, scaling, tmp_path):
         fs = d["frame_sharded"]
         assert fs["value"] > 0 and fs["unit"] == "frames/s" and fs["scaling"] == "strong" and fs["ms_per_step"] > 0
         assert fs["frames_per_rank"] == [3, 3] and fs["world_size_seen"] == 2
+        # ... and the OpenVIS row of SURVEY.md 8e: ONE OpenVIS clip over the same ranks (split-KV decoder), with rank 0's un-split run beside it
+        sc = d["split_clip"]
+        assert sc["value"] > 0 and sc["scaling"] == "strong" and sc["frames_per_rank"] == [2, 1] and sc["unsplit_on_one_gpu"]["ms_per_step"] > 0
+        assert {"partial_all_gather", "logit_all_gather"} <= set(sc["collective_ms"]["per_rank"][0])
         cm = fs["collective_ms"]
         assert len(cm["per_rank"]) == 2 and all({"all_gather_wait", "linker", "temporal_resampler", "logit_all_reduce"} <= set(r) for r in cm["per_rank"])
         assert all(v >= 0 for v in cm["max_over_ranks"].values())
@@ -129,6 +133,29 @@ def test_bench_brivis_under_a_one_rank_rccl_group():
     cm = line["collective_ms"]
     assert {"all_gather_wait", "linker", "temporal_resampler", "logit_all_reduce", "mask_gather"} <= set(cm["per_rank"][0])
     assert line["value"] > 0 and line["frames_per_rank"] == [6]
+    # stdout is the ONE JSON line: RCCL's version banner (printed to the C stdout at the first communicator) goes to stderr
+    assert [ln for ln in p.stdout.splitlines() if ln.strip()] == [ln for ln in p.stdout.splitlines() if ln.startswith("{")], p.stdout[-1500:]
+    assert len([ln for ln in p.stdout.splitlines() if ln.strip()]) == 1
+
+
+def test_bench_openvis_split_clip_under_a_one_rank_rccl_group():
+    """`bench.py --process-group` (default model): the headline as always plus `split_clip` -- ONE OpenVIS clip through the split-KV decoder's
+    exchange (9 all-gathers of flash partials, 1 of crop logits, mask gather) over a 1-rank RCCL group, with the un-split forward beside it."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29680")
+    for k in ("OVIS_BENCH_TEST_RIG", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--process-group", "--steps", "5", "--warmup", "1", "--split-frames", "6", "--gather-masks",
+                        "--no-alt-splits", "--no-cpu-baseline", "--no-other-configs", "--no-in-flight"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-1500:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["process_group"] == "nccl" and line["scaling"] == "weak" and line["value"] > 0
+    sc = line["split_clip"]
+    assert sc["frames_per_rank"] == [6] and sc["value"] > 0 and sc["unsplit_on_one_gpu"]["value"] > 0
+    assert {"partial_all_gather", "logit_all_gather", "mask_gather"} <= set(sc["collective_ms"]["per_rank"][0])
+    # one rank: the split path is the un-split forward plus the exchange bookkeeping -- within 25 % of it
+    assert sc["ms_per_step"] <= 1.25 * sc["unsplit_on_one_gpu"]["ms_per_step"], sc
 
 
 # ---- ONE OpenVIS clip over several ranks: split-KV offline decoder (SURVEY.md 8e, OpenVIS row) -------------------------------------------
