@@ -24,6 +24,7 @@ if [ "${1:-}" != "quick" ]; then
   python bench.py --streams 2 --steps 32 --warmup 4 --no-cpu-baseline > $R/bench_streams2.json 2>> $R/bench_models.err
 fi
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > $R/bench_torchrun_n1.json 2> $R/bench_torchrun_n1.err
+python bench.py --process-group --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-alt-splits --no-in-flight --gather-masks > $R/bench_process_group.json 2> $R/bench_process_group.err   # split_clip over a ONE-rank RCCL group
 python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.txt 2>&1
 # keep only the summaries (the raw traces are large)
 find $R -name "*kernel_trace.csv" -delete; find $R -name "*agent_info.csv" -delete; find $R -name "*counter_collection.csv" -delete
