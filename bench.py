@@ -289,8 +289,8 @@ def collective_spans(model_fn, inputs, steps=3):
     D.SPANS = None
     per_rank = D.gather_objects(mine)
     return {"per_rank": per_rank, "max_over_ranks": {k: max(r.get(k, 0.0) for r in per_rank) for k in per_rank[0]},
-            "note": f"mean of {steps} untimed steps; all_gather_wait / logit_all_reduce / mask_gather = host wall time around the call, "
-                    "linker / temporal_resampler = HIP-event time of the replicated work"}
+            "note": f"mean of {steps} untimed steps; all_gather_wait / logit_all_reduce / logit_all_gather / mask_gather = host wall time around the call, "
+                    "linker / temporal_resampler / partial_all_gather (one of the nine per clip; RCCL) = HIP-event time on the compute stream"}
 
 
 def measure_frame_sharded(device, rank, world, rig, args, sync_all):
