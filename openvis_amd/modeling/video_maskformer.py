@@ -228,6 +228,9 @@ class VideoMaskFormer:
         # the host to read the indices back (the reference syncs on .tolist() here, video_maskformer.py:267-272)
         idx, score, ent, sel_q = ops.topk_entropy(probs, rid, topk)          # raises if rows*K < topk (as torch.topk)
         Q, T, h, w = pred_masks_lowres.shape
+        if self.output_rle and self.mask_gather is not None:
+            raise ValueError("MODEL.MASK_FORMER.TEST.OUTPUT_RLE with gather_masks_to: the run-length hand-off covers this rank's frames only; "
+                             "keep the masks sharded (gather_masks_to=None) and merge the per-rank RLEs in the evaluator")
         if self.output_rle:
             # hand the evaluator COCO RLE instead of dense masks -- the masks are produced column-major
             # and run-length encoded on the GPU, only the run lengths cross PCIe (ytvis_eval.py:258-301 does this per
