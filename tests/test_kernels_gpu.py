@@ -152,6 +152,39 @@ def test_attention_keys_split_over_gpus(H, Nq, D, blocks, nsplit):
     assert _rel(ops.attention_merge(torch.stack(parts).contiguous(), 1, H, Nq, D), ref0) < 2e-5
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_attention_keys_split_per_batch_masks_and_random_blocks(seed):
+    """The same pair of entry points with B > 1 and one mask per batch element (mask_bs != 0: the frame decoders' form,
+    frame_mask2former_transformer_decoder.py:85-94), key blocks of random sizes down to ONE key, and rows closed in random patterns."""
+    from openvis_amd import ops
+    g = torch.Generator().manual_seed(1000 + seed)
+    B, H, Nq, D = 3, 8, 100, 32
+    C = H * D
+    blocks = [int(v) for v in torch.randint(1, 700, (int(torch.randint(2, 7, (1,), generator=g)),), generator=g)] + [1]
+    Nk = sum(blocks)
+    q = torch.randn(B, Nq, C, generator=g)
+    kv = torch.randn(B, Nk, 2 * C, generator=g)
+    logits = torch.randn(B * Nq, Nk, generator=g) + 0.5
+    edges = [0] + list(torch.tensor(blocks).cumsum(0))
+    for r in torch.randint(0, B * Nq, (40,), generator=g).tolist():           # close rows on random runs of blocks (some on all of them)
+        i, j = sorted(torch.randint(0, len(blocks) + 1, (2,), generator=g).tolist())
+        logits[r, int(edges[i]):int(edges[j])] = -6.0
+    logits[5] = -6.0
+    mask = (torch.sigmoid(logits) < 0.5).view(B, Nq, Nk)
+    ref = torch.cat([_attn_ref(q[b:b + 1].view(1, Nq, H, D), kv[b:b + 1, :, :C].reshape(1, Nk, H, D), kv[b:b + 1, :, C:].reshape(1, Nk, H, D), mask[b])
+                     for b in range(B)])
+    qd = q.cuda()
+    parts = []
+    for i, n in enumerate(blocks):
+        k0 = int(edges[i])
+        kvb = kv[:, k0:k0 + n].contiguous().cuda()
+        md, ro = ops.attn_mask_from_logits(logits[:, k0:k0 + n].contiguous().cuda())
+        parts.append(ops.attention_partial(qd, kvb, kvb[..., C:], B, H, Nq, n, D, Nq * C, C, n * 2 * C, 2 * C, n * 2 * C, 2 * C, md, ro,
+                                           nsplit=1 + i % 3, mask_per_batch=True))
+    out = ops.attention_merge(torch.stack(parts).contiguous(), B, H, Nq, D)
+    assert _rel(out, ref) < 2e-5
+
+
 @pytest.mark.parametrize("B,H,N", [(3, 12, 197), (2, 4, 64), (1, 16, 577), (5, 2, 33), (2, 3, 193), (2, 3, 205), (2, 3, 215), (2, 3, 224), (2, 2, 208)])
 def test_attention_f16(B, H, N):
     from openvis_amd import ops
