@@ -13,17 +13,29 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(world, out, port, extra_env=None, worker="_brivis_sharded_worker.py"):
+def _spawn(world, out, port, extra_env=None, worker="_brivis_sharded_worker.py"):
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # a few host threads per rank: several groups of ranks run side by side, and a default-sized OpenMP pool per process (one thread per
+        # core of the box, spinning) makes eleven of them slower than one after the other
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="8", MKL_NUM_THREADS="8")
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", worker), out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    return procs, out
+
+
+def _collect(spawned):
+    procs, out = spawned
     for p in procs:
-        o, e = p.communicate(timeout=600)
+        o, e = p.communicate(timeout=900)
         assert p.returncode == 0, e[-3000:]
-    return [json.load(open(f"{out}.{r}")) for r in range(world)]
+    return [json.load(open(f"{out}.{r}")) for r in range(len(procs))]
+
+
+def _run(world, out, port, extra_env=None, worker="_brivis_sharded_worker.py"):
+    return _collect(_spawn(world, out, port, extra_env, worker))
 
 
 def test_two_rank_frame_sharded_brivis_equals_single_rank(tmp_path):
@@ -52,7 +64,7 @@ def test_bench_multi_rank_control_flow(model, scaling, tmp_path):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="29651",
-                   OVIS_BENCH_TEST_RIG="1")
+                   OVIS_BENCH_TEST_RIG="1", OMP_NUM_THREADS="8")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                                        "--model", model, "--frames", "6" if model == "brivis" else "0", "--sharded-frames", "6", "--split-frames", "3"]
                                       + (["--gather-masks"] if model == "brivis" else []), env=env,
@@ -110,7 +122,7 @@ def test_one_rank_rccl_group_runs_the_frame_sharded_path(tmp_path):
     device tensors -- the branches no gloo rig takes -- run under BriVIS(frame_range=(0, T), gather_masks_to=0) and give the un-sharded
     forward's outputs; an out-of-memory error behind the all-gather re-raises without a second collective (tests/_rccl_one_rank_worker.py)."""
     out = str(tmp_path / "rccl1.json")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29678")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="8", MASTER_ADDR="127.0.0.1", MASTER_PORT="29678")
     for k in ("OVIS_BENCH_TEST_RIG", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_one_rank_worker.py"), out], env=env, capture_output=True, text=True, timeout=900)
@@ -122,7 +134,7 @@ def test_one_rank_rccl_group_runs_the_frame_sharded_path(tmp_path):
 def test_bench_brivis_under_a_one_rank_rccl_group():
     """`bench.py --model brivis --process-group` : the frame-sharded bench control flow (warm_up, all-gather on the side stream, logit
     all-reduce, mask gather, collective_ms) over a 1-rank RCCL group -- what `--gpus 8` runs, minus the peers."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29679")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="8", MASTER_ADDR="127.0.0.1", MASTER_PORT="29679")
     for k in ("OVIS_BENCH_TEST_RIG", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "brivis", "--process-group", "--frames", "6", "--steps", "2", "--warmup", "1",
@@ -141,7 +153,7 @@ def test_bench_brivis_under_a_one_rank_rccl_group():
 def test_bench_openvis_split_clip_under_a_one_rank_rccl_group():
     """`bench.py --process-group` (default model): the headline as always plus `split_clip` -- ONE OpenVIS clip through the split-KV decoder's
     exchange (9 all-gathers of flash partials, 1 of crop logits, mask gather) over a 1-rank RCCL group, with the un-split forward beside it."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29680")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="8", MASTER_ADDR="127.0.0.1", MASTER_PORT="29680")
     for k in ("OVIS_BENCH_TEST_RIG", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--process-group", "--steps", "5", "--warmup", "1", "--split-frames", "6", "--gather-masks",
@@ -170,21 +182,26 @@ def test_openvis_clip_split_over_ranks_equals_one_rank(tmp_path):
     """5 frames, 192x256, exact-f32 policy: 2 ranks (3 + 2 frames) and 5 ranks (one frame each; OVIS_TEST_ALL_WORLDS=1 adds 3 ranks, 2 + 2 + 1) against the one-GPU forward.  The split changes
     only the order in which the cross-attention's softmax sums are merged (f32 rounding): mask logits to 1e-3 of their scale, class
     probabilities to 1e-5, the same top-10, and the masks' bits up to logits that sit within rounding of zero."""
-    one = _run(1, str(tmp_path / "one"), 29661, {"OVIS_SPLIT_OFF": "1"}, SPLIT)[0]
-    m1 = _masks(str(tmp_path / "one"), 1)
+    # every group of ranks is started at once (independent rendezvous ports, all on cuda:0): the test's time is one model build, not six
+    cases = [(2, 29663, [[0, 3], [3, 5]]), (5, 29667, [[0, 1], [1, 2], [2, 3], [3, 4], [4, 5]])]      # ragged blocks; ONE frame per rank
+    if os.environ.get("OVIS_TEST_ALL_WORLDS") == "1":
+        cases.insert(1, (3, 29664, [[0, 2], [2, 4], [4, 5]]))                                      # 2 + 2 + 1 (measured like the others, DESIGN section 5)
+    sp_one = _spawn(1, str(tmp_path / "one"), 29661, {"OVIS_SPLIT_OFF": "1"}, SPLIT)
     # R = 1 through the partial / all-gather / merge path, in a ONE-rank RCCL group (the only way to run the RCCL branches of the exchange
     # on a one-GPU box): the same partials merged by the same arithmetic
-    solo = _run(1, str(tmp_path / "solo"), 29662, {"OVIS_SPLIT_BACKEND": "nccl", "OVIS_GATHER_TO": "0"}, SPLIT)[0]
+    sp_solo = _spawn(1, str(tmp_path / "solo"), 29662, {"OVIS_SPLIT_BACKEND": "nccl", "OVIS_GATHER_TO": "0"}, SPLIT)
+    sp_cases = [_spawn(world, str(tmp_path / f"w{world}"), port, None, SPLIT) for world, port, _ in cases]
+    sp_gather = _spawn(2, str(tmp_path / "gather"), 29665, {"OVIS_GATHER_TO": "0", "OVIS_SPLIT_CROP_LIST": "device"}, SPLIT)
+    one = _collect(sp_one)[0]
+    m1 = _masks(str(tmp_path / "one"), 1)
+    solo = _collect(sp_solo)[0]
     ms = _masks(str(tmp_path / "solo"), 1)
     assert solo["backend"] == "nccl" and one["backend"] == "gloo"
     assert np.abs(ms - m1).max() <= 1e-4 * np.abs(m1).max() and solo["labels"] == one["labels"] and solo["queries"] == one["queries"]
     assert np.abs(np.array(solo["mask_sums"]) - np.array(one["mask_sums"])).max() <= 8 and np.abs(np.array(solo["probs"]) - np.array(one["probs"])).max() <= 2e-4
     assert {"partial_all_gather", "logit_all_gather", "mask_gather"} <= set(solo["spans"])
-    cases = [(2, 29663, [[0, 3], [3, 5]]), (5, 29667, [[0, 1], [1, 2], [2, 3], [3, 4], [4, 5]])]      # ragged blocks; ONE frame per rank
-    if os.environ.get("OVIS_TEST_ALL_WORLDS") == "1":
-        cases.insert(1, (3, 29664, [[0, 2], [2, 4], [4, 5]]))                                      # 2 + 2 + 1 (measured like the others, DESIGN section 5)
-    for world, port, ranges in cases:
-        rs = _run(world, str(tmp_path / f"w{world}"), port, None, SPLIT)
+    for (world, port, ranges), sp in zip(cases, sp_cases):
+        rs = _collect(sp)
         assert [r["range"] for r in rs] == ranges
         mw = _masks(str(tmp_path / f"w{world}"), world)
         assert mw.shape == m1.shape
@@ -209,7 +226,7 @@ def test_openvis_clip_split_over_ranks_equals_one_rank(tmp_path):
             for q, l, n in zip(r["queries"], r["labels"], r["mask_sums"]):
                 tot[order[(q, l)]] += n
         assert np.abs(tot - np.array(one["mask_sums"])).max() <= 16, (tot.tolist(), one["mask_sums"])
-    g = _run(2, str(tmp_path / "gather"), 29665, {"OVIS_GATHER_TO": "0", "OVIS_SPLIT_CROP_LIST": "device"}, SPLIT)
+    g = _collect(sp_gather)
     assert g[0]["mask_shape"] == one["mask_shape"] and g[1]["mask_shape"] == [] and g[1]["labels"] == g[0]["labels"]
     assert np.abs(np.array(g[0]["frame_sums"]) - np.array(one["frame_sums"])).max() <= 16
     assert np.abs(np.array(g[0]["probs"]) - np.array(one["probs"])).max() <= 1e-3                     # device crop list on the ranks, same result
