@@ -349,6 +349,8 @@ def measure_split_clip(model, device, rank, world, rig, args, sync_all):
     inputs = [[{"image": [f for f in c], "dataset_name": "synthetic_burst_val"}] for c in clips]
     fn = lambda inp: model(inp, **kw)
     D.warm_up(device if not rig else "cpu")
+    if os.environ.get("OVIS_BENCH_FAIL_SIDE_RANK") == str(rank):       # tests: this rank leaves the collective sequence here
+        raise RuntimeError("injected by OVIS_BENCH_FAIL_SIDE_RANK")
     n = max(2, min(20, args.steps // 5))
     for i in range(2):
         fn(inputs[i % 2])
@@ -383,6 +385,42 @@ def measure_split_clip(model, device, rank, world, rig, args, sync_all):
                         f"[100 x 8 x (32 + 2) + 100] f32 flash partials + 1 x all-gather of the [t,100,483] crop logits"
                         + (" + mask gather to rank 0" if args.gather_masks else ""),
             "note": "SURVEY.md 8(e), OpenVIS row (optional split-KV) in the process group of the clip-replica headline; not the headline"}
+
+
+class _SideGuard:
+    """Deadline around a side measurement that runs collectives (frame_sharded, split_clip).  The JSON line is complete before they start; if
+    one of them has not returned within `seconds` -- a peer died, the collective sequences diverged, RCCL hangs -- rank 0 prints the line with
+    an error in that field and every rank leaves with os._exit(0) (no teardown handshake with peers that may be gone).  One line, once."""
+
+    def __init__(self, line, seconds):
+        import threading
+        self.line, self.seconds, self._lock, self._done, self._timer, self.key = line, seconds, threading.Lock(), False, None, None
+
+    def arm(self, key):
+        import threading
+        self.key = key
+        self._timer = threading.Timer(self.seconds, self._expired)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def disarm(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+    def emit(self):
+        with self._lock:
+            if not self._done and self.line is not None:
+                print(json.dumps(self.line), flush=True)
+            self._done = True
+
+    def _expired(self):
+        if self.line is not None and not self._done:
+            self.line[self.key] = {"error": f"no result within {self.seconds} s: a rank failed or a collective did not complete; the fields measured before it stand"}
+        self.emit()
+        sys.stderr.write(f"bench.py: side measurement `{self.key}` exceeded {self.seconds} s; leaving\n")
+        sys.stderr.flush()
+        os._exit(0)
 
 
 def _respawn_ranks(args):
@@ -435,6 +473,8 @@ def main():
     ap.add_argument("--split-frames", type=int, default=8,
                     help="N > 1 (or --process-group) with the default model: frames of the ONE OpenVIS clip that is additionally run split over the "
                          "ranks, split-KV offline decoder (`split_clip` on the JSON line; at least one frame per rank); 0 skips it")
+    ap.add_argument("--side-timeout", type=float, default=420.0,
+                    help="seconds a multi-rank side measurement (frame_sharded, split_clip) may take before the line is printed without it")
     ap.add_argument("--process-group", action="store_true",
                     help="N = 1: create a ONE-rank RCCL process group anyway and (online models) run the frame-sharded control flow over it -- "
                          "the all-gather on the side stream, the logit all-reduce, the mask gather -- so that the RCCL code path executes on a "
@@ -645,22 +685,6 @@ def main():
     # ---- frame-sharded runs: what every rank spends in the exchange steps, untimed extra steps --------------------
     collective_ms = collective_spans(model, inputs) if frame_sharded else None
 
-    # ---- N > 1, default model: north_star's own multi-GPU split next to the clip-replica headline ---------------------------------
-    # The OpenVIS offline decoder attends over all frames of a clip, so the headline shards by CLIP and its only collective is the
-    # timing's scalar.  The frame-sharded BriVIS pass (configs[3]) is what moves data over RCCL / xGMI: one command measures both.
-    frame_sharded_side = None
-    if world > 1 and not frame_sharded and args.model == "openvis" and args.sharded_frames > 0:
-        if world > args.sharded_frames:
-            # more ranks than frames: inference_shard() would hand some ranks an EMPTY frame block and they would fall out of the collective
-            # sequence (frames[0] of an empty list) -- skipped on every rank alike, with the reason on the line
-            frame_sharded_side = {"skipped": f"--sharded-frames {args.sharded_frames} < world size {world}: a rank would own no frame"}
-        else:
-            frame_sharded_side = measure_frame_sharded(device, rank, world, rig, args, sync_all)
-
-    split_clip_side = None
-    if (world > 1 or args.process_group) and not frame_sharded and args.model == "openvis" and args.split_frames > 0 and args.streams == 1:
-        split_clip_side = measure_split_clip(_model, device, rank, world, rig, args, sync_all)
-
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream -----------
     # Per-launch events around every GEMM / K1 launch (ops.PROFILE).  Two untimed passes:
     #   in situ : the K clips again exactly as in the timed region (with `--streams` > 1 the kernels of different clips
@@ -844,6 +868,7 @@ def main():
                                  "achieved": round(gathered / (ksecs / kn) / 1e12, 2), "peak": 18.8, "unit": "TB/s",
                                  "frac": round(gathered / (ksecs / kn) / 1e12 / 18.8, 3),
                                  "peak_note": "16.8-18.8 TB/s: the guide's measured rate for rows gathered from the XCD's L2 (66-73 GB/s per CU)"}
+    line = None
     if rank == 0:
         frames_total = T * args.steps * (1 if frame_sharded else world)
         n_valid = int(st["valid"].sum()) if "valid" in st else 0
@@ -861,7 +886,7 @@ def main():
             "crop_list": getattr(getattr(_model, "clip_adapter", None), "crop_list", None), "alt_f32_split": alt, "alt_f32_splits": alts,
             "inputs": ("resident in HBM (uint8 [T,3,H,W] device tensors) when the timed region starts" if args.inputs == "device" else
                        "pinned host memory: every step uploads its frames (PCIe-inclusive)"), "host_inputs": host_inputs,
-            "alt_backbone_f32": alt_bb, "two_clips_in_flight": in_flight2, "frame_sharded": frame_sharded_side, "split_clip": split_clip_side,
+            "alt_backbone_f32": alt_bb, "two_clips_in_flight": in_flight2, "frame_sharded": None, "split_clip": None,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if frame_sharded else "weak",
             "vs_baseline": None, "dtype": "f16" if "fp16" in (bb_prec, _model.clip_adapter.precision) else "f32", "data": "synthetic",
@@ -896,7 +921,41 @@ def main():
                                           "steps between device synchronisations, clips resident in HBM, D2H of the masks included); not the headline")
         if not args.no_cpu_baseline and world == 1 and args.model == "openvis":
             line["cpu_baseline"] = cpu_baseline(sd)
-        print(json.dumps(line))
+
+    # ---- N > 1 (or --process-group), default model: the two single-clip splits next to the clip-replica headline, LAST and guarded ----------
+    # The OpenVIS offline decoder attends over all frames of a clip, so the headline shards by CLIP and its only collective is the timing's
+    # scalar.  What moves data over RCCL / xGMI is (a) the frame-sharded BriVIS pass (configs[3]) and (b) ONE OpenVIS clip over the ranks
+    # (split-KV decoder): one command measures all three.  Both run after every headline field exists, under a deadline (_SideGuard): a rank
+    # that fails or a collective that hangs costs the side field, never the line.
+    sides = []
+    if world > 1 and not frame_sharded and args.model == "openvis" and args.sharded_frames > 0:
+        if world > args.sharded_frames:
+            # more ranks than frames: inference_shard() would hand some ranks an EMPTY frame block and they would fall out of the collective
+            # sequence (frames[0] of an empty list) -- skipped on every rank alike, with the reason on the line
+            if rank == 0:
+                line["frame_sharded"] = {"skipped": f"--sharded-frames {args.sharded_frames} < world size {world}: a rank would own no frame"}
+        else:
+            sides.append(("frame_sharded", lambda: measure_frame_sharded(device, rank, world, rig, args, sync_all)))
+    if (world > 1 or args.process_group) and not frame_sharded and args.model == "openvis" and args.split_frames > 0 and args.streams == 1:
+        sides.append(("split_clip", lambda: measure_split_clip(_model, device, rank, world, rig, args, sync_all)))
+    guard = _SideGuard(line if rank == 0 else None, args.side_timeout)
+    diverged = False
+    for key, fn in sides:
+        guard.arm(key)
+        try:
+            res = fn()
+        except Exception as e:                               # this rank left the collective sequence: no further collectives from here on
+            res, diverged = {"error": f"{type(e).__name__}: {e}"[:400]}, True
+        guard.disarm()
+        if rank == 0:
+            line[key] = res
+        if diverged:
+            break
+    if rank == 0:
+        guard.emit()
+    if diverged:
+        sys.stdout.flush()
+        os._exit(0)                                          # the peers are (or will be) stuck in a collective this rank never joins: no teardown handshake
     if D.backend_name() is not None:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -196,3 +196,29 @@ def test_forced_one_rank_process_group():
     p = ctx.Process(target=_forced_one_rank, args=(port, q))
     p.start(); p.join(120)
     assert p.exitcode == 0 and q.get(timeout=5) == "ok"
+
+
+def test_bench_side_guard_prints_the_line_once_and_leaves_when_a_side_measurement_hangs():
+    """bench.py's multi-rank side measurements (frame_sharded, split_clip) run collectives after the headline is complete; _SideGuard is what
+    keeps a hung collective from costing the JSON line: past the deadline rank 0 prints the line with an error in that field, exit code 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "line = {'metric': 'm', 'value': 1.5, 'split_clip': None}\n"
+            "g = bench._SideGuard(line, 0.5)\n"
+            "g.arm('frame_sharded'); g.disarm()\n"                  # a side measurement that returns in time: nothing happens
+            "g.arm('split_clip'); time.sleep(30)\n"                  # one that hangs
+            "print('NOT REACHED')\n") % root
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["value"] == 1.5 and "no result within" in d["split_clip"]["error"] and "split_clip" in p.stderr
+    # ... and a guard that was emitted normally does not print again when a late timer fires
+    code2 = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+             "g = bench._SideGuard({'value': 2}, 0.3); g.arm('x'); g.emit(); time.sleep(5)\n") % root
+    p = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and [ln for ln in p.stdout.splitlines() if ln.strip()] == ['{"value": 2}'], (p.stdout, p.stderr[-500:])

@@ -253,3 +253,26 @@ def test_openvis_c2_split_over_two_ranks_against_the_oracle_golden(tmp_path):
     print("C2 over two ranks vs the oracle: top-10 sets equal (labels %s), max score diff %.2e, max probability diff %.2e, pixel counts within %.2e"
           % (sorted({l for _, l in sr}), ds, dp, dc))
     assert dc <= 2e-3
+
+
+@pytest.mark.parametrize("fail_rank", [0, 1])
+def test_bench_line_survives_a_rank_that_fails_inside_a_side_measurement(fail_rank):
+    """The multi-rank side measurements run collectives; a rank that raises inside one leaves its peer waiting in a collective nobody will
+    complete.  bench.py runs them LAST under a deadline (_SideGuard): rank 0 prints the complete headline line with an error in that field
+    and every rank exits 0 -- whichever rank failed."""
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29691 + fail_rank),
+                   OVIS_BENCH_TEST_RIG="1", OMP_NUM_THREADS="8", OVIS_BENCH_FAIL_SIDE_RANK=str(fail_rank))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--sharded-frames", "0",
+                                       "--split-frames", "2", "--side-timeout", "25", "--no-alt-splits"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-3000:]
+        outs.append([ln for ln in o.splitlines() if ln.strip()])
+    assert len(outs[0]) == 1 and outs[1] == []
+    d = json.loads(outs[0][0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "roofline" in d and d["frame_sharded"] is None
+    assert "error" in d["split_clip"], d["split_clip"]
