@@ -96,25 +96,3 @@ class BriVIS(SANOnline):
         return out
 
     __call__ = forward
-
-    def classify_sharded(self, logits, T_total, sharded):
-        """softmax(mean over ALL frames of the logits)[:, :-1]; sharded: per-rank frame sums are all-reduced."""
-        if not sharded:
-            return self.classify(logits.unsqueeze(0))
-        t, Q, K1 = logits.shape
-        # mean over the local frames (kernel) weighted by the shard's share of the clip -> all-reduce = mean over ALL frames
-        # -> softmax through the aggregate kernel.  The weighting is one elementwise scale of a [Q,K+1] tensor.
-        local = ops.mean_over_dim0(logits.contiguous()) * (float(t) / float(T_total))
-        flag = self._forward_flag()
-        with D.span("logit_all_reduce", host=True):
-            if flag is not None:
-                # fp16x2: every constant-weight GEMM of this forward is queued by now; the range flags of the ranks ride on this all-reduce
-                # (one more element), so that all ranks agree on whether the clip has to be repeated under bf16x3 (inference_video, sync_guard)
-                packed = D.all_reduce_sum(torch.cat([local.reshape(-1), flag.to(torch.float32)]))
-                total = packed[:-1].view_as(local)
-                flag.copy_((packed[-1:] > 0).to(torch.int32))
-            else:
-                total = D.all_reduce_sum(local)
-        one = torch.arange(Q, dtype=torch.int32, device=logits.device).view(1, Q)
-        probs, _ = ops.openvis_aggregate(total.contiguous(), one)
-        return probs[:, :-1].contiguous()

@@ -53,9 +53,25 @@ class MinVIS(VideoMaskFormer):
         args["window_size"] = cfg.MODEL.MASK_FORMER.TEST.WINDOW_SIZE
         return args
 
-    def post_processing(self, outputs):
-        """Reorder per-frame logits and masks by the tracker's assignment (minvis.py:320-338)."""
-        idx, _ = batch_video_match_via_embeds(outputs["pred_embeds"])
+    def post_processing(self, outputs, shard=None):
+        """Reorder per-frame logits and masks by the tracker's assignment (minvis.py:320-338).
+
+        shard = (T_total, b0): `outputs` hold the frames [b0, b0 + t) of a clip whose frames are sharded over ranks.
+        The tracker is a sequential chain over ALL frames: the per-frame query embeddings are all-gathered (distributed.all_gather_frames,
+        [t,Q,256] f32 per rank), every rank runs the identical chain (one deterministic kernel: no broadcast) and applies the rows of its own
+        frames.  out["indices"] is then the clip's [1, T_total, Q]."""
+        if shard is None:
+            idx, _ = batch_video_match_via_embeds(outputs["pred_embeds"])
+            idx_all = idx
+        else:
+            from .. import distributed as D
+            T_total, b0 = shard
+            local = outputs["pred_embeds"][0].contiguous()                # [t,Q,C]
+            with D.span("all_gather_wait", host=True):
+                full = D.all_gather_frames(local, T_total)
+            with D.span("linker"):
+                idx_all, _ = batch_video_match_via_embeds(full.unsqueeze(0))
+            idx = idx_all[:, b0:b0 + local.shape[0]].contiguous()
         _, T, Q = idx.shape
         idx2 = idx.view(T, Q)
         masks = outputs["pred_masks"][0]                                 # [Q,T,h,w]
@@ -74,5 +90,5 @@ class MinVIS(VideoMaskFormer):
             else:                                                        # tiny / odd K (class-agnostic 2 logits): plain gather
                 lo = torch.gather(lg, 1, idx2.long().unsqueeze(-1).expand(-1, -1, K))
             out["pred_logits"] = lo.unsqueeze(0)
-        out["indices"] = idx
+        out["indices"] = idx_all
         return out

@@ -226,32 +226,63 @@ class OpenVISOnline(OpenVIS):
         return args
 
     @retry_if_oom
-    def forward(self, batched_inputs, stages=None):
+    def forward(self, batched_inputs, stages=None, frame_range=None, gather_masks_to=None):
+        """frame_range / gather_masks_to: ONE clip's frames sharded over ranks: the per-frame decoder runs on the rank's own
+        frames, the query embeddings are all-gathered in front of the replicated tracker (MinVIS.post_processing), the crop logits of all
+        frames are all-gathered for the per-query mean (OpenVIS._classify_split)."""
         dataset_name = batched_inputs[0]["dataset_name"]
         class_names = self.get_class_name_list(dataset_name)
         self.sem_seg_head.num_classes = len(class_names)
-        frames = self._frames_to_device(batched_inputs)
+        sharded = frame_range is not None
+        if sharded:
+            from . import distributed as D
+            all_frames = [f for video in batched_inputs for f in video["image"]]
+            T_total = len(all_frames)
+            b0, b1 = frame_range
+            if not (0 <= b0 < b1 <= T_total):
+                raise ValueError(f"frame_range {frame_range} of a {T_total}-frame clip: every rank needs at least one frame")
+            frames = self._frames_to_device([{"image": all_frames[b0:b1]}])
+        else:
+            frames = self._frames_to_device(batched_inputs)
         images, image_size, padded = self.preprocess(frames)
         features = None
 
-        def per_window(b0, b1):                                            # openvis.py:283-305 (run_window_inference)
+        def per_window(b0_, b1_):                                          # openvis.py:283-305 (run_window_inference)
             nonlocal features
-            features = self.backbone(images[b0:b1])
+            features = self.backbone(images[b0_:b1_])
             return self.sem_seg_head(features)
 
-        outputs = self._post(self, self._windowed(self, per_window, images.shape[0]))   # tracker (minvis.py:320-338)
+        raw = self._windowed(self, per_window, images.shape[0])
+        outputs = self._post(self, raw, shard=(T_total, b0)) if sharded else self._post(self, raw)   # tracker (minvis.py:320-338)
         masks_lowres = outputs["pred_masks"][0]
-        probs, row_ids, extras = self.open_vocabulary_inference(outputs["pred_logits"][0], masks_lowres, frames,
-                                                                class_names, padded)
+        if sharded:
+            probs, row_ids, n_valid, extras = self._classify_split(masks_lowres, frames, class_names, padded, T_total)
+        else:
+            probs, row_ids, extras = self.open_vocabulary_inference(outputs["pred_logits"][0], masks_lowres, frames,
+                                                                    class_names, padded)
+            dc = extras.get("device_crops")
+            n_valid = dc.counts if dc is not None else None
         if stages is not None:
             extras = self._host_view_of_crops(extras)
             stages.update(dict(images=images, features=features, pred_masks=outputs["pred_masks"],
                                pred_embeds=outputs["pred_embeds"], indices=outputs["indices"], probs=probs,
                                row_ids=row_ids, **extras))
         inp = batched_inputs[0]
-        dc = extras.get("device_crops")
-        return self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
-                                    inp.get("height", image_size[0]), inp.get("width", image_size[1]),
-                                    redo=lambda: self.forward(batched_inputs, stages), n_valid=dc.counts if dc is not None else None)
+        self.mask_gather = None
+        if sharded and gather_masks_to is not None:
+            def _mg(m):
+                with D.span("mask_gather", host=True):
+                    return D.gather_frame_masks(m, T_total, gather_masks_to)
+            self.mask_gather = _mg
+        try:
+            out = self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
+                                       inp.get("height", image_size[0]), inp.get("width", image_size[1]),
+                                       redo=lambda: self.forward(batched_inputs, stages, frame_range, gather_masks_to), n_valid=n_valid,
+                                       sync_guard=sharded)
+        finally:
+            self.mask_gather = None
+        if sharded and gather_masks_to is None:
+            out["pred_masks_frames"] = (b0, b1)
+        return out
 
     __call__ = forward

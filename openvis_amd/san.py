@@ -7,6 +7,7 @@ import torch
 
 from .config import side_adapter_precision
 from . import ops
+from . import distributed as D
 from .catalog import MetadataCatalog
 from .modeling.clip_adapter.side_adapter import SideAdapter
 from .modeling.minvis import MinVIS
@@ -130,14 +131,27 @@ class SANOnline(MinVIS):
         return _classify(pred_logits)
 
     @retry_if_oom
-    def forward(self, batched_inputs, stages=None):
+    def forward(self, batched_inputs, stages=None, frame_range=None, gather_masks_to=None):
+        """frame_range=(begin, end): this rank's contiguous frame block of the clip (frame-sharded mode; needs an initialised
+        process group whose ranks hold the blocks of `distributed.inference_shard`): every tensor up to the query embeddings is per-frame; ONE
+        all-gather of the embeddings in front of the replicated tracker, ONE all-reduce of the per-frame logit sums for the temporal mean
+        (san.py:257).  gather_masks_to=r: the selected masks of all frames end up on rank r; None: every rank keeps its own frames' masks."""
         dataset_name = list(set(x["dataset_name"] for x in batched_inputs))[0]
         class_names = self.get_class_name_list(dataset_name)
         self.sem_seg_head.num_classes = len(class_names)
-        frames = self._frames_to_device(batched_inputs)
+        sharded = frame_range is not None
+        if sharded:
+            all_frames = [f for video in batched_inputs for f in video["image"]]
+            T_total = len(all_frames)
+            b0, b1 = frame_range
+            if not (0 <= b0 < b1 <= T_total):
+                raise ValueError(f"frame_range {frame_range} of a {T_total}-frame clip: every rank needs at least one frame")
+            frames = self._frames_to_device([{"image": all_frames[b0:b1]}])
+        else:
+            frames = self._frames_to_device(batched_inputs)
         outputs, images, image_size, padded = self.image_outputs(frames, class_names)
-        outputs = self.post_processing(outputs)                                               # tracker (minvis.py:320-338)
-        probs = self.classify(outputs["pred_logits"])
+        outputs = self.post_processing(outputs, shard=(T_total, b0) if sharded else None)     # tracker (minvis.py:320-338)
+        probs = self.classify_sharded(outputs["pred_logits"][0], T_total, True) if sharded else self.classify(outputs["pred_logits"])
         masks_lowres = outputs["pred_masks"][0]
         if stages is not None:
             stages.update(dict(images=images, pred_masks=outputs["pred_masks"], pred_logits=outputs["pred_logits"],
@@ -145,8 +159,42 @@ class SANOnline(MinVIS):
                                pred_embeds=outputs["pred_embeds"]))
         inp = batched_inputs[0]
         row_ids = np.arange(self.num_queries, dtype=np.int32)
-        return self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
-                                    inp.get("height", image_size[0]), inp.get("width", image_size[1]),
-                                    redo=lambda: self.forward(batched_inputs, stages))
+        self.mask_gather = None
+        if sharded and gather_masks_to is not None:
+            def _mg(m):
+                with D.span("mask_gather", host=True):
+                    return D.gather_frame_masks(m, T_total, gather_masks_to)
+            self.mask_gather = _mg
+        try:
+            out = self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
+                                       inp.get("height", image_size[0]), inp.get("width", image_size[1]),
+                                       redo=lambda: self.forward(batched_inputs, stages, frame_range, gather_masks_to), sync_guard=sharded)
+        finally:
+            self.mask_gather = None
+        if sharded and gather_masks_to is None:
+            out["pred_masks_frames"] = (b0, b1)
+        return out
 
     __call__ = forward
+
+    def classify_sharded(self, logits, T_total, sharded):
+        """softmax(mean over ALL frames of the logits)[:, :-1]; sharded: per-rank frame sums are all-reduced."""
+        if not sharded:
+            return self.classify(logits.unsqueeze(0))
+        t, Q, K1 = logits.shape
+        # mean over the local frames (kernel) weighted by the shard's share of the clip -> all-reduce = mean over ALL frames
+        # -> softmax through the aggregate kernel.  The weighting is one elementwise scale of a [Q,K+1] tensor.
+        local = ops.mean_over_dim0(logits.contiguous()) * (float(t) / float(T_total))
+        flag = self._forward_flag()
+        with D.span("logit_all_reduce", host=True):
+            if flag is not None:
+                # fp16x2: every constant-weight GEMM of this forward is queued by now; the range flags of the ranks ride on this all-reduce
+                # (one more element), so that all ranks agree on whether the clip has to be repeated under bf16x3 (inference_video, sync_guard)
+                packed = D.all_reduce_sum(torch.cat([local.reshape(-1), flag.to(torch.float32)]))
+                total = packed[:-1].view_as(local)
+                flag.copy_((packed[-1:] > 0).to(torch.int32))
+            else:
+                total = D.all_reduce_sum(local)
+        one = torch.arange(Q, dtype=torch.int32, device=logits.device).view(1, Q)
+        probs, _ = ops.openvis_aggregate(total.contiguous(), one)
+        return probs[:, :-1].contiguous()

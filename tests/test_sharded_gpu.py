@@ -58,6 +58,28 @@ def test_two_rank_frame_sharded_brivis_equals_single_rank(tmp_path):
     assert g[1]["mask_shape"] == [] and g[1]["labels"] == single["labels"]
 
 
+@pytest.mark.parametrize("arch,port", [("san_online", 29644), ("openvis_online", 29647)])
+def test_two_rank_frame_sharded_online_models_equal_single_rank(arch, port, tmp_path):
+    """SURVEY.md 8e row 1 names three frame-shardable architectures: SANOnline and OpenVISOnline share BriVIS' exchange -- all-gather of the
+    query embeddings in front of the replicated MinVIS tracker (minvis.py:320-338) -- and then average logits over the clip's frames (SANOnline:
+    all-reduce of the per-frame logit sums, san.py:257) or classify CLIP crops (OpenVISOnline: all-gather of the crop logits for the per-query
+    mean, openvis.py:130-138).  Two ranks (4 + 3 frames) against one: the same tracks, probabilities, top-10 and masks."""
+    env = {"OVIS_SHARD_ARCH": arch}
+    sp1 = _spawn(1, str(tmp_path / "single"), port, env)
+    sp2 = _spawn(2, str(tmp_path / "two"), port + 1, env)
+    spg = _spawn(2, str(tmp_path / "gather"), port + 2, dict(env, OVIS_GATHER_TO="1"))
+    single, two, g = _collect(sp1)[0], _collect(sp2), _collect(spg)
+    assert two[0]["range"] == [0, 4] and two[1]["range"] == [4, 7]
+    for r in two + g:
+        assert r["indices"] == single["indices"]                                      # replicated tracker on the gathered embeddings
+        assert np.abs(np.array(r["probs"]) - np.array(single["probs"])).max() < 1e-5
+        assert r["labels"] == single["labels"] and r["queries"] == single["queries"]
+        assert np.abs(np.array(r["scores"]) - np.array(single["scores"])).max() < 1e-5
+    assert [a + b for a, b in zip(two[0]["mask_sums"], two[1]["mask_sums"])] == single["mask_sums"]
+    assert two[0]["mask_frames"] == [0, 4] and two[1]["mask_frames"] == [4, 7]
+    assert g[1]["mask_shape"] == single["mask_shape"] and g[1]["frame_sums"] == single["frame_sums"] and g[0]["mask_shape"] == []
+
+
 @pytest.mark.parametrize("model,scaling", [("openvis", "weak"), ("brivis", "strong")])
 def test_bench_multi_rank_control_flow(model, scaling, tmp_path):
     """bench.py with WORLD_SIZE=2 (test rig: both ranks on cuda:0, gloo): rank 0 prints ONE JSON line with n_gpus = 2."""
