@@ -470,6 +470,9 @@ def main():
     ap.add_argument("--sharded-frames", type=int, default=36,
                     help="N > 1 with the default model: frames of the ONE BriVIS clip that is additionally run frame-sharded over the ranks "
                          "(`frame_sharded` on the JSON line; BASELINE.json configs[3]: 36); 0 skips it")
+    ap.add_argument("--frame-sharded", action="store_true",
+                    help="--model san_online / openvis_online with N > 1 (or --process-group): shard ONE clip's frames over the ranks as --model brivis "
+                         "does (tracker all-gather, logit all-reduce / crop-logit all-gather) instead of running clip replicas")
     ap.add_argument("--split-frames", type=int, default=8,
                     help="N > 1 (or --process-group) with the default model: frames of the ONE OpenVIS clip that is additionally run split over the "
                          "ranks, split-KV offline decoder (`split_clip` on the JSON line; at least one frame per rank); 0 skips it")
@@ -515,8 +518,12 @@ def main():
     f32_split = args.f32_split if args.f32_split != "auto" else ("bf16x3" if args.precision == "fp32" else "fp16x2")
     model, sd, text = build_model(device, clip_precision=args.clip_precision, precision=args.precision, model_name=args.model, f32_split=args.f32_split,
                                   crop_list=args.crop_list)
-    frame_sharded = args.model.startswith("brivis") and (world > 1 or args.process_group)
+    # one clip over the ranks: BriVIS always (configs[3] is a 36-frame clip); the other two per-frame architectures on request
+    frame_sharded = ((args.model.startswith("brivis") or (args.frame_sharded and args.model in ("san_online", "openvis_online")))
+                     and (world > 1 or args.process_group))
     T = args.frames or (36 if args.model.startswith("brivis") else T_CLIP)
+    if frame_sharded and T < world:
+        raise SystemExit(f"bench.py: a {T}-frame clip cannot be frame-sharded over {world} ranks (a rank would own no frame): pass --frames >= {world}")
     res = args.resolution or (1080 if args.model.endswith("_swinl") else 720)
     FH, FW = res, res * 16 // 9                          # frame size of this run
     fwd_kw = {}

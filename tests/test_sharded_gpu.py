@@ -172,6 +172,24 @@ def test_bench_brivis_under_a_one_rank_rccl_group():
     assert len([ln for ln in p.stdout.splitlines() if ln.strip()]) == 1
 
 
+@pytest.mark.parametrize("model,spans", [("san_online", {"all_gather_wait", "linker", "logit_all_reduce", "mask_gather"}),
+                                         ("openvis_online", {"all_gather_wait", "linker", "logit_all_gather", "mask_gather"})])
+def test_bench_online_models_frame_sharded_under_a_one_rank_rccl_group(model, spans):
+    """`bench.py --model san_online|openvis_online --frame-sharded --process-group`: the other two frame-shardable architectures through the
+    bench's frame-sharded control flow over RCCL (one rank)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="8", MASTER_ADDR="127.0.0.1", MASTER_PORT="29682")
+    for k in ("OVIS_BENCH_TEST_RIG", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", model, "--frame-sharded", "--process-group", "--frames", "4", "--steps", "2",
+                        "--warmup", "1", "--gather-masks", "--no-alt-splits", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-1500:]
+    line = json.loads(lines[0])
+    assert line["process_group"] == "nccl" and line["scaling"] == "strong" and line["value"] > 0 and line["frames_per_rank"] == [4]
+    assert spans <= set(line["collective_ms"]["per_rank"][0]), line["collective_ms"]
+
+
 def test_bench_openvis_split_clip_under_a_one_rank_rccl_group():
     """`bench.py --process-group` (default model): the headline as always plus `split_clip` -- ONE OpenVIS clip through the split-KV decoder's
     exchange (9 all-gathers of flash partials, 1 of crop logits, mask gather) over a 1-rank RCCL group, with the un-split forward beside it."""
