@@ -25,6 +25,8 @@ def main():
     which = os.environ.get("OVIS_SHARD_ARCH", "brivis")          # brivis | san_online | openvis_online: the three frame-shardable architectures
     cfg = config.get_cfg()
     cfg.MODEL.PRECISION = "fp32"
+    if os.environ.get("OVIS_SHARD_WINDOWS") == "1":              # the rank's own frames as windows of 2 (minvis.py:340-362) in front of the exchange
+        cfg.MODEL.MASK_FORMER.TEST.WINDOW_INFERENCE, cfg.MODEL.MASK_FORMER.TEST.WINDOW_SIZE = True, 2
     if which == "openvis_online":
         cfg.MODEL.META_ARCHITECTURE = "OpenVISOnline"
         cfg.MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME = "FrameMultiScaleMaskedTransformerDecoder"

@@ -78,6 +78,13 @@ def test_two_rank_frame_sharded_online_models_equal_single_rank(arch, port, tmp_
     assert [a + b for a, b in zip(two[0]["mask_sums"], two[1]["mask_sums"])] == single["mask_sums"]
     assert two[0]["mask_frames"] == [0, 4] and two[1]["mask_frames"] == [4, 7]
     assert g[1]["mask_shape"] == single["mask_shape"] and g[1]["frame_sums"] == single["frame_sums"] and g[0]["mask_shape"] == []
+    # window inference on every rank (its 4 / 3 frames as windows of 2) in front of the same exchange
+    w = _run(2, str(tmp_path / "windows"), port + 3, dict(env, OVIS_SHARD_WINDOWS="1"))
+    for r in w:
+        assert r["indices"] == single["indices"] and r["labels"] == single["labels"] and r["queries"] == single["queries"]
+        assert np.abs(np.array(r["probs"]) - np.array(single["probs"])).max() < 1e-5
+    # (a window of 2 frames reaches other GEMM tilings than a block of 4: f32 summation order, a handful of pixels at |logit| ~ 1e-6)
+    assert max(abs(a + b - c) for a, b, c in zip(w[0]["mask_sums"], w[1]["mask_sums"], single["mask_sums"])) <= 16
 
 
 @pytest.mark.parametrize("model,scaling", [("openvis", "weak"), ("brivis", "strong")])
