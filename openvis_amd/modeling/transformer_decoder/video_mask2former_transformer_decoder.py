@@ -171,7 +171,7 @@ class VideoMultiScaleMaskedTransformerDecoder:
             src.append(s)
             if shard is None:
                 pos = self._pos(T, H, W)
-            else:                                                   # the 3-D sine embedding normalises z by the CLIP's length: slice the clip's table
+            else:                                                   # the 3-D sine embedding normalises z by the clip's length: slice the clip's table
                 pos = self._pos(shard[0], H, W)[shard[1] * H * W:(shard[1] + T) * H * W]
             kin.append(ops.add_bcast(s, pos))                                                          # memory + pos
             sc = hm // H
