@@ -323,3 +323,29 @@ def test_bench_line_survives_a_rank_that_fails_inside_a_side_measurement(fail_ra
     d = json.loads(outs[0][0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and "roofline" in d and d["frame_sharded"] is None
     assert "error" in d["split_clip"], d["split_clip"]
+
+
+def test_bench_eight_rank_control_flow_on_one_gpu():
+    """The command the driver's scaling run issues at N = 8, on the rig (eight ranks on cuda:0, gloo): one JSON line from rank 0 with the
+    clip-replica headline, `frame_sharded` (36 BriVIS frames -> 5,5,5,5,4,4,4,4) and `split_clip` (8 OpenVIS frames, one per rank: the
+    decoder's partials merged from EIGHT blocks).  The numbers mean nothing here (one GPU, host-staged collectives); the control flow at the
+    world size of the real run is what is under test."""
+    W = 8
+    procs = []
+    for r in range(W):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(W), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="29699",
+                   OVIS_BENCH_TEST_RIG="1", OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(W), "--steps", "2", "--warmup", "1", "--no-alt-splits",
+                                       "--gather-masks"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=1200)
+        assert p.returncode == 0, e[-3000:]
+        outs.append([ln for ln in o.splitlines() if ln.strip()])
+    assert [len(o) for o in outs] == [1] + [0] * (W - 1)
+    d = json.loads(outs[0][0])
+    assert d["n_gpus"] == W and d["world_size_seen"] == W and d["scaling"] == "weak" and d["value"] > 0 and d["frames_per_rank"] == [5] * W
+    fs, sc = d["frame_sharded"], d["split_clip"]
+    assert fs["frames_per_rank"] == [5, 5, 5, 5, 4, 4, 4, 4] and fs["value"] > 0 and fs["world_size_seen"] == W
+    assert sc["frames_per_rank"] == [1] * W and sc["value"] > 0 and sc["unsplit_on_one_gpu"]["ms_per_step"] > 0
+    assert len(sc["collective_ms"]["per_rank"]) == W and {"partial_all_gather", "logit_all_gather", "mask_gather"} <= set(sc["collective_ms"]["per_rank"][0])
