@@ -196,16 +196,29 @@ class VideoMaskFormer:
 
     sticky_range_flag = None  # optional StickyFlag: OR of the fp16x2 range flags of every forward since it was set (never read by the model)
     output_rle = False        # MODEL.MASK_FORMER.TEST.OUTPUT_RLE (not a reference key): RLE hand-off instead of dense masks
-    mask_gather = None        # frame-sharded runs: callable(device masks [n,t_local,H,W]) -> masks of all frames on the output rank / None
+
+    @staticmethod
+    def gather_masks_fn(total_frames, dst):
+        """`mask_gather` argument of inference_video for gather_masks_to=dst (None -> None: every rank keeps the masks of its own frames)."""
+        if dst is None:
+            return None
+        from .. import distributed as D
+
+        def gather(m):
+            with D.span("mask_gather", host=True):
+                return D.gather_frame_masks(m, total_frames, dst)
+        return gather
 
     def inference_video(self, num_queries, num_classes, probs, row_ids, pred_masks_lowres, padded_hw, img_size,
-                        output_height, output_width, topk=10, redo=None, sync_guard=False, n_valid=None):
+                        output_height, output_width, topk=10, redo=None, sync_guard=False, n_valid=None, mask_gather=None):
         """video_maskformer.py:262-298.  probs [Q,K] (rows of valid queries filled), row_ids = valid query ids.
         redo: callable repeating this forward (fp16x2 only: used when the range flag came back set, _range_guard); sync_guard: read the
         flag back NOW instead of with the outputs (frame-sharded runs: every rank holds the all-reduced flag, distributed.reduce_flag, and
         all of them must repeat the clip at the same point of their collective sequence).  n_valid: device int32 [1], the number of
         non-empty masks when the crop list was built on the device (row_ids then names EVERY query): read back with the outputs; 0 means
-        what `row_ids is None` means on the host path -- an empty result."""
+        what `row_ids is None` means on the host path -- an empty result.  mask_gather: frame-sharded runs, callable(device masks
+        [n,t_local,H,W]) -> the masks of ALL frames on the output rank, None on the others (`gather_masks_to`); an argument, not model state:
+        forwards of one model may run on several host threads."""
         flag = self._forward_flag()
         if flag is not None and self.sticky_range_flag is not None:
             self.sticky_range_flag.or_(flag)                  # callers that drop outputs unread (bench.py's timed loop) still learn of an overflow
@@ -228,7 +241,7 @@ class VideoMaskFormer:
         # the host to read the indices back (the reference syncs on .tolist() here, video_maskformer.py:267-272)
         idx, score, ent, sel_q = ops.topk_entropy(probs, rid, topk)          # raises if rows*K < topk (as torch.topk)
         Q, T, h, w = pred_masks_lowres.shape
-        if self.output_rle and self.mask_gather is not None:
+        if self.output_rle and mask_gather is not None:
             raise ValueError("MODEL.MASK_FORMER.TEST.OUTPUT_RLE with gather_masks_to: the run-length hand-off covers this rank's frames only; "
                              "keep the masks sharded (gather_masks_to=None) and merge the per-rank RLEs in the evaluator")
         if self.output_rle:
@@ -256,8 +269,8 @@ class VideoMaskFormer:
                     "pred_queries": sel_q.cpu().tolist()}
         masks = ops.final_masks(pred_masks_lowres, sel_q, padded_hw[0], padded_hw[1], img_size[0], img_size[1],
                                 output_height, output_width)
-        if self.mask_gather is not None:
-            masks = self.mask_gather(masks)
+        if mask_gather is not None:
+            masks = mask_gather(masks)
             if masks is None:                                                 # not the output rank
                 again = self._range_guard(flag.cpu()[0] if flag is not None else None, redo)
                 if again is not None:

@@ -94,19 +94,11 @@ class OpenVIS(VideoMaskFormer):
             stages.update(dict(images=images, features=features, pred_masks=outputs["pred_masks"], pred_logits=outputs["pred_logits"],
                                probs=probs, row_ids=row_ids, **extras))
         inp = batched_inputs[0]
-        self.mask_gather = None
-        if gather_masks_to is not None:
-            def _mg(m):
-                with D.span("mask_gather", host=True):
-                    return D.gather_frame_masks(m, T_total, gather_masks_to)
-            self.mask_gather = _mg
-        try:
-            out = self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
-                                       inp.get("height", image_size[0]), inp.get("width", image_size[1]),
-                                       redo=lambda: self.forward(batched_inputs, stages, frame_range, gather_masks_to), sync_guard=True,
-                                       n_valid=n_valid)
-        finally:
-            self.mask_gather = None
+        out = self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
+                                   inp.get("height", image_size[0]), inp.get("width", image_size[1]),
+                                   redo=lambda: self.forward(batched_inputs, stages, frame_range, gather_masks_to), sync_guard=True,
+                                   n_valid=n_valid,
+                                   mask_gather=self.gather_masks_fn(T_total, gather_masks_to))
         if gather_masks_to is None:
             out["pred_masks_frames"] = (b0, b1)
         return out
@@ -235,7 +227,6 @@ class OpenVISOnline(OpenVIS):
         self.sem_seg_head.num_classes = len(class_names)
         sharded = frame_range is not None
         if sharded:
-            from . import distributed as D
             all_frames = [f for video in batched_inputs for f in video["image"]]
             T_total = len(all_frames)
             b0, b1 = frame_range
@@ -268,19 +259,11 @@ class OpenVISOnline(OpenVIS):
                                pred_embeds=outputs["pred_embeds"], indices=outputs["indices"], probs=probs,
                                row_ids=row_ids, **extras))
         inp = batched_inputs[0]
-        self.mask_gather = None
-        if sharded and gather_masks_to is not None:
-            def _mg(m):
-                with D.span("mask_gather", host=True):
-                    return D.gather_frame_masks(m, T_total, gather_masks_to)
-            self.mask_gather = _mg
-        try:
-            out = self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
-                                       inp.get("height", image_size[0]), inp.get("width", image_size[1]),
-                                       redo=lambda: self.forward(batched_inputs, stages, frame_range, gather_masks_to), n_valid=n_valid,
-                                       sync_guard=sharded)
-        finally:
-            self.mask_gather = None
+        out = self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
+                                   inp.get("height", image_size[0]), inp.get("width", image_size[1]),
+                                   redo=lambda: self.forward(batched_inputs, stages, frame_range, gather_masks_to), n_valid=n_valid,
+                                   sync_guard=sharded,
+                                   mask_gather=self.gather_masks_fn(T_total, gather_masks_to) if sharded else None)
         if sharded and gather_masks_to is None:
             out["pred_masks_frames"] = (b0, b1)
         return out

@@ -159,18 +159,10 @@ class SANOnline(MinVIS):
                                pred_embeds=outputs["pred_embeds"]))
         inp = batched_inputs[0]
         row_ids = np.arange(self.num_queries, dtype=np.int32)
-        self.mask_gather = None
-        if sharded and gather_masks_to is not None:
-            def _mg(m):
-                with D.span("mask_gather", host=True):
-                    return D.gather_frame_masks(m, T_total, gather_masks_to)
-            self.mask_gather = _mg
-        try:
-            out = self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
-                                       inp.get("height", image_size[0]), inp.get("width", image_size[1]),
-                                       redo=lambda: self.forward(batched_inputs, stages, frame_range, gather_masks_to), sync_guard=sharded)
-        finally:
-            self.mask_gather = None
+        out = self.inference_video(self.num_queries, len(class_names), probs, row_ids, masks_lowres, padded, image_size,
+                                   inp.get("height", image_size[0]), inp.get("width", image_size[1]),
+                                   redo=lambda: self.forward(batched_inputs, stages, frame_range, gather_masks_to), sync_guard=sharded,
+                                   mask_gather=self.gather_masks_fn(T_total, gather_masks_to) if sharded else None)
         if sharded and gather_masks_to is None:
             out["pred_masks_frames"] = (b0, b1)
         return out
